@@ -1,0 +1,274 @@
+"""ctypes binding of the CPU oracle (oracle/libgravitas_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  Never imported by the engine package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libgravitas_oracle.so")
+
+KERR_BL, KERR_KS, SCHWARZSCHILD = 0, 1, 2
+TERM_NONE, TERM_HORIZON, TERM_ESCAPE, TERM_MAXSTEPS, TERM_DISK = 0, 1, 2, 3, 4
+METHOD_RKF45, METHOD_RK4, METHOD_SYMPLECTIC = 0, 1, 2
+
+
+class Metric(C.Structure):
+    _fields_ = [("kind", C.c_int), ("mass", C.c_double), ("spin", C.c_double)]
+
+
+class State(C.Structure):
+    _fields_ = [("x", C.c_double * 4), ("p", C.c_double * 4)]
+
+
+class Options(C.Structure):
+    _fields_ = [("method", C.c_int), ("tolerance", C.c_double), ("initial_step", C.c_double),
+                ("max_steps", C.c_uint64), ("escape_radius", C.c_double),
+                ("renormalize_interval", C.c_uint64), ("step_size", C.c_double)]
+
+
+class Trajectory(C.Structure):
+    _fields_ = [("final_state", State), ("termination", C.c_int), ("steps_taken", C.c_uint64),
+                ("max_hamiltonian_drift", C.c_double), ("rkf_tries", C.c_uint64)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("position", C.c_double * 3), ("inv_view", C.c_double * 16),
+                ("inv_proj", C.c_double * 16), ("pixel_offset", C.c_double * 2)]
+
+
+class FrameParams(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("metric_kind", C.c_int),
+                ("mass", C.c_double), ("spin", C.c_double), ("opt", Options),
+                ("shading", C.c_int), ("disk_inner", C.c_double), ("disk_outer", C.c_double),
+                ("disk_temp", C.c_double), ("disk_opacity", C.c_double), ("exposure", C.c_double),
+                ("lut_width", C.c_uint32), ("lut_height", C.c_uint32),
+                ("lut_max_temp", C.c_double)]
+
+
+class FrameStats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("accepted_steps", C.c_uint64), ("rkf_tries", C.c_uint64),
+                ("term_count", C.c_uint64 * 5), ("crossings", C.c_uint64),
+                ("max_drift", C.c_double)]
+
+
+def build(force=False):
+    """Compile the oracle with its Makefile (gcc)."""
+    if force or not os.path.exists(_LIB_PATH) or any(
+            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
+            for f in ("gravitas_oracle.c", "gravitas_oracle.h", "frame_oracle.c",
+                      "frame_oracle.h", "Makefile")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        d, i, u64, p = C.c_double, C.c_int, C.c_uint64, C.c_void_p
+        MP, SP, OP = C.POINTER(Metric), C.POINTER(State), C.POINTER(Options)
+        L.orc_metric_make.restype = Metric
+        L.orc_metric_make.argtypes = [i, d, d]
+        L.orc_options_default.restype = Options
+        for name in ("orc_event_horizon", "orc_cauchy_horizon", "orc_photon_sphere"):
+            getattr(L, name).restype = d
+            getattr(L, name).argtypes = [MP]
+        L.orc_isco.restype = d
+        L.orc_isco.argtypes = [MP, i]
+        L.orc_ergosphere.restype = d
+        L.orc_ergosphere.argtypes = [MP, d]
+        L.orc_keplerian_frequency.restype = d
+        L.orc_keplerian_frequency.argtypes = [MP, d]
+        L.orc_time_dilation.restype = d
+        L.orc_time_dilation.argtypes = [MP, d, d]
+        L.orc_compute_dilation.restype = d
+        L.orc_compute_dilation.argtypes = [MP, d]
+        L.orc_covariant.argtypes = [MP, d, d, p]
+        L.orc_contravariant.argtypes = [MP, d, d, p]
+        L.orc_hamiltonian_derivatives.argtypes = [MP, d, d, p, p, p]
+        L.orc_contract.restype = d
+        L.orc_contract.argtypes = [p, p]
+        L.orc_state_derivative.restype = State
+        L.orc_state_derivative.argtypes = [SP, MP]
+        L.orc_hamiltonian.restype = d
+        L.orc_hamiltonian.argtypes = [SP, MP]
+        L.orc_renormalize_null.argtypes = [SP, MP]
+        L.orc_carter_constant.restype = d
+        L.orc_carter_constant.argtypes = [SP, MP]
+        L.orc_rkf45_step.restype = d
+        L.orc_rkf45_step.argtypes = [SP, MP, d, SP]
+        L.orc_adaptive_step.restype = d
+        L.orc_adaptive_step.argtypes = [SP, MP, d, d, C.POINTER(u64)]
+        L.orc_step_rk4.argtypes = [SP, MP, d]
+        L.orc_step_symplectic.argtypes = [SP, MP, d]
+        L.orc_integrate.argtypes = [SP, MP, OP, C.POINTER(Trajectory)]
+        L.orc_integrate_path.restype = C.c_size_t
+        L.orc_integrate_path.argtypes = [SP, MP, OP, C.POINTER(Trajectory), p, C.c_size_t]
+        L.orc_integrate_ray_relativistic.restype = C.c_size_t
+        L.orc_integrate_ray_relativistic.argtypes = [d, d, p, C.c_size_t, u64, d, i, p]
+        L.orc_integrate_batch.argtypes = [MP, OP, C.c_size_t, p, p, p, p, p, p, i]
+        L.orc_kerr_g_factor.restype = d
+        L.orc_kerr_g_factor.argtypes = [d, d, d, d]
+        L.orc_intensity_scaling.restype = d
+        L.orc_intensity_scaling.argtypes = [d, i]
+        L.orc_doppler_factor.restype = d
+        L.orc_doppler_factor.argtypes = [d, d]
+        L.orc_gravitational_factor.restype = d
+        L.orc_gravitational_factor.argtypes = [d, d]
+        L.orc_planck_law.restype = d
+        L.orc_planck_law.argtypes = [d, d]
+        L.orc_integrate_planck_xyz.argtypes = [d, p]
+        L.orc_cie_1931.argtypes = [d, p]
+        L.orc_xyz_to_linear_rgb.argtypes = [d, d, d, p]
+        L.orc_generate_blackbody_lut.argtypes = [C.c_size_t, C.c_size_t, d, p]
+        L.orc_max_threads.restype = i
+        CP, FP = C.POINTER(Camera), C.POINTER(FrameParams)
+        L.orc_camera_look_at.argtypes = [p, p, p, d, d, CP]
+        L.orc_pixel_state.argtypes = [CP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, SP]
+        L.orc_render_frame.argtypes = [CP, FP, p, C.c_uint32, C.c_uint32, p, p, p, p, p,
+                                       C.POINTER(FrameStats), i]
+        L.orc_lut_sample.argtypes = [p, C.c_uint32, C.c_uint32, d, d, d, p]
+        L.orc_disk_temp_profile.restype = d
+        L.orc_disk_temp_profile.argtypes = [d, d]
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def metric(kind, mass, spin):
+    return lib().orc_metric_make(kind, float(mass), float(spin))
+
+
+def options(method=METHOD_RKF45, tolerance=1e-8, initial_step=0.01, max_steps=10000,
+            escape_radius=1000.0, renormalize_interval=10, step_size=0.0):
+    return Options(method, tolerance, initial_step, max_steps, escape_radius,
+                   renormalize_interval, step_size)
+
+
+def make_state(v8):
+    s = State()
+    for k in range(4):
+        s.x[k] = float(v8[k])
+        s.p[k] = float(v8[4 + k])
+    return s
+
+
+def state_to_list(s):
+    return [s.x[0], s.x[1], s.x[2], s.x[3], s.p[0], s.p[1], s.p[2], s.p[3]]
+
+
+def contravariant(m, r, theta):
+    g = np.zeros(16)
+    lib().orc_contravariant(C.byref(m), r, theta, _ptr(g))
+    return g
+
+
+def covariant(m, r, theta):
+    g = np.zeros(16)
+    lib().orc_covariant(C.byref(m), r, theta, _ptr(g))
+    return g
+
+
+def hamiltonian_derivatives(m, r, theta, p4):
+    p = np.asarray(p4, dtype=np.float64)
+    a, b = C.c_double(), C.c_double()
+    lib().orc_hamiltonian_derivatives(C.byref(m), r, theta, _ptr(p), C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def integrate(v8, m, opt):
+    s = make_state(v8)
+    t = Trajectory()
+    lib().orc_integrate(C.byref(s), C.byref(m), C.byref(opt), C.byref(t))
+    return t
+
+
+def integrate_path(v8, m, opt, cap=20000):
+    s = make_state(v8)
+    t = Trajectory()
+    path = np.zeros((cap, 8))
+    n = lib().orc_integrate_path(C.byref(s), C.byref(m), C.byref(opt), C.byref(t), _ptr(path), cap)
+    return t, path[:n].copy()
+
+
+def integrate_ray_relativistic(mass, spin, initial, steps, tolerance, use_ks):
+    a = np.ascontiguousarray(initial, dtype=np.float64)
+    out = np.zeros(max(8, a.size))
+    n = lib().orc_integrate_ray_relativistic(mass, spin, _ptr(a), a.size, steps, tolerance,
+                                             1 if use_ks else 0, _ptr(out))
+    return out[:n].copy()
+
+
+def integrate_batch(m, opt, states, nthreads=1):
+    """states: (n, 8) f64 AoS.  Returns dict of arrays."""
+    a = np.ascontiguousarray(states, dtype=np.float64)
+    n = a.shape[0]
+    out = np.zeros_like(a)
+    steps = np.zeros(n, np.uint32)
+    term = np.zeros(n, np.uint8)
+    drift = np.zeros(n, np.float64)
+    tries = np.zeros(n, np.uint32)
+    lib().orc_integrate_batch(C.byref(m), C.byref(opt), n, _ptr(a), _ptr(out), _ptr(steps),
+                              _ptr(term), _ptr(drift), _ptr(tries), nthreads)
+    return dict(states=out, steps=steps, term=term, drift=drift, tries=tries)
+
+
+def blackbody_lut(width, height, max_temp):
+    out = np.zeros(width * height * 4, np.float32)
+    lib().orc_generate_blackbody_lut(width, height, max_temp, _ptr(out))
+    return out
+
+
+def camera_look_at(eye, target=(0, 0, 0), up=(0, 1, 0), fovy_deg=60.0, aspect=16 / 9):
+    cam = Camera()
+    e = np.asarray(eye, np.float64)
+    t = np.asarray(target, np.float64)
+    u = np.asarray(up, np.float64)
+    lib().orc_camera_look_at(_ptr(e), _ptr(t), _ptr(u), np.deg2rad(fovy_deg), aspect,
+                             C.byref(cam))
+    return cam
+
+
+def pixel_state(cam, width, height, i, j):
+    s = State()
+    lib().orc_pixel_state(C.byref(cam), width, height, i, j, C.byref(s))
+    return np.array(state_to_list(s))
+
+
+def frame_params(width, height, mass=1.0, spin=0.999, metric_kind=KERR_KS, opt=None, shading=1,
+                 disk_inner=0.0, disk_outer=30.0, disk_temp=9500.0, disk_opacity=0.6,
+                 exposure=1.0, lut_width=512, lut_height=64, lut_max_temp=1e5):
+    if opt is None:
+        opt = options(max_steps=2048)
+    return FrameParams(width, height, metric_kind, mass, spin, opt, shading, disk_inner,
+                       disk_outer, disk_temp, disk_opacity, exposure, lut_width, lut_height,
+                       lut_max_temp)
+
+
+def render_frame(cam, fp, lut=None, stride=(1, 1), nthreads=1, want_states=True):
+    nx = (fp.width + stride[0] - 1) // stride[0]
+    ny = (fp.height + stride[1] - 1) // stride[1]
+    n = nx * ny
+    rgba = np.zeros((ny, nx, 4), np.float32)
+    states = np.zeros((n, 8), np.float64) if want_states else None
+    steps = np.zeros(n, np.uint32)
+    term = np.zeros(n, np.uint8)
+    drift = np.zeros(n, np.float64)
+    st = FrameStats()
+    lib().orc_render_frame(C.byref(cam), C.byref(fp), _ptr(lut), stride[0], stride[1],
+                           _ptr(rgba), _ptr(states), _ptr(steps), _ptr(term), _ptr(drift),
+                           C.byref(st), nthreads)
+    return dict(rgba=rgba, states=states, steps=steps, term=term, drift=drift, stats=st,
+                shape=(ny, nx))
