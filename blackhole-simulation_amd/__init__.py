@@ -1,0 +1,13 @@
+"""MI355X-native Kerr geodesic ray-marching engine (HIP, gfx950).
+
+Host-side mirror of the reference's physics FFI
+(physics-engine/gravitas-wasm/src/lib.rs:56-465, `PhysicsEngine`) over the C ABI
+of include/gravitas_abi.h.  All compute runs in libgravitas_hip.so on the GPU;
+there is no CPU fallback in this package.
+"""
+from .engine import (  # noqa: F401
+    ARITH_FAST, ARITH_STRICT, KERR_BL, KERR_KS, METHOD_RK4, METHOD_RKF45, METHOD_SYMPLECTIC,
+    SCHWARZSCHILD, TERM_DISK_CROSSING, TERM_ESCAPE, TERM_HORIZON, TERM_MAXSTEPS, TERM_NONE,
+    Camera, FrameBuffers, FrameStats, GravitasError, Options, PhysicsEngine, RenderParams,
+    build_library, camera_look_at, library_path, load_library, render_params, unpack_tiles,
+)

@@ -1,0 +1,103 @@
+// engine_types.hpp -- plain structs shared by the host engine and the device
+// translation units (kernels_strict.hip / kernels_fast.hip), plus the launcher
+// entry points those units export.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gravitas_abi.h"
+
+namespace grvhip {
+
+constexpr int kBlock = 256;
+constexpr int kMaxCrossRec = 4;
+
+// flags word: bits 0-2 termination, bit 3 forced-min-step pending, bits 4-7 crossing
+// count, bit 8 slot holds a real ray.
+constexpr uint32_t kFlagTermMask = 0x7u;
+constexpr uint32_t kFlagForced = 0x8u;
+constexpr uint32_t kFlagCrossShift = 4;
+constexpr uint32_t kFlagCrossMask = 0xF0u;
+constexpr uint32_t kFlagValid = 0x100u;
+
+struct RayWorkspace {
+    double *t, *r, *th, *ph, *pr, *pth; // evolving components
+    double *pt, *pph;                   // constants of motion (E = -p_t, L_z = p_phi)
+    double *h;                          // carried adaptive step
+    double *drift;                      // max |H|
+    double *rc;                         // [kMaxCrossRec][n] disk-plane crossing radii
+    uint32_t *steps, *tries, *flags;
+    uint32_t n; // slots
+};
+
+struct SegmentParams {
+    double M, a, a2;
+    double horizon_limit; // r_+ * 1.001
+    double escape_radius;
+    double tolerance;
+    double step_size; // RK4 / symplectic
+    uint32_t max_steps;
+    uint32_t renorm_interval;
+    uint32_t max_tries; // per launch
+    // disk-plane crossing recorder (shading)
+    int32_t shading;
+    double disk_inner, disk_outer;
+    uint32_t max_crossings;
+};
+
+struct FrameGeom {
+    uint32_t width, height;
+    uint32_t tiles_x, tiles_y;
+    uint32_t tile_world, tile_rank;
+    uint32_t n_tiles_local;
+};
+
+struct CameraDev {
+    double pos[3];
+    double inv_view[16];
+    double inv_proj[16];
+    double off[2];
+};
+
+struct ShadeParams {
+    double M, spin;
+    double disk_inner, disk_temp, disk_opacity, exposure;
+    uint32_t lut_w, lut_h;
+    double lut_max_temp;
+    uint32_t lds_row0, lds_rows; // LUT rows staged in LDS
+};
+
+struct FrameStatsDev {
+    unsigned long long accepted_steps, rkf_tries, term_count[5], crossings, rays;
+    unsigned long long max_drift_bits;
+};
+
+
+// ---- launchers (kernels_strict.hip: -ffp-contract=off) ----
+hipError_t launch_segment_strict(int kind, int method, const RayWorkspace &ws,
+                                 const SegmentParams &P, const uint32_t *live_in, uint32_t n_live,
+                                 uint32_t *live_out, uint32_t *live_out_count, hipStream_t s);
+hipError_t launch_init_states(int kind, const RayWorkspace &ws, const SegmentParams &P,
+                              const double *states, double h0, int adaptive, hipStream_t s);
+hipError_t launch_init_pixels(int kind, const RayWorkspace &ws, const SegmentParams &P,
+                              const FrameGeom &G, const CameraDev &cam, double h0, int adaptive,
+                              hipStream_t s);
+hipError_t launch_build_live(const RayWorkspace &ws, uint32_t *live_out, uint32_t *count,
+                             hipStream_t s);
+hipError_t launch_finalize_batch(const RayWorkspace &ws, double *out_states, uint32_t *out_steps,
+                                 uint8_t *out_term, double *out_drift, FrameStatsDev *st,
+                                 hipStream_t s);
+hipError_t launch_finalize_frame(const RayWorkspace &ws, const FrameGeom &G, const ShadeParams &S,
+                                 int shading, const float *lut, float *out_rgba,
+                                 double *out_states, uint32_t *out_steps, uint8_t *out_term,
+                                 double *out_drift, FrameStatsDev *st, int n_blocks,
+                                 hipStream_t s);
+hipError_t launch_spectrum_lut(float *out, uint32_t width, uint32_t height, double max_temp,
+                               hipStream_t s);
+// ---- launcher (kernels_fast.hip: -ffp-contract=fast) ----
+hipError_t launch_segment_fast(int kind, int method, const RayWorkspace &ws,
+                               const SegmentParams &P, const uint32_t *live_in, uint32_t n_live,
+                               uint32_t *live_out, uint32_t *live_out_count, hipStream_t s);
+
+} // namespace grvhip

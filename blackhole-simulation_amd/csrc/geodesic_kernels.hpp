@@ -1,0 +1,527 @@
+// geodesic_kernels.hpp -- wavefront geodesic integrator kernels for gfx950.
+//
+// Execution model (one "segment" launch):
+//   * per-ray state lives in HBM as struct-of-arrays (RayWorkspace): lane i of a
+//     wave touches element i of each array -> every load/store is one coalesced
+//     512-byte transaction per f64 component;
+//   * a launch loads the state of the live rays listed in `live_in`, runs up to
+//     `max_tries` integrator tries per ray entirely in registers, stores it back;
+//   * a wave leaves the loop as soon as __ballot(live) == 0 (adaptive-step early out);
+//   * surviving rays are appended to `live_out` with one wave-aggregated atomic
+//     (ballot + popcount + mbcnt prefix): this is the ray compaction between launches.
+//
+// Reference behaviour restated (physics-engine/gravitas-core/src):
+//   integrate()               geodesic/mod.rs:180-253
+//   check_termination         geodesic/mod.rs:256-265
+//   AdaptiveStepper::step     geodesic/integrator.rs:72-107 (constants :61-68)
+//   adaptive_rkf45_step       geodesic/integrator.rs:113-190
+//   step_rk4 / step_symplectic geodesic/integrator.rs:193-226
+// Compiled twice (STRICT: -ffp-contract=off, FAST: -ffp-contract=fast); GRV_TU_ARITH
+// selects which arithmetic contract this translation unit instantiates.
+#pragma once
+
+#include "engine_types.hpp"
+#include "kerr_device.hpp"
+
+namespace {
+
+using namespace grvhip;
+
+// ---------------------------------------------------------------------------
+// register-resident ray
+// ---------------------------------------------------------------------------
+struct RayRegs {
+    double t, r, th, ph, pr, pth;
+    double pt, pph;
+    double h;
+    double drift;
+    uint32_t steps, tries, flags;
+};
+
+__device__ __forceinline__ double clamp_rs(double x, double lo, double hi) {
+    // Rust f64::clamp
+    return x < lo ? lo : (x > hi ? hi : x);
+}
+__device__ __forceinline__ double signum_rs(double x) {
+    return (x != x) ? x : (signbit(x) ? -1.0 : 1.0);
+}
+
+// One Fehlberg 4(5) evaluation on the reduced state.  Writes the 5th-order
+// candidate into `n` and returns the error estimate (max-abs over t,r,theta,phi).
+template <int KIND, int ARITH>
+__device__ __forceinline__ double rkf45_try(const Hole<double> &bh, const RayRegs &y, double h,
+                                            RayRegs &n) {
+    // stage scale factors, same expressions as integrator.rs:119-160
+    double s21, s31, s32, s41, s42, s43, s51, s52, s53, s54, s61, s62, s63, s64, s65;
+    if constexpr (ARITH == GRV_ARITH_STRICT) {
+        s21 = h / 4.0;
+        s31 = 3.0 * h / 32.0;
+        s32 = 9.0 * h / 32.0;
+        s41 = 1932.0 * h / 2197.0;
+        s42 = -7200.0 * h / 2197.0;
+        s43 = 7296.0 * h / 2197.0;
+        s51 = 439.0 * h / 216.0;
+        s52 = -8.0 * h;
+        s53 = 3680.0 * h / 513.0;
+        s54 = -845.0 * h / 4104.0;
+        s61 = -8.0 * h / 27.0;
+        s62 = 2.0 * h;
+        s63 = -3544.0 * h / 2565.0;
+        s64 = 1859.0 * h / 4104.0;
+        s65 = -11.0 * h / 40.0;
+    } else {
+        s21 = h * 0.25;
+        s31 = h * (3.0 / 32.0);
+        s32 = h * (9.0 / 32.0);
+        s41 = h * (1932.0 / 2197.0);
+        s42 = h * (-7200.0 / 2197.0);
+        s43 = h * (7296.0 / 2197.0);
+        s51 = h * (439.0 / 216.0);
+        s52 = h * -8.0;
+        s53 = h * (3680.0 / 513.0);
+        s54 = h * (-845.0 / 4104.0);
+        s61 = h * (-8.0 / 27.0);
+        s62 = h * 2.0;
+        s63 = h * (-3544.0 / 2565.0);
+        s64 = h * (1859.0 / 4104.0);
+        s65 = h * (-11.0 / 40.0);
+    }
+    constexpr double c1 = 16.0 / 135.0, c3 = 6656.0 / 12825.0, c4 = 28561.0 / 56430.0,
+                     c5 = 9.0 / 50.0, c6 = 2.0 / 55.0;
+    constexpr double e1 = 16.0 / 135.0 - 25.0 / 216.0, e3 = 6656.0 / 12825.0 - 1408.0 / 2565.0,
+                     e4 = 28561.0 / 56430.0 - 2197.0 / 4104.0, e5 = -9.0 / 50.0 + 1.0 / 5.0;
+
+    const Deriv<double> k1 = rhs<KIND, ARITH>(bh, y.r, y.th, y.pt, y.pr, y.pth, y.pph);
+    // t and phi never feed back into the right-hand side: keep only their running
+    // 5th-order and error sums (same left-to-right order as the reference).
+    double a5_t = c1 * k1.dt, a5_ph = c1 * k1.dph;
+    double ae_t = e1 * k1.dt, ae_ph = e1 * k1.dph;
+
+    const Deriv<double> k2 = rhs<KIND, ARITH>(bh, y.r + k1.dr * s21, y.th + k1.dth * s21, y.pt,
+                                              y.pr + k1.dpr * s21, y.pth + k1.dpth * s21, y.pph);
+
+    const Deriv<double> k3 = rhs<KIND, ARITH>(
+        bh, y.r + (k1.dr * s31 + k2.dr * s32), y.th + (k1.dth * s31 + k2.dth * s32), y.pt,
+        y.pr + (k1.dpr * s31 + k2.dpr * s32), y.pth + (k1.dpth * s31 + k2.dpth * s32), y.pph);
+    a5_t = a5_t + c3 * k3.dt;
+    a5_ph = a5_ph + c3 * k3.dph;
+    ae_t = ae_t + e3 * k3.dt;
+    ae_ph = ae_ph + e3 * k3.dph;
+
+    const Deriv<double> k4 = rhs<KIND, ARITH>(
+        bh, y.r + (k1.dr * s41 + k2.dr * s42 + k3.dr * s43),
+        y.th + (k1.dth * s41 + k2.dth * s42 + k3.dth * s43), y.pt,
+        y.pr + (k1.dpr * s41 + k2.dpr * s42 + k3.dpr * s43),
+        y.pth + (k1.dpth * s41 + k2.dpth * s42 + k3.dpth * s43), y.pph);
+    a5_t = a5_t + c4 * k4.dt;
+    a5_ph = a5_ph + c4 * k4.dph;
+    ae_t = ae_t + e4 * k4.dt;
+    ae_ph = ae_ph + e4 * k4.dph;
+
+    const Deriv<double> k5 = rhs<KIND, ARITH>(
+        bh, y.r + (k1.dr * s51 + k2.dr * s52 + k3.dr * s53 + k4.dr * s54),
+        y.th + (k1.dth * s51 + k2.dth * s52 + k3.dth * s53 + k4.dth * s54), y.pt,
+        y.pr + (k1.dpr * s51 + k2.dpr * s52 + k3.dpr * s53 + k4.dpr * s54),
+        y.pth + (k1.dpth * s51 + k2.dpth * s52 + k3.dpth * s53 + k4.dpth * s54), y.pph);
+    a5_t = a5_t - c5 * k5.dt;
+    a5_ph = a5_ph - c5 * k5.dph;
+    ae_t = ae_t + e5 * k5.dt;
+    ae_ph = ae_ph + e5 * k5.dph;
+
+    const Deriv<double> k6 = rhs<KIND, ARITH>(
+        bh, y.r + (k1.dr * s61 + k2.dr * s62 + k3.dr * s63 + k4.dr * s64 + k5.dr * s65),
+        y.th + (k1.dth * s61 + k2.dth * s62 + k3.dth * s63 + k4.dth * s64 + k5.dth * s65), y.pt,
+        y.pr + (k1.dpr * s61 + k2.dpr * s62 + k3.dpr * s63 + k4.dpr * s64 + k5.dpr * s65),
+        y.pth + (k1.dpth * s61 + k2.dpth * s62 + k3.dpth * s63 + k4.dpth * s64 + k5.dpth * s65),
+        y.pph);
+    a5_t = a5_t + c6 * k6.dt;
+    a5_ph = a5_ph + c6 * k6.dph;
+    ae_t = ae_t + c6 * k6.dt;
+    ae_ph = ae_ph + c6 * k6.dph;
+
+    n = y;
+    n.t = y.t + h * a5_t;
+    n.ph = y.ph + h * a5_ph;
+    n.r = y.r + h * (c1 * k1.dr + c3 * k3.dr + c4 * k4.dr - c5 * k5.dr + c6 * k6.dr);
+    n.th = y.th + h * (c1 * k1.dth + c3 * k3.dth + c4 * k4.dth - c5 * k5.dth + c6 * k6.dth);
+    n.pr = y.pr + h * (c1 * k1.dpr + c3 * k3.dpr + c4 * k4.dpr - c5 * k5.dpr + c6 * k6.dpr);
+    n.pth = y.pth + h * (c1 * k1.dpth + c3 * k3.dpth + c4 * k4.dpth - c5 * k5.dpth + c6 * k6.dpth);
+
+    const double err_r = h * (e1 * k1.dr + e3 * k3.dr + e4 * k4.dr + e5 * k5.dr + c6 * k6.dr);
+    const double err_th = h * (e1 * k1.dth + e3 * k3.dth + e4 * k4.dth + e5 * k5.dth + c6 * k6.dth);
+    double error = fmax(0.0, fabs(h * ae_t));
+    error = fmax(error, fabs(err_r));
+    error = fmax(error, fabs(err_th));
+    error = fmax(error, fabs(h * ae_ph));
+    return error;
+}
+
+template <int KIND, int ARITH>
+__device__ __forceinline__ void rk4_step(const Hole<double> &bh, RayRegs &y, double h) {
+    const double hh = 0.5 * h;
+    const Deriv<double> k1 = rhs<KIND, ARITH>(bh, y.r, y.th, y.pt, y.pr, y.pth, y.pph);
+    const Deriv<double> k2 = rhs<KIND, ARITH>(bh, y.r + k1.dr * hh, y.th + k1.dth * hh, y.pt,
+                                              y.pr + k1.dpr * hh, y.pth + k1.dpth * hh, y.pph);
+    const Deriv<double> k3 = rhs<KIND, ARITH>(bh, y.r + k2.dr * hh, y.th + k2.dth * hh, y.pt,
+                                              y.pr + k2.dpr * hh, y.pth + k2.dpth * hh, y.pph);
+    const Deriv<double> k4 = rhs<KIND, ARITH>(bh, y.r + k3.dr * h, y.th + k3.dth * h, y.pt,
+                                              y.pr + k3.dpr * h, y.pth + k3.dpth * h, y.pph);
+    const double h6 = h / 6.0;
+    y.t += h6 * (k1.dt + 2.0 * k2.dt + 2.0 * k3.dt + k4.dt);
+    y.r += h6 * (k1.dr + 2.0 * k2.dr + 2.0 * k3.dr + k4.dr);
+    y.th += h6 * (k1.dth + 2.0 * k2.dth + 2.0 * k3.dth + k4.dth);
+    y.ph += h6 * (k1.dph + 2.0 * k2.dph + 2.0 * k3.dph + k4.dph);
+    y.pr += h6 * (k1.dpr + 2.0 * k2.dpr + 2.0 * k3.dpr + k4.dpr);
+    y.pth += h6 * (k1.dpth + 2.0 * k2.dpth + 2.0 * k3.dpth + k4.dpth);
+}
+
+template <int KIND, int ARITH>
+__device__ __forceinline__ void symplectic_step(const Hole<double> &bh, RayRegs &y, double h) {
+    // implicit midpoint, exactly two fixed-point sweeps (integrator.rs:209-226).
+    // t and phi of the midpoint never enter the right-hand side.
+    double mr = y.r, mth = y.th, mpr = y.pr, mpth = y.pth;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const Deriv<double> d = rhs<KIND, ARITH>(bh, mr, mth, y.pt, mpr, mpth, y.pph);
+        mr = 0.5 * (y.r + (y.r + d.dr * h));
+        mth = 0.5 * (y.th + (y.th + d.dth * h));
+        mpr = 0.5 * (y.pr + (y.pr + d.dpr * h));
+        mpth = 0.5 * (y.pth + (y.pth + d.dpth * h));
+    }
+    const Deriv<double> f = rhs<KIND, ARITH>(bh, mr, mth, y.pt, mpr, mpth, y.pph);
+    y.t += f.dt * h;
+    y.r += f.dr * h;
+    y.th += f.dth * h;
+    y.ph += f.dph * h;
+    y.pr += f.dpr * h;
+    y.pth += f.dpth * h;
+}
+
+__device__ __forceinline__ uint32_t termination_of(double r, const SegmentParams &P) {
+    if (r < P.horizon_limit) return GRV_TERM_HORIZON;
+    if (r > P.escape_radius) return GRV_TERM_ESCAPE;
+    return GRV_TERM_NONE;
+}
+
+// A live ray has flags & kFlagTermMask == NONE and steps < max_steps.
+__device__ __forceinline__ bool ray_live(const RayRegs &y) {
+    return (y.flags & (kFlagTermMask | kFlagValid)) == kFlagValid;
+}
+
+// Start-of-trajectory bookkeeping: mod.rs:200 (initial renormalisation), the
+// clamp of AdaptiveStepper::step's first h_try, and the first loop-top checks.
+template <int KIND>
+__device__ __forceinline__ void ray_begin(const Hole<double> &bh, RayRegs &y,
+                                          const SegmentParams &P, bool adaptive) {
+    const GInv<double> g = contravariant_at<KIND, double>(bh, y.r, y.th);
+    y.pr = renormalized_pr<KIND, double>(g, y.pt, y.pr, y.pth, y.pph);
+    if (adaptive) y.h = clamp_rs(y.h, -10.0, 10.0);
+    uint32_t term = GRV_TERM_NONE;
+    if (P.max_steps == 0)
+        term = GRV_TERM_MAXSTEPS;
+    else
+        term = termination_of(y.r, P);
+    y.flags = (y.flags & ~kFlagTermMask) | term;
+}
+
+// Everything integrate() does after a completed step (mod.rs:228-239), then the
+// next iteration's loop-top checks, plus the disk-plane crossing recorder.
+template <int KIND>
+__device__ __forceinline__ void after_step(const Hole<double> &bh, RayRegs &y, double r_prev,
+                                           double th_prev, const SegmentParams &P,
+                                           const RayWorkspace &ws, uint32_t slot) {
+    GInv<double> g = contravariant_at<KIND, double>(bh, y.r, y.th);
+    if (P.renorm_interval != 0 && (y.steps % P.renorm_interval) == 0)
+        y.pr = renormalized_pr<KIND, double>(g, y.pt, y.pr, y.pth, y.pph);
+    const double hv = fabs(hamiltonian_of<KIND, double>(g, y.pt, y.pr, y.pth, y.pph));
+    if (hv > y.drift) y.drift = hv;
+    y.steps += 1;
+
+    uint32_t term = GRV_TERM_NONE;
+    if (P.shading) {
+        constexpr double kPi2 = 1.57079632679489661923;
+        if ((th_prev - kPi2) * (y.th - kPi2) <= 0.0) {
+            const double dth = y.th - th_prev;
+            const double f = (dth == 0.0) ? 0.0 : (kPi2 - th_prev) / dth;
+            const double r_c = r_prev + f * (y.r - r_prev);
+            if (r_c > P.disk_inner && r_c < P.disk_outer) {
+                uint32_t nc = (y.flags & kFlagCrossMask) >> kFlagCrossShift;
+                if (nc < (uint32_t)kMaxCrossRec) ws.rc[(size_t)nc * ws.n + slot] = r_c;
+                nc = nc < 15u ? nc + 1u : nc;
+                y.flags = (y.flags & ~kFlagCrossMask) | (nc << kFlagCrossShift);
+                if (nc >= P.max_crossings) term = GRV_TERM_DISK_CROSSING;
+            }
+        }
+    }
+    if (term == GRV_TERM_NONE) {
+        if (y.steps >= P.max_steps)
+            term = GRV_TERM_MAXSTEPS;
+        else
+            term = termination_of(y.r, P);
+    }
+    y.flags = (y.flags & ~kFlagTermMask) | term;
+}
+
+__device__ __forceinline__ void load_ray(const RayWorkspace &ws, uint32_t s, RayRegs &y) {
+    y.t = ws.t[s];
+    y.r = ws.r[s];
+    y.th = ws.th[s];
+    y.ph = ws.ph[s];
+    y.pr = ws.pr[s];
+    y.pth = ws.pth[s];
+    y.pt = ws.pt[s];
+    y.pph = ws.pph[s];
+    y.h = ws.h[s];
+    y.drift = ws.drift[s];
+    y.steps = ws.steps[s];
+    y.tries = ws.tries[s];
+    y.flags = ws.flags[s];
+}
+
+__device__ __forceinline__ void store_ray(const RayWorkspace &ws, uint32_t s, const RayRegs &y) {
+    ws.t[s] = y.t;
+    ws.r[s] = y.r;
+    ws.th[s] = y.th;
+    ws.ph[s] = y.ph;
+    ws.pr[s] = y.pr;
+    ws.pth[s] = y.pth;
+    ws.h[s] = y.h;
+    ws.drift[s] = y.drift;
+    ws.steps[s] = y.steps;
+    ws.tries[s] = y.tries;
+    ws.flags[s] = y.flags;
+}
+
+// ---------------------------------------------------------------------------
+// The segment kernel.
+// ---------------------------------------------------------------------------
+template <int KIND, int ARITH, int METHOD>
+__global__ __launch_bounds__(kBlock) void integrate_segment_kernel(
+    RayWorkspace ws, SegmentParams P, const uint32_t *__restrict__ live_in, uint32_t n_live,
+    uint32_t *__restrict__ live_out, uint32_t *__restrict__ live_out_count) {
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    const bool have = k < n_live;
+    const uint32_t slot = have ? (live_in ? live_in[k] : k) : 0u;
+
+    RayRegs y;
+    y.flags = 0;
+    if (have) load_ray(ws, slot, y);
+    const Hole<double> bh{P.M, P.a, P.a2};
+
+    bool live = have && ray_live(y);
+    for (uint32_t it = 0; it < P.max_tries; ++it) {
+        if (__ballot(live) == 0ull) break; // whole wave finished: early out
+        if (live) {
+            const double r_prev = y.r, th_prev = y.th;
+            bool stepped;
+            if constexpr (METHOD == GRV_METHOD_RKF45) {
+                RayRegs n;
+                const double err = rkf45_try<KIND, ARITH>(bh, y, y.h, n);
+                y.tries += 1;
+                const bool forced = (y.flags & kFlagForced) != 0u;
+                const double ratio = (err == 0.0) ? 0.0 : err / P.tolerance;
+                if (forced) {
+                    // integrator.rs:99-104: the forced minimum step is taken unconditionally
+                    // and its own size is handed back as the next h.
+                    const double hk = y.h;
+                    n.h = hk;
+                    n.tries = y.tries;
+                    n.flags = y.flags & ~kFlagForced;
+                    y = n;
+                    stepped = true;
+                } else if (ratio <= 1.0) {
+                    const double growth = (ratio < 1e-4) ? 5.0 : 0.9 * pow(ratio, -0.2);
+                    const double next_h = y.h * fmin(growth, 5.0);
+                    n.h = clamp_rs(next_h, -10.0, 10.0);
+                    n.tries = y.tries;
+                    y = n;
+                    stepped = true;
+                } else {
+                    const double shrink = 0.9 * pow(ratio, -0.25);
+                    double hn = y.h * fmax(shrink, 0.1);
+                    if (fabs(hn) < 1e-5) {
+                        hn = 1e-5 * signum_rs(hn);
+                        y.flags |= kFlagForced;
+                    }
+                    y.h = hn;
+                    stepped = false;
+                }
+            } else if constexpr (METHOD == GRV_METHOD_RK4) {
+                rk4_step<KIND, ARITH>(bh, y, P.step_size);
+                y.tries += 1;
+                stepped = true;
+            } else {
+                symplectic_step<KIND, ARITH>(bh, y, P.step_size);
+                y.tries += 1;
+                stepped = true;
+            }
+            if (stepped) {
+                after_step<KIND>(bh, y, r_prev, th_prev, P, ws, slot);
+                live = ray_live(y);
+            }
+        }
+    }
+
+    if (have) store_ray(ws, slot, y);
+
+    // wave-aggregated append of the survivors (ray compaction for the next launch)
+    if (live_out) {
+        const unsigned long long mask = __ballot(live);
+        if (mask != 0ull) {
+            const uint32_t lane = threadIdx.x & 63u;
+            const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(live_out_count, (uint32_t)__popcll(mask));
+            base = __shfl(base, (int)leader, 64);
+            if (live) {
+                const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                live_out[base + rank] = slot;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// init kernels
+// ---------------------------------------------------------------------------
+// batch: AoS GeodesicState [n][8] -> SoA workspace (geodesic/mod.rs:23-30 layout)
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void init_from_states_kernel(
+    RayWorkspace ws, SegmentParams P, const double *__restrict__ states, double h0, int adaptive) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= ws.n) return;
+    const double2 *src = reinterpret_cast<const double2 *>(states + (size_t)i * 8);
+    const double2 a = src[0], b = src[1], c = src[2], d = src[3];
+    RayRegs y;
+    y.t = a.x;
+    y.r = a.y;
+    y.th = b.x;
+    y.ph = b.y;
+    y.pt = c.x;
+    y.pr = c.y;
+    y.pth = d.x;
+    y.pph = d.y;
+    y.h = h0;
+    y.drift = 0.0;
+    y.steps = 0;
+    y.tries = 0;
+    y.flags = kFlagValid;
+    const Hole<double> bh{P.M, P.a, P.a2};
+    ray_begin<KIND>(bh, y, P, adaptive != 0);
+    store_ray(ws, i, y);
+    ws.pt[i] = y.pt;
+    ws.pph[i] = y.pph;
+}
+
+// slot -> pixel of this rank's tile set.  A slot block of 4096 is one 64x64 tile;
+// inside it every 64 consecutive slots (one wave) cover an 8x8 pixel block, the
+// launch shape of the reference's compute pass (compute.wgsl.ts:147).
+__device__ __forceinline__ bool slot_to_pixel(const FrameGeom &G, uint32_t slot, uint32_t &X,
+                                              uint32_t &Y, uint32_t &out_index) {
+    const uint32_t tile_local = slot >> 12;
+    const uint32_t within = slot & 4095u;
+    const uint32_t w = within >> 6, lane = within & 63u;
+    const uint32_t px = ((w & 7u) << 3) + (lane & 7u);
+    const uint32_t py = ((w >> 3) << 3) + (lane >> 3);
+    const uint32_t tile = tile_local * G.tile_world + G.tile_rank;
+    const uint32_t tx = tile % G.tiles_x, ty = tile / G.tiles_x;
+    X = tx * 64u + px;
+    Y = ty * 64u + py;
+    out_index = (G.tile_world <= 1u) ? (Y * G.width + X) : (tile_local * 4096u + py * 64u + px);
+    return tile_local < G.n_tiles_local && ty < G.tiles_y && X < G.width && Y < G.height;
+}
+
+__device__ __forceinline__ void mat4_mul(const double *m, double x, double y, double z, double w,
+                                         double out[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[r] = m[0 + r] * x + m[4 + r] * y + m[8 + r] * z + m[12 + r] * w;
+}
+
+// pixel -> Kerr-Schild initial state: src/shaders/compute.wgsl.ts:159-187 in f64
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void init_from_pixels_kernel(RayWorkspace ws, SegmentParams P,
+                                                                  FrameGeom G, CameraDev cam,
+                                                                  double h0, int adaptive) {
+    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+    if (slot >= ws.n) return;
+    uint32_t X, Y, oi;
+    const bool valid = slot_to_pixel(G, slot, X, Y, oi);
+    RayRegs y;
+    y.drift = 0.0;
+    y.steps = 0;
+    y.tries = 0;
+    y.h = h0;
+    if (!valid) {
+        y.t = y.r = y.th = y.ph = y.pr = y.pth = y.pt = y.pph = 0.0;
+        y.flags = 0;
+        store_ray(ws, slot, y);
+        ws.pt[slot] = 0.0;
+        ws.pph[slot] = 0.0;
+        return;
+    }
+    const double ux = ((double)X + cam.off[0]) / (double)G.width;
+    const double uy = ((double)Y + cam.off[1]) / (double)G.height;
+    const double ndc_x = ux * 2.0 - 1.0;
+    const double ndc_y = uy * 2.0 - 1.0;
+    double vt[4];
+    mat4_mul(cam.inv_proj, ndc_x, -ndc_y, 1.0, 1.0, vt);
+    double vx = vt[0] / vt[3], vy = vt[1] / vt[3], vz = vt[2] / vt[3];
+    double len = sqrt(vx * vx + vy * vy + vz * vz);
+    vx /= len;
+    vy /= len;
+    vz /= len;
+    double wd[4];
+    mat4_mul(cam.inv_view, vx, vy, vz, 0.0, wd);
+    len = sqrt(wd[0] * wd[0] + wd[1] * wd[1] + wd[2] * wd[2]);
+    const double wx = wd[0] / len, wy = wd[1] / len, wz = wd[2] / len;
+
+    const double r0 = sqrt(cam.pos[0] * cam.pos[0] + cam.pos[1] * cam.pos[1] + cam.pos[2] * cam.pos[2]);
+    double cy = cam.pos[1] / r0;
+    cy = cy < -1.0 ? -1.0 : (cy > 1.0 ? 1.0 : cy);
+    const double theta0 = acos(cy);
+    const double phi0 = atan2(cam.pos[2], cam.pos[0]);
+    double st, ct, sp, cp;
+    sincos(theta0, &st, &ct);
+    sincos(phi0, &sp, &cp);
+    const double pr_far = wx * (st * cp) + wy * ct + wz * (st * sp);
+    const double pth_far = (wx * (ct * cp) + wy * (-st) + wz * (ct * sp)) / r0;
+    const double safe_st = fmax(st, 1e-4);
+    const double pph_far = (wx * (-sp) + wy * 0.0 + wz * cp) / (r0 * safe_st);
+
+    y.t = 0.0;
+    y.r = r0;
+    y.th = theta0;
+    y.ph = phi0;
+    y.pt = -1.0;
+    y.pr = pr_far;
+    y.pth = pth_far * r0 * r0;
+    y.pph = pph_far * r0 * r0 * st * st;
+    y.flags = kFlagValid;
+    const Hole<double> bh{P.M, P.a, P.a2};
+    ray_begin<KIND>(bh, y, P, adaptive != 0);
+    store_ray(ws, slot, y);
+    ws.pt[slot] = y.pt;
+    ws.pph[slot] = y.pph;
+}
+
+// initial compaction: list the slots that are live after init
+__global__ __launch_bounds__(kBlock) void build_live_list_kernel(RayWorkspace ws,
+                                                                 uint32_t *__restrict__ live_out,
+                                                                 uint32_t *__restrict__ count) {
+    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+    bool live = false;
+    if (slot < ws.n) {
+        const uint32_t f = ws.flags[slot];
+        live = (f & (kFlagTermMask | kFlagValid)) == kFlagValid;
+    }
+    const unsigned long long mask = __ballot(live);
+    if (mask == 0ull) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(mask));
+    base = __shfl(base, (int)leader, 64);
+    if (live) live_out[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = slot;
+}
+
+} // namespace

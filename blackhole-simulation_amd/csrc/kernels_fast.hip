@@ -1,0 +1,42 @@
+// kernels_fast.hip -- FAST arithmetic contract: compiled with -ffp-contract=fast.
+// Instantiates the segment kernel with the shared-reciprocal Kerr-Schild
+// right-hand side (kerr_device.hpp: rhs_ks_fast) and FMA contraction.
+#include "geodesic_kernels.hpp"
+
+namespace grvhip {
+
+namespace {
+template <int KIND, int METHOD>
+hipError_t go(const RayWorkspace &ws, const SegmentParams &P, const uint32_t *live_in,
+              uint32_t n_live, uint32_t *live_out, uint32_t *live_out_count, hipStream_t s) {
+    const uint32_t grid = (n_live + kBlock - 1) / kBlock;
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL((integrate_segment_kernel<KIND, GRV_ARITH_FAST, METHOD>), dim3(grid),
+                       dim3(kBlock), 0, s, ws, P, live_in, n_live, live_out, live_out_count);
+    return hipGetLastError();
+}
+template <int KIND>
+hipError_t by_method(int method, const RayWorkspace &ws, const SegmentParams &P,
+                     const uint32_t *live_in, uint32_t n_live, uint32_t *live_out,
+                     uint32_t *live_out_count, hipStream_t s) {
+    switch (method) {
+    case GRV_METHOD_RKF45: return go<KIND, GRV_METHOD_RKF45>(ws, P, live_in, n_live, live_out, live_out_count, s);
+    case GRV_METHOD_RK4: return go<KIND, GRV_METHOD_RK4>(ws, P, live_in, n_live, live_out, live_out_count, s);
+    case GRV_METHOD_SYMPLECTIC: return go<KIND, GRV_METHOD_SYMPLECTIC>(ws, P, live_in, n_live, live_out, live_out_count, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+} // namespace
+
+hipError_t launch_segment_fast(int kind, int method, const RayWorkspace &ws,
+                               const SegmentParams &P, const uint32_t *live_in, uint32_t n_live,
+                               uint32_t *live_out, uint32_t *live_out_count, hipStream_t s) {
+    switch (kind) {
+    case GRV_METRIC_KERR_KS: return by_method<GRV_METRIC_KERR_KS>(method, ws, P, live_in, n_live, live_out, live_out_count, s);
+    case GRV_METRIC_KERR_BL: return by_method<GRV_METRIC_KERR_BL>(method, ws, P, live_in, n_live, live_out, live_out_count, s);
+    case GRV_METRIC_SCHWARZSCHILD: return by_method<GRV_METRIC_SCHWARZSCHILD>(method, ws, P, live_in, n_live, live_out, live_out_count, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+} // namespace grvhip

@@ -1,0 +1,132 @@
+// kernels_strict.hip -- STRICT arithmetic contract: compiled with
+// -ffp-contract=off (reference operation order, IEEE divide/sqrt, no FMA).
+// Also holds the kernels that exist once: init, live-list, finalize/shade, LUT.
+#include "frame_kernels.hpp"
+
+namespace grvhip {
+
+namespace {
+template <int KIND, int METHOD>
+hipError_t go(const RayWorkspace &ws, const SegmentParams &P, const uint32_t *live_in,
+              uint32_t n_live, uint32_t *live_out, uint32_t *live_out_count, hipStream_t s) {
+    const uint32_t grid = (n_live + kBlock - 1) / kBlock;
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL((integrate_segment_kernel<KIND, GRV_ARITH_STRICT, METHOD>), dim3(grid),
+                       dim3(kBlock), 0, s, ws, P, live_in, n_live, live_out, live_out_count);
+    return hipGetLastError();
+}
+template <int KIND>
+hipError_t by_method(int method, const RayWorkspace &ws, const SegmentParams &P,
+                     const uint32_t *live_in, uint32_t n_live, uint32_t *live_out,
+                     uint32_t *live_out_count, hipStream_t s) {
+    switch (method) {
+    case GRV_METHOD_RKF45: return go<KIND, GRV_METHOD_RKF45>(ws, P, live_in, n_live, live_out, live_out_count, s);
+    case GRV_METHOD_RK4: return go<KIND, GRV_METHOD_RK4>(ws, P, live_in, n_live, live_out, live_out_count, s);
+    case GRV_METHOD_SYMPLECTIC: return go<KIND, GRV_METHOD_SYMPLECTIC>(ws, P, live_in, n_live, live_out, live_out_count, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+} // namespace
+
+hipError_t launch_segment_strict(int kind, int method, const RayWorkspace &ws,
+                                 const SegmentParams &P, const uint32_t *live_in, uint32_t n_live,
+                                 uint32_t *live_out, uint32_t *live_out_count, hipStream_t s) {
+    switch (kind) {
+    case GRV_METRIC_KERR_KS: return by_method<GRV_METRIC_KERR_KS>(method, ws, P, live_in, n_live, live_out, live_out_count, s);
+    case GRV_METRIC_KERR_BL: return by_method<GRV_METRIC_KERR_BL>(method, ws, P, live_in, n_live, live_out, live_out_count, s);
+    case GRV_METRIC_SCHWARZSCHILD: return by_method<GRV_METRIC_SCHWARZSCHILD>(method, ws, P, live_in, n_live, live_out, live_out_count, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_init_states(int kind, const RayWorkspace &ws, const SegmentParams &P,
+                              const double *states, double h0, int adaptive, hipStream_t s) {
+    const uint32_t grid = (ws.n + kBlock - 1) / kBlock;
+    if (grid == 0) return hipSuccess;
+    switch (kind) {
+    case GRV_METRIC_KERR_KS:
+        hipLaunchKernelGGL((init_from_states_kernel<GRV_METRIC_KERR_KS>), dim3(grid), dim3(kBlock), 0, s, ws, P, states, h0, adaptive);
+        break;
+    case GRV_METRIC_KERR_BL:
+        hipLaunchKernelGGL((init_from_states_kernel<GRV_METRIC_KERR_BL>), dim3(grid), dim3(kBlock), 0, s, ws, P, states, h0, adaptive);
+        break;
+    case GRV_METRIC_SCHWARZSCHILD:
+        hipLaunchKernelGGL((init_from_states_kernel<GRV_METRIC_SCHWARZSCHILD>), dim3(grid), dim3(kBlock), 0, s, ws, P, states, h0, adaptive);
+        break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_init_pixels(int kind, const RayWorkspace &ws, const SegmentParams &P,
+                              const FrameGeom &G, const CameraDev &cam, double h0, int adaptive,
+                              hipStream_t s) {
+    const uint32_t grid = (ws.n + kBlock - 1) / kBlock;
+    if (grid == 0) return hipSuccess;
+    switch (kind) {
+    case GRV_METRIC_KERR_KS:
+        hipLaunchKernelGGL((init_from_pixels_kernel<GRV_METRIC_KERR_KS>), dim3(grid), dim3(kBlock), 0, s, ws, P, G, cam, h0, adaptive);
+        break;
+    case GRV_METRIC_KERR_BL:
+        hipLaunchKernelGGL((init_from_pixels_kernel<GRV_METRIC_KERR_BL>), dim3(grid), dim3(kBlock), 0, s, ws, P, G, cam, h0, adaptive);
+        break;
+    case GRV_METRIC_SCHWARZSCHILD:
+        hipLaunchKernelGGL((init_from_pixels_kernel<GRV_METRIC_SCHWARZSCHILD>), dim3(grid), dim3(kBlock), 0, s, ws, P, G, cam, h0, adaptive);
+        break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_build_live(const RayWorkspace &ws, uint32_t *live_out, uint32_t *count,
+                             hipStream_t s) {
+    const uint32_t grid = (ws.n + kBlock - 1) / kBlock;
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL(build_live_list_kernel, dim3(grid), dim3(kBlock), 0, s, ws, live_out, count);
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize_batch(const RayWorkspace &ws, double *out_states, uint32_t *out_steps,
+                                 uint8_t *out_term, double *out_drift, FrameStatsDev *st,
+                                 hipStream_t s) {
+    const uint32_t grid = (ws.n + kBlock - 1) / kBlock;
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL(finalize_batch_kernel, dim3(grid), dim3(kBlock), 0, s, ws, out_states,
+                       out_steps, out_term, out_drift, st);
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize_frame(const RayWorkspace &ws, const FrameGeom &G, const ShadeParams &S,
+                                 int shading, const float *lut, float *out_rgba,
+                                 double *out_states, uint32_t *out_steps, uint8_t *out_term,
+                                 double *out_drift, FrameStatsDev *st, int n_blocks,
+                                 hipStream_t s) {
+    if (ws.n == 0) return hipSuccess;
+    const size_t lds = (shading && lut) ? (size_t)S.lds_rows * S.lut_w * sizeof(float4) : 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(finalize_frame_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const uint32_t need = (ws.n + 1023u) / 1024u;
+    uint32_t grid = (uint32_t)n_blocks;
+    if (grid > need) grid = need;
+    if (grid == 0) grid = 1;
+    hipLaunchKernelGGL(finalize_frame_kernel, dim3(grid), dim3(1024), lds, s, ws, G, S, shading,
+                       reinterpret_cast<const float4 *>(lut), reinterpret_cast<float4 *>(out_rgba),
+                       out_states, out_steps, out_term, out_drift, st);
+    return hipGetLastError();
+}
+
+hipError_t launch_spectrum_lut(float *out, uint32_t width, uint32_t height, double max_temp,
+                               hipStream_t s) {
+    const uint32_t n = width * height;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(spectrum_lut_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
+                       reinterpret_cast<float4 *>(out), width, height, max_temp);
+    return hipGetLastError();
+}
+
+} // namespace grvhip

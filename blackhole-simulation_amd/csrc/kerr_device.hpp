@@ -1,0 +1,346 @@
+// kerr_device.hpp -- device-side Kerr / Schwarzschild Hamiltonian right-hand side
+// for gfx950.  Everything has internal linkage: this header is compiled twice,
+// once with -ffp-contract=off (STRICT translation unit) and once with
+// -ffp-contract=fast (FAST translation unit).
+//
+// Reference behaviour restated (paths under physics-engine/gravitas-core/src):
+//   get_state_derivative        geodesic/hamiltonian.rs:13-35
+//   Kerr::contravariant_ks      metric/kerr.rs:412-440
+//   Kerr::hamiltonian_derivs_ks metric/kerr.rs:442-499
+//   Kerr::contravariant_bl      metric/kerr.rs:266-293
+//   Kerr::hamiltonian_derivs_bl metric/kerr.rs:295-372
+//   Schwarzschild               metric/schwarzschild.rs:62-111
+//   hamiltonian                 invariants/mod.rs:25-37
+//   renormalize_null            invariants/renormalization.rs:13-45
+//
+// Only the six evolving components (t, r, theta, phi, p_r, p_theta) are carried:
+// dp_t/dl = dp_phi/dl = 0 exactly (hamiltonian.rs:33), so p_t and p_phi are
+// per-ray constants and every `p += 0 * s` of the reference is the identity.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/gravitas_abi.h"
+
+namespace {
+
+template <typename T> struct Hole {
+    T M;  // mass
+    T a;  // spin * mass
+    T a2; // a * a
+};
+
+template <typename T> struct Deriv {
+    T dt, dr, dth, dph, dpr, dpth;
+};
+
+// metric components shared by the Hamiltonian and the null renormalisation
+template <typename T> struct GInv {
+    T tt, tr, tph, rr, thth, phph, rph;
+};
+
+template <typename T> __device__ __forceinline__ T fmax_t(T a, T b);
+template <> __device__ __forceinline__ double fmax_t<double>(double a, double b) { return fmax(a, b); }
+template <> __device__ __forceinline__ float fmax_t<float>(float a, float b) { return fmaxf(a, b); }
+template <typename T> __device__ __forceinline__ T fabs_t(T a);
+template <> __device__ __forceinline__ double fabs_t<double>(double a) { return fabs(a); }
+template <> __device__ __forceinline__ float fabs_t<float>(float a) { return fabsf(a); }
+template <typename T> __device__ __forceinline__ T sqrt_t(T a);
+template <> __device__ __forceinline__ double sqrt_t<double>(double a) { return sqrt(a); }
+template <> __device__ __forceinline__ float sqrt_t<float>(float a) { return sqrtf(a); }
+template <typename T> __device__ __forceinline__ void sincos_t(T x, T *s, T *c);
+template <> __device__ __forceinline__ void sincos_t<double>(double x, double *s, double *c) { sincos(x, s, c); }
+template <> __device__ __forceinline__ void sincos_t<float>(float x, float *s, float *c) { sincosf(x, s, c); }
+
+// ---------------------------------------------------------------------------
+// Reference-order inverse metric.  KIND = GRV_METRIC_*.
+// ---------------------------------------------------------------------------
+template <int KIND, typename T>
+__device__ __forceinline__ GInv<T> contravariant_ref(const Hole<T> &bh, T r, T sin_theta,
+                                                     T cos_theta) {
+    GInv<T> g;
+    g.tr = T(0);
+    g.tph = T(0);
+    g.rph = T(0);
+    const T m = bh.M;
+    if constexpr (KIND == GRV_METRIC_KERR_KS) {
+        const T r2 = r * r;
+        const T sin2 = fmax_t(sin_theta * sin_theta, T(1e-12));
+        const T cos2 = T(1) - sin2;
+        const T sigma = r2 + bh.a2 * cos2;
+        const T delta = r2 - T(2) * m * r + bh.a2;
+        g.tt = -(T(1) + T(2) * m * r / sigma);
+        g.tr = T(2) * m * r / sigma;
+        g.rr = delta / sigma;
+        g.thth = T(1) / sigma;
+        g.phph = T(1) / (sigma * sin2);
+        g.rph = bh.a / sigma;
+    } else if constexpr (KIND == GRV_METRIC_KERR_BL) {
+        const T r2 = r * r;
+        const T sin2 = sin_theta * sin_theta;
+        const T cos2 = cos_theta * cos_theta;
+        const T sigma = r2 + bh.a2 * cos2;
+        const T delta = r2 - T(2) * m * r + bh.a2;
+        g.tt = -((sigma * (r2 + bh.a2) + T(2) * m * r * bh.a2 * sin2) / (delta * sigma));
+        g.rr = delta / sigma;
+        g.thth = T(1) / sigma;
+        g.phph = (sin2 < T(1e-9)) ? T(0) : (delta - bh.a2 * sin2) / (delta * sigma * sin2);
+        g.tph = -(T(2) * m * r * bh.a) / (delta * sigma);
+    } else {
+        const T rs = T(2) * m;
+        const T sin2 = fmax_t(sin_theta * sin_theta, T(1e-12));
+        g.tt = T(-1) / (T(1) - rs / r);
+        g.rr = T(1) - rs / r;
+        g.thth = T(1) / (r * r);
+        g.phph = T(1) / (r * r * sin2);
+    }
+    return g;
+}
+
+// ---------------------------------------------------------------------------
+// Reference-order right-hand side (used by the STRICT build for every metric
+// and by the FAST build for BL / Schwarzschild).
+// ---------------------------------------------------------------------------
+template <int KIND, typename T>
+__device__ __forceinline__ Deriv<T> rhs_ref(const Hole<T> &bh, T r, T theta, T p_t, T p_r,
+                                            T p_th, T p_ph) {
+    T sin_theta, cos_theta;
+    sincos_t(theta, &sin_theta, &cos_theta);
+    const GInv<T> g = contravariant_ref<KIND>(bh, r, sin_theta, cos_theta);
+    Deriv<T> d;
+    const T m = bh.M;
+    const T a = bh.a;
+    const T a2 = bh.a2;
+
+    if constexpr (KIND == GRV_METRIC_KERR_KS) {
+        d.dt = g.tt * p_t + g.tr * p_r;
+        d.dr = g.tr * p_t + g.rr * p_r + g.rph * p_ph;
+        d.dth = g.thth * p_th;
+        d.dph = g.rph * p_r + g.phph * p_ph;
+
+        const T r2 = r * r;
+        const T sin2 = fmax_t(sin_theta * sin_theta, T(1e-12));
+        const T cos2 = T(1) - sin2;
+        const T sigma = r2 + a2 * cos2;
+        const T sigma2 = sigma * sigma;
+        const T delta = r2 - T(2) * m * r + a2;
+
+        const T dsigma_dr = T(2) * r;
+        const T dsigma_dtheta = T(-2) * a2 * sin_theta * cos_theta;
+        const T ddelta_dr = T(2) * r - T(2) * m;
+
+        const T dg_tt_dr = -(T(2) * m * (sigma - r * dsigma_dr)) / sigma2;
+        const T dg_tt_dtheta = (T(2) * m * r * dsigma_dtheta) / sigma2;
+        const T dg_tr_dr = -dg_tt_dr;
+        const T dg_tr_dtheta = -dg_tt_dtheta;
+        const T dg_rr_dr = (ddelta_dr * sigma - delta * dsigma_dr) / sigma2;
+        const T dg_rr_dtheta = -(delta * dsigma_dtheta) / sigma2;
+        const T dg_thth_dr = -dsigma_dr / sigma2;
+        const T dg_thth_dtheta = -dsigma_dtheta / sigma2;
+        const T dg_phph_dr = -dsigma_dr / (sigma2 * sin2);
+        const T dg_phph_dtheta =
+            -(dsigma_dtheta * sin2 + sigma * T(2) * sin_theta * cos_theta) / (sigma2 * sin2 * sin2);
+        const T dg_rph_dr = -(a * dsigma_dr) / sigma2;
+        const T dg_rph_dtheta = -(a * dsigma_dtheta) / sigma2;
+
+        const T dh_dr = T(0.5) * (dg_tt_dr * p_t * p_t + dg_rr_dr * p_r * p_r +
+                                  dg_thth_dr * p_th * p_th + dg_phph_dr * p_ph * p_ph +
+                                  T(2) * dg_tr_dr * p_t * p_r + T(2) * dg_rph_dr * p_r * p_ph);
+        T dh_dtheta = T(0.5) * (dg_tt_dtheta * p_t * p_t + dg_rr_dtheta * p_r * p_r +
+                                dg_thth_dtheta * p_th * p_th + dg_phph_dtheta * p_ph * p_ph +
+                                T(2) * dg_tr_dtheta * p_t * p_r + T(2) * dg_rph_dtheta * p_r * p_ph);
+        if (fabs_t(sin_theta) < T(1e-10)) dh_dtheta = T(0);
+        d.dpr = -dh_dr;
+        d.dpth = -dh_dtheta;
+    } else if constexpr (KIND == GRV_METRIC_KERR_BL) {
+        d.dt = g.tt * p_t + g.tph * p_ph;
+        d.dr = g.rr * p_r;
+        d.dth = g.thth * p_th;
+        d.dph = g.tph * p_t + g.phph * p_ph;
+
+        const T r2 = r * r;
+        const T sin2 = sin_theta * sin_theta;
+        const T cos2 = cos_theta * cos_theta;
+        const T sigma = r2 + a2 * cos2;
+        const T delta = r2 - T(2) * m * r + a2;
+        const T sigma_sq = sigma * sigma;
+
+        const T dsigma_dr = T(2) * r;
+        const T dsigma_dtheta = T(-2) * a2 * cos_theta * sin_theta;
+        const T ddelta_dr = T(2) * r - T(2) * m;
+
+        const T dg_rr_dr = (ddelta_dr * sigma - delta * dsigma_dr) / sigma_sq;
+        const T dg_rr_dtheta = -(delta * dsigma_dtheta) / sigma_sq;
+        const T dg_thth_dr = -dsigma_dr / sigma_sq;
+        const T dg_thth_dtheta = -dsigma_dtheta / sigma_sq;
+
+        const T num_tphi = T(-2) * m * r * a;
+        const T den_tphi = delta * sigma;
+        const T dnum_tphi_dr = T(-2) * m * a;
+        const T dden_tphi_dr = ddelta_dr * sigma + delta * dsigma_dr;
+        const T dg_tphi_dr =
+            (dnum_tphi_dr * den_tphi - num_tphi * dden_tphi_dr) / (den_tphi * den_tphi);
+        const T dden_tphi_dtheta = delta * dsigma_dtheta;
+        const T dg_tphi_dtheta = -(num_tphi * dden_tphi_dtheta) / (den_tphi * den_tphi);
+
+        const T du_dr = dsigma_dr * (r2 + a2) + sigma * T(2) * r + T(2) * m * a2 * sin2;
+        const T dv_dr = dden_tphi_dr;
+        const T u_val = sigma * (r2 + a2) + T(2) * m * r * a2 * sin2;
+        const T dg_tt_dr = -(du_dr * den_tphi - u_val * dv_dr) / (den_tphi * den_tphi);
+
+        const T du_dtheta =
+            dsigma_dtheta * (r2 + a2) + T(2) * m * r * a2 * T(2) * sin_theta * cos_theta;
+        const T dv_dtheta = dden_tphi_dtheta;
+        const T dg_tt_dtheta = -(du_dtheta * den_tphi - u_val * dv_dtheta) / (den_tphi * den_tphi);
+
+        const T da_dr = -dsigma_dr / (sigma_sq * sin2);
+        const T db_dr = -a2 * dden_tphi_dr / (den_tphi * den_tphi);
+        const T dg_phph_dr = da_dr - db_dr;
+
+        const T d_denom_a_dtheta = dsigma_dtheta * sin2 + sigma * T(2) * sin_theta * cos_theta;
+        const T da_dtheta = -d_denom_a_dtheta / (sigma_sq * sin2 * sin2);
+        const T db_dtheta = -a2 * dden_tphi_dtheta / (den_tphi * den_tphi);
+        const T dg_phph_dtheta = da_dtheta - db_dtheta;
+
+        const T dh_dr =
+            T(0.5) * (p_t * p_t * dg_tt_dr + p_r * p_r * dg_rr_dr + p_th * p_th * dg_thth_dr +
+                      p_ph * p_ph * dg_phph_dr + T(2) * p_t * p_ph * dg_tphi_dr);
+        const T dh_dtheta = T(0.5) * (p_t * p_t * dg_tt_dtheta + p_r * p_r * dg_rr_dtheta +
+                                      p_th * p_th * dg_thth_dtheta + p_ph * p_ph * dg_phph_dtheta +
+                                      T(2) * p_t * p_ph * dg_tphi_dtheta);
+        d.dpr = -dh_dr;
+        d.dpth = -dh_dtheta;
+    } else {
+        d.dt = g.tt * p_t;
+        d.dr = g.rr * p_r;
+        d.dth = g.thth * p_th;
+        d.dph = g.phph * p_ph;
+
+        const T r2 = r * r;
+        const T r3 = r2 * r;
+        const T sin2 = sin_theta * sin_theta;
+        const T f = T(1) - T(2) * m / r;
+        const T dg_tt_dr = T(-2) * m / (r2 * f * f);
+        const T dg_rr_dr = T(2) * m / r2;
+        const T dg_thth_dr = T(-2) / r3;
+        const T dg_phph_dr = (sin2 < T(1e-12)) ? T(0) : T(-2) / (r3 * sin2);
+        const T dg_phph_dtheta =
+            (sin2 < T(1e-12)) ? T(0) : T(-2) * cos_theta / (r2 * sin_theta * sin2);
+        const T dh_dr = T(0.5) * (dg_tt_dr * p_t * p_t + dg_rr_dr * p_r * p_r +
+                                  dg_thth_dr * p_th * p_th + dg_phph_dr * p_ph * p_ph);
+        const T dh_dtheta = T(0.5) * dg_phph_dtheta * p_ph * p_ph;
+        d.dpr = -dh_dr;
+        d.dpth = -dh_dtheta;
+    }
+    return d;
+}
+
+// ---------------------------------------------------------------------------
+// FAST Kerr-Schild right-hand side: the same Hamilton equations with one
+// shared reciprocal 1/(Sigma sin^2) and everything factored over 1/Sigma^2.
+// Algebraically identical to rhs_ref<KS>; differs by rounding only.
+// ~55 flops + sincos + 1 reciprocal instead of 16 IEEE divides.
+// ---------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ Deriv<T> rhs_ks_fast(const Hole<T> &bh, T r, T theta, T p_t, T p_r,
+                                                T p_th, T p_ph) {
+    T s, c;
+    sincos_t(theta, &s, &c);
+    const T m = bh.M, a = bh.a, a2 = bh.a2;
+    const T r2 = r * r;
+    const T sin2 = fmax_t(s * s, T(1e-12));
+    const T cos2 = T(1) - sin2;
+    const T sigma = r2 + a2 * cos2;
+    const T delta = r2 - T(2) * m * r + a2;
+    const T inv_ss = T(1) / (sigma * sin2); // the only reciprocal
+    const T isig = inv_ss * sin2;           // 1/Sigma
+    const T isin2 = inv_ss * sigma;         // 1/sin^2
+    const T isig2 = isig * isig;
+
+    const T two_mr_isig = T(2) * m * r * isig;
+    const T g_rph = a * isig;
+    Deriv<T> d;
+    d.dt = two_mr_isig * (p_r - p_t) - p_t;                    // g^tt p_t + g^tr p_r
+    d.dr = two_mr_isig * p_t + (delta * p_r + a * p_ph) * isig; // g^tr p_t + g^rr p_r + g^rph p_ph
+    d.dth = isig * p_th;
+    d.dph = g_rph * p_r + inv_ss * p_ph;
+
+    const T two_r = T(2) * r;
+    const T sc = s * c;
+    const T dsig_dth = T(-2) * a2 * sc;
+    const T pt_mix = p_t * (p_t - T(2) * p_r); // p_t^2 - 2 p_t p_r
+    const T pph2_isin2 = p_ph * p_ph * isin2;
+    const T pr2 = p_r * p_r;
+    const T pth2 = p_th * p_th;
+    const T apr_pph2 = T(2) * a * p_r * p_ph;
+
+    // dH/dr * 2 Sigma^2
+    const T ar = T(-2) * m * (sigma - two_r * r) * pt_mix +
+                 ((two_r - T(2) * m) * sigma - delta * two_r) * pr2 -
+                 two_r * (pth2 + pph2_isin2 + apr_pph2);
+    // dH/dtheta * 2 Sigma^2
+    const T ath = dsig_dth * (T(2) * m * r * pt_mix - delta * pr2 - pth2 - apr_pph2 - pph2_isin2) -
+                  T(2) * sigma * sc * pph2_isin2 * isin2;
+    const T half_isig2 = T(0.5) * isig2;
+    d.dpr = -(half_isig2 * ar);
+    T dpth = -(half_isig2 * ath);
+    if (fabs_t(s) < T(1e-10)) dpth = T(0);
+    d.dpth = dpth;
+    return d;
+}
+
+template <int KIND, int ARITH, typename T>
+__device__ __forceinline__ Deriv<T> rhs(const Hole<T> &bh, T r, T theta, T p_t, T p_r, T p_th,
+                                        T p_ph) {
+    if constexpr (ARITH == GRV_ARITH_FAST && KIND == GRV_METRIC_KERR_KS)
+        return rhs_ks_fast<T>(bh, r, theta, p_t, p_r, p_th, p_ph);
+    else
+        return rhs_ref<KIND, T>(bh, r, theta, p_t, p_r, p_th, p_ph);
+}
+
+// ---------------------------------------------------------------------------
+// hamiltonian (invariants/mod.rs:25-37) and renormalize_null
+// (invariants/renormalization.rs:13-45) from one metric evaluation.
+// `do_renorm` first projects p_r, then H is evaluated on the projected state,
+// exactly as geodesic/mod.rs:229-237 does with two contravariant() calls.
+// ---------------------------------------------------------------------------
+template <int KIND, typename T>
+__device__ __forceinline__ T hamiltonian_of(const GInv<T> &g, T p_t, T p_r, T p_th, T p_ph) {
+    T h = g.tt * p_t * p_t + g.rr * p_r * p_r + g.thth * p_th * p_th + g.phph * p_ph * p_ph;
+    if constexpr (KIND == GRV_METRIC_KERR_BL) h = h + T(2) * g.tph * p_t * p_ph;
+    if constexpr (KIND == GRV_METRIC_KERR_KS) {
+        h = h + T(2) * g.tr * p_t * p_r;
+        h = h + T(2) * g.rph * p_r * p_ph;
+    }
+    return T(0.5) * h;
+}
+
+template <int KIND, typename T>
+__device__ __forceinline__ T renormalized_pr(const GInv<T> &g, T p_t, T p_r, T p_th, T p_ph) {
+    const T a_quad = g.rr;
+    T b_quad = T(0);
+    if constexpr (KIND == GRV_METRIC_KERR_KS) b_quad = T(2) * (g.tr * p_t + g.rph * p_ph);
+    T c_quad = g.tt * p_t * p_t + g.thth * p_th * p_th + g.phph * p_ph * p_ph;
+    if constexpr (KIND == GRV_METRIC_KERR_BL) c_quad = c_quad + T(2) * g.tph * p_t * p_ph;
+    T out = p_r;
+    if (fabs_t(a_quad) > T(1e-12)) {
+        const T disc = b_quad * b_quad - T(4) * a_quad * c_quad;
+        if (disc >= T(0)) {
+            const T sq = sqrt_t(disc);
+            const T sol1 = (-b_quad + sq) / (T(2) * a_quad);
+            const T sol2 = (-b_quad - sq) / (T(2) * a_quad);
+            out = (fabs_t(sol1 - p_r) < fabs_t(sol2 - p_r)) ? sol1 : sol2;
+        }
+    }
+    return out;
+}
+
+// metric at (r, theta) for the post-step bookkeeping
+template <int KIND, typename T>
+__device__ __forceinline__ GInv<T> contravariant_at(const Hole<T> &bh, T r, T theta) {
+    T s, c;
+    sincos_t(theta, &s, &c);
+    return contravariant_ref<KIND, T>(bh, r, s, c);
+}
+
+} // namespace

@@ -1,0 +1,321 @@
+"""ctypes host binding of libgravitas_hip.so.
+
+`PhysicsEngine` keeps the method names, argument meaning and error behaviour of
+the reference's wasm-bindgen class (physics-engine/gravitas-wasm/src/lib.rs:56-465;
+TS consumers src/engine/physics-bridge.ts, src/workers/physics.worker.ts), plus the
+batch / frame extensions of include/gravitas_abi.h.  PyTorch is optional plumbing:
+device-pointer entry points accept any object exposing ``data_ptr()``.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libgravitas_hip.so")
+
+KERR_BL, KERR_KS, SCHWARZSCHILD = 0, 1, 2
+METHOD_RKF45, METHOD_RK4, METHOD_SYMPLECTIC = 0, 1, 2
+ARITH_STRICT, ARITH_FAST = 0, 1
+TERM_NONE, TERM_HORIZON, TERM_ESCAPE, TERM_MAXSTEPS, TERM_DISK_CROSSING = 0, 1, 2, 3, 4
+_STATUS = {0: "GRV_OK", 1: "GRV_ERR_INVALID", 2: "GRV_ERR_NO_DEVICE", 3: "GRV_ERR_HIP",
+           4: "GRV_ERR_OOM"}
+
+
+class GravitasError(RuntimeError):
+    pass
+
+
+class Options(C.Structure):
+    _fields_ = [("method", C.c_int32), ("metric_kind", C.c_int32), ("tolerance", C.c_double),
+                ("initial_step", C.c_double), ("max_steps", C.c_uint64),
+                ("escape_radius", C.c_double), ("renormalize_interval", C.c_uint64),
+                ("step_size", C.c_double), ("arith", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("position", C.c_double * 3), ("inv_view", C.c_double * 16),
+                ("inv_proj", C.c_double * 16), ("pixel_offset", C.c_double * 2)]
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("opt", Options),
+                ("shading", C.c_int32), ("precision", C.c_int32), ("disk_inner", C.c_double),
+                ("disk_outer", C.c_double), ("disk_temp", C.c_double),
+                ("disk_opacity", C.c_double), ("exposure", C.c_double),
+                ("lut_width", C.c_uint32), ("lut_height", C.c_uint32),
+                ("lut_max_temp", C.c_double), ("tile_world", C.c_uint32),
+                ("tile_rank", C.c_uint32), ("segment_tries", C.c_uint32),
+                ("profile", C.c_uint32)]
+
+
+class FrameStats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("accepted_steps", C.c_uint64), ("rkf_tries", C.c_uint64),
+                ("term_count", C.c_uint64 * 5), ("crossings", C.c_uint64),
+                ("max_drift", C.c_double), ("launches", C.c_uint32), ("init_ms", C.c_float),
+                ("integrate_ms", C.c_float), ("compact_ms", C.c_float), ("shade_ms", C.c_float),
+                ("total_ms", C.c_float)]
+
+
+class FrameBuffers(C.Structure):
+    _fields_ = [("rgba", C.c_void_p), ("final_state", C.c_void_p), ("steps", C.c_void_p),
+                ("termination", C.c_void_p), ("drift", C.c_void_p)]
+
+
+def library_path():
+    return _LIB
+
+
+def build_library(force=False):
+    """Compile libgravitas_hip.so for gfx950 with the in-tree Makefile (hipcc)."""
+    csrc = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-C", csrc, "-s", "clean"])
+    subprocess.check_call(["make", "-C", csrc, "-s", "-j4"])
+    return _LIB
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the engine.  Raises if the HIP library has not been built: this
+    package has no other compute path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB):
+        raise GravitasError(
+            "libgravitas_hip.so is missing (%s): run __graft_entry__.build() / make -C "
+            "blackhole-simulation_amd/csrc; there is no CPU fallback" % _LIB)
+    L = C.CDLL(_LIB)
+    d, i, p, sz = C.c_double, C.c_int, C.c_void_p, C.c_size_t
+    L.grv_abi_version.restype = i
+    L.grv_engine_create.restype = i
+    L.grv_engine_create.argtypes = [d, d, i, C.POINTER(p)]
+    L.grv_engine_destroy.argtypes = [p]
+    L.grv_last_error.restype = C.c_char_p
+    L.grv_last_error.argtypes = [p]
+    L.grv_update_params.restype = i
+    L.grv_update_params.argtypes = [p, d, d]
+    for name in ("grv_compute_horizon", "grv_compute_isco", "grv_compute_photon_sphere"):
+        getattr(L, name).restype = d
+        getattr(L, name).argtypes = [p]
+    L.grv_compute_dilation.restype = d
+    L.grv_compute_dilation.argtypes = [p, d]
+    L.grv_compute_g_factor.restype = d
+    L.grv_compute_g_factor.argtypes = [p, d, d]
+    L.grv_integrate_ray_relativistic.restype = sz
+    L.grv_integrate_ray_relativistic.argtypes = [p, p, sz, sz, d, i, p]
+    L.grv_integrate_batch.restype = i
+    L.grv_integrate_batch.argtypes = [p, sz, p, C.POINTER(Options), p, p, p, p]
+    L.grv_integrate_batch_device.restype = i
+    L.grv_integrate_batch_device.argtypes = [p, sz, p, C.POINTER(Options), p, p, p, p, p]
+    L.grv_frame_ray_count.restype = sz
+    L.grv_frame_ray_count.argtypes = [C.POINTER(RenderParams)]
+    L.grv_render_frame.restype = i
+    L.grv_render_frame.argtypes = [p, C.POINTER(Camera), C.POINTER(RenderParams), p,
+                                   C.POINTER(FrameStats)]
+    L.grv_render_frame_device.restype = i
+    L.grv_render_frame_device.argtypes = [p, C.POINTER(Camera), C.POINTER(RenderParams),
+                                          C.POINTER(FrameBuffers), p]
+    L.grv_frame_stats.restype = i
+    L.grv_frame_stats.argtypes = [p, p, C.POINTER(FrameStats)]
+    L.grv_unpack_tiles.restype = i
+    L.grv_unpack_tiles.argtypes = [C.POINTER(RenderParams), C.c_uint32, p, p, sz]
+    L.grv_camera_look_at.argtypes = [p, p, p, d, d, C.POINTER(Camera)]
+    L.grv_camera_from_uniforms.argtypes = [p, C.POINTER(Camera)]
+    L.grv_render_params_default.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(RenderParams)]
+    L.grv_options_default.argtypes = [C.POINTER(Options)]
+    L.grv_generate_spectrum_lut.restype = i
+    L.grv_generate_spectrum_lut.argtypes = [p, sz, sz, d, p]
+    L.grv_generate_spectrum_lut_device.restype = i
+    L.grv_generate_spectrum_lut_device.argtypes = [p, sz, sz, d, p, p]
+    L.grv_get_sab_ptr.restype = p
+    L.grv_get_sab_ptr.argtypes = [p]
+    L.grv_get_sab_layout.argtypes = [p]
+    _lib = L
+    return L
+
+
+def _np_ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _dev_ptr(t):
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return C.c_void_p(t)
+    return C.c_void_p(t.data_ptr())
+
+
+def default_options(**kw):
+    o = Options()
+    load_library().grv_options_default(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def camera_look_at(eye, target=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), fovy_deg=60.0,
+                   aspect=16.0 / 9.0, pixel_offset=(0.5, 0.5)):
+    cam = Camera()
+    e = np.asarray(eye, np.float64)
+    t = np.asarray(target, np.float64)
+    u = np.asarray(up, np.float64)
+    load_library().grv_camera_look_at(_np_ptr(e), _np_ptr(t), _np_ptr(u),
+                                      float(np.deg2rad(fovy_deg)), float(aspect), C.byref(cam))
+    cam.pixel_offset[0], cam.pixel_offset[1] = pixel_offset
+    return cam
+
+
+def render_params(width, height, **kw):
+    p = RenderParams()
+    load_library().grv_render_params_default(width, height, C.byref(p))
+    for k, v in kw.items():
+        if hasattr(p.opt, k) and not hasattr(p, k):
+            setattr(p.opt, k, v)
+        else:
+            setattr(p, k, v)
+    return p
+
+
+def unpack_tiles(params, rank, packed, channels, dtype):
+    """Host scatter of one rank's packed tile-order pixels into a row-major image."""
+    packed = np.ascontiguousarray(packed)
+    img = np.zeros((params.height, params.width, channels), dtype)
+    rc = load_library().grv_unpack_tiles(C.byref(params), rank, _np_ptr(packed), _np_ptr(img),
+                                         channels * np.dtype(dtype).itemsize)
+    if rc != 0:
+        raise GravitasError("grv_unpack_tiles: %s" % _STATUS.get(rc, rc))
+    return img
+
+
+class PhysicsEngine:
+    """`new PhysicsEngine(mass, spin)` (gravitas-wasm/src/lib.rs:59)."""
+
+    def __init__(self, mass, spin, device=0):
+        self._lib = load_library()
+        h = C.c_void_p()
+        rc = self._lib.grv_engine_create(float(mass), float(spin), int(device), C.byref(h))
+        if rc != 0:
+            raise GravitasError("grv_engine_create failed: %s (no usable HIP device? this engine "
+                                "has no CPU path)" % _STATUS.get(rc, rc))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.grv_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self._lib.grv_last_error(self._h)
+            raise GravitasError("%s: %s: %s" % (what, _STATUS.get(rc, rc),
+                                                msg.decode() if msg else ""))
+
+    # ---- lib.rs:78-105, 202-205 ----
+    def update_params(self, mass, spin):
+        self._check(self._lib.grv_update_params(self._h, float(mass), float(spin)), "update_params")
+
+    def compute_horizon(self):
+        return self._lib.grv_compute_horizon(self._h)
+
+    def compute_isco(self):
+        return self._lib.grv_compute_isco(self._h)
+
+    def compute_photon_sphere(self):
+        return self._lib.grv_compute_photon_sphere(self._h)
+
+    def compute_dilation(self, r):
+        return self._lib.grv_compute_dilation(self._h, float(r))
+
+    def compute_g_factor(self, r, lam):
+        return self._lib.grv_compute_g_factor(self._h, float(r), float(lam))
+
+    # ---- lib.rs:422-464 ----
+    def integrate_ray_relativistic(self, initial_state, steps, tolerance, use_kerr_schild):
+        a = np.ascontiguousarray(initial_state, dtype=np.float64)
+        out = np.zeros(max(8, a.size), np.float64)
+        n = self._lib.grv_integrate_ray_relativistic(self._h, _np_ptr(a), a.size, int(steps),
+                                                     float(tolerance), 1 if use_kerr_schild else 0,
+                                                     _np_ptr(out))
+        return out[:n].copy()
+
+    integratePhotonGeodesic = integrate_ray_relativistic  # BASELINE.json's name for the same export
+
+    # ---- batch extension ----
+    def integrate_batch(self, states, options):
+        a = np.ascontiguousarray(states, dtype=np.float64).reshape(-1, 8)
+        n = a.shape[0]
+        out = np.zeros_like(a)
+        steps = np.zeros(n, np.uint32)
+        term = np.zeros(n, np.uint8)
+        drift = np.zeros(n, np.float64)
+        self._check(self._lib.grv_integrate_batch(self._h, n, _np_ptr(a), C.byref(options),
+                                                  _np_ptr(out), _np_ptr(steps), _np_ptr(term),
+                                                  _np_ptr(drift)), "integrate_batch")
+        return dict(states=out, steps=steps, term=term, drift=drift)
+
+    def integrate_batch_device(self, n, d_states, options, d_out, d_steps=None, d_term=None,
+                               d_drift=None, stream=None):
+        self._check(self._lib.grv_integrate_batch_device(
+            self._h, int(n), _dev_ptr(d_states), C.byref(options), _dev_ptr(d_out),
+            _dev_ptr(d_steps), _dev_ptr(d_term), _dev_ptr(d_drift),
+            C.c_void_p(stream) if stream else None), "integrate_batch_device")
+
+    # ---- frame ----
+    def frame_ray_count(self, params):
+        return self._lib.grv_frame_ray_count(C.byref(params))
+
+    def render_frame(self, camera, params):
+        """Host-buffer frame: returns (rgba[n,4] float32 in this rank's pixel order, FrameStats)."""
+        n = self.frame_ray_count(params)
+        rgba = np.zeros((n, 4), np.float32)
+        st = FrameStats()
+        self._check(self._lib.grv_render_frame(self._h, C.byref(camera), C.byref(params),
+                                               _np_ptr(rgba), C.byref(st)), "render_frame")
+        return rgba, st
+
+    renderFrame = render_frame
+
+    def render_frame_device(self, camera, params, rgba=None, final_state=None, steps=None,
+                            termination=None, drift=None, stream=None):
+        fb = FrameBuffers(_dev_ptr(rgba), _dev_ptr(final_state), _dev_ptr(steps),
+                          _dev_ptr(termination), _dev_ptr(drift))
+        self._check(self._lib.grv_render_frame_device(
+            self._h, C.byref(camera), C.byref(params), C.byref(fb),
+            C.c_void_p(stream) if stream else None), "render_frame_device")
+
+    def frame_stats(self, stream=None):
+        st = FrameStats()
+        self._check(self._lib.grv_frame_stats(self._h, C.c_void_p(stream) if stream else None,
+                                              C.byref(st)), "frame_stats")
+        return st
+
+    # ---- lib.rs:128-136 ----
+    def generate_spectrum_lut(self, width, height, max_temp):
+        out = np.zeros(width * height * 4, np.float32)
+        self._check(self._lib.grv_generate_spectrum_lut(self._h, width, height, float(max_temp),
+                                                        _np_ptr(out)), "generate_spectrum_lut")
+        return out
+
+    # ---- lib.rs:411-419 ----
+    def get_sab_layout(self):
+        a = (C.c_size_t * 5)()
+        self._lib.grv_get_sab_layout(a)
+        return list(a)

@@ -1,0 +1,190 @@
+/*
+ * gravitas_abi.h -- C ABI of the MI355X geodesic engine (libgravitas_hip.so).
+ *
+ * Drop-in boundary for the reference's physics FFI:
+ *   physics-engine/gravitas-wasm/src/lib.rs:56-465  (#[wasm_bindgen] impl PhysicsEngine)
+ * Every entry point names the reference interface it replaces.  Plain C types
+ * only: opaque handle, int status codes, caller-allocated outputs, no
+ * exceptions across the boundary.  A handle is not thread-safe; distinct
+ * handles are independent (same contract as one PhysicsEngine per JS realm,
+ * src/workers/physics.worker.ts:35-105).
+ *
+ * All compute entry points run on the GPU.  There is no CPU fallback: without
+ * a usable HIP device grv_engine_create fails with GRV_ERR_NO_DEVICE.
+ */
+#ifndef GRAVITAS_ABI_H
+#define GRAVITAS_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GRV_ABI_VERSION 1
+
+typedef struct grv_engine grv_engine;
+
+/* status codes */
+enum {
+    GRV_OK = 0,
+    GRV_ERR_INVALID = 1,   /* bad argument */
+    GRV_ERR_NO_DEVICE = 2, /* no HIP device / device index out of range */
+    GRV_ERR_HIP = 3,       /* HIP runtime error, see grv_last_error */
+    GRV_ERR_OOM = 4
+};
+
+/* gravitas-core/src/geodesic/termination.rs:4-17 (#[repr(C)] TerminationReason) */
+enum {
+    GRV_TERM_NONE = 0,
+    GRV_TERM_HORIZON = 1,
+    GRV_TERM_ESCAPE = 2,
+    GRV_TERM_MAXSTEPS = 3,
+    GRV_TERM_DISK_CROSSING = 4
+};
+
+/* gravitas-core/src/metric/kerr.rs:17-22 CoordinateSystem + metric/schwarzschild.rs */
+enum { GRV_METRIC_KERR_BL = 0, GRV_METRIC_KERR_KS = 1, GRV_METRIC_SCHWARZSCHILD = 2 };
+
+/* gravitas-core/src/geodesic/integrator.rs:13-21 IntegrationMethod */
+enum { GRV_METHOD_RKF45 = 0, GRV_METHOD_RK4 = 1, GRV_METHOD_SYMPLECTIC = 2 };
+
+/* arithmetic contract of the RKF45 kernel:
+ *  STRICT: reference operation order, IEEE divide/sqrt, no FMA contraction;
+ *  FAST  : algebraically identical right-hand side with shared reciprocals and
+ *          FMA contraction (differs from STRICT by rounding only). */
+enum { GRV_ARITH_STRICT = 0, GRV_ARITH_FAST = 1 };
+
+/* gravitas-core/src/geodesic/integrator.rs:24-33 IntegrationOptions
+ * (+ step_size carried by IntegrationMethod::{RK4,Symplectic}) */
+typedef struct {
+    int32_t method;
+    int32_t metric_kind;
+    double tolerance;
+    double initial_step;
+    uint64_t max_steps;
+    double escape_radius;
+    uint64_t renormalize_interval; /* 0 = never (Rust would panic) */
+    double step_size;
+    int32_t arith;                 /* GRV_ARITH_* */
+    int32_t reserved;
+} GrvOptions;
+
+/* f64 mirror of the CameraUniforms fields the compute kernel reads
+ * (src/shaders/types.wgsl.ts:6-17; src/types/webgpu.ts:95-116).  Matrices are
+ * column-major (gl-matrix / WGSL). */
+typedef struct {
+    double position[3];
+    double inv_view[16];
+    double inv_proj[16];
+    double pixel_offset[2]; /* uv = (id + offset)/size; (0.5,0.5) = pixel centres;
+                               WGSL frame-0 Halton jitter = (0, -1/6) */
+} GrvCamera;
+
+typedef struct {
+    uint32_t width, height;
+    GrvOptions opt;
+    int32_t shading;      /* 0 endpoints only, 1 thin-disk (T x g) LUT shading */
+    int32_t precision;    /* 0 = f64 state, 1 = f32 state (fixed-step kernels only) */
+    double disk_inner;    /* <= 0: prograde ISCO */
+    double disk_outer;    /* src/shaders/compute.wgsl.ts:217 -> 30 M */
+    double disk_temp;     /* K */
+    double disk_opacity;  /* alpha per plane crossing */
+    double exposure;
+    uint32_t lut_width, lut_height;
+    double lut_max_temp;
+    /* image-plane partition for multi-GPU: this call renders the 64x64-pixel
+     * tiles k with k % tile_world == tile_rank, packed in tile order
+     * (physics-engine/_legacy_src/tiling.rs:38-56 row-major grid). 1/0 = whole frame. */
+    uint32_t tile_world, tile_rank;
+    uint32_t segment_tries; /* RKF45 tries per launch before live-ray compaction; 0 = engine default */
+    uint32_t profile;       /* 1: bracket each kernel with HIP events (GrvFrameStats.*_ms) */
+} GrvRenderParams;
+
+typedef struct {
+    uint64_t rays;
+    uint64_t accepted_steps;
+    uint64_t rkf_tries;
+    uint64_t term_count[5];
+    uint64_t crossings;
+    double max_drift;
+    uint32_t launches;      /* integrate-kernel launches (segments) */
+    float init_ms, integrate_ms, compact_ms, shade_ms, total_ms; /* HIP-event times, profile=1 */
+} GrvFrameStats;
+
+/* Device-resident outputs of one frame (all optional except none: pass NULL to skip).
+ * Pixel order: row-major over the rendered tile set (whole frame when tile_world<=1). */
+typedef struct {
+    float *rgba;           /* [n][4] */
+    double *final_state;   /* [n][8] AoS GeodesicState (geodesic/mod.rs:23-30) */
+    uint32_t *steps;       /* [n] accepted steps */
+    uint8_t *termination;  /* [n] */
+    double *drift;         /* [n] max |H| */
+} GrvFrameBuffers;
+
+/* ---- lifecycle: `new PhysicsEngine(mass, spin)` lib.rs:59 ; update_params lib.rs:78 ---- */
+int grv_engine_create(double mass, double spin, int device, grv_engine **out);
+void grv_engine_destroy(grv_engine *e);
+const char *grv_last_error(const grv_engine *e);
+int grv_abi_version(void);
+int grv_update_params(grv_engine *e, double mass, double spin);
+
+/* ---- closed forms: lib.rs:85-105, 202-205 ---- */
+double grv_compute_horizon(const grv_engine *e);
+double grv_compute_isco(const grv_engine *e);
+double grv_compute_photon_sphere(const grv_engine *e);
+double grv_compute_dilation(const grv_engine *e, double r);
+double grv_compute_g_factor(const grv_engine *e, double r, double lambda);
+
+/* ---- the path entry: integrate_ray_relativistic lib.rs:422-464
+ * (== integratePhotonGeodesic in BASELINE.json).  n < 8 echoes the input
+ * (lib.rs:429-431).  Returns the number of doubles written to out. */
+size_t grv_integrate_ray_relativistic(grv_engine *e, const double *initial_state, size_t n,
+                                      size_t steps, double tolerance, int use_kerr_schild,
+                                      double *out);
+
+/* ---- batch extension: n independent integrate() calls (geodesic/mod.rs:180-253).
+ * Host pointers; states AoS [n][8].  steps/termination/drift may be NULL. */
+int grv_integrate_batch(grv_engine *e, size_t n, const double *states, const GrvOptions *opt,
+                        double *out_states, uint32_t *steps, uint8_t *termination,
+                        double *drift);
+/* same with device pointers, asynchronous on `stream` (a hipStream_t, NULL = default) */
+int grv_integrate_batch_device(grv_engine *e, size_t n, const double *d_states,
+                               const GrvOptions *opt, double *d_out_states, uint32_t *d_steps,
+                               uint8_t *d_termination, double *d_drift, void *stream);
+
+/* ---- frame: pixel->state of src/shaders/compute.wgsl.ts:159-187 + integrate + shading ---- */
+size_t grv_frame_ray_count(const GrvRenderParams *p); /* rays this rank renders */
+int grv_render_frame(grv_engine *e, const GrvCamera *cam, const GrvRenderParams *p,
+                     float *rgba_host, GrvFrameStats *stats);
+int grv_render_frame_device(grv_engine *e, const GrvCamera *cam, const GrvRenderParams *p,
+                            const GrvFrameBuffers *out, void *stream);
+/* synchronises `stream` and reads the counters of the last frame */
+int grv_frame_stats(grv_engine *e, void *stream, GrvFrameStats *stats);
+/* host-only: scatter packed tile-order pixels of `rank` into a row-major W x H x C image */
+int grv_unpack_tiles(const GrvRenderParams *p, uint32_t rank, const void *packed, void *image,
+                     size_t bytes_per_pixel);
+
+/* camera helpers (gl-matrix lookAt/perspective as src/components/canvas/WebGPUCanvas.tsx:143-157) */
+void grv_camera_look_at(const double eye[3], const double target[3], const double up[3],
+                        double fovy_rad, double aspect, GrvCamera *cam);
+/* from the 352-byte f32 CameraUniforms block (src/types/webgpu.ts:25) */
+void grv_camera_from_uniforms(const float *camera_uniforms_88f, GrvCamera *cam);
+void grv_render_params_default(uint32_t width, uint32_t height, GrvRenderParams *p);
+void grv_options_default(GrvOptions *o); /* integrator.rs:35-47 */
+
+/* ---- LUTs: generate_spectrum_lut lib.rs:128-136 (physics/spectrum.rs:76-102) ---- */
+int grv_generate_spectrum_lut(grv_engine *e, size_t width, size_t height, double max_temp,
+                              float *out_host);
+int grv_generate_spectrum_lut_device(grv_engine *e, size_t width, size_t height,
+                                     double max_temp, float *d_out, void *stream);
+
+/* ---- SAB protocol: lib.rs:36-40, 116-118, 411-419 (offsets in f32 elements) ---- */
+const float *grv_get_sab_ptr(const grv_engine *e);
+void grv_get_sab_layout(size_t out5[5]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
