@@ -215,6 +215,7 @@ SegmentParams make_segment_params(const grv_engine *e, const GrvOptions &o) {
     P.horizon_limit = event_horizon(e->mass, spin) * 1.001; // geodesic/mod.rs:258
     P.escape_radius = o.escape_radius;
     P.tolerance = o.tolerance;
+    P.inv_tolerance = 1.0 / o.tolerance;
     P.step_size = o.step_size;
     P.max_steps = o.max_steps > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)o.max_steps;
     P.renorm_interval =
@@ -243,15 +244,15 @@ hipError_t launch_segment(int arith, int kind, int method, const RayWorkspace &w
                : launch_segment_strict(kind, method, ws, P, live_in, n_live, live_out, cnt, s);
 }
 
-// Runs segments until no ray is live.  The workspace must have been initialised
-// and e->live[0] / d_counters[0] must hold the initial live list.
+// Runs segments until no ray is live.  The workspace must have been initialised;
+// the first launch walks every slot (identity live list), later launches walk the
+// compacted list the previous one appended.
 int run_segments(grv_engine *e, const GrvOptions &o, SegmentParams P, uint32_t seg_tries,
                  hipStream_t s, bool profile) {
     if (seg_tries == 0) seg_tries = 16;
     P.max_tries = seg_tries;
-    GRV_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    GRV_HIP(e, hipStreamSynchronize(s));
-    uint32_t n_live = e->h_counters[0];
+    uint32_t n_live = e->ws.n;
+    const uint32_t *live_in = nullptr;
     int cur = 0;
     e->last_launches = 0;
     // every live ray completes a step within <= 9 tries (<= 7 shrinks by >= 10x from
@@ -264,7 +265,7 @@ int run_segments(grv_engine *e, const GrvOptions &o, SegmentParams P, uint32_t s
         const int nxt = cur ^ 1;
         GRV_HIP(e, hipMemsetAsync(e->d_counters + nxt, 0, sizeof(uint32_t), s));
         if (profile) GRV_HIP(e, hipEventRecord(e->ev[2], s));
-        GRV_HIP(e, launch_segment(o.arith, o.metric_kind, o.method, e->ws, P, e->live[cur], n_live,
+        GRV_HIP(e, launch_segment(o.arith, o.metric_kind, o.method, e->ws, P, live_in, n_live,
                                   e->live[nxt], e->d_counters + nxt, s));
         if (profile) GRV_HIP(e, hipEventRecord(e->ev[3], s));
         GRV_HIP(e, hipMemcpyAsync(e->h_counters + nxt, e->d_counters + nxt, sizeof(uint32_t),
@@ -276,6 +277,7 @@ int run_segments(grv_engine *e, const GrvOptions &o, SegmentParams P, uint32_t s
             integ_ms += ms;
         }
         n_live = e->h_counters[nxt];
+        live_in = e->live[nxt];
         cur = nxt;
         e->last_launches++;
     }
@@ -430,7 +432,6 @@ int grv_integrate_batch_device(grv_engine *e, size_t n, const double *d_states,
     GRV_HIP(e, hipMemsetAsync(e->d_stats, 0, sizeof(FrameStatsDev), s));
     GRV_HIP(e, launch_init_states(opt->metric_kind, e->ws, P, d_states, opt->initial_step,
                                   opt->method == GRV_METHOD_RKF45, s));
-    GRV_HIP(e, launch_build_live(e->ws, e->live[0], e->d_counters, s));
     rc = run_segments(e, *opt, P, 0, s, false);
     if (rc != GRV_OK) return rc;
     GRV_HIP(e, launch_finalize_batch(e->ws, d_out_states, d_steps, d_termination, d_drift,
@@ -583,7 +584,6 @@ int grv_render_frame_device(grv_engine *e, const GrvCamera *cam, const GrvRender
     if (profile) GRV_HIP(e, hipEventRecord(e->ev[0], s));
     GRV_HIP(e, launch_init_pixels(p->opt.metric_kind, e->ws, P, G, cd, p->opt.initial_step,
                                   p->opt.method == GRV_METHOD_RKF45, s));
-    GRV_HIP(e, launch_build_live(e->ws, e->live[0], e->d_counters, s));
     if (profile) GRV_HIP(e, hipEventRecord(e->ev[1], s));
     rc = run_segments(e, p->opt, P, p->segment_tries, s, profile);
     if (rc != GRV_OK) return rc;
@@ -672,6 +672,19 @@ int grv_unpack_tiles(const GrvRenderParams *p, uint32_t rank, const void *packed
                         src + ((size_t)tl * 4096u + (size_t)py * 64u) * bpp, (size_t)w * bpp);
         }
     }
+    return GRV_OK;
+}
+
+int grv_unpack_tiles_device(grv_engine *e, const GrvRenderParams *p, uint32_t rank,
+                            const void *d_packed, void *d_image, size_t bpp, void *stream) {
+    if (!e) return GRV_ERR_INVALID;
+    if (!p || !d_packed || !d_image || bpp == 0 || (bpp & 3u)) return fail(e, GRV_ERR_INVALID, "bad unpack request");
+    GrvRenderParams q = *p;
+    q.tile_rank = rank;
+    FrameGeom G;
+    frame_geometry(q, G);
+    GRV_HIP(e, hipSetDevice(e->device));
+    GRV_HIP(e, launch_unpack_tiles(G, d_packed, d_image, (uint32_t)(bpp / 4), static_cast<hipStream_t>(stream)));
     return GRV_OK;
 }
 

@@ -36,7 +36,8 @@ struct SegmentParams {
     double horizon_limit; // r_+ * 1.001
     double escape_radius;
     double tolerance;
-    double step_size; // RK4 / symplectic
+    double inv_tolerance; // FAST contract: err * (1/tol)
+    double step_size;     // RK4 / symplectic
     uint32_t max_steps;
     uint32_t renorm_interval;
     uint32_t max_tries; // per launch
@@ -83,8 +84,6 @@ hipError_t launch_init_states(int kind, const RayWorkspace &ws, const SegmentPar
 hipError_t launch_init_pixels(int kind, const RayWorkspace &ws, const SegmentParams &P,
                               const FrameGeom &G, const CameraDev &cam, double h0, int adaptive,
                               hipStream_t s);
-hipError_t launch_build_live(const RayWorkspace &ws, uint32_t *live_out, uint32_t *count,
-                             hipStream_t s);
 hipError_t launch_finalize_batch(const RayWorkspace &ws, double *out_states, uint32_t *out_steps,
                                  uint8_t *out_term, double *out_drift, FrameStatsDev *st,
                                  hipStream_t s);
@@ -93,6 +92,8 @@ hipError_t launch_finalize_frame(const RayWorkspace &ws, const FrameGeom &G, con
                                  double *out_states, uint32_t *out_steps, uint8_t *out_term,
                                  double *out_drift, FrameStatsDev *st, int n_blocks,
                                  hipStream_t s);
+hipError_t launch_unpack_tiles(const FrameGeom &G, const void *packed, void *image,
+                               uint32_t words_per_pixel, hipStream_t s);
 hipError_t launch_spectrum_lut(float *out, uint32_t width, uint32_t height, double max_temp,
                                hipStream_t s);
 // ---- launcher (kernels_fast.hip: -ffp-contract=fast) ----

@@ -27,28 +27,57 @@ __device__ __forceinline__ double wave_max_f64(double v) {
     return v;
 }
 
-__device__ __forceinline__ void accumulate_stats(FrameStatsDev *st, bool valid, uint32_t steps,
-                                                 uint32_t tries, uint32_t term, uint32_t ncross,
-                                                 double drift) {
-    const uint32_t lane = threadIdx.x & 63u;
-    unsigned long long s = wave_sum_u64(valid ? steps : 0u);
-    unsigned long long t = wave_sum_u64(valid ? tries : 0u);
-    unsigned long long c = wave_sum_u64(valid ? ncross : 0u);
-    unsigned long long n = wave_sum_u64(valid ? 1u : 0u);
-    double d = wave_max_f64(valid ? drift : 0.0);
-    unsigned long long tc[5];
+// per-thread partial statistics, reduced once per block
+struct StatAcc {
+    unsigned long long steps = 0, tries = 0, cross = 0, rays = 0;
+    unsigned long long tc[5] = {0, 0, 0, 0, 0};
+    double drift = 0.0;
+    __device__ __forceinline__ void add(uint32_t s, uint32_t t, uint32_t term, uint32_t nc, double d) {
+        steps += s;
+        tries += t;
+        cross += nc;
+        rays += 1;
 #pragma unroll
-    for (int k = 0; k < 5; ++k) tc[k] = (unsigned long long)__popcll(__ballot(valid && term == (uint32_t)k));
-    if (lane == 0 && n != 0ull) {
-        atomicAdd(&st->accepted_steps, s);
-        atomicAdd(&st->rkf_tries, t);
-        atomicAdd(&st->crossings, c);
-        atomicAdd(&st->rays, n);
+        for (int k = 0; k < 5; ++k) tc[k] += (term == (uint32_t)k) ? 1ull : 0ull;
+        drift = fmax(drift, d);
+    }
+};
+
+// all threads of the block must call this (wave shuffles + LDS + one atomic set per block)
+__device__ __forceinline__ void flush_stats(FrameStatsDev *st, const StatAcc &a) {
+    __shared__ unsigned long long s_part[16][9];
+    __shared__ double s_drift[16];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t n_waves = (blockDim.x + 63u) >> 6;
+    unsigned long long v[9] = {a.steps, a.tries, a.cross, a.rays, a.tc[0], a.tc[1], a.tc[2], a.tc[3], a.tc[4]};
 #pragma unroll
-        for (int k = 0; k < 5; ++k)
-            if (tc[k]) atomicAdd(&st->term_count[k], tc[k]);
-        // non-negative doubles order like their bit patterns
-        atomicMax(&st->max_drift_bits, (unsigned long long)__double_as_longlong(d));
+    for (int k = 0; k < 9; ++k) v[k] = wave_sum_u64(v[k]);
+    const double d = wave_max_f64(a.drift);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s_part[wave][k] = v[k];
+        s_drift[wave] = d;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        double dm = 0.0;
+        for (uint32_t w = 0; w < n_waves; ++w) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) t[k] += s_part[w][k];
+            dm = fmax(dm, s_drift[w]);
+        }
+        if (t[3] != 0ull) {
+            atomicAdd(&st->accepted_steps, t[0]);
+            atomicAdd(&st->rkf_tries, t[1]);
+            atomicAdd(&st->crossings, t[2]);
+            atomicAdd(&st->rays, t[3]);
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+                if (t[4 + k]) atomicAdd(&st->term_count[k], t[4 + k]);
+            // non-negative doubles order like their bit patterns
+            atomicMax(&st->max_drift_bits, (unsigned long long)__double_as_longlong(dm));
+        }
     }
 }
 
@@ -58,15 +87,13 @@ __device__ __forceinline__ void accumulate_stats(FrameStatsDev *st, bool valid, 
 __global__ __launch_bounds__(kBlock) void finalize_batch_kernel(
     RayWorkspace ws, double *__restrict__ out_states, uint32_t *__restrict__ out_steps,
     uint8_t *__restrict__ out_term, double *__restrict__ out_drift, FrameStatsDev *st) {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    const bool valid = i < ws.n;
-    uint32_t steps = 0, tries = 0, flags = 0;
-    double drift = 0.0;
-    if (valid) {
-        steps = ws.steps[i];
-        tries = ws.tries[i];
-        flags = ws.flags[i];
-        drift = ws.drift[i];
+    StatAcc acc;
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < ws.n; i += stride) {
+        const uint32_t steps = ws.steps[i];
+        const uint32_t tries = ws.tries[i];
+        const uint32_t flags = ws.flags[i];
+        const double drift = ws.drift[i];
         if (out_states) {
             double2 *dst = reinterpret_cast<double2 *>(out_states + (size_t)i * 8);
             dst[0] = make_double2(ws.t[i], ws.r[i]);
@@ -77,10 +104,9 @@ __global__ __launch_bounds__(kBlock) void finalize_batch_kernel(
         if (out_steps) out_steps[i] = steps;
         if (out_term) out_term[i] = (uint8_t)(flags & kFlagTermMask);
         if (out_drift) out_drift[i] = drift;
+        acc.add(steps, tries, flags & kFlagTermMask, (flags & kFlagCrossMask) >> kFlagCrossShift, drift);
     }
-    if (st)
-        accumulate_stats(st, valid, steps, tries, flags & kFlagTermMask,
-                         (flags & kFlagCrossMask) >> kFlagCrossShift, drift);
+    if (st) flush_stats(st, acc);
 }
 
 // ---------------------------------------------------------------------------
@@ -136,14 +162,14 @@ __global__ __launch_bounds__(1024) void finalize_frame_kernel(
     }
     __syncthreads();
 
+    StatAcc acc;
     const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t n_round = (ws.n + 63u) & ~63u;
-    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n_round; slot += stride) {
+    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < ws.n; slot += stride) {
         uint32_t X, Y, oi;
         bool valid = false;
         uint32_t steps = 0, tries = 0, flags = 0;
         double drift = 0.0;
-        if (slot < ws.n) valid = slot_to_pixel(G, slot, X, Y, oi);
+        valid = slot_to_pixel(G, slot, X, Y, oi);
         if (valid) {
             steps = ws.steps[slot];
             tries = ws.tries[slot];
@@ -202,9 +228,33 @@ __global__ __launch_bounds__(1024) void finalize_frame_kernel(
                 out_rgba[oi] = make_float4((float)col[0], (float)col[1], (float)col[2], 1.0f);
             }
         }
-        if (st)
-            accumulate_stats(st, valid, steps, tries, flags & kFlagTermMask,
-                             (flags & kFlagCrossMask) >> kFlagCrossShift, drift);
+        if (valid)
+            acc.add(steps, tries, flags & kFlagTermMask, (flags & kFlagCrossMask) >> kFlagCrossShift, drift);
+    }
+    if (st) flush_stats(st, acc);
+}
+
+// ---------------------------------------------------------------------------
+// rank-0 de-interleave after the tile gather: packed [tile_local][64][64] pixels of
+// `G.tile_rank` -> row-major image.  One thread per 4-byte word of a pixel.
+// (tile grid as physics-engine/_legacy_src/tiling.rs:38-56)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void unpack_tiles_kernel(FrameGeom G,
+                                                              const uint32_t *__restrict__ packed,
+                                                              uint32_t *__restrict__ image,
+                                                              uint32_t words_per_pixel) {
+    const size_t total = (size_t)G.n_tiles_local * 4096u * words_per_pixel;
+    for (size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x; k < total;
+         k += (size_t)gridDim.x * kBlock) {
+        const uint32_t w = (uint32_t)(k % words_per_pixel);
+        const size_t pix = k / words_per_pixel;
+        const uint32_t tile_local = (uint32_t)(pix >> 12);
+        const uint32_t within = (uint32_t)(pix & 4095u);
+        const uint32_t px = within & 63u, py = within >> 6;
+        const uint32_t tile = tile_local * G.tile_world + G.tile_rank;
+        const uint32_t X = (tile % G.tiles_x) * 64u + px, Y = (tile / G.tiles_x) * 64u + py;
+        if (X < G.width && Y < G.height)
+            image[((size_t)Y * G.width + X) * words_per_pixel + w] = packed[k];
     }
 }
 

@@ -210,11 +210,11 @@ __device__ __forceinline__ bool ray_live(const RayRegs &y) {
 
 // Start-of-trajectory bookkeeping: mod.rs:200 (initial renormalisation), the
 // clamp of AdaptiveStepper::step's first h_try, and the first loop-top checks.
-template <int KIND>
+template <int KIND, int ARITH = GRV_ARITH_STRICT>
 __device__ __forceinline__ void ray_begin(const Hole<double> &bh, RayRegs &y,
                                           const SegmentParams &P, bool adaptive) {
-    const GInv<double> g = contravariant_at<KIND, double>(bh, y.r, y.th);
-    y.pr = renormalized_pr<KIND, double>(g, y.pt, y.pr, y.pth, y.pph);
+    const GInv<double> g = contravariant_at<KIND, ARITH, double>(bh, y.r, y.th);
+    y.pr = renormalized_pr<KIND, ARITH, double>(g, y.pt, y.pr, y.pth, y.pph);
     if (adaptive) y.h = clamp_rs(y.h, -10.0, 10.0);
     uint32_t term = GRV_TERM_NONE;
     if (P.max_steps == 0)
@@ -226,13 +226,13 @@ __device__ __forceinline__ void ray_begin(const Hole<double> &bh, RayRegs &y,
 
 // Everything integrate() does after a completed step (mod.rs:228-239), then the
 // next iteration's loop-top checks, plus the disk-plane crossing recorder.
-template <int KIND>
+template <int KIND, int ARITH>
 __device__ __forceinline__ void after_step(const Hole<double> &bh, RayRegs &y, double r_prev,
                                            double th_prev, const SegmentParams &P,
                                            const RayWorkspace &ws, uint32_t slot) {
-    GInv<double> g = contravariant_at<KIND, double>(bh, y.r, y.th);
+    GInv<double> g = contravariant_at<KIND, ARITH, double>(bh, y.r, y.th);
     if (P.renorm_interval != 0 && (y.steps % P.renorm_interval) == 0)
-        y.pr = renormalized_pr<KIND, double>(g, y.pt, y.pr, y.pth, y.pph);
+        y.pr = renormalized_pr<KIND, ARITH, double>(g, y.pt, y.pr, y.pth, y.pph);
     const double hv = fabs(hamiltonian_of<KIND, double>(g, y.pt, y.pr, y.pth, y.pph));
     if (hv > y.drift) y.drift = hv;
     y.steps += 1;
@@ -319,7 +319,11 @@ __global__ __launch_bounds__(kBlock) void integrate_segment_kernel(
                 const double err = rkf45_try<KIND, ARITH>(bh, y, y.h, n);
                 y.tries += 1;
                 const bool forced = (y.flags & kFlagForced) != 0u;
-                const double ratio = (err == 0.0) ? 0.0 : err / P.tolerance;
+                double ratio;
+                if constexpr (ARITH == GRV_ARITH_FAST)
+                    ratio = err * P.inv_tolerance; // err == 0 -> 0 without the special case
+                else
+                    ratio = (err == 0.0) ? 0.0 : err / P.tolerance;
                 if (forced) {
                     // integrator.rs:99-104: the forced minimum step is taken unconditionally
                     // and its own size is handed back as the next h.
@@ -330,14 +334,22 @@ __global__ __launch_bounds__(kBlock) void integrate_segment_kernel(
                     y = n;
                     stepped = true;
                 } else if (ratio <= 1.0) {
-                    const double growth = (ratio < 1e-4) ? 5.0 : 0.9 * pow(ratio, -0.2);
+                    double growth;
+                    if constexpr (ARITH == GRV_ARITH_FAST)
+                        growth = (ratio < 1e-4) ? 5.0 : 0.9 * fast_pow_m1_5(ratio);
+                    else
+                        growth = (ratio < 1e-4) ? 5.0 : 0.9 * pow(ratio, -0.2);
                     const double next_h = y.h * fmin(growth, 5.0);
                     n.h = clamp_rs(next_h, -10.0, 10.0);
                     n.tries = y.tries;
                     y = n;
                     stepped = true;
                 } else {
-                    const double shrink = 0.9 * pow(ratio, -0.25);
+                    double shrink;
+                    if constexpr (ARITH == GRV_ARITH_FAST)
+                        shrink = 0.9 * fast_pow_m1_4(ratio);
+                    else
+                        shrink = 0.9 * pow(ratio, -0.25);
                     double hn = y.h * fmax(shrink, 0.1);
                     if (fabs(hn) < 1e-5) {
                         hn = 1e-5 * signum_rs(hn);
@@ -356,7 +368,7 @@ __global__ __launch_bounds__(kBlock) void integrate_segment_kernel(
                 stepped = true;
             }
             if (stepped) {
-                after_step<KIND>(bh, y, r_prev, th_prev, P, ws, slot);
+                after_step<KIND, ARITH>(bh, y, r_prev, th_prev, P, ws, slot);
                 live = ray_live(y);
             }
         }
@@ -364,19 +376,26 @@ __global__ __launch_bounds__(kBlock) void integrate_segment_kernel(
 
     if (have) store_ray(ws, slot, y);
 
-    // wave-aggregated append of the survivors (ray compaction for the next launch)
+    // block-aggregated append of the survivors (ray compaction for the next launch):
+    // per-wave ballot/popcount, one atomic per block, mbcnt-style prefix inside the wave.
     if (live_out) {
+        __shared__ uint32_t s_wave_cnt[kBlock / 64];
+        __shared__ uint32_t s_base;
         const unsigned long long mask = __ballot(live);
-        if (mask != 0ull) {
-            const uint32_t lane = threadIdx.x & 63u;
-            const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
-            uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(live_out_count, (uint32_t)__popcll(mask));
-            base = __shfl(base, (int)leader, 64);
-            if (live) {
-                const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-                live_out[base + rank] = slot;
-            }
+        const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+        if (lane == 0) s_wave_cnt[wave] = (uint32_t)__popcll(mask);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t total = 0;
+#pragma unroll
+            for (int w = 0; w < kBlock / 64; ++w) total += s_wave_cnt[w];
+            s_base = total ? atomicAdd(live_out_count, total) : 0u;
+        }
+        __syncthreads();
+        if (live) {
+            uint32_t off = s_base;
+            for (uint32_t w = 0; w < wave; ++w) off += s_wave_cnt[w];
+            live_out[off + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = slot;
         }
     }
 }
@@ -502,26 +521,6 @@ __global__ __launch_bounds__(kBlock) void init_from_pixels_kernel(RayWorkspace w
     store_ray(ws, slot, y);
     ws.pt[slot] = y.pt;
     ws.pph[slot] = y.pph;
-}
-
-// initial compaction: list the slots that are live after init
-__global__ __launch_bounds__(kBlock) void build_live_list_kernel(RayWorkspace ws,
-                                                                 uint32_t *__restrict__ live_out,
-                                                                 uint32_t *__restrict__ count) {
-    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
-    bool live = false;
-    if (slot < ws.n) {
-        const uint32_t f = ws.flags[slot];
-        live = (f & (kFlagTermMask | kFlagValid)) == kFlagValid;
-    }
-    const unsigned long long mask = __ballot(live);
-    if (mask == 0ull) return;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(mask));
-    base = __shfl(base, (int)leader, 64);
-    if (live) live_out[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = slot;
 }
 
 } // namespace

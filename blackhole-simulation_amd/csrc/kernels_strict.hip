@@ -78,19 +78,12 @@ hipError_t launch_init_pixels(int kind, const RayWorkspace &ws, const SegmentPar
     return hipGetLastError();
 }
 
-hipError_t launch_build_live(const RayWorkspace &ws, uint32_t *live_out, uint32_t *count,
-                             hipStream_t s) {
-    const uint32_t grid = (ws.n + kBlock - 1) / kBlock;
-    if (grid == 0) return hipSuccess;
-    hipLaunchKernelGGL(build_live_list_kernel, dim3(grid), dim3(kBlock), 0, s, ws, live_out, count);
-    return hipGetLastError();
-}
-
 hipError_t launch_finalize_batch(const RayWorkspace &ws, double *out_states, uint32_t *out_steps,
                                  uint8_t *out_term, double *out_drift, FrameStatsDev *st,
                                  hipStream_t s) {
-    const uint32_t grid = (ws.n + kBlock - 1) / kBlock;
+    uint32_t grid = (ws.n + kBlock - 1) / kBlock;
     if (grid == 0) return hipSuccess;
+    if (grid > 2048u) grid = 2048u;
     hipLaunchKernelGGL(finalize_batch_kernel, dim3(grid), dim3(kBlock), 0, s, ws, out_states,
                        out_steps, out_term, out_drift, st);
     return hipGetLastError();
@@ -106,7 +99,7 @@ hipError_t launch_finalize_frame(const RayWorkspace &ws, const FrameGeom &G, con
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(finalize_frame_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -117,6 +110,18 @@ hipError_t launch_finalize_frame(const RayWorkspace &ws, const FrameGeom &G, con
     hipLaunchKernelGGL(finalize_frame_kernel, dim3(grid), dim3(1024), lds, s, ws, G, S, shading,
                        reinterpret_cast<const float4 *>(lut), reinterpret_cast<float4 *>(out_rgba),
                        out_states, out_steps, out_term, out_drift, st);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack_tiles(const FrameGeom &G, const void *packed, void *image,
+                               uint32_t words_per_pixel, hipStream_t s) {
+    const size_t total = (size_t)G.n_tiles_local * 4096u * words_per_pixel;
+    if (total == 0) return hipSuccess;
+    size_t grid = (total + kBlock - 1) / kBlock;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(unpack_tiles_kernel, dim3((uint32_t)grid), dim3(kBlock), 0, s, G,
+                       static_cast<const uint32_t *>(packed), static_cast<uint32_t *>(image),
+                       words_per_pixel);
     return hipGetLastError();
 }
 

@@ -53,6 +53,74 @@ template <> __device__ __forceinline__ void sincos_t<double>(double x, double *s
 template <> __device__ __forceinline__ void sincos_t<float>(float x, float *s, float *c) { sincosf(x, s, c); }
 
 // ---------------------------------------------------------------------------
+// FAST-contract math: short, branch-free replacements for the OCML calls on the
+// hot path.  They are only instantiated in the -ffp-contract=fast unit.
+// ---------------------------------------------------------------------------
+
+// sin/cos for |x| << 2^20 * pi/2: three-constant Cody-Waite reduction by pi/2 with
+// fma, then the fdlibm __kernel_sin / __kernel_cos minimax polynomials on
+// [-pi/4, pi/4].  <= 1 ulp-level error; no large-argument (Payne-Hanek) path --
+// theta of a geodesic is O(1..100).
+__device__ __forceinline__ void fast_sincos(double x, double *sn, double *cs) {
+    const double j = rint(x * 6.36619772367581382433e-01); // 2/pi
+    double r = fma(-j, 1.57079632679489655800e+00, x);
+    r = fma(-j, 6.12323399573676603587e-17, r);
+    r = fma(-j, -1.49738490485916983765e-33, r); // pi/2 = hi + mid + lo (lo < 0)
+    const double z = r * r;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    const double sr = fma(r * z, ps, r);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double cr = fma(z, fma(z, pc, -0.5), 1.0);
+    const int q = (int)j;
+    const double s0 = (q & 1) ? cr : sr;
+    const double c0 = (q & 1) ? sr : cr;
+    *sn = (q & 2) ? -s0 : s0;
+    *cs = ((q + 1) & 2) ? -c0 : c0;
+}
+
+// 1/x: v_rcp_f64 seed (~2^-23 relative) + two Newton steps -> ~1 ulp.
+__device__ __forceinline__ double fast_rcp(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    return y;
+}
+
+// x^(-1/5) and x^(-1/4) for the step-size controller: f32 exp2/log2 seed
+// (~2e-7) + two Newton steps on y^-n = x (error -> ~3e^2 each) -> ~2 ulp.
+// x = +inf or huge -> 0 (or NaN), which the caller's fmax(.., 0.1) maps to 0.1.
+__device__ __forceinline__ double fast_pow_m1_5(double x) {
+    double y = (double)__builtin_amdgcn_exp2f(-0.2f * __builtin_amdgcn_logf((float)x));
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double y2 = y * y;
+        const double y5 = y2 * y2 * y;
+        y = y * fma(-0.2 * x, y5, 1.2);
+    }
+    return y;
+}
+__device__ __forceinline__ double fast_pow_m1_4(double x) {
+    double y = (double)__builtin_amdgcn_exp2f(-0.25f * __builtin_amdgcn_logf((float)x));
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double y2 = y * y;
+        const double y4 = y2 * y2;
+        y = y * fma(-0.25 * x, y4, 1.25);
+    }
+    return y;
+}
+
+// ---------------------------------------------------------------------------
 // Reference-order inverse metric.  KIND = GRV_METRIC_*.
 // ---------------------------------------------------------------------------
 template <int KIND, typename T>
@@ -241,18 +309,18 @@ __device__ __forceinline__ Deriv<T> rhs_ref(const Hole<T> &bh, T r, T theta, T p
 // Algebraically identical to rhs_ref<KS>; differs by rounding only.
 // ~55 flops + sincos + 1 reciprocal instead of 16 IEEE divides.
 // ---------------------------------------------------------------------------
-template <typename T>
+template <typename T = double>
 __device__ __forceinline__ Deriv<T> rhs_ks_fast(const Hole<T> &bh, T r, T theta, T p_t, T p_r,
                                                 T p_th, T p_ph) {
     T s, c;
-    sincos_t(theta, &s, &c);
+    fast_sincos(theta, &s, &c);
     const T m = bh.M, a = bh.a, a2 = bh.a2;
     const T r2 = r * r;
     const T sin2 = fmax_t(s * s, T(1e-12));
     const T cos2 = T(1) - sin2;
     const T sigma = r2 + a2 * cos2;
     const T delta = r2 - T(2) * m * r + a2;
-    const T inv_ss = T(1) / (sigma * sin2); // the only reciprocal
+    const T inv_ss = fast_rcp(sigma * sin2); // the only reciprocal
     const T isig = inv_ss * sin2;           // 1/Sigma
     const T isin2 = inv_ss * sigma;         // 1/sin^2
     const T isig2 = isig * isig;
@@ -315,7 +383,7 @@ __device__ __forceinline__ T hamiltonian_of(const GInv<T> &g, T p_t, T p_r, T p_
     return T(0.5) * h;
 }
 
-template <int KIND, typename T>
+template <int KIND, int ARITH, typename T>
 __device__ __forceinline__ T renormalized_pr(const GInv<T> &g, T p_t, T p_r, T p_th, T p_ph) {
     const T a_quad = g.rr;
     T b_quad = T(0);
@@ -327,8 +395,15 @@ __device__ __forceinline__ T renormalized_pr(const GInv<T> &g, T p_t, T p_r, T p
         const T disc = b_quad * b_quad - T(4) * a_quad * c_quad;
         if (disc >= T(0)) {
             const T sq = sqrt_t(disc);
-            const T sol1 = (-b_quad + sq) / (T(2) * a_quad);
-            const T sol2 = (-b_quad - sq) / (T(2) * a_quad);
+            T sol1, sol2;
+            if constexpr (ARITH == GRV_ARITH_FAST) {
+                const T inv2a = fast_rcp(T(2) * a_quad);
+                sol1 = (-b_quad + sq) * inv2a;
+                sol2 = (-b_quad - sq) * inv2a;
+            } else {
+                sol1 = (-b_quad + sq) / (T(2) * a_quad);
+                sol2 = (-b_quad - sq) / (T(2) * a_quad);
+            }
             out = (fabs_t(sol1 - p_r) < fabs_t(sol2 - p_r)) ? sol1 : sol2;
         }
     }
@@ -336,11 +411,30 @@ __device__ __forceinline__ T renormalized_pr(const GInv<T> &g, T p_t, T p_r, T p
 }
 
 // metric at (r, theta) for the post-step bookkeeping
-template <int KIND, typename T>
+template <int KIND, int ARITH, typename T>
 __device__ __forceinline__ GInv<T> contravariant_at(const Hole<T> &bh, T r, T theta) {
-    T s, c;
-    sincos_t(theta, &s, &c);
-    return contravariant_ref<KIND, T>(bh, r, s, c);
+    if constexpr (ARITH == GRV_ARITH_FAST && KIND == GRV_METRIC_KERR_KS) {
+        T s, c;
+        fast_sincos(theta, &s, &c);
+        const T sin2 = fmax_t(s * s, T(1e-12));
+        const T sigma = r * r + bh.a2 * (T(1) - sin2);
+        const T delta = r * r - T(2) * bh.M * r + bh.a2;
+        const T inv_ss = fast_rcp(sigma * sin2);
+        const T isig = inv_ss * sin2;
+        GInv<T> g;
+        g.tr = T(2) * bh.M * r * isig;
+        g.tt = -(T(1) + g.tr);
+        g.tph = T(0);
+        g.rr = delta * isig;
+        g.thth = isig;
+        g.phph = inv_ss;
+        g.rph = bh.a * isig;
+        return g;
+    } else {
+        T s, c;
+        sincos_t(theta, &s, &c);
+        return contravariant_ref<KIND, T>(bh, r, s, c);
+    }
 }
 
 } // namespace

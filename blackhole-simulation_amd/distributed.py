@@ -1,0 +1,94 @@
+"""Image-plane partition across the GPUs of one node: one process per GPU, each
+rank renders the 64x64 tiles k with k % world == rank (round-robin, so shadow and
+photon-ring tiles spread evenly; tile grid as physics-engine/_legacy_src/tiling.rs:38-56),
+then ONE gather of the finished tiles to rank 0 (RCCL over xGMI when the backend
+is "nccl") and a de-interleave on rank 0.  No other collective touches the path.
+
+torch / torch.distributed are plumbing only (device buffers, process group).
+"""
+import ctypes as C
+
+from . import engine as _eng
+
+TILE = 64
+
+
+def tiles_total(width, height):
+    return ((width + TILE - 1) // TILE) * ((height + TILE - 1) // TILE)
+
+
+def tiles_of_rank(width, height, world, rank):
+    """Global tile ids rendered by `rank`, in its packed order."""
+    return list(range(rank, tiles_total(width, height), world))
+
+
+def max_tiles_per_rank(width, height, world):
+    return (tiles_total(width, height) + world - 1) // world
+
+
+def rank_params(params, world, rank):
+    """Copy of `params` restricted to this rank's tiles."""
+    p = _eng.RenderParams()
+    C.memmove(C.byref(p), C.byref(params), C.sizeof(p))
+    p.tile_world = world
+    p.tile_rank = rank
+    return p
+
+
+def gather_tiles(local_packed, params, world, rank, group=None, unpack=None):
+    """Gather every rank's packed tiles on rank 0 and de-interleave them.
+
+    local_packed: tensor [n_tiles_local * 4096, C] (this rank's tiles, tile order).
+    unpack(rank_params, r, packed_tensor, image_tensor): scatters rank r's tiles into
+    the row-major image (device kernel or host memcpy, chosen by the caller).
+    Returns the [H, W, C] image on rank 0, None elsewhere.
+    """
+    import torch
+    import torch.distributed as dist
+
+    chans = local_packed.shape[1]
+    n_max = max_tiles_per_rank(params.width, params.height, world) * TILE * TILE
+    send = local_packed
+    if local_packed.shape[0] != n_max:  # ranks differ by at most one tile: pad to equal size
+        send = torch.zeros((n_max, chans), dtype=local_packed.dtype, device=local_packed.device)
+        send[: local_packed.shape[0]] = local_packed
+    if world == 1:
+        parts = [send]
+    else:
+        parts = ([torch.empty_like(send) for _ in range(world)] if rank == 0 else None)
+        dist.gather(send, parts, dst=0, group=group)
+    if rank != 0:
+        return None
+    image = torch.zeros((params.height, params.width, chans), dtype=send.dtype, device=send.device)
+    for r in range(world):
+        unpack(rank_params(params, world, r), r, parts[r], image)
+    return image
+
+
+def host_unpack(rparams, r, packed, image):
+    """CPU-tensor de-interleave through the C ABI's host helper."""
+    rc = _eng.load_library().grv_unpack_tiles(
+        C.byref(rparams), r, C.c_void_p(packed.data_ptr()), C.c_void_p(image.data_ptr()),
+        packed.shape[1] * packed.element_size())
+    if rc != 0:
+        raise _eng.GravitasError("grv_unpack_tiles failed: %d" % rc)
+
+
+def render_frame_distributed(eng, camera, params, group=None, stream=None):
+    """Render this rank's tiles on its GPU, gather on rank 0.  Returns (image|None, FrameStats)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    p = rank_params(params, world, rank)
+    n = eng.frame_ray_count(p)
+    rgba = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+    eng.render_frame_device(camera, p, rgba=rgba, stream=stream)
+    st = eng.frame_stats(stream)
+
+    def dev_unpack(rp, r, packed, image):
+        eng.unpack_tiles_device(rp, r, packed, image, packed.shape[1] * packed.element_size(), stream)
+
+    image = gather_tiles(rgba, params, world, rank, group, dev_unpack)
+    return image, st

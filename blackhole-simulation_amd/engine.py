@@ -124,6 +124,8 @@ def load_library():
     L.grv_frame_stats.argtypes = [p, p, C.POINTER(FrameStats)]
     L.grv_unpack_tiles.restype = i
     L.grv_unpack_tiles.argtypes = [C.POINTER(RenderParams), C.c_uint32, p, p, sz]
+    L.grv_unpack_tiles_device.restype = i
+    L.grv_unpack_tiles_device.argtypes = [p, C.POINTER(RenderParams), C.c_uint32, p, p, sz, p]
     L.grv_camera_look_at.argtypes = [p, p, p, d, d, C.POINTER(Camera)]
     L.grv_camera_from_uniforms.argtypes = [p, C.POINTER(Camera)]
     L.grv_render_params_default.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(RenderParams)]
@@ -306,6 +308,11 @@ class PhysicsEngine:
         self._check(self._lib.grv_frame_stats(self._h, C.c_void_p(stream) if stream else None,
                                               C.byref(st)), "frame_stats")
         return st
+
+    def unpack_tiles_device(self, params, rank, d_packed, d_image, bytes_per_pixel, stream=None):
+        self._check(self._lib.grv_unpack_tiles_device(
+            self._h, C.byref(params), int(rank), _dev_ptr(d_packed), _dev_ptr(d_image),
+            int(bytes_per_pixel), C.c_void_p(stream) if stream else None), "unpack_tiles_device")
 
     # ---- lib.rs:128-136 ----
     def generate_spectrum_lut(self, width, height, max_temp):

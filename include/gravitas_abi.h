@@ -166,6 +166,11 @@ int grv_frame_stats(grv_engine *e, void *stream, GrvFrameStats *stats);
 int grv_unpack_tiles(const GrvRenderParams *p, uint32_t rank, const void *packed, void *image,
                      size_t bytes_per_pixel);
 
+/* device version (rank-0 side of the RCCL gather); bytes_per_pixel must be a multiple of 4 */
+int grv_unpack_tiles_device(grv_engine *e, const GrvRenderParams *p, uint32_t rank,
+                            const void *d_packed, void *d_image, size_t bytes_per_pixel,
+                            void *stream);
+
 /* camera helpers (gl-matrix lookAt/perspective as src/components/canvas/WebGPUCanvas.tsx:143-157) */
 void grv_camera_look_at(const double eye[3], const double target[3], const double up[3],
                         double fovy_rad, double aspect, GrvCamera *cam);

@@ -1,0 +1,59 @@
+"""The oracle must reproduce the committed golden vectors bit-for-bit on this
+machine class (same libm): guards the checker itself against silent change."""
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _cases():
+    z = np.load(os.path.join(GOLD, "rays_v1.npz"))
+    return z, [str(c) for c in z["cases"]]
+
+
+def test_golden_files_present():
+    assert os.path.exists(os.path.join(GOLD, "rays_v1.npz"))
+    assert os.path.exists(os.path.join(GOLD, "frame_v1.npz"))
+    assert os.path.exists(os.path.join(GOLD, "make_golden.py"))
+
+
+def test_oracle_reproduces_ray_golden(oracle):
+    z, cases = _cases()
+    assert len(cases) >= 20
+    for key in cases:
+        kind, spin, method, tol, max_steps, step, esc, renorm, h0 = z[key + "_meta"]
+        m = oracle.metric(int(kind), 1.0, float(spin))
+        opt = oracle.options(method=int(method), tolerance=float(tol), initial_step=float(h0),
+                             max_steps=int(max_steps), escape_radius=float(esc),
+                             renormalize_interval=int(renorm), step_size=float(step))
+        res = oracle.integrate_batch(m, opt, z[key + "_in"], nthreads=2)
+        assert np.array_equal(res["term"], z[key + "_term"]), key
+        assert np.array_equal(res["steps"], z[key + "_steps"]), key
+        # libm last-ulp differences across hosts are allowed for; same host -> identical
+        np.testing.assert_allclose(res["states"], z[key + "_out"], rtol=1e-9, atol=1e-9, err_msg=key)
+
+
+def test_oracle_reproduces_frame_golden(oracle):
+    z = np.load(os.path.join(GOLD, "frame_v1.npz"))
+    W, H = int(z["width"]), int(z["height"])
+    cam = oracle.camera_look_at(tuple(z["eye"]), aspect=W / H)
+    fp = oracle.frame_params(W, H, spin=float(z["spin"]))
+    fr = oracle.render_frame(cam, fp, None, nthreads=4)
+    assert fr["stats"].accepted_steps == int(z["accepted_steps"])
+    assert np.array_equal(fr["term"], z["term"])
+    assert np.array_equal(fr["steps"], z["steps"])
+    np.testing.assert_allclose(fr["rgba"], z["rgba"], rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(fr["states"], z["states"], rtol=1e-9, atol=1e-9)
+    ps = np.array([oracle.pixel_state(cam, W, H, i, j) for j in (0, 17, 35) for i in (0, 31, 63)])
+    np.testing.assert_allclose(ps, z["pixel_states"], rtol=1e-14, atol=1e-14)
+
+
+def test_single_ray_ffi_matches_batch(oracle):
+    z, _ = _cases()
+    key = "ks_a0.9_rkf45"
+    v = z[key + "_in"][0]
+    out = oracle.integrate_ray_relativistic(1.0, 0.9, v, 2048, 1e-8, True)
+    # the FFI fixes h0=0.01, escape=1000, renorm=10 (gravitas-wasm/src/lib.rs:444-452)
+    np.testing.assert_array_equal(out, z[key + "_out"][0])

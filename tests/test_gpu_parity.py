@@ -1,0 +1,314 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the CPU
+oracle and the committed golden vectors.  Floating-point path (f64): tolerance-
+based, with the tolerance written next to each check.
+
+Stated tolerances (relative = max_i |d_i| / max(1, |x_i|) over the 8 state words):
+  STRICT arithmetic : <= 1e-6 on every ray of the fixtures, median <= 1e-9
+  FAST   arithmetic : <= 1e-5 on every ray of the fixtures, median <= 1e-8
+plus identical termination class and identical accepted-step count.  Both are far
+below the integrator's own truncation error (local tolerance 1e-8 per step).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL_MAX = {0: 1e-6, 1: 1e-5}
+TOL_MED = {0: 1e-9, 1: 1e-8}
+
+
+def rel_err(a, b):
+    return (np.abs(a - b) / np.maximum(1.0, np.abs(b))).max(axis=1)
+
+
+@pytest.fixture(scope="module")
+def bh():
+    import blackhole_simulation_amd as m
+    return m
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def test_native_library_is_the_hip_build(bh):
+    """Fail loudly if the in-tree HIP extension is missing: nothing else can run the path."""
+    assert os.path.exists(bh.library_path())
+    lib = bh.load_library()
+    assert lib.grv_abi_version() == 1
+    with bh.PhysicsEngine(1.0, 0.9) as e:
+        assert abs(e.compute_horizon() - 1.4358898943540672) < 1e-15
+
+
+@pytest.mark.parametrize("arith", [0, 1])
+def test_golden_rays(bh, arith):
+    z = np.load(os.path.join(GOLD, "rays_v1.npz"))
+    worst = 0.0
+    for key in [str(c) for c in z["cases"]]:
+        kind, spin, method, tol, max_steps, step, esc, renorm, h0 = z[key + "_meta"]
+        with bh.PhysicsEngine(1.0, float(spin)) as e:
+            o = bh.engine.default_options(method=int(method), metric_kind=int(kind),
+                                          tolerance=float(tol), initial_step=float(h0),
+                                          max_steps=int(max_steps), escape_radius=float(esc),
+                                          renormalize_interval=int(renorm), step_size=float(step),
+                                          arith=arith)
+            got = e.integrate_batch(z[key + "_in"], o)
+        assert np.array_equal(got["term"], z[key + "_term"]), key
+        assert np.array_equal(got["steps"], z[key + "_steps"]), key
+        err = rel_err(got["states"], z[key + "_out"])
+        if int(kind) == bh.SCHWARZSCHILD or key.startswith("bl_"):
+            # BL / Schwarzschild coordinates are singular at the horizon: captured rays end
+            # with |p_r| ~ 1e3 and amplify rounding; judged on escaping rays only
+            err = err[z[key + "_term"] == 2]
+        worst = max(worst, err.max(initial=0.0))
+        assert err.max(initial=0.0) <= TOL_MAX[arith], (key, err.max())
+        assert np.median(err) <= TOL_MED[arith], (key, np.median(err))
+        # E and L_z are exact constants of motion (hamiltonian.rs:33)
+        assert np.array_equal(got["states"][:, 4], z[key + "_in"][:, 4])
+        assert np.array_equal(got["states"][:, 7], z[key + "_in"][:, 7])
+        d = np.abs(got["drift"] - z[key + "_drift"])
+        assert np.all(d <= 1e-6 * np.maximum(1.0, z[key + "_drift"]) + 1e-9), key
+    print("worst relative endpoint error, arith", arith, worst)
+
+
+@pytest.mark.parametrize("arith", [0, 1])
+def test_golden_frame(bh, torch_mod, arith):
+    torch = torch_mod
+    z = np.load(os.path.join(GOLD, "frame_v1.npz"))
+    W, H = int(z["width"]), int(z["height"])
+    n = W * H
+    with bh.PhysicsEngine(1.0, float(z["spin"])) as e:
+        cam = bh.camera_look_at(tuple(z["eye"]), aspect=W / H)
+        p = bh.render_params(W, H, arith=arith)
+        dev = "cuda:0"
+        rgba = torch.zeros(n, 4, dtype=torch.float32, device=dev)
+        fs = torch.zeros(n, 8, dtype=torch.float64, device=dev)
+        steps = torch.zeros(n, dtype=torch.int32, device=dev)
+        term = torch.zeros(n, dtype=torch.uint8, device=dev)
+        drift = torch.zeros(n, dtype=torch.float64, device=dev)
+        e.render_frame_device(cam, p, rgba, fs, steps, term, drift)
+        st = e.frame_stats()
+        # host-pointer entry point gives the same pixels
+        rgba_h, st_h = e.render_frame(cam, p)
+    assert st.rays == n and st.accepted_steps == int(z["accepted_steps"])
+    assert st.rkf_tries == int(z["rkf_tries"]) and st.crossings == int(z["crossings"])
+    assert list(st.term_count) == list(z["term_count"])
+    assert np.array_equal(term.cpu().numpy(), z["term"])
+    assert np.array_equal(steps.cpu().numpy().astype(np.uint32), z["steps"])
+    err = rel_err(fs.cpu().numpy(), z["states"])
+    assert err.max() <= TOL_MAX[arith] and np.median(err) <= TOL_MED[arith]
+    ref = z["rgba"].reshape(n, 4)
+    scale = ref[:, :3].max()
+    assert np.abs(rgba.cpu().numpy() - ref).max() <= 1e-5 * scale  # f32 colour, 1e-5 of peak
+    assert np.array_equal(rgba_h, rgba.cpu().numpy())
+    assert st_h.accepted_steps == st.accepted_steps
+
+
+def test_single_ray_ffi(bh, oracle):
+    """integrate_ray_relativistic (gravitas-wasm/src/lib.rs:422-464), both metrics."""
+    v = [0, 20.0, np.pi / 2, 0, -1.0, -1.0, 0.0, 3.5]  # geodesic/mod.rs:175 doc-test ray
+    with bh.PhysicsEngine(1.0, 0.9) as e:
+        for ks in (True, False):
+            got = e.integrate_ray_relativistic(v, 10000, 1e-8, ks)
+            ref = oracle.integrate_ray_relativistic(1.0, 0.9, v, 10000, 1e-8, ks)
+            assert got.shape == (8,)
+            assert rel_err(got[None], ref[None])[0] <= 1e-6
+        assert e.integrate_ray_relativistic([1.0, 2.0, 3.0], 10, 1e-8, True).tolist() == [1.0, 2.0, 3.0]
+        assert e.integratePhotonGeodesic(v, 5, 1e-8, True).shape == (8,)
+        # update_params rebuilds both metrics (lib.rs:78-83)
+        e.update_params(1.0, 0.5)
+        got = e.integrate_ray_relativistic(v, 10000, 1e-8, True)
+        ref = oracle.integrate_ray_relativistic(1.0, 0.5, v, 10000, 1e-8, True)
+        assert rel_err(got[None], ref[None])[0] <= 1e-6
+        # spin is clamped like Kerr::new (kerr.rs:48-54)
+        e.update_params(1.0, 1.7)
+        assert e.compute_horizon() == 1.0
+
+
+def test_edge_cases(bh, oracle):
+    m = oracle.metric(oracle.KERR_KS, 1.0, 0.9)
+    with bh.PhysicsEngine(1.0, 0.9) as e:
+        o = bh.engine.default_options(max_steps=50)
+        # empty batch
+        r = e.integrate_batch(np.zeros((0, 8)), o)
+        assert r["states"].shape == (0, 8)
+        # ragged sizes around the wave / block widths
+        rng = np.random.default_rng(7)
+        for n in (1, 63, 64, 65, 257, 1000):
+            st = np.zeros((n, 8))
+            st[:, 1] = rng.uniform(3, 40, n)
+            st[:, 2] = rng.uniform(0.2, 2.9, n)
+            st[:, 4] = -1
+            st[:, 5] = rng.uniform(-1, 1, n)
+            st[:, 6] = rng.uniform(-5, 5, n)
+            st[:, 7] = rng.uniform(-5, 5, n)
+            got = e.integrate_batch(st, o)
+            ref = oracle.integrate_batch(m, oracle.options(max_steps=50), st)
+            assert np.array_equal(got["term"], ref["term"]) and np.array_equal(got["steps"], ref["steps"])
+            assert rel_err(got["states"], ref["states"]).max() <= 1e-6
+        # max_steps = 0 -> MaxSteps immediately, state only renormalised (mod.rs:200-202,246)
+        st = np.array([[0, 10.0, 1.0, 0, -1, -0.5, 1.0, 2.0]])
+        got = e.integrate_batch(st, bh.engine.default_options(max_steps=0))
+        ref = oracle.integrate_batch(m, oracle.options(max_steps=0), st)
+        assert got["term"][0] == bh.TERM_MAXSTEPS == ref["term"][0] and got["steps"][0] == 0
+        assert rel_err(got["states"], ref["states"]).max() <= 1e-12
+        # already inside 1.001 r+ / already beyond the escape radius: zero steps
+        st = np.array([[0, 1.2, 1.0, 0, -1, -0.5, 1.0, 2.0], [0, 2000.0, 1.0, 0, -1, 0.5, 1.0, 2.0]])
+        got = e.integrate_batch(st, o)
+        assert got["term"].tolist() == [bh.TERM_HORIZON, bh.TERM_ESCAPE] and got["steps"].tolist() == [0, 0]
+        # polar ray: sin^2 clamp and dH/dtheta := 0 branch (kerr.rs:417,449,494)
+        st = np.array([[0, 15.0, 1e-12, 0, -1, -1.0, 0.0, 0.0]])
+        got = e.integrate_batch(st, bh.engine.default_options(max_steps=400))
+        ref = oracle.integrate_batch(m, oracle.options(max_steps=400), st)
+        assert got["term"][0] == ref["term"][0] and got["steps"][0] == ref["steps"][0]
+        # invalid options are rejected, not guessed
+        with pytest.raises(bh.GravitasError):
+            e.integrate_batch(st, bh.engine.default_options(method=7))
+        with pytest.raises(bh.GravitasError):
+            e.integrate_batch(st, bh.engine.default_options(tolerance=0.0))
+
+
+def test_spectrum_lut(bh, oracle):
+    """generate_spectrum_lut (lib.rs:128-136, spectrum.rs:76-102): the two shapes the
+    reference's callers use in miniature + the frame LUT."""
+    with bh.PhysicsEngine(1.0, 0.9) as e:
+        for (w, h, tmax) in ((512, 1, 1e5), (512, 64, 1e5), (256, 16, 1e7)):
+            got = e.generate_spectrum_lut(w, h, tmax)
+            ref = oracle.blackbody_lut(w, h, tmax)
+            assert got.shape == ref.shape
+            nz = ref != 0
+            assert np.array_equal(got == 0, ref == 0)
+            assert np.max(np.abs(got[nz] - ref[nz]) / np.abs(ref[nz])) <= 2e-6  # f32 texels, ~1 ulp of exp
+            assert np.all(got.reshape(-1, 4)[:, 3] == 1.0)
+
+
+# ---------------------------------------------------------------------------
+# full-size checks (BASELINE config 3 / 5 shapes) through size-independent properties
+# ---------------------------------------------------------------------------
+W4K, H4K = 3840, 2160
+EYE = (60.0 * np.sin(np.deg2rad(97.0)), 60.0 * np.cos(np.deg2rad(97.0)), 0.0)
+
+
+@pytest.fixture(scope="module")
+def frame4k(bh, torch_mod):
+    torch = torch_mod
+    n = W4K * H4K
+    out = {}
+    with bh.PhysicsEngine(1.0, 0.999) as e:
+        cam = bh.camera_look_at(EYE, aspect=W4K / H4K)
+        for name, kw in (("fast", dict(arith=1)), ("fast_k8", dict(arith=1, segment_tries=8)),
+                         ("strict", dict(arith=0))):
+            p = bh.render_params(W4K, H4K, **kw)
+            rgba = torch.zeros(n, 4, dtype=torch.float32, device="cuda:0")
+            fs = torch.zeros(n, 8, dtype=torch.float64, device="cuda:0")
+            steps = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+            term = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
+            drift = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+            e.render_frame_device(cam, p, rgba, fs, steps, term, drift)
+            st = e.frame_stats()
+            out[name] = dict(rgba=rgba.cpu().numpy(), fs=fs.cpu().numpy(), steps=steps.cpu().numpy(),
+                             term=term.cpu().numpy(), drift=drift.cpu().numpy(), st=st)
+        # two-"rank" tile partition on one GPU
+        from blackhole_simulation_amd import distributed as D
+        p = bh.render_params(W4K, H4K, arith=1)
+        img = np.zeros((H4K, W4K, 4), np.float32)
+        tot = 0
+        for r in range(2):
+            rp = D.rank_params(p, 2, r)
+            nr = e.frame_ray_count(rp)
+            buf = torch.zeros(nr, 4, dtype=torch.float32, device="cuda:0")
+            e.render_frame_device(cam, rp, buf)
+            tot += e.frame_stats().accepted_steps
+            full = torch.zeros(H4K, W4K, 4, dtype=torch.float32, device="cuda:0")
+            e.unpack_tiles_device(rp, r, buf, full, 16)
+            torch.cuda.synchronize()
+            img += full.cpu().numpy()
+        out["tiled_rgba"], out["tiled_steps"] = img, tot
+    return out
+
+
+def test_4k_invariants(frame4k):
+    f = frame4k["fast"]
+    st = f["st"]
+    n = W4K * H4K
+    assert st.rays == n and sum(st.term_count) == n and st.term_count[0] == 0
+    assert st.accepted_steps == int(f["steps"].sum()) and st.rkf_tries >= st.accepted_steps
+    assert f["steps"].max() <= 2048
+    assert np.all(f["fs"][:, 4] == -1.0)                      # E exactly conserved
+    assert st.max_drift < 1e-4 and np.all(f["drift"] <= st.max_drift)
+    esc = f["term"] == 2
+    assert np.all(f["fs"][esc, 1] > 1000.0)
+    hor = f["term"] == 1
+    assert np.all(f["fs"][hor, 1] < 1.001 * (1.0 + np.sqrt(1.0 - 0.999 ** 2)))
+    assert np.all(np.isfinite(f["rgba"])) and np.all(f["rgba"][:, 3] == 1.0)
+    assert np.all(f["rgba"][f["term"] == 1][:, :3].sum(axis=1) >= 0.0)
+
+
+def test_4k_compaction_does_not_change_results(frame4k):
+    """Segmented launches + ray compaction are bookkeeping only: bitwise identical output."""
+    a, b = frame4k["fast"], frame4k["fast_k8"]
+    assert b["st"].launches > a["st"].launches
+    for k in ("rgba", "fs", "steps", "term", "drift"):
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_4k_tile_partition_matches_whole_frame(frame4k):
+    assert np.array_equal(frame4k["tiled_rgba"].reshape(-1, 4), frame4k["fast"]["rgba"])
+    assert frame4k["tiled_steps"] == frame4k["fast"]["st"].accepted_steps
+
+
+def test_4k_strict_vs_fast(frame4k):
+    a, b = frame4k["strict"], frame4k["fast"]
+    same_term = a["term"] == b["term"]
+    same_steps = a["steps"] == b["steps"]
+    print("strict/fast class mismatches:", int((~same_term).sum()), "step mismatches:", int((~same_steps).sum()))
+    assert (~same_term).mean() <= 1e-5 and (~same_steps).mean() <= 1e-4
+    err = rel_err(a["fs"][same_steps], b["fs"][same_steps])
+    print("strict vs fast rel err p50/p99.9/max:", np.median(err), np.percentile(err, 99.9), err.max())
+    assert np.percentile(err, 99.9) <= 1e-5
+
+
+@pytest.mark.parametrize("arith,tol", [(0, 1e-9), (1, 1e-9), (1, 1e-8)])
+def test_4k_strided_subset_vs_oracle(bh, oracle, torch_mod, arith, tol):
+    """BASELINE config 5: 3840x2160, a=0.999, RKF45 tol=1e-9, compared with the CPU
+    restatement on the 1/64 pixel-strided subset (129 600 rays)."""
+    torch = torch_mod
+    n = W4K * H4K
+    with bh.PhysicsEngine(1.0, 0.999) as e:
+        cam = bh.camera_look_at(EYE, aspect=W4K / H4K)
+        p = bh.render_params(W4K, H4K, arith=arith, tolerance=tol)
+        fs = torch.zeros(n, 8, dtype=torch.float64, device="cuda:0")
+        steps = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+        term = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
+        rgba = torch.zeros(n, 4, dtype=torch.float32, device="cuda:0")
+        e.render_frame_device(cam, p, rgba, fs, steps, term)
+        torch.cuda.synchronize()
+    sel = (slice(None, None, 8), slice(None, None, 8))
+    g_fs = fs.cpu().numpy().reshape(H4K, W4K, 8)[sel].reshape(-1, 8)
+    g_steps = steps.cpu().numpy().reshape(H4K, W4K)[sel].reshape(-1)
+    g_term = term.cpu().numpy().reshape(H4K, W4K)[sel].reshape(-1)
+    g_rgba = rgba.cpu().numpy().reshape(H4K, W4K, 4)[sel].reshape(-1, 4)
+    ocam = oracle.camera_look_at(EYE, aspect=W4K / H4K)
+    fp = oracle.frame_params(W4K, H4K, spin=0.999, opt=oracle.options(max_steps=2048, tolerance=tol))
+    ref = oracle.render_frame(ocam, fp, None, stride=(8, 8), nthreads=max(1, os.cpu_count() or 1))
+    mism = g_term != ref["term"]
+    dsteps = np.abs(g_steps.astype(np.int64) - ref["steps"].astype(np.int64))
+    ok = (~mism) & (dsteps == 0)
+    err = rel_err(g_fs[ok], ref["states"][ok])
+    print(f"arith={arith} tol={tol}: class mismatches {int(mism.sum())}/{mism.size}, step mismatches "
+          f"{int((dsteps > 0).sum())}, rel err p50 {np.median(err):.2e} p99.9 {np.percentile(err, 99.9):.2e} "
+          f"max {err.max():.2e}")
+    assert mism.mean() <= 1e-4          # near-critical rays may flip class; bounded fraction
+    assert (dsteps > 0).mean() <= 1e-3
+    assert np.percentile(err, 99.9) <= (1e-7 if arith == 0 else 1e-6)
+    assert err.max() <= (1e-5 if arith == 0 else 1e-4)
+    scale = ref["rgba"][..., :3].max()
+    d = np.abs(g_rgba - ref["rgba"].reshape(-1, 4))[ok]
+    assert d.max() <= 1e-4 * scale

@@ -75,6 +75,12 @@ def timing():
     n = W*H
     dev = torch.device("cuda:0")
     rgba = torch.zeros(n, 4, dtype=torch.float32, device=dev)
+    steps = torch.zeros(n, dtype=torch.int32, device=dev)
+    p = bh.render_params(W, H, arith=1, segment_tries=4096)
+    eng.render_frame_device(cam, p, rgba, None, steps); torch.cuda.synchronize()
+    st2 = steps.view(H // 8, 8, W // 8, 8).permute(0, 2, 1, 3).reshape(-1, 64).double()
+    print("wave(8x8) efficiency mean/max:", (st2.sum() / (st2.max(dim=1).values.sum() * 64)).item(),
+          " steps mean", st2.mean().item(), "max", st2.max().item())
     for arith in (1, 0):
         for K in (8, 16, 32, 64, 4096):
             p = bh.render_params(W, H, arith=arith, segment_tries=K, profile=1)
