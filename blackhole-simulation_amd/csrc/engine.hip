@@ -249,7 +249,7 @@ hipError_t launch_segment(int arith, int kind, int method, const RayWorkspace &w
 // compacted list the previous one appended.
 int run_segments(grv_engine *e, const GrvOptions &o, SegmentParams P, uint32_t seg_tries,
                  hipStream_t s, bool profile) {
-    if (seg_tries == 0) seg_tries = 16;
+    if (seg_tries == 0) seg_tries = 4096;
     P.max_tries = seg_tries;
     uint32_t n_live = e->ws.n;
     const uint32_t *live_in = nullptr;
@@ -432,7 +432,8 @@ int grv_integrate_batch_device(grv_engine *e, size_t n, const double *d_states,
     GRV_HIP(e, hipMemsetAsync(e->d_stats, 0, sizeof(FrameStatsDev), s));
     GRV_HIP(e, launch_init_states(opt->metric_kind, e->ws, P, d_states, opt->initial_step,
                                   opt->method == GRV_METHOD_RKF45, s));
-    rc = run_segments(e, *opt, P, 0, s, false);
+    // independent rays diverge freely in a batch: compact every 64 tries
+    rc = run_segments(e, *opt, P, 64, s, false);
     if (rc != GRV_OK) return rc;
     GRV_HIP(e, launch_finalize_batch(e->ws, d_out_states, d_steps, d_termination, d_drift,
                                      e->d_stats, s));
@@ -585,6 +586,9 @@ int grv_render_frame_device(grv_engine *e, const GrvCamera *cam, const GrvRender
     GRV_HIP(e, launch_init_pixels(p->opt.metric_kind, e->ws, P, G, cd, p->opt.initial_step,
                                   p->opt.method == GRV_METHOD_RKF45, s));
     if (profile) GRV_HIP(e, hipEventRecord(e->ev[1], s));
+    // neighbouring pixels take near-identical step counts (8x8-pixel waves run at >99 %
+    // lane efficiency at 4K), so the frame default is one long segment; segment_tries
+    // selects the compacting wavefront form
     rc = run_segments(e, p->opt, P, p->segment_tries, s, profile);
     if (rc != GRV_OK) return rc;
 

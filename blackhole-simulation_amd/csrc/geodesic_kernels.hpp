@@ -36,7 +36,10 @@ struct RayRegs {
     double h;
     double drift;
     uint32_t steps, tries, flags;
+    KsGeom geom; // FAST Kerr-Schild only: geometry at (r, th), reused by stage 1 of a try
 };
+
+template <int KIND, int ARITH> constexpr bool kGeomCache = (KIND == GRV_METRIC_KERR_KS && ARITH == GRV_ARITH_FAST);
 
 __device__ __forceinline__ double clamp_rs(double x, double lo, double hi) {
     // Rust f64::clamp
@@ -91,49 +94,70 @@ __device__ __forceinline__ double rkf45_try(const Hole<double> &bh, const RayReg
     constexpr double e1 = 16.0 / 135.0 - 25.0 / 216.0, e3 = 6656.0 / 12825.0 - 1408.0 / 2565.0,
                      e4 = 28561.0 / 56430.0 - 2197.0 / 4104.0, e5 = -9.0 / 50.0 + 1.0 / 5.0;
 
-    const Deriv<double> k1 = rhs<KIND, ARITH>(bh, y.r, y.th, y.pt, y.pr, y.pth, y.pph);
+    Deriv<double> k1;
+    if constexpr (kGeomCache<KIND, ARITH>)
+        k1 = rhs_ks_geom(bh, y.geom, y.r, y.pt, y.pr, y.pth, y.pph);
+    else
+        k1 = rhs<KIND, ARITH>(bh, y.r, y.th, y.pt, y.pr, y.pth, y.pph);
     // t and phi never feed back into the right-hand side: keep only their running
     // 5th-order and error sums (same left-to-right order as the reference).
     double a5_t = c1 * k1.dt, a5_ph = c1 * k1.dph;
     double ae_t = e1 * k1.dt, ae_ph = e1 * k1.dph;
 
+    // FAST: nested-fma stage sums (one instruction per term); STRICT keeps the reference's
+    // (k1*s1 + k2*s2 + ...) grouping.
+    auto st2 = [&](double y0, double a1, double a2) {
+        if constexpr (ARITH == GRV_ARITH_FAST) return fma(a2, s32, fma(a1, s31, y0));
+        else return y0 + (a1 * s31 + a2 * s32);
+    };
+    auto st3 = [&](double y0, double a1, double a2, double a3) {
+        if constexpr (ARITH == GRV_ARITH_FAST) return fma(a3, s43, fma(a2, s42, fma(a1, s41, y0)));
+        else return y0 + (a1 * s41 + a2 * s42 + a3 * s43);
+    };
+    auto st4 = [&](double y0, double a1, double a2, double a3, double a4) {
+        if constexpr (ARITH == GRV_ARITH_FAST)
+            return fma(a4, s54, fma(a3, s53, fma(a2, s52, fma(a1, s51, y0))));
+        else return y0 + (a1 * s51 + a2 * s52 + a3 * s53 + a4 * s54);
+    };
+    auto st5 = [&](double y0, double a1, double a2, double a3, double a4, double a5) {
+        if constexpr (ARITH == GRV_ARITH_FAST)
+            return fma(a5, s65, fma(a4, s64, fma(a3, s63, fma(a2, s62, fma(a1, s61, y0)))));
+        else return y0 + (a1 * s61 + a2 * s62 + a3 * s63 + a4 * s64 + a5 * s65);
+    };
+
     const Deriv<double> k2 = rhs<KIND, ARITH>(bh, y.r + k1.dr * s21, y.th + k1.dth * s21, y.pt,
                                               y.pr + k1.dpr * s21, y.pth + k1.dpth * s21, y.pph);
 
-    const Deriv<double> k3 = rhs<KIND, ARITH>(
-        bh, y.r + (k1.dr * s31 + k2.dr * s32), y.th + (k1.dth * s31 + k2.dth * s32), y.pt,
-        y.pr + (k1.dpr * s31 + k2.dpr * s32), y.pth + (k1.dpth * s31 + k2.dpth * s32), y.pph);
+    const Deriv<double> k3 = rhs<KIND, ARITH>(bh, st2(y.r, k1.dr, k2.dr), st2(y.th, k1.dth, k2.dth),
+                                              y.pt, st2(y.pr, k1.dpr, k2.dpr),
+                                              st2(y.pth, k1.dpth, k2.dpth), y.pph);
     a5_t = a5_t + c3 * k3.dt;
     a5_ph = a5_ph + c3 * k3.dph;
     ae_t = ae_t + e3 * k3.dt;
     ae_ph = ae_ph + e3 * k3.dph;
 
     const Deriv<double> k4 = rhs<KIND, ARITH>(
-        bh, y.r + (k1.dr * s41 + k2.dr * s42 + k3.dr * s43),
-        y.th + (k1.dth * s41 + k2.dth * s42 + k3.dth * s43), y.pt,
-        y.pr + (k1.dpr * s41 + k2.dpr * s42 + k3.dpr * s43),
-        y.pth + (k1.dpth * s41 + k2.dpth * s42 + k3.dpth * s43), y.pph);
+        bh, st3(y.r, k1.dr, k2.dr, k3.dr), st3(y.th, k1.dth, k2.dth, k3.dth), y.pt,
+        st3(y.pr, k1.dpr, k2.dpr, k3.dpr), st3(y.pth, k1.dpth, k2.dpth, k3.dpth), y.pph);
     a5_t = a5_t + c4 * k4.dt;
     a5_ph = a5_ph + c4 * k4.dph;
     ae_t = ae_t + e4 * k4.dt;
     ae_ph = ae_ph + e4 * k4.dph;
 
     const Deriv<double> k5 = rhs<KIND, ARITH>(
-        bh, y.r + (k1.dr * s51 + k2.dr * s52 + k3.dr * s53 + k4.dr * s54),
-        y.th + (k1.dth * s51 + k2.dth * s52 + k3.dth * s53 + k4.dth * s54), y.pt,
-        y.pr + (k1.dpr * s51 + k2.dpr * s52 + k3.dpr * s53 + k4.dpr * s54),
-        y.pth + (k1.dpth * s51 + k2.dpth * s52 + k3.dpth * s53 + k4.dpth * s54), y.pph);
+        bh, st4(y.r, k1.dr, k2.dr, k3.dr, k4.dr), st4(y.th, k1.dth, k2.dth, k3.dth, k4.dth), y.pt,
+        st4(y.pr, k1.dpr, k2.dpr, k3.dpr, k4.dpr), st4(y.pth, k1.dpth, k2.dpth, k3.dpth, k4.dpth),
+        y.pph);
     a5_t = a5_t - c5 * k5.dt;
     a5_ph = a5_ph - c5 * k5.dph;
     ae_t = ae_t + e5 * k5.dt;
     ae_ph = ae_ph + e5 * k5.dph;
 
     const Deriv<double> k6 = rhs<KIND, ARITH>(
-        bh, y.r + (k1.dr * s61 + k2.dr * s62 + k3.dr * s63 + k4.dr * s64 + k5.dr * s65),
-        y.th + (k1.dth * s61 + k2.dth * s62 + k3.dth * s63 + k4.dth * s64 + k5.dth * s65), y.pt,
-        y.pr + (k1.dpr * s61 + k2.dpr * s62 + k3.dpr * s63 + k4.dpr * s64 + k5.dpr * s65),
-        y.pth + (k1.dpth * s61 + k2.dpth * s62 + k3.dpth * s63 + k4.dpth * s64 + k5.dpth * s65),
-        y.pph);
+        bh, st5(y.r, k1.dr, k2.dr, k3.dr, k4.dr, k5.dr),
+        st5(y.th, k1.dth, k2.dth, k3.dth, k4.dth, k5.dth), y.pt,
+        st5(y.pr, k1.dpr, k2.dpr, k3.dpr, k4.dpr, k5.dpr),
+        st5(y.pth, k1.dpth, k2.dpth, k3.dpth, k4.dpth, k5.dpth), y.pph);
     a5_t = a5_t + c6 * k6.dt;
     a5_ph = a5_ph + c6 * k6.dph;
     ae_t = ae_t + c6 * k6.dt;
@@ -213,7 +237,13 @@ __device__ __forceinline__ bool ray_live(const RayRegs &y) {
 template <int KIND, int ARITH = GRV_ARITH_STRICT>
 __device__ __forceinline__ void ray_begin(const Hole<double> &bh, RayRegs &y,
                                           const SegmentParams &P, bool adaptive) {
-    const GInv<double> g = contravariant_at<KIND, ARITH, double>(bh, y.r, y.th);
+    GInv<double> g;
+    if constexpr (kGeomCache<KIND, ARITH>) {
+        y.geom = ks_geom(bh, y.r, y.th);
+        g = ginv_from_geom(bh, y.geom, y.r);
+    } else {
+        g = contravariant_at<KIND, ARITH, double>(bh, y.r, y.th);
+    }
     y.pr = renormalized_pr<KIND, ARITH, double>(g, y.pt, y.pr, y.pth, y.pph);
     if (adaptive) y.h = clamp_rs(y.h, -10.0, 10.0);
     uint32_t term = GRV_TERM_NONE;
@@ -230,7 +260,13 @@ template <int KIND, int ARITH>
 __device__ __forceinline__ void after_step(const Hole<double> &bh, RayRegs &y, double r_prev,
                                            double th_prev, const SegmentParams &P,
                                            const RayWorkspace &ws, uint32_t slot) {
-    GInv<double> g = contravariant_at<KIND, ARITH, double>(bh, y.r, y.th);
+    GInv<double> g;
+    if constexpr (kGeomCache<KIND, ARITH>) {
+        y.geom = ks_geom(bh, y.r, y.th); // also stage 1 of the next try
+        g = ginv_from_geom(bh, y.geom, y.r);
+    } else {
+        g = contravariant_at<KIND, ARITH, double>(bh, y.r, y.th);
+    }
     if (P.renorm_interval != 0 && (y.steps % P.renorm_interval) == 0)
         y.pr = renormalized_pr<KIND, ARITH, double>(g, y.pt, y.pr, y.pth, y.pph);
     const double hv = fabs(hamiltonian_of<KIND, double>(g, y.pt, y.pr, y.pth, y.pph));
@@ -309,6 +345,9 @@ __global__ __launch_bounds__(kBlock) void integrate_segment_kernel(
     const Hole<double> bh{P.M, P.a, P.a2};
 
     bool live = have && ray_live(y);
+    if constexpr (kGeomCache<KIND, ARITH>) {
+        if (live) y.geom = ks_geom(bh, y.r, y.th); // state came from HBM: rebuild the cache
+    }
     for (uint32_t it = 0; it < P.max_tries; ++it) {
         if (__ballot(live) == 0ull) break; // whole wave finished: early out
         if (live) {

@@ -307,54 +307,108 @@ __device__ __forceinline__ Deriv<T> rhs_ref(const Hole<T> &bh, T r, T theta, T p
 // FAST Kerr-Schild right-hand side: the same Hamilton equations with one
 // shared reciprocal 1/(Sigma sin^2) and everything factored over 1/Sigma^2.
 // Algebraically identical to rhs_ref<KS>; differs by rounding only.
-// ~55 flops + sincos + 1 reciprocal instead of 16 IEEE divides.
+// The point-only part (KsGeom) is split off so the first stage of a try can
+// reuse the geometry the post-step bookkeeping already evaluated there.
 // ---------------------------------------------------------------------------
+struct KsGeom {
+    double sin2;   // max(sin^2, 1e-12)
+    double sc;     // sin * cos
+    double sigma;  // r^2 + a^2 cos^2
+    double delta;  // r^2 - 2Mr + a^2
+    double inv_ss; // 1 / (sigma sin^2)
+    bool polar;    // |sin| < 1e-10  (dH/dtheta := 0, kerr.rs:494)
+};
+
+// sin^2 and sin*cos are all the right-hand side needs, so the quadrant logic of a
+// full sincos collapses to one swap and one sign.
+__device__ __forceinline__ KsGeom ks_geom(const Hole<double> &bh, double r, double theta) {
+    const double j = rint(theta * 6.36619772367581382433e-01); // 2/pi
+    double x = fma(-j, 1.57079632679489655800e+00, theta);
+    x = fma(-j, 6.12323399573676603587e-17, x);
+    x = fma(-j, -1.49738490485916983765e-33, x);
+    const double z = x * x;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    const double sr = fma(x * z, ps, x);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double cr = fma(z, fma(z, pc, -0.5), 1.0);
+    const bool odd = ((int)j & 1) != 0; // odd quadrant: sin <-> cos, product changes sign
+    const double sn = odd ? cr : sr;
+    const double prod = sr * cr;
+    KsGeom g;
+    const double s2 = sn * sn;
+    g.polar = s2 < 1e-20;
+    g.sin2 = fmax(s2, 1e-12);
+    g.sc = odd ? -prod : prod;
+    g.sigma = fma(bh.a2, 1.0 - g.sin2, r * r);
+    g.delta = fma(r, r - 2.0 * bh.M, bh.a2);
+    g.inv_ss = fast_rcp(g.sigma * g.sin2);
+    return g;
+}
+
+__device__ __forceinline__ Deriv<double> rhs_ks_geom(const Hole<double> &bh, const KsGeom &g,
+                                                     double r, double p_t, double p_r,
+                                                     double p_th, double p_ph) {
+    const double m = bh.M, a = bh.a, a2 = bh.a2;
+    const double sigma = g.sigma, delta = g.delta, inv_ss = g.inv_ss;
+    const double isig = inv_ss * g.sin2; // 1/Sigma
+    const double isin2 = inv_ss * sigma; // 1/sin^2
+    const double isig2 = isig * isig;
+
+    const double two_mr_isig = 2.0 * m * r * isig;
+    Deriv<double> d;
+    d.dt = two_mr_isig * (p_r - p_t) - p_t;                     // g^tt p_t + g^tr p_r
+    d.dr = two_mr_isig * p_t + (delta * p_r + a * p_ph) * isig; // g^tr p_t + g^rr p_r + g^rph p_ph
+    d.dth = isig * p_th;
+    d.dph = (a * isig) * p_r + inv_ss * p_ph;
+
+    const double two_r = 2.0 * r;
+    const double dsig_dth = -2.0 * a2 * g.sc;
+    const double pt_mix = p_t * (p_t - 2.0 * p_r); // p_t^2 - 2 p_t p_r
+    const double pph2_isin2 = p_ph * p_ph * isin2;
+    const double pr2 = p_r * p_r;
+    const double pth2 = p_th * p_th;
+    const double apr_pph2 = 2.0 * a * p_r * p_ph;
+
+    // 2 Sigma^2 dH/dr
+    const double ar = -2.0 * m * (sigma - two_r * r) * pt_mix +
+                      ((two_r - 2.0 * m) * sigma - delta * two_r) * pr2 -
+                      two_r * (pth2 + pph2_isin2 + apr_pph2);
+    // 2 Sigma^2 dH/dtheta
+    const double ath =
+        dsig_dth * (2.0 * m * r * pt_mix - delta * pr2 - pth2 - apr_pph2 - pph2_isin2) -
+        2.0 * sigma * g.sc * pph2_isin2 * isin2;
+    const double half_isig2 = 0.5 * isig2;
+    d.dpr = -(half_isig2 * ar);
+    d.dpth = g.polar ? 0.0 : -(half_isig2 * ath);
+    return d;
+}
+
 template <typename T = double>
 __device__ __forceinline__ Deriv<T> rhs_ks_fast(const Hole<T> &bh, T r, T theta, T p_t, T p_r,
                                                 T p_th, T p_ph) {
-    T s, c;
-    fast_sincos(theta, &s, &c);
-    const T m = bh.M, a = bh.a, a2 = bh.a2;
-    const T r2 = r * r;
-    const T sin2 = fmax_t(s * s, T(1e-12));
-    const T cos2 = T(1) - sin2;
-    const T sigma = r2 + a2 * cos2;
-    const T delta = r2 - T(2) * m * r + a2;
-    const T inv_ss = fast_rcp(sigma * sin2); // the only reciprocal
-    const T isig = inv_ss * sin2;           // 1/Sigma
-    const T isin2 = inv_ss * sigma;         // 1/sin^2
-    const T isig2 = isig * isig;
+    return rhs_ks_geom(bh, ks_geom(bh, r, theta), r, p_t, p_r, p_th, p_ph);
+}
 
-    const T two_mr_isig = T(2) * m * r * isig;
-    const T g_rph = a * isig;
-    Deriv<T> d;
-    d.dt = two_mr_isig * (p_r - p_t) - p_t;                    // g^tt p_t + g^tr p_r
-    d.dr = two_mr_isig * p_t + (delta * p_r + a * p_ph) * isig; // g^tr p_t + g^rr p_r + g^rph p_ph
-    d.dth = isig * p_th;
-    d.dph = g_rph * p_r + inv_ss * p_ph;
-
-    const T two_r = T(2) * r;
-    const T sc = s * c;
-    const T dsig_dth = T(-2) * a2 * sc;
-    const T pt_mix = p_t * (p_t - T(2) * p_r); // p_t^2 - 2 p_t p_r
-    const T pph2_isin2 = p_ph * p_ph * isin2;
-    const T pr2 = p_r * p_r;
-    const T pth2 = p_th * p_th;
-    const T apr_pph2 = T(2) * a * p_r * p_ph;
-
-    // dH/dr * 2 Sigma^2
-    const T ar = T(-2) * m * (sigma - two_r * r) * pt_mix +
-                 ((two_r - T(2) * m) * sigma - delta * two_r) * pr2 -
-                 two_r * (pth2 + pph2_isin2 + apr_pph2);
-    // dH/dtheta * 2 Sigma^2
-    const T ath = dsig_dth * (T(2) * m * r * pt_mix - delta * pr2 - pth2 - apr_pph2 - pph2_isin2) -
-                  T(2) * sigma * sc * pph2_isin2 * isin2;
-    const T half_isig2 = T(0.5) * isig2;
-    d.dpr = -(half_isig2 * ar);
-    T dpth = -(half_isig2 * ath);
-    if (fabs_t(s) < T(1e-10)) dpth = T(0);
-    d.dpth = dpth;
-    return d;
+__device__ __forceinline__ GInv<double> ginv_from_geom(const Hole<double> &bh, const KsGeom &g,
+                                                       double r) {
+    const double isig = g.inv_ss * g.sin2;
+    GInv<double> o;
+    o.tr = 2.0 * bh.M * r * isig;
+    o.tt = -(1.0 + o.tr);
+    o.tph = 0.0;
+    o.rr = g.delta * isig;
+    o.thth = isig;
+    o.phph = g.inv_ss;
+    o.rph = bh.a * isig;
+    return o;
 }
 
 template <int KIND, int ARITH, typename T>
@@ -414,22 +468,7 @@ __device__ __forceinline__ T renormalized_pr(const GInv<T> &g, T p_t, T p_r, T p
 template <int KIND, int ARITH, typename T>
 __device__ __forceinline__ GInv<T> contravariant_at(const Hole<T> &bh, T r, T theta) {
     if constexpr (ARITH == GRV_ARITH_FAST && KIND == GRV_METRIC_KERR_KS) {
-        T s, c;
-        fast_sincos(theta, &s, &c);
-        const T sin2 = fmax_t(s * s, T(1e-12));
-        const T sigma = r * r + bh.a2 * (T(1) - sin2);
-        const T delta = r * r - T(2) * bh.M * r + bh.a2;
-        const T inv_ss = fast_rcp(sigma * sin2);
-        const T isig = inv_ss * sin2;
-        GInv<T> g;
-        g.tr = T(2) * bh.M * r * isig;
-        g.tt = -(T(1) + g.tr);
-        g.tph = T(0);
-        g.rr = delta * isig;
-        g.thth = isig;
-        g.phph = inv_ss;
-        g.rph = bh.a * isig;
-        return g;
+        return ginv_from_geom(bh, ks_geom(bh, r, theta), r);
     } else {
         T s, c;
         sincos_t(theta, &s, &c);

@@ -89,6 +89,13 @@ def load_library():
         raise GravitasError(
             "libgravitas_hip.so is missing (%s): run __graft_entry__.build() / make -C "
             "blackhole-simulation_amd/csrc; there is no CPU fallback" % _LIB)
+    try:
+        # PyTorch-ROCm ships its own libamdhip64; two HIP runtimes in one process cannot
+        # both open the device.  Import torch first so this library binds to the copy
+        # torch already loaded.  (Standalone C/N-API hosts use the system runtime.)
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = C.CDLL(_LIB)
     d, i, p, sz = C.c_double, C.c_int, C.c_void_p, C.c_size_t
     L.grv_abi_version.restype = i

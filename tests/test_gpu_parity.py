@@ -67,9 +67,10 @@ def test_golden_rays(bh, arith):
             # BL / Schwarzschild coordinates are singular at the horizon: captured rays end
             # with |p_r| ~ 1e3 and amplify rounding; judged on escaping rays only
             err = err[z[key + "_term"] == 2]
-        worst = max(worst, err.max(initial=0.0))
-        assert err.max(initial=0.0) <= TOL_MAX[arith], (key, err.max())
-        assert np.median(err) <= TOL_MED[arith], (key, np.median(err))
+        if err.size:
+            worst = max(worst, err.max())
+            assert err.max() <= TOL_MAX[arith], (key, err.max())
+            assert np.median(err) <= TOL_MED[arith], (key, np.median(err))
         # E and L_z are exact constants of motion (hamiltonian.rs:33)
         assert np.array_equal(got["states"][:, 4], z[key + "_in"][:, 4])
         assert np.array_equal(got["states"][:, 7], z[key + "_in"][:, 7])

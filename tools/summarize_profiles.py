@@ -1,0 +1,69 @@
+"""Turns the rocprofv3 rocpd databases under gpurun_out/prof into the committed
+text/JSON summaries under profiles/ (kernel-trace stats + PMC counters)."""
+import json
+import os
+import sqlite3
+import sys
+
+SRC = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
+DST = sys.argv[2] if len(sys.argv) > 2 else "profiles"
+TAG = sys.argv[3] if len(sys.argv) > 3 else "r01"
+os.makedirs(DST, exist_ok=True)
+
+
+def q(db, sql):
+    return sqlite3.connect(db).execute(sql).fetchall()
+
+
+def short(name):
+    if "integrate_segment_kernel" in name:
+        return "integrate_segment_kernel" + name[name.index("<"):name.index(">") + 1] if "<" in name else name
+    return name.split("(")[0]
+
+
+def trace_summary(dbpath, label):
+    rows = q(dbpath, "select name, total_calls, total_duration, average, percentage from top_kernels")
+    lines = ["# rocprofv3 --kernel-trace --stats  (%s)" % label,
+             "%-110s %8s %14s %14s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "pct")]
+    for n, c, t, a, p in rows:
+        lines.append("%-110s %8d %14d %14.1f %7.2f" % (short(n)[:110], c, t, a, p))
+    reg = q(dbpath, "select name, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size, "
+                    "workgroup_x, min(grid_x), max(grid_x), count(*), avg(duration), min(duration), max(duration) "
+                    "from kernels group by name")
+    lines.append("")
+    lines.append("%-80s %5s %5s %5s %7s %7s %5s %10s %10s %6s %12s %12s %12s" % (
+        "kernel", "vgpr", "agpr", "sgpr", "lds", "scratch", "wg", "grid_min", "grid_max", "n", "avg_ns", "min_ns", "max_ns"))
+    for r in reg:
+        lines.append("%-80s %5d %5d %5d %7d %7d %5d %10d %10d %6d %12.0f %12d %12d" % ((short(r[0])[:80],) + tuple(r[1:])))
+    return "\n".join(lines) + "\n", rows
+
+
+def pmc_summary(dbpath):
+    rows = q(dbpath, "select kernel_name, counter_name, count(*), avg(value), sum(value) from "
+                     "counters_collection group by kernel_name, counter_name")
+    return rows
+
+
+out = {}
+for label in ("trace", "trace_k16"):
+    p = os.path.join(SRC, label, "bench_results.db")
+    if os.path.exists(p):
+        txt, rows = trace_summary(p, "python bench.py --steps 10 --warmup 2 --no-cpu-baseline" +
+                                  (" --segment-tries 16" if label.endswith("k16") else ""))
+        bj = os.path.join(SRC, label + "_bench.json")
+        if os.path.exists(bj):
+            txt += "\n# bench.py line of the same run\n" + open(bj).read().strip() + "\n"
+        open(os.path.join(DST, "%s_%s_kernel_stats.txt" % (TAG, label)), "w").write(txt)
+        print(txt)
+
+pm = {}
+for label in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_fetch_k16", "pmc_write_k16"):
+    p = os.path.join(SRC, label, "bench_results.db")
+    if os.path.exists(p):
+        for k, c, n, avg, tot in pmc_summary(p):
+            pm.setdefault(label, []).append(dict(kernel=short(k), counter=c, dispatches=n, avg=avg, total=tot))
+open(os.path.join(DST, "%s_pmc_counters.json" % TAG), "w").write(json.dumps(pm, indent=1))
+for label, items in pm.items():
+    for it in items:
+        if "integrate" in it["kernel"] or "finalize" in it["kernel"] or "init_from" in it["kernel"]:
+            print(label, it)
