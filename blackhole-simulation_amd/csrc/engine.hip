@@ -15,6 +15,7 @@
 #include <string>
 #include <vector>
 
+#include "control_plane.hpp"
 #include "engine_types.hpp"
 
 using namespace grvhip;
@@ -118,6 +119,9 @@ struct grv_engine {
     bool ev_ok = false;
 
     std::vector<float> sab;
+    float *sab_ext = nullptr; // attach_sab (lib.rs:74)
+    CameraFilter camera, last_good_camera;
+    float *sab_block() { return sab_ext ? sab_ext : sab.data(); }
 };
 
 namespace {
@@ -769,6 +773,74 @@ int grv_generate_spectrum_lut(grv_engine *e, size_t width, size_t height, double
 }
 
 const float *grv_get_sab_ptr(const grv_engine *e) { return e ? e->sab.data() : nullptr; }
+
+int grv_attach_sab(grv_engine *e, float *ptr) {
+    if (!e) return GRV_ERR_INVALID;
+    e->sab_ext = ptr;
+    return GRV_OK;
+}
+
+void grv_set_camera_state(grv_engine *e, double px, double py, double pz) {
+    if (!e) return;
+    e->camera.position[0] = px;
+    e->camera.position[1] = py;
+    e->camera.position[2] = pz;
+}
+
+void grv_set_auto_spin(grv_engine *e, int enabled) {
+    if (e) e->camera.auto_spin = enabled != 0;
+}
+
+int grv_tick_sab(grv_engine *e, double dt_override) {
+    if (!e) return GRV_ERR_INVALID;
+    tick_sab_host(e->sab_block(), e->mass, e->spin, e->spin_c, event_horizon(e->mass, e->spin_c),
+                  isco_prograde(e->mass, e->spin_c), e->camera, e->last_good_camera, dt_override);
+    return GRV_OK;
+}
+
+double grv_compute_disk_flux(const grv_engine *e, double r) {
+    return page_thorne_flux_host(r, e->mass, e->spin_c, 1.0);
+}
+
+double grv_compute_shadow_radius(const grv_engine *e) { return schwarzschild_shadow_radius_host(e->mass); }
+
+size_t grv_compute_shadow_curve(const grv_engine *e, double theta_obs, size_t n_points, float *out) {
+    if (!e || !out) return 0;
+    const std::vector<double> c = bardeen_shadow_host(e->mass, e->spin_c, theta_obs, n_points);
+    for (size_t i = 0; i < c.size(); ++i) out[i] = (float)c[i];
+    return c.size() / 2;
+}
+
+int grv_compute_shadow_shift(const grv_engine *e, double theta_obs, float out2[2]) {
+    if (!e || !out2) return GRV_ERR_INVALID;
+    const std::vector<double> c = bardeen_shadow_host(e->mass, e->spin_c, theta_obs, 32);
+    double lo = 0.0, hi = 0.0;
+    if (!c.empty()) {
+        lo = hi = c[0];
+        for (size_t i = 0; i < c.size(); i += 2) {
+            lo = c[i] < lo ? c[i] : lo;
+            hi = c[i] > hi ? c[i] : hi;
+        }
+    }
+    out2[0] = (float)lo;
+    out2[1] = (float)hi;
+    return GRV_OK;
+}
+
+int grv_generate_disk_lut(grv_engine *e, float *out512) {
+    if (!e) return GRV_ERR_INVALID;
+    if (!out512) return fail(e, GRV_ERR_INVALID, "null output");
+    GRV_HIP(e, hipSetDevice(e->device));
+    const uint32_t w = 512; // lut_width, lib.rs:65
+    int rc = ensure_stage(e, 4096 + w * sizeof(double));
+    if (rc != GRV_OK) return rc;
+    float *d_out = static_cast<float *>(e->stage_mem);
+    double *d_tmp = reinterpret_cast<double *>(static_cast<char *>(e->stage_mem) + 4096);
+    GRV_HIP(e, launch_disk_temperature_lut(d_out, d_tmp, w, e->mass, e->spin_c, nullptr));
+    GRV_HIP(e, hipDeviceSynchronize());
+    GRV_HIP(e, hipMemcpy(out512, d_out, w * sizeof(float), hipMemcpyDeviceToHost));
+    return GRV_OK;
+}
 
 void grv_get_sab_layout(size_t out5[5]) {
     if (!out5) return;

@@ -141,6 +141,22 @@ def load_library():
     L.grv_generate_spectrum_lut.argtypes = [p, sz, sz, d, p]
     L.grv_generate_spectrum_lut_device.restype = i
     L.grv_generate_spectrum_lut_device.argtypes = [p, sz, sz, d, p, p]
+    L.grv_generate_disk_lut.restype = i
+    L.grv_generate_disk_lut.argtypes = [p, p]
+    L.grv_compute_disk_flux.restype = d
+    L.grv_compute_disk_flux.argtypes = [p, d]
+    L.grv_compute_shadow_curve.restype = sz
+    L.grv_compute_shadow_curve.argtypes = [p, d, sz, p]
+    L.grv_compute_shadow_radius.restype = d
+    L.grv_compute_shadow_radius.argtypes = [p]
+    L.grv_compute_shadow_shift.restype = i
+    L.grv_compute_shadow_shift.argtypes = [p, d, p]
+    L.grv_attach_sab.restype = i
+    L.grv_attach_sab.argtypes = [p, p]
+    L.grv_set_camera_state.argtypes = [p, d, d, d]
+    L.grv_set_auto_spin.argtypes = [p, i]
+    L.grv_tick_sab.restype = i
+    L.grv_tick_sab.argtypes = [p, d]
     L.grv_get_sab_ptr.restype = p
     L.grv_get_sab_ptr.argtypes = [p]
     L.grv_get_sab_layout.argtypes = [p]
@@ -327,6 +343,49 @@ class PhysicsEngine:
         self._check(self._lib.grv_generate_spectrum_lut(self._h, width, height, float(max_temp),
                                                         _np_ptr(out)), "generate_spectrum_lut")
         return out
+
+    # ---- lib.rs:107-110, 161-205 ----
+    def generate_disk_lut(self):
+        out = np.zeros(512, np.float32)
+        self._check(self._lib.grv_generate_disk_lut(self._h, _np_ptr(out)), "generate_disk_lut")
+        return out
+
+    def compute_disk_flux(self, r):
+        return self._lib.grv_compute_disk_flux(self._h, float(r))
+
+    def compute_shadow_curve(self, theta_obs, n_points):
+        out = np.zeros(4 * n_points + 4, np.float32)
+        n = self._lib.grv_compute_shadow_curve(self._h, float(theta_obs), int(n_points), _np_ptr(out))
+        return out[:2 * n].copy()
+
+    def compute_shadow_radius(self):
+        return self._lib.grv_compute_shadow_radius(self._h)
+
+    def compute_shadow_shift(self, theta_obs):
+        out = np.zeros(2, np.float32)
+        self._check(self._lib.grv_compute_shadow_shift(self._h, float(theta_obs), _np_ptr(out)),
+                    "compute_shadow_shift")
+        return out
+
+    # ---- SAB protocol: lib.rs:74, 116-126, 308-409 ----
+    def attach_sab(self, array):
+        """`array`: C-contiguous float32 numpy array of >= 2048 elements kept alive by the caller."""
+        self._sab_keepalive = array
+        self._check(self._lib.grv_attach_sab(self._h, _np_ptr(array)), "attach_sab")
+
+    def set_camera_state(self, px, py, pz, lx=0.0, ly=0.0, lz=0.0):
+        self._lib.grv_set_camera_state(self._h, float(px), float(py), float(pz))
+
+    def set_auto_spin(self, enabled):
+        self._lib.grv_set_auto_spin(self._h, 1 if enabled else 0)
+
+    def tick_sab(self, dt_override):
+        self._check(self._lib.grv_tick_sab(self._h, float(dt_override)), "tick_sab")
+
+    def sab_view(self):
+        """Float32 view of the engine-owned 2048-float block (get_sab_ptr, lib.rs:116)."""
+        ptr = self._lib.grv_get_sab_ptr(self._h)
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(2048,))
 
     # ---- lib.rs:411-419 ----
     def get_sab_layout(self):

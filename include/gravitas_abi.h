@@ -185,9 +185,25 @@ int grv_generate_spectrum_lut(grv_engine *e, size_t width, size_t height, double
 int grv_generate_spectrum_lut_device(grv_engine *e, size_t width, size_t height,
                                      double max_temp, float *d_out, void *stream);
 
-/* ---- SAB protocol: lib.rs:36-40, 116-118, 411-419 (offsets in f32 elements) ---- */
+/* ---- disk / shadow helpers next to the path ---- */
+/* generate_disk_lut lib.rs:107-110 (physics/disk.rs:175-201): 512 normalised temperatures */
+int grv_generate_disk_lut(grv_engine *e, float *out512);
+/* compute_disk_flux lib.rs:198-200 (physics/disk.rs:90-151, m_dot = 1) */
+double grv_compute_disk_flux(const grv_engine *e, double r);
+/* compute_shadow_curve lib.rs:161-169 (physics/shadow.rs:81-183): writes (alpha, beta) pairs as
+ * f32; `out` must hold 4 * n_points floats; returns the number of points (n or 2n) */
+size_t grv_compute_shadow_curve(const grv_engine *e, double theta_obs, size_t n_points, float *out);
+/* compute_shadow_radius lib.rs:172-174 ; compute_shadow_shift lib.rs:178-195 */
+double grv_compute_shadow_radius(const grv_engine *e);
+int grv_compute_shadow_shift(const grv_engine *e, double theta_obs, float out2[2]);
+
+/* ---- SAB protocol: lib.rs:36-40, 74, 116-126, 308-419 (offsets in f32 elements) ---- */
 const float *grv_get_sab_ptr(const grv_engine *e);
 void grv_get_sab_layout(size_t out5[5]);
+int grv_attach_sab(grv_engine *e, float *ptr);                     /* attach_sab lib.rs:74 */
+void grv_set_camera_state(grv_engine *e, double px, double py, double pz); /* lib.rs:120 */
+void grv_set_auto_spin(grv_engine *e, int enabled);                /* lib.rs:124 */
+int grv_tick_sab(grv_engine *e, double dt_override);               /* lib.rs:308-409 */
 
 #ifdef __cplusplus
 }

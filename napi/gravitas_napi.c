@@ -1,0 +1,388 @@
+/*
+ * gravitas_napi.c -- thin N-API addon over the C ABI of include/gravitas_abi.h.
+ *
+ * Presents the surface wasm-pack generates for the reference's
+ * `#[wasm_bindgen] impl PhysicsEngine`
+ * (physics-engine/gravitas-wasm/src/lib.rs:56-465; consumers
+ * src/engine/physics-bridge.ts, src/workers/physics.worker.ts):
+ *   default export  init()  -> Promise<{memory: {buffer: ArrayBuffer}}>
+ *   class PhysicsEngine(mass, spin) with the wasm-bindgen method names
+ *   init_hooks()
+ * `memory.buffer` + `get_sab_ptr()` are emulated with one module-wide arena:
+ * each engine's 2048-float SAB block (lib.rs:67) lives inside it and
+ * get_sab_ptr() returns its byte offset, so
+ *   new Float32Array(wasm.memory.buffer, engine.get_sab_ptr(), 2048)
+ * (physics.worker.ts:61-68) works unchanged.
+ *
+ * Plain C, N-API v3 (works on Node >= 10; Bun implements the same API).
+ * Build: make -C napi   (gcc against /usr/include/node/node_api.h)
+ */
+#include <node_api.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/gravitas_abi.h"
+
+#define ARENA_BYTES (1u << 20)
+#define SAB_BYTES (2048u * 4u)
+
+static uint8_t *g_arena = NULL;
+static size_t g_arena_used = 0;
+static napi_ref g_arena_ref = NULL;
+
+typedef struct {
+    grv_engine *h;
+    size_t sab_off;
+} engine_box;
+
+#define NAPI_OK(call)                                                        \
+    do {                                                                     \
+        if ((call) != napi_ok) {                                             \
+            napi_throw_error(env, NULL, "N-API call failed: " #call);        \
+            return NULL;                                                     \
+        }                                                                    \
+    } while (0)
+
+static napi_value get_arena(napi_env env) {
+    napi_value buf;
+    if (g_arena_ref) {
+        if (napi_get_reference_value(env, g_arena_ref, &buf) == napi_ok && buf) return buf;
+    }
+    if (!g_arena) g_arena = (uint8_t *)calloc(1, ARENA_BYTES);
+    if (napi_create_external_arraybuffer(env, g_arena, ARENA_BYTES, NULL, NULL, &buf) != napi_ok)
+        return NULL;
+    napi_create_reference(env, buf, 1, &g_arena_ref);
+    return buf;
+}
+
+static engine_box *unwrap(napi_env env, napi_callback_info info, size_t *argc, napi_value *argv) {
+    napi_value self;
+    engine_box *box = NULL;
+    if (napi_get_cb_info(env, info, argc, argv, &self, NULL) != napi_ok) return NULL;
+    if (napi_unwrap(env, self, (void **)&box) != napi_ok || !box || !box->h) {
+        napi_throw_error(env, NULL, "PhysicsEngine: invalid receiver");
+        return NULL;
+    }
+    return box;
+}
+
+static double arg_f64(napi_env env, napi_value v) {
+    double d = 0.0;
+    napi_get_value_double(env, v, &d);
+    return d;
+}
+
+static napi_value mk_f64(napi_env env, double d) {
+    napi_value v;
+    napi_create_double(env, d, &v);
+    return v;
+}
+
+static void engine_finalize(napi_env env, void *data, void *hint) {
+    (void)env;
+    (void)hint;
+    engine_box *box = (engine_box *)data;
+    if (box) {
+        if (box->h) grv_engine_destroy(box->h);
+        free(box);
+    }
+}
+
+/* new PhysicsEngine(mass, spin)  -- lib.rs:59 */
+static napi_value engine_new(napi_env env, napi_callback_info info) {
+    size_t argc = 2;
+    napi_value argv[2], self;
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, &self, NULL));
+    double mass = argc > 0 ? arg_f64(env, argv[0]) : 1.0;
+    double spin = argc > 1 ? arg_f64(env, argv[1]) : 0.0;
+    engine_box *box = (engine_box *)calloc(1, sizeof *box);
+    int rc = grv_engine_create(mass, spin, 0, &box->h);
+    if (rc != GRV_OK) {
+        free(box);
+        napi_throw_error(env, NULL, rc == GRV_ERR_NO_DEVICE
+                                        ? "PhysicsEngine: no HIP device (this engine has no CPU path)"
+                                        : "PhysicsEngine: grv_engine_create failed");
+        return NULL;
+    }
+    (void)get_arena(env);
+    if (g_arena && g_arena_used + SAB_BYTES <= ARENA_BYTES) {
+        box->sab_off = g_arena_used;
+        g_arena_used += SAB_BYTES;
+        grv_attach_sab(box->h, (float *)(g_arena + box->sab_off)); /* attach_sab lib.rs:74 */
+    }
+    NAPI_OK(napi_wrap(env, self, box, engine_finalize, NULL, NULL));
+    return self;
+}
+
+static napi_value m_update_params(napi_env env, napi_callback_info info) { /* lib.rs:78 */
+    size_t argc = 2;
+    napi_value argv[2];
+    engine_box *b = unwrap(env, info, &argc, argv);
+    if (!b) return NULL;
+    grv_update_params(b->h, arg_f64(env, argv[0]), arg_f64(env, argv[1]));
+    return NULL;
+}
+
+#define SCALAR0(name, fn)                                                      \
+    static napi_value name(napi_env env, napi_callback_info info) {            \
+        size_t argc = 0;                                                       \
+        engine_box *b = unwrap(env, info, &argc, NULL);                        \
+        return b ? mk_f64(env, fn(b->h)) : NULL;                               \
+    }
+SCALAR0(m_compute_horizon, grv_compute_horizon)             /* lib.rs:85 */
+SCALAR0(m_compute_isco, grv_compute_isco)                   /* lib.rs:89 */
+SCALAR0(m_compute_photon_sphere, grv_compute_photon_sphere) /* lib.rs:93 */
+
+static napi_value m_compute_dilation(napi_env env, napi_callback_info info) { /* lib.rs:97 */
+    size_t argc = 1;
+    napi_value argv[1];
+    engine_box *b = unwrap(env, info, &argc, argv);
+    return b ? mk_f64(env, grv_compute_dilation(b->h, arg_f64(env, argv[0]))) : NULL;
+}
+
+static napi_value m_compute_g_factor(napi_env env, napi_callback_info info) { /* lib.rs:203 */
+    size_t argc = 2;
+    napi_value argv[2];
+    engine_box *b = unwrap(env, info, &argc, argv);
+    return b ? mk_f64(env, grv_compute_g_factor(b->h, arg_f64(env, argv[0]), arg_f64(env, argv[1])))
+             : NULL;
+}
+
+/* integrate_ray_relativistic(Float64Array|number[], steps, tolerance, useKS) -> Float64Array
+ * lib.rs:422-464 */
+static napi_value m_integrate_ray(napi_env env, napi_callback_info info) {
+    size_t argc = 4;
+    napi_value argv[4];
+    engine_box *b = unwrap(env, info, &argc, argv);
+    if (!b) return NULL;
+    double in[64];
+    size_t n = 0;
+    bool is_ta = false;
+    napi_is_typedarray(env, argv[0], &is_ta);
+    if (is_ta) {
+        napi_typedarray_type ty;
+        size_t len;
+        void *data;
+        NAPI_OK(napi_get_typedarray_info(env, argv[0], &ty, &len, &data, NULL, NULL));
+        if (ty != napi_float64_array) {
+            napi_throw_type_error(env, NULL, "initial_state must be a Float64Array");
+            return NULL;
+        }
+        n = len > 64 ? 64 : len;
+        memcpy(in, data, n * sizeof(double));
+    } else {
+        uint32_t len = 0;
+        NAPI_OK(napi_get_array_length(env, argv[0], &len));
+        n = len > 64 ? 64 : len;
+        for (uint32_t i = 0; i < n; i++) {
+            napi_value e;
+            napi_get_element(env, argv[0], i, &e);
+            in[i] = arg_f64(env, e);
+        }
+    }
+    uint32_t steps = 0;
+    napi_get_value_uint32(env, argv[1], &steps);
+    double tol = arg_f64(env, argv[2]);
+    bool ks = false;
+    napi_get_value_bool(env, argv[3], &ks);
+    double out[64];
+    size_t m = grv_integrate_ray_relativistic(b->h, in, n, steps, tol, ks ? 1 : 0, out);
+    napi_value ab, ta;
+    void *dst;
+    NAPI_OK(napi_create_arraybuffer(env, m * sizeof(double), &dst, &ab));
+    memcpy(dst, out, m * sizeof(double));
+    NAPI_OK(napi_create_typedarray(env, napi_float64_array, m, ab, 0, &ta));
+    return ta;
+}
+
+/* generate_spectrum_lut(w, h, maxTemp) -> Float32Array[w*h*4]   lib.rs:128-136 */
+static napi_value m_generate_spectrum_lut(napi_env env, napi_callback_info info) {
+    size_t argc = 3;
+    napi_value argv[3];
+    engine_box *b = unwrap(env, info, &argc, argv);
+    if (!b) return NULL;
+    uint32_t w = 0, h = 0;
+    napi_get_value_uint32(env, argv[0], &w);
+    napi_get_value_uint32(env, argv[1], &h);
+    double tmax = arg_f64(env, argv[2]);
+    size_t n = (size_t)w * h * 4;
+    napi_value ab, ta;
+    void *dst;
+    NAPI_OK(napi_create_arraybuffer(env, n * sizeof(float), &dst, &ab));
+    if (n && grv_generate_spectrum_lut(b->h, w, h, tmax, (float *)dst) != GRV_OK) {
+        napi_throw_error(env, NULL, grv_last_error(b->h));
+        return NULL;
+    }
+    NAPI_OK(napi_create_typedarray(env, napi_float32_array, n, ab, 0, &ta));
+    return ta;
+}
+
+/* generate_disk_lut() -> Float32Array[512]   lib.rs:107-110 */
+static napi_value m_generate_disk_lut(napi_env env, napi_callback_info info) {
+    size_t argc = 0;
+    engine_box *b = unwrap(env, info, &argc, NULL);
+    if (!b) return NULL;
+    napi_value ab, ta;
+    void *dst;
+    NAPI_OK(napi_create_arraybuffer(env, 512 * sizeof(float), &dst, &ab));
+    grv_generate_disk_lut(b->h, (float *)dst);
+    NAPI_OK(napi_create_typedarray(env, napi_float32_array, 512, ab, 0, &ta));
+    return ta;
+}
+
+/* compute_shadow_curve(theta_obs, n) -> Float32Array[2n]   lib.rs:161-169 */
+static napi_value m_compute_shadow_curve(napi_env env, napi_callback_info info) {
+    size_t argc = 2;
+    napi_value argv[2];
+    engine_box *b = unwrap(env, info, &argc, argv);
+    if (!b) return NULL;
+    uint32_t n = 0;
+    napi_get_value_uint32(env, argv[1], &n);
+    if (n > 4096) n = 4096;
+    float *tmp = (float *)malloc((size_t)2 * (n + 4) * sizeof(float));
+    size_t m = grv_compute_shadow_curve(b->h, arg_f64(env, argv[0]), n, tmp);
+    napi_value ab, ta;
+    void *dst;
+    NAPI_OK(napi_create_arraybuffer(env, 2 * m * sizeof(float), &dst, &ab));
+    memcpy(dst, tmp, 2 * m * sizeof(float));
+    free(tmp);
+    NAPI_OK(napi_create_typedarray(env, napi_float32_array, 2 * m, ab, 0, &ta));
+    return ta;
+}
+
+static napi_value m_compute_shadow_radius(napi_env env, napi_callback_info info) { /* lib.rs:172 */
+    size_t argc = 0;
+    engine_box *b = unwrap(env, info, &argc, NULL);
+    return b ? mk_f64(env, grv_compute_shadow_radius(b->h)) : NULL;
+}
+
+static napi_value m_compute_disk_flux(napi_env env, napi_callback_info info) { /* lib.rs:198 */
+    size_t argc = 1;
+    napi_value argv[1];
+    engine_box *b = unwrap(env, info, &argc, argv);
+    return b ? mk_f64(env, grv_compute_disk_flux(b->h, arg_f64(env, argv[0]))) : NULL;
+}
+
+static napi_value m_set_camera_state(napi_env env, napi_callback_info info) { /* lib.rs:120 */
+    size_t argc = 6;
+    napi_value argv[6];
+    engine_box *b = unwrap(env, info, &argc, argv);
+    if (!b) return NULL;
+    grv_set_camera_state(b->h, arg_f64(env, argv[0]), arg_f64(env, argv[1]), arg_f64(env, argv[2]));
+    return NULL;
+}
+
+static napi_value m_set_auto_spin(napi_env env, napi_callback_info info) { /* lib.rs:124 */
+    size_t argc = 1;
+    napi_value argv[1];
+    engine_box *b = unwrap(env, info, &argc, argv);
+    if (!b) return NULL;
+    bool on = false;
+    napi_get_value_bool(env, argv[0], &on);
+    grv_set_auto_spin(b->h, on ? 1 : 0);
+    return NULL;
+}
+
+static napi_value m_tick_sab(napi_env env, napi_callback_info info) { /* lib.rs:308 */
+    size_t argc = 1;
+    napi_value argv[1];
+    engine_box *b = unwrap(env, info, &argc, argv);
+    if (!b) return NULL;
+    grv_tick_sab(b->h, argc > 0 ? arg_f64(env, argv[0]) : 0.0);
+    return NULL;
+}
+
+static napi_value m_get_sab_ptr(napi_env env, napi_callback_info info) { /* lib.rs:116 */
+    size_t argc = 0;
+    engine_box *b = unwrap(env, info, &argc, NULL);
+    if (!b) return NULL;
+    napi_value v;
+    napi_create_uint32(env, (uint32_t)b->sab_off, &v);
+    return v;
+}
+
+static napi_value m_get_sab_layout(napi_env env, napi_callback_info info) { /* lib.rs:411 */
+    (void)info;
+    size_t off[5];
+    grv_get_sab_layout(off);
+    napi_value arr;
+    NAPI_OK(napi_create_array_with_length(env, 5, &arr));
+    for (uint32_t i = 0; i < 5; i++) {
+        napi_value v;
+        napi_create_uint32(env, (uint32_t)off[i], &v);
+        napi_set_element(env, arr, i, v);
+    }
+    return arr;
+}
+
+static napi_value m_free(napi_env env, napi_callback_info info) { /* wasm-bindgen's .free() */
+    size_t argc = 0;
+    napi_value self;
+    engine_box *box = NULL;
+    NAPI_OK(napi_get_cb_info(env, info, &argc, NULL, &self, NULL));
+    if (napi_unwrap(env, self, (void **)&box) == napi_ok && box && box->h) {
+        grv_engine_destroy(box->h);
+        box->h = NULL;
+    }
+    return NULL;
+}
+
+/* default export: init() -> { memory: { buffer } }  (physics-bridge.ts:87-88) */
+static napi_value f_init(napi_env env, napi_callback_info info) {
+    (void)info;
+    napi_value mem, out, buf = get_arena(env);
+    NAPI_OK(napi_create_object(env, &mem));
+    NAPI_OK(napi_set_named_property(env, mem, "buffer", buf));
+    NAPI_OK(napi_create_object(env, &out));
+    NAPI_OK(napi_set_named_property(env, out, "memory", mem));
+    napi_deferred d;
+    napi_value promise;
+    NAPI_OK(napi_create_promise(env, &d, &promise));
+    napi_resolve_deferred(env, d, out);
+    return promise;
+}
+
+static napi_value f_init_hooks(napi_env env, napi_callback_info info) { /* lib.rs:30-33 */
+    (void)env;
+    (void)info;
+    return NULL;
+}
+
+#define METHOD(n, f) {n, NULL, f, NULL, NULL, NULL, napi_default, NULL}
+
+static napi_value module_init(napi_env env, napi_value exports) {
+    napi_property_descriptor props[] = {
+        METHOD("update_params", m_update_params),
+        METHOD("compute_horizon", m_compute_horizon),
+        METHOD("compute_isco", m_compute_isco),
+        METHOD("compute_photon_sphere", m_compute_photon_sphere),
+        METHOD("compute_dilation", m_compute_dilation),
+        METHOD("compute_g_factor", m_compute_g_factor),
+        METHOD("integrate_ray_relativistic", m_integrate_ray),
+        METHOD("integratePhotonGeodesic", m_integrate_ray),
+        METHOD("generate_spectrum_lut", m_generate_spectrum_lut),
+        METHOD("generate_disk_lut", m_generate_disk_lut),
+        METHOD("compute_shadow_curve", m_compute_shadow_curve),
+        METHOD("compute_shadow_radius", m_compute_shadow_radius),
+        METHOD("compute_disk_flux", m_compute_disk_flux),
+        METHOD("set_camera_state", m_set_camera_state),
+        METHOD("set_auto_spin", m_set_auto_spin),
+        METHOD("tick_sab", m_tick_sab),
+        METHOD("get_sab_ptr", m_get_sab_ptr),
+        METHOD("get_sab_layout", m_get_sab_layout),
+        METHOD("free", m_free),
+    };
+    napi_value cls, fn;
+    NAPI_OK(napi_define_class(env, "PhysicsEngine", NAPI_AUTO_LENGTH, engine_new, NULL,
+                              sizeof props / sizeof props[0], props, &cls));
+    NAPI_OK(napi_set_named_property(env, exports, "PhysicsEngine", cls));
+    NAPI_OK(napi_create_function(env, "init", NAPI_AUTO_LENGTH, f_init, NULL, &fn));
+    NAPI_OK(napi_set_named_property(env, exports, "default", fn));
+    NAPI_OK(napi_set_named_property(env, exports, "init", fn));
+    NAPI_OK(napi_create_function(env, "init_hooks", NAPI_AUTO_LENGTH, f_init_hooks, NULL, &fn));
+    NAPI_OK(napi_set_named_property(env, exports, "init_hooks", fn));
+    return exports;
+}
+
+NAPI_MODULE(blackhole_physics, module_init)

@@ -56,12 +56,22 @@ class FrameStats(C.Structure):
                 ("max_drift", C.c_double)]
 
 
+class CameraState(C.Structure):
+    _fields_ = [("position", C.c_double * 3), ("velocity", C.c_double * 3),
+                ("orientation", C.c_double * 4), ("auto_spin", C.c_int)]
+
+
+class SabEngine(C.Structure):
+    _fields_ = [("mass", C.c_double), ("spin", C.c_double), ("camera", CameraState),
+                ("last_good", CameraState), ("sab", C.c_float * 2048)]
+
+
 def build(force=False):
     """Compile the oracle with its Makefile (gcc)."""
     if force or not os.path.exists(_LIB_PATH) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
             for f in ("gravitas_oracle.c", "gravitas_oracle.h", "frame_oracle.c",
-                      "frame_oracle.h", "Makefile")):
+                      "frame_oracle.h", "control_oracle.c", "control_oracle.h", "Makefile")):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _LIB_PATH
 
@@ -139,6 +149,18 @@ def lib():
         L.orc_lut_sample.argtypes = [p, C.c_uint32, C.c_uint32, d, d, d, p]
         L.orc_disk_temp_profile.restype = d
         L.orc_disk_temp_profile.argtypes = [d, d]
+        L.orc_page_thorne_flux.restype = d
+        L.orc_page_thorne_flux.argtypes = [d, d, d, d]
+        L.orc_disk_temperature.restype = d
+        L.orc_disk_temperature.argtypes = [d, d, d, d]
+        L.orc_generate_temperature_lut.argtypes = [d, d, C.c_size_t, p]
+        L.orc_schwarzschild_shadow_radius.restype = d
+        L.orc_schwarzschild_shadow_radius.argtypes = [d]
+        L.orc_bardeen_shadow.restype = C.c_size_t
+        L.orc_bardeen_shadow.argtypes = [d, d, d, C.c_size_t, p]
+        L.orc_sab_engine_init.argtypes = [C.POINTER(SabEngine), d, d]
+        L.orc_camera_update.argtypes = [C.POINTER(CameraState), d, d, d, d]
+        L.orc_tick_sab.argtypes = [C.POINTER(SabEngine), d]
         _lib = L
     return _lib
 
@@ -272,3 +294,26 @@ def render_frame(cam, fp, lut=None, stride=(1, 1), nthreads=1, want_states=True)
                            C.byref(st), nthreads)
     return dict(rgba=rgba, states=states, steps=steps, term=term, drift=drift, stats=st,
                 shape=(ny, nx))
+
+
+def temperature_lut(mass, spin, width=512):
+    out = np.zeros(width, np.float32)
+    lib().orc_generate_temperature_lut(mass, spin, width, _ptr(out))
+    return out
+
+
+def bardeen_shadow(mass, spin, theta_obs, n_points):
+    out = np.zeros(4 * n_points + 4, np.float64)
+    n = lib().orc_bardeen_shadow(mass, spin, theta_obs, n_points, _ptr(out))
+    return out[:2 * n].reshape(n, 2).copy()
+
+
+def sab_engine(mass, spin):
+    e = SabEngine()
+    lib().orc_sab_engine_init(C.byref(e), mass, spin)
+    return e
+
+
+def tick_sab(e, dt_override):
+    lib().orc_tick_sab(C.byref(e), dt_override)
+    return np.frombuffer(e.sab, dtype=np.float32).copy()
