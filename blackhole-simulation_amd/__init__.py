@@ -8,6 +8,7 @@ there is no CPU fallback in this package.
 from .engine import (  # noqa: F401
     ARITH_FAST, ARITH_STRICT, KERR_BL, KERR_KS, METHOD_RK4, METHOD_RKF45, METHOD_SYMPLECTIC,
     SCHWARZSCHILD, TERM_DISK_CROSSING, TERM_ESCAPE, TERM_HORIZON, TERM_MAXSTEPS, TERM_NONE,
-    Camera, FrameBuffers, FrameStats, GravitasError, Options, PhysicsEngine, RenderParams,
-    build_library, camera_look_at, library_path, load_library, render_params, unpack_tiles,
+    Camera, FrameBuffers, FrameStats, GlslParams, GravitasError, Options, PhysicsEngine,
+    RenderParams, WgslParams, build_library, camera_look_at, glsl_params, library_path,
+    load_library, render_params, unpack_tiles, wgsl_params,
 )

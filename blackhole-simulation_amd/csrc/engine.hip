@@ -333,6 +333,33 @@ void stats_to_abi(const grv_engine *e, const FrameStatsDev &d, GrvFrameStats *ou
 
 } // namespace
 
+namespace {
+template <typename Launch>
+int run_shader_frame(grv_engine *e, uint32_t width, uint32_t height, uint32_t tw, uint32_t tr,
+                     uint64_t *total_steps, hipStream_t s, Launch &&launch) {
+    if (width == 0 || height == 0) return fail(e, GRV_ERR_INVALID, "empty frame");
+    if (tw > 1 && tr >= tw) return fail(e, GRV_ERR_INVALID, "tile_rank >= tile_world");
+    GRV_HIP(e, hipSetDevice(e->device));
+    GrvRenderParams q{};
+    q.width = width;
+    q.height = height;
+    q.tile_world = tw;
+    q.tile_rank = tr;
+    FrameGeom G;
+    frame_geometry(q, G);
+    const size_t slots = (size_t)G.n_tiles_local * 4096u;
+    GRV_HIP(e, hipMemsetAsync(e->d_stats, 0, sizeof(FrameStatsDev), s));
+    if (slots > 0x7FFFFFFFull) return fail(e, GRV_ERR_INVALID, "frame too large for one rank");
+    GRV_HIP(e, launch(G, (uint32_t)slots, &e->d_stats->accepted_steps));
+    if (total_steps) {
+        GRV_HIP(e, hipMemcpyAsync(e->h_stats, e->d_stats, sizeof(FrameStatsDev), hipMemcpyDeviceToHost, s));
+        GRV_HIP(e, hipStreamSynchronize(s));
+        *total_steps = e->h_stats->accepted_steps;
+    }
+    return GRV_OK;
+}
+} // namespace
+
 // ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
@@ -681,6 +708,95 @@ int grv_unpack_tiles(const GrvRenderParams *p, uint32_t rank, const void *packed
         }
     }
     return GRV_OK;
+}
+
+void grv_wgsl_params_default(uint32_t width, uint32_t height, const GrvCamera *cam, double mass,
+                             double spin, GrvWgslParams *p) {
+    if (!p) return;
+    std::memset(p, 0, sizeof *p);
+    p->width = width;
+    p->height = height;
+    if (cam) {
+        for (int k = 0; k < 16; ++k) {
+            p->inv_view[k] = (float)cam->inv_view[k];
+            p->inv_proj[k] = (float)cam->inv_proj[k];
+        }
+        for (int k = 0; k < 3; ++k) p->position[k] = (float)cam->position[k];
+    }
+    p->mass = (float)mass;
+    p->spin = (float)spin;
+    p->max_steps = 150; // compute.wgsl.ts:13
+    p->tile_world = 1;
+}
+
+void grv_glsl_params_default(uint32_t width, uint32_t height, double mass, double spin,
+                             GrvGlslParams *p) {
+    if (!p) return;
+    std::memset(p, 0, sizeof *p);
+    p->width = width;
+    p->height = height;
+    p->mass = (float)mass;
+    p->spin = (float)(spin * mass);              // renderer.ts:326
+    p->zoom = 30.0f * 2.0f;                       // simulation.config.ts:118-119, renderer.ts:327
+    p->mouse[0] = 0.5f;
+    p->mouse[1] = 97.0f / 180.0f;                 // simulation.config.ts:106-107
+    p->disk_size = 50.0f;                         // simulation.config.ts:138-139
+    p->disk_scale_height = 0.2f;                  // :147-148
+    p->disk_density = 4.0f;                       // :167-168
+    p->disk_temp = (float)(9500.0 * std::pow(mass, -0.25)); // renderer.ts:352-356
+    p->lensing_strength = 1.0f;                   // renderer.ts:340
+    p->time = 0.0f;
+    p->turbulence = 0.75f;
+    p->max_ray_steps = 256;                       // simulation.config.ts:205-211 (ultra)
+    p->tone_map = 0;
+    p->tile_world = 1;
+}
+
+
+int grv_render_frame_wgsl(grv_engine *e, const GrvWgslParams *p, float *d_rgba, uint32_t *d_steps,
+                          uint64_t *total_steps, void *stream) {
+    if (!e) return GRV_ERR_INVALID;
+    if (!p || !d_rgba) return fail(e, GRV_ERR_INVALID, "null argument");
+    WgslParams P{};
+    std::memcpy(P.inv_view, p->inv_view, sizeof P.inv_view);
+    std::memcpy(P.inv_proj, p->inv_proj, sizeof P.inv_proj);
+    std::memcpy(P.position, p->position, sizeof P.position);
+    P.mass = p->mass;
+    P.spin = p->spin;
+    P.jitter[0] = p->jitter[0];
+    P.jitter[1] = p->jitter[1];
+    P.max_steps = p->max_steps;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return run_shader_frame(e, p->width, p->height, p->tile_world, p->tile_rank, total_steps, s,
+                            [&](const FrameGeom &G, uint32_t n, unsigned long long *tot) {
+                                return launch_wgsl_symplectic(G, P, d_rgba, d_steps, tot, n, s);
+                            });
+}
+
+int grv_render_frame_glsl(grv_engine *e, const GrvGlslParams *p, float *d_rgba, uint32_t *d_steps,
+                          uint64_t *total_steps, void *stream) {
+    if (!e) return GRV_ERR_INVALID;
+    if (!p || !d_rgba) return fail(e, GRV_ERR_INVALID, "null argument");
+    GlslParams P{};
+    P.mass = p->mass;
+    P.spin = p->spin;
+    P.zoom = p->zoom;
+    P.mouse[0] = p->mouse[0];
+    P.mouse[1] = p->mouse[1];
+    P.disk_size = p->disk_size;
+    P.disk_scale_height = p->disk_scale_height;
+    P.disk_density = p->disk_density;
+    P.disk_temp = p->disk_temp;
+    P.lensing_strength = p->lensing_strength;
+    P.time = p->time;
+    P.turbulence = p->turbulence;
+    P.max_ray_steps = p->max_ray_steps;
+    P.tone_map = p->tone_map;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return run_shader_frame(e, p->width, p->height, p->tile_world, p->tile_rank, total_steps, s,
+                            [&](const FrameGeom &G, uint32_t n, unsigned long long *tot) {
+                                return launch_glsl_verlet(G, P, d_rgba, d_steps, tot, n, s);
+                            });
 }
 
 int grv_unpack_tiles_device(grv_engine *e, const GrvRenderParams *p, uint32_t rank,

@@ -69,6 +69,23 @@ struct ShadeParams {
     uint32_t lds_row0, lds_rows; // LUT rows staged in LDS
 };
 
+// uniforms of the two f32 shader kernels (mirrors GrvWgslParams / GrvGlslParams)
+struct WgslParams {
+    float inv_view[16];
+    float inv_proj[16];
+    float position[3];
+    float mass, spin;
+    float jitter[2];
+    int32_t max_steps;
+};
+struct GlslParams {
+    float mass, spin, zoom;
+    float mouse[2];
+    float disk_size, disk_scale_height, disk_density, disk_temp;
+    float lensing_strength, time, turbulence;
+    int32_t max_ray_steps, tone_map;
+};
+
 struct FrameStatsDev {
     unsigned long long accepted_steps, rkf_tries, term_count[5], crossings, rays;
     unsigned long long max_drift_bits;
@@ -94,6 +111,12 @@ hipError_t launch_finalize_frame(const RayWorkspace &ws, const FrameGeom &G, con
                                  hipStream_t s);
 hipError_t launch_unpack_tiles(const FrameGeom &G, const void *packed, void *image,
                                uint32_t words_per_pixel, hipStream_t s);
+hipError_t launch_wgsl_symplectic(const FrameGeom &G, const WgslParams &P, float *out_rgba,
+                                  uint32_t *out_steps, unsigned long long *total_steps,
+                                  uint32_t n_slots, hipStream_t s);
+hipError_t launch_glsl_verlet(const FrameGeom &G, const GlslParams &P, float *out_rgba,
+                              uint32_t *out_steps, unsigned long long *total_steps,
+                              uint32_t n_slots, hipStream_t s);
 hipError_t launch_spectrum_lut(float *out, uint32_t width, uint32_t height, double max_temp,
                                hipStream_t s);
 // ---- launcher (kernels_fast.hip: -ffp-contract=fast) ----

@@ -1,7 +1,7 @@
 // kernels_strict.hip -- STRICT arithmetic contract: compiled with
 // -ffp-contract=off (reference operation order, IEEE divide/sqrt, no FMA).
 // Also holds the kernels that exist once: init, live-list, finalize/shade, LUT.
-#include "frame_kernels.hpp"
+#include "shader_kernels.hpp"
 
 namespace grvhip {
 
@@ -122,6 +122,24 @@ hipError_t launch_unpack_tiles(const FrameGeom &G, const void *packed, void *ima
     hipLaunchKernelGGL(unpack_tiles_kernel, dim3((uint32_t)grid), dim3(kBlock), 0, s, G,
                        static_cast<const uint32_t *>(packed), static_cast<uint32_t *>(image),
                        words_per_pixel);
+    return hipGetLastError();
+}
+
+hipError_t launch_wgsl_symplectic(const FrameGeom &G, const WgslParams &P, float *out_rgba,
+                                  uint32_t *out_steps, unsigned long long *total_steps,
+                                  uint32_t n_slots, hipStream_t s) {
+    if (n_slots == 0) return hipSuccess;
+    hipLaunchKernelGGL(wgsl_symplectic_kernel, dim3((n_slots + kBlock - 1) / kBlock), dim3(kBlock), 0,
+                       s, G, P, reinterpret_cast<float4 *>(out_rgba), out_steps, total_steps, n_slots);
+    return hipGetLastError();
+}
+
+hipError_t launch_glsl_verlet(const FrameGeom &G, const GlslParams &P, float *out_rgba,
+                              uint32_t *out_steps, unsigned long long *total_steps,
+                              uint32_t n_slots, hipStream_t s) {
+    if (n_slots == 0) return hipSuccess;
+    hipLaunchKernelGGL(glsl_verlet_kernel, dim3((n_slots + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
+                       G, P, reinterpret_cast<float4 *>(out_rgba), out_steps, total_steps, n_slots);
     return hipGetLastError();
 }
 

@@ -58,6 +58,23 @@ class FrameStats(C.Structure):
                 ("total_ms", C.c_float)]
 
 
+class WgslParams(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("inv_view", C.c_float * 16),
+                ("inv_proj", C.c_float * 16), ("position", C.c_float * 3), ("mass", C.c_float),
+                ("spin", C.c_float), ("jitter", C.c_float * 2), ("max_steps", C.c_int32),
+                ("tile_world", C.c_uint32), ("tile_rank", C.c_uint32)]
+
+
+class GlslParams(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("mass", C.c_float),
+                ("spin", C.c_float), ("zoom", C.c_float), ("mouse", C.c_float * 2),
+                ("disk_size", C.c_float), ("disk_scale_height", C.c_float),
+                ("disk_density", C.c_float), ("disk_temp", C.c_float),
+                ("lensing_strength", C.c_float), ("time", C.c_float), ("turbulence", C.c_float),
+                ("max_ray_steps", C.c_int32), ("tone_map", C.c_int32),
+                ("tile_world", C.c_uint32), ("tile_rank", C.c_uint32)]
+
+
 class FrameBuffers(C.Structure):
     _fields_ = [("rgba", C.c_void_p), ("final_state", C.c_void_p), ("steps", C.c_void_p),
                 ("termination", C.c_void_p), ("drift", C.c_void_p)]
@@ -141,6 +158,13 @@ def load_library():
     L.grv_generate_spectrum_lut.argtypes = [p, sz, sz, d, p]
     L.grv_generate_spectrum_lut_device.restype = i
     L.grv_generate_spectrum_lut_device.argtypes = [p, sz, sz, d, p, p]
+    L.grv_wgsl_params_default.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(Camera), d, d,
+                                          C.POINTER(WgslParams)]
+    L.grv_glsl_params_default.argtypes = [C.c_uint32, C.c_uint32, d, d, C.POINTER(GlslParams)]
+    L.grv_render_frame_wgsl.restype = i
+    L.grv_render_frame_wgsl.argtypes = [p, C.POINTER(WgslParams), p, p, C.POINTER(C.c_uint64), p]
+    L.grv_render_frame_glsl.restype = i
+    L.grv_render_frame_glsl.argtypes = [p, C.POINTER(GlslParams), p, p, C.POINTER(C.c_uint64), p]
     L.grv_generate_disk_lut.restype = i
     L.grv_generate_disk_lut.argtypes = [p, p]
     L.grv_compute_disk_flux.restype = d
@@ -204,6 +228,22 @@ def render_params(width, height, **kw):
             setattr(p.opt, k, v)
         else:
             setattr(p, k, v)
+    return p
+
+
+def wgsl_params(width, height, camera, mass=1.0, spin=0.999, **kw):
+    p = WgslParams()
+    load_library().grv_wgsl_params_default(width, height, C.byref(camera), mass, spin, C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def glsl_params(width, height, mass=1.0, spin=0.999, **kw):
+    p = GlslParams()
+    load_library().grv_glsl_params_default(width, height, mass, spin, C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
     return p
 
 
@@ -325,6 +365,22 @@ class PhysicsEngine:
         self._check(self._lib.grv_render_frame_device(
             self._h, C.byref(camera), C.byref(params), C.byref(fb),
             C.c_void_p(stream) if stream else None), "render_frame_device")
+
+    def render_frame_wgsl(self, params, rgba, steps=None, stream=None):
+        """f32 WGSL-semantics frame (compute.wgsl.ts); returns total symplectic steps."""
+        tot = C.c_uint64(0)
+        self._check(self._lib.grv_render_frame_wgsl(
+            self._h, C.byref(params), _dev_ptr(rgba), _dev_ptr(steps), C.byref(tot),
+            C.c_void_p(stream) if stream else None), "render_frame_wgsl")
+        return tot.value
+
+    def render_frame_glsl(self, params, rgba, steps=None, stream=None):
+        """f32 GLSL-semantics frame (fragment.glsl.ts march); returns total Verlet steps."""
+        tot = C.c_uint64(0)
+        self._check(self._lib.grv_render_frame_glsl(
+            self._h, C.byref(params), _dev_ptr(rgba), _dev_ptr(steps), C.byref(tot),
+            C.c_void_p(stream) if stream else None), "render_frame_glsl")
+        return tot.value
 
     def frame_stats(self, stream=None):
         st = FrameStats()

@@ -171,6 +171,42 @@ int grv_unpack_tiles_device(grv_engine *e, const GrvRenderParams *p, uint32_t ra
                             const void *d_packed, void *d_image, size_t bytes_per_pixel,
                             void *stream);
 
+/* ---- f32 march loops of the reference's GPU shaders ----
+ * Uniform blocks as the shaders receive them.  Outputs are device pointers: RGBA f32
+ * [n][4] and (optional) per-pixel step counts, in this rank's pixel order. */
+typedef struct { /* src/shaders/compute.wgsl.ts + types.wgsl.ts:6-30 */
+    uint32_t width, height;
+    float inv_view[16], inv_proj[16], position[3];
+    float mass, spin;        /* PhysicsParams.mass / .spin */
+    float jitter[2];         /* halton(frame)-0.5 in pixels (compute.wgsl.ts:154-157); 0 = none */
+    int32_t max_steps;       /* override MAX_STEPS, default 150 (compute.wgsl.ts:13) */
+    uint32_t tile_world, tile_rank;
+} GrvWgslParams;
+
+typedef struct { /* src/shaders/blackhole/chunks/common.ts:8-35 uniforms used by the march */
+    uint32_t width, height;
+    float mass;              /* u_mass */
+    float spin;              /* u_spin as uploaded: spin * mass (src/rendering/webgl/renderer.ts:326) */
+    float zoom;              /* u_zoom = zoom * 2 (renderer.ts:327) */
+    float mouse[2];          /* u_mouse */
+    float disk_size, disk_scale_height, disk_density, disk_temp, lensing_strength, time;
+    float turbulence;        /* stands in for the two unseeded noise() fetches of disk.ts:55 */
+    int32_t max_ray_steps;   /* u_maxRaySteps (shader clamps to 500, fragment.glsl.ts:115) */
+    int32_t tone_map;        /* 0: ENABLE_LINEAR_OUTPUT, 1: ACES + gamma (fragment.glsl.ts:327-331) */
+    uint32_t tile_world, tile_rank;
+} GrvGlslParams;
+
+void grv_wgsl_params_default(uint32_t width, uint32_t height, const GrvCamera *cam, double mass,
+                             double spin, GrvWgslParams *p);
+void grv_glsl_params_default(uint32_t width, uint32_t height, double mass, double spin,
+                             GrvGlslParams *p);
+/* accepted steps of the last shader frame are returned through *total_steps (host) after a
+ * stream synchronise; d_steps may be NULL */
+int grv_render_frame_wgsl(grv_engine *e, const GrvWgslParams *p, float *d_rgba, uint32_t *d_steps,
+                          uint64_t *total_steps, void *stream);
+int grv_render_frame_glsl(grv_engine *e, const GrvGlslParams *p, float *d_rgba, uint32_t *d_steps,
+                          uint64_t *total_steps, void *stream);
+
 /* camera helpers (gl-matrix lookAt/perspective as src/components/canvas/WebGPUCanvas.tsx:143-157) */
 void grv_camera_look_at(const double eye[3], const double target[3], const double up[3],
                         double fovy_rad, double aspect, GrvCamera *cam);

@@ -66,12 +66,29 @@ class SabEngine(C.Structure):
                 ("last_good", CameraState), ("sab", C.c_float * 2048)]
 
 
+class WgslParams(C.Structure):
+    _fields_ = [("inv_view", C.c_float * 16), ("inv_proj", C.c_float * 16),
+                ("position", C.c_float * 3), ("mass", C.c_float), ("spin", C.c_float),
+                ("width", C.c_uint32), ("height", C.c_uint32), ("jitter", C.c_float * 2),
+                ("max_steps", C.c_int32)]
+
+
+class GlslParams(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("mass", C.c_float),
+                ("spin", C.c_float), ("zoom", C.c_float), ("mouse", C.c_float * 2),
+                ("disk_size", C.c_float), ("disk_scale_height", C.c_float),
+                ("disk_density", C.c_float), ("disk_temp", C.c_float),
+                ("lensing_strength", C.c_float), ("time", C.c_float), ("turbulence", C.c_float),
+                ("max_ray_steps", C.c_int32), ("tone_map", C.c_int32)]
+
+
 def build(force=False):
     """Compile the oracle with its Makefile (gcc)."""
     if force or not os.path.exists(_LIB_PATH) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
             for f in ("gravitas_oracle.c", "gravitas_oracle.h", "frame_oracle.c",
-                      "frame_oracle.h", "control_oracle.c", "control_oracle.h", "Makefile")):
+                      "frame_oracle.h", "control_oracle.c", "control_oracle.h", "shader_oracle.c",
+                      "shader_oracle.h", "Makefile")):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _LIB_PATH
 
@@ -158,6 +175,8 @@ def lib():
         L.orc_schwarzschild_shadow_radius.argtypes = [d]
         L.orc_bardeen_shadow.restype = C.c_size_t
         L.orc_bardeen_shadow.argtypes = [d, d, d, C.c_size_t, p]
+        L.orc_wgsl_frame.argtypes = [C.POINTER(WgslParams), C.c_uint32, C.c_uint32, p, p, i]
+        L.orc_glsl_frame.argtypes = [C.POINTER(GlslParams), C.c_uint32, C.c_uint32, p, p, i]
         L.orc_sab_engine_init.argtypes = [C.POINTER(SabEngine), d, d]
         L.orc_camera_update.argtypes = [C.POINTER(CameraState), d, d, d, d]
         L.orc_tick_sab.argtypes = [C.POINTER(SabEngine), d]
@@ -317,3 +336,45 @@ def sab_engine(mass, spin):
 def tick_sab(e, dt_override):
     lib().orc_tick_sab(C.byref(e), dt_override)
     return np.frombuffer(e.sab, dtype=np.float32).copy()
+
+
+def wgsl_params_from(gp):
+    """oracle WgslParams from the engine's GrvWgslParams (same uniform values)."""
+    o = WgslParams()
+    for k in range(16):
+        o.inv_view[k] = gp.inv_view[k]
+        o.inv_proj[k] = gp.inv_proj[k]
+    for k in range(3):
+        o.position[k] = gp.position[k]
+    o.mass, o.spin, o.width, o.height = gp.mass, gp.spin, gp.width, gp.height
+    o.jitter[0], o.jitter[1] = gp.jitter[0], gp.jitter[1]
+    o.max_steps = gp.max_steps
+    return o
+
+
+def glsl_params_from(gp):
+    o = GlslParams()
+    for f, _ in GlslParams._fields_:
+        v = getattr(gp, f)
+        if f == "mouse":
+            o.mouse[0], o.mouse[1] = v[0], v[1]
+        else:
+            setattr(o, f, v)
+    return o
+
+
+def _shader_frame(fn, params, stride, nthreads):
+    nx = (params.width + stride[0] - 1) // stride[0]
+    ny = (params.height + stride[1] - 1) // stride[1]
+    rgba = np.zeros((ny, nx, 4), np.float32)
+    steps = np.zeros((ny, nx), np.uint32)
+    fn(C.byref(params), stride[0], stride[1], _ptr(rgba), _ptr(steps), nthreads)
+    return rgba, steps
+
+
+def wgsl_frame(params, stride=(1, 1), nthreads=1):
+    return _shader_frame(lib().orc_wgsl_frame, params, stride, nthreads)
+
+
+def glsl_frame(params, stride=(1, 1), nthreads=1):
+    return _shader_frame(lib().orc_glsl_frame, params, stride, nthreads)

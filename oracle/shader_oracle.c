@@ -1,0 +1,482 @@
+/*
+ * shader_oracle.c -- f32 restatement of the reference's GPU march loops.
+ * TEST INFRASTRUCTURE ONLY; see shader_oracle.h.
+ *
+ * Restated as written: every formula of the cited shader lines, in f32, in the
+ * shader's evaluation order.  Deliberately fixed (the reference is not
+ * reproducible there):
+ *   - WGSL star hash (compute.wgsl.ts:201-204): omitted, background = 0;
+ *   - GLSL blue-noise dither (fragment.glsl.ts:105-108): bNoise = 0;
+ *   - GLSL disk turbulence (disk.ts:55): the two noise() fetches are replaced by the
+ *     caller's `turbulence` value (0.75 = a uniform texture of 1.0);
+ *   - GLSL jets / stars / photon-ring glow / ergosphere glow: not part of a16/a17.
+ * GLSL built-ins: normalize(v) = v / sqrt(dot(v,v)); smoothstep, clamp, mix, sign as in
+ * the GLSL ES 3.00 specification.
+ */
+#include "shader_oracle.h"
+
+#include <math.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ helpers */
+typedef struct { float x, y, z; } v3;
+
+static float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+static float dot3(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static v3 cross3(v3 a, v3 b) {
+    v3 r = {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+    return r;
+}
+static v3 scale3(v3 a, float s) { v3 r = {a.x * s, a.y * s, a.z * s}; return r; }
+static v3 add3(v3 a, v3 b) { v3 r = {a.x + b.x, a.y + b.y, a.z + b.z}; return r; }
+static float length3(v3 a) { return sqrtf(dot3(a, a)); }
+static v3 normalize3(v3 a) {
+    float l = length3(a);
+    v3 r = {a.x / l, a.y / l, a.z / l};
+    return r;
+}
+static float smoothstepf(float e0, float e1, float x) {
+    float t = clampf((x - e0) / (e1 - e0), 0.0f, 1.0f);
+    return t * t * (3.0f - 2.0f * t);
+}
+static float signf(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+
+/* ========================================================================== */
+/* WGSL compute kernel                                                         */
+/* ========================================================================== */
+typedef struct { float x[4]; float p[4]; } ray32;
+
+/* compute.wgsl.ts:28-32 */
+static float wgsl_horizon(float M, float a) {
+    float disc = M * M - a * a;
+    if (disc < 0.0f) return M;
+    return M + sqrtf(disc);
+}
+/* compute.wgsl.ts:34-40 */
+static float wgsl_isco(float M, float a) {
+    float rs = a / M;
+    float absS = fabsf(clampf(rs, -0.999f, 0.999f));
+    float z1 = 1.0f + powf(1.0f - absS * absS, 1.0f / 3.0f) *
+                          (powf(1.0f + absS, 1.0f / 3.0f) + powf(1.0f - absS, 1.0f / 3.0f));
+    float z2 = sqrtf(3.0f * absS * absS + z1 * z1);
+    return M * (3.0f + z2 - sqrtf((3.0f - z1) * (3.0f + z1 + 2.0f * z2)));
+}
+
+/* compute.wgsl.ts:42-120 */
+static void wgsl_derivs(const ray32 *s, float M, float spin, float dx[4], float dp[4]) {
+    float a = spin * M;
+    float r = s->x[1], theta = s->x[2];
+    float r2 = r * r, a2 = a * a;
+    float sint = sinf(theta), cost = cosf(theta);
+    float sin2 = fmaxf(sint * sint, 1e-12f);
+    float cos2 = 1.0f - sin2;
+    float sigma = r2 + a2 * cos2;
+    float sigma2 = sigma * sigma;
+    float delta = r2 - 2.0f * M * r + a2;
+
+    float g_tt = -(1.0f + 2.0f * M * r / sigma);
+    float g_tr = 2.0f * M * r / sigma;
+    float g_rr = delta / sigma;
+    float g_thth = 1.0f / sigma;
+    float g_phph = 1.0f / (sigma * sin2);
+    float g_rph = a / sigma;
+    const float *p = s->p;
+
+    dx[0] = g_tt * p[0] + g_tr * p[1];
+    dx[1] = g_tr * p[0] + g_rr * p[1] + g_rph * p[3];
+    dx[2] = g_thth * p[2];
+    dx[3] = g_rph * p[1] + g_phph * p[3];
+
+    float dsigma_dr = 2.0f * r;
+    float dsigma_dth = -2.0f * a2 * sint * cost;
+    float ddelta_dr = 2.0f * r - 2.0f * M;
+
+    float dg_tt_dr = -(2.0f * M * (sigma - r * dsigma_dr)) / sigma2;
+    float dg_tt_dth = (2.0f * M * r * dsigma_dth) / sigma2;
+    float dg_tr_dr = -dg_tt_dr;
+    float dg_tr_dth = -dg_tt_dth;
+    float dg_rr_dr = (ddelta_dr * sigma - delta * dsigma_dr) / sigma2;
+    float dg_rr_dth = -(delta * dsigma_dth) / sigma2;
+    float dg_thth_dr = -dsigma_dr / sigma2;
+    float dg_thth_dth = -dsigma_dth / sigma2;
+    float dg_phph_dr = -dsigma_dr / (sigma2 * sin2);
+    float dg_phph_dth = -(dsigma_dth * sin2 + sigma * sinf(2.0f * theta)) / (sigma2 * sin2 * sin2);
+    float dg_rph_dr = -(a * dsigma_dr) / sigma2;
+    float dg_rph_dth = -(a * dsigma_dth) / sigma2;
+
+    float dh_dr = 0.5f * (dg_tt_dr * p[0] * p[0] + dg_rr_dr * p[1] * p[1] + dg_thth_dr * p[2] * p[2] +
+                          dg_phph_dr * p[3] * p[3] + 2.0f * dg_tr_dr * p[0] * p[1] +
+                          2.0f * dg_rph_dr * p[1] * p[3]);
+    float dh_dth = 0.5f * (dg_tt_dth * p[0] * p[0] + dg_rr_dth * p[1] * p[1] +
+                           dg_thth_dth * p[2] * p[2] + dg_phph_dth * p[3] * p[3] +
+                           2.0f * dg_tr_dth * p[0] * p[1] + 2.0f * dg_rph_dth * p[1] * p[3]);
+    dp[0] = 0.0f;
+    dp[1] = -dh_dr;
+    dp[2] = -dh_dth;
+    dp[3] = 0.0f;
+}
+
+/* compute.wgsl.ts:122-133 */
+static ray32 wgsl_symplectic(const ray32 *s, float h, float M, float spin) {
+    ray32 mid = *s;
+    float dx[4], dp[4];
+    for (int it = 0; it < 2; it++) {
+        wgsl_derivs(&mid, M, spin, dx, dp);
+        for (int k = 0; k < 4; k++) {
+            float nx = s->x[k] + dx[k] * h, np = s->p[k] + dp[k] * h;
+            mid.x[k] = (s->x[k] + nx) * 0.5f;
+            mid.p[k] = (s->p[k] + np) * 0.5f;
+        }
+    }
+    wgsl_derivs(&mid, M, spin, dx, dp);
+    ray32 out;
+    for (int k = 0; k < 4; k++) {
+        out.x[k] = s->x[k] + dx[k] * h;
+        out.p[k] = s->p[k] + dp[k] * h;
+    }
+    return out;
+}
+
+static void m4v4(const float *m, const float v[4], float out[4]) {
+    for (int r = 0; r < 4; r++)
+        out[r] = m[0 + r] * v[0] + m[4 + r] * v[1] + m[8 + r] * v[2] + m[12 + r] * v[3];
+}
+
+/* compute.wgsl.ts:147-258 */
+uint32_t orc_wgsl_pixel(const orc_wgsl_params *P, uint32_t ix, uint32_t iy, float rgba[4]) {
+    const float PI = 3.14159265f;
+    float fw = (float)P->width, fh = (float)P->height;
+    float jx = P->jitter[0] / fw, jy = P->jitter[1] / fh;
+    float uvx = (float)ix / fw, uvy = (float)iy / fh;
+    float ndcx = (uvx + jx) * 2.0f - 1.0f;
+    float ndcy = (uvy + jy) * 2.0f - 1.0f;
+
+    float clip[4] = {ndcx, -ndcy, 1.0f, 1.0f}, vt[4];
+    m4v4(P->inv_proj, clip, vt);
+    v3 vd = {vt[0] / vt[3], vt[1] / vt[3], vt[2] / vt[3]};
+    vd = normalize3(vd);
+    float vd4[4] = {vd.x, vd.y, vd.z, 0.0f}, wd4[4];
+    m4v4(P->inv_view, vd4, wd4);
+    v3 wd = {wd4[0], wd4[1], wd4[2]};
+    wd = normalize3(wd);
+
+    v3 cam = {P->position[0], P->position[1], P->position[2]};
+    float r0 = length3(cam);
+    float theta0 = acosf(clampf(cam.y / r0, -1.0f, 1.0f));
+    float phi0 = atan2f(cam.z, cam.x);
+    float st = sinf(theta0), ct = cosf(theta0), sp = sinf(phi0), cp = cosf(phi0);
+
+    v3 e_r = {st * cp, ct, st * sp}, e_th = {ct * cp, -st, ct * sp}, e_ph = {-sp, 0.0f, cp};
+    float pr_far = dot3(wd, e_r);
+    float pth_far = dot3(wd, e_th) / r0;
+    float safe_st = fmaxf(st, 1e-4f);
+    float pph_far = dot3(wd, e_ph) / (r0 * safe_st);
+
+    ray32 s;
+    s.x[0] = 0.0f; s.x[1] = r0; s.x[2] = theta0; s.x[3] = phi0;
+    s.p[0] = -1.0f; s.p[1] = pr_far; s.p[2] = pth_far * r0 * r0; s.p[3] = pph_far * r0 * r0 * st * st;
+
+    float M = P->mass;
+    float a = P->spin * M;
+    float rh = wgsl_horizon(M, a);
+    float isco = wgsl_isco(M, a);
+
+    float color[3] = {0.0f, 0.0f, 0.0f};
+    float alpha = 0.0f;
+    uint32_t steps = 0;
+
+    for (int i = 0; i < P->max_steps; i++) {
+        float r = s.x[1];
+        if (r < rh * 1.001f) break;
+        if (r > 100.0f) break; /* stars omitted */
+        float prev_theta = s.x[2];
+        float h = clampf((r - rh) * 0.15f, 0.05f, 1.0f);
+        s = wgsl_symplectic(&s, h, M, P->spin);
+        steps++;
+        float curr_theta = s.x[2];
+        if ((prev_theta - PI * 0.5f) * (curr_theta - PI * 0.5f) <= 0.0f && r > isco && r < 30.0f) {
+            float Omega = 1.0f / (powf(r, 1.5f) + a);
+            float u_t = 1.0f / sqrtf(fmaxf(1.0f - 2.0f * M / r - Omega * Omega * (r * r + a * a), 1e-4f));
+            float u_phi = Omega * u_t;
+            float g_factor = -s.p[0] / fmaxf(-(u_t * s.p[0] + u_phi * s.p[3]), 1e-4f);
+            float artistic_T = (1.0f / powf(fmaxf(r / isco, 1.0f), 0.75f)) * g_factor;
+            float base[3] = {1.0f, 0.5f, 0.1f}, blue[3] = {0.5f, 0.7f, 1.0f}, red[3] = {1.0f, 0.2f, 0.0f};
+            float bs = fmaxf(g_factor - 1.0f, 0.0f), rs = fmaxf(1.0f - g_factor, 0.0f) * 0.5f;
+            float target_opacity = 0.6f * artistic_T;
+            float g4 = powf(g_factor, 4.0f);
+            float mri_shear = powf(r, -1.5f);
+            float mri_sat = 1.0f + 0.0001f * sinf(r * 100.0f * mri_shear);
+            for (int c = 0; c < 3; c++) {
+                float target = (base[c] + blue[c] * bs - red[c] * rs) * artistic_T * 4.0f;
+                float I_em = target * target_opacity / fmaxf(g4, 1e-5f);
+                float j_nu = I_em * mri_sat;
+                float I_obs = g4 * j_nu;
+                color[c] += I_obs * (1.0f - alpha);
+            }
+            alpha += target_opacity * mri_sat;
+        }
+        if (alpha > 0.99f) break;
+    }
+    rgba[0] = color[0]; rgba[1] = color[1]; rgba[2] = color[2]; rgba[3] = 1.0f;
+    return steps;
+}
+
+void orc_wgsl_frame(const orc_wgsl_params *p, uint32_t sx, uint32_t sy, float *rgba,
+                    uint32_t *steps, int nthreads) {
+    if (sx == 0) sx = 1;
+    if (sy == 0) sy = 1;
+    if (nthreads < 1) nthreads = 1;
+    uint32_t nx = (p->width + sx - 1) / sx, ny = (p->height + sy - 1) / sy;
+    long long total = (long long)nx * ny;
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nthreads) if (nthreads > 1)
+    for (long long k = 0; k < total; k++) {
+        float px[4];
+        uint32_t st = orc_wgsl_pixel(p, (uint32_t)(k % nx) * sx, (uint32_t)(k / nx) * sy, px);
+        if (rgba) memcpy(&rgba[k * 4], px, sizeof px);
+        if (steps) steps[k] = st;
+    }
+}
+
+/* ========================================================================== */
+/* GLSL fragment march                                                         */
+/* ========================================================================== */
+#define GL_PI 3.14159265359f
+#define GL_MAX_DIST 10000.0f /* physics.config.ts:60 */
+#define GL_MIN_STEP 0.01f    /* :61 */
+#define GL_MAX_STEP 1.2f     /* :62 */
+#define GL_HORIZON_THRESHOLD 1.15f /* :63 */
+
+/* chunks/metric.ts:13-37 */
+static float gl_horizon(float M, float a) { return M + sqrtf(fmaxf(0.0f, M * M - a * a)); }
+static float gl_isco(float M, float a) {
+    float rs = a / M;
+    float absS = fabsf(clampf(rs, -0.9999f, 0.9999f));
+    float z1 = 1.0f + powf(1.0f - absS * absS, 1.0f / 3.0f) *
+                          (powf(1.0f + absS, 1.0f / 3.0f) + powf(1.0f - absS, 1.0f / 3.0f));
+    float z2 = sqrtf(3.0f * absS * absS + z1 * z1);
+    float signOfA = signf(a);
+    if (signOfA == 0.0f) signOfA = 1.0f;
+    return M * (3.0f + z2 - signOfA * sqrtf((3.0f - z1) * (3.0f + z1 + 2.0f * z2)));
+}
+static float gl_photon_sphere(float M, float a) {
+    float a_star = clampf(a / M, -0.9999f, 0.9999f);
+    float arg = clampf(-a_star, -1.0f, 1.0f);
+    float theta = (2.0f / 3.0f) * acosf(arg);
+    return 2.0f * M * (1.0f + cosf(theta));
+}
+
+/* chunks/metric.ts:96-149 */
+static v3 gl_kerr_accel(v3 p, v3 v, float M, float a, float *omega) {
+    float a2 = a * a;
+    float rho2 = dot3(p, p);
+    float diff = rho2 - a2;
+    float disc = diff * diff + 4.0f * a2 * p.y * p.y;
+    float r2 = 0.5f * (diff + sqrtf(fmaxf(0.0f, disc)));
+    float r_k = sqrtf(fmaxf(1e-8f, r2));
+
+    float sigma = r2 + a2 * (p.y * p.y / fmaxf(1e-8f, r2));
+    v3 L = cross3(p, v);
+    float Ly = L.y;
+    float Ly_eff = Ly - a;
+    float L2_eff = Ly_eff * Ly_eff + (dot3(L, L) - Ly * Ly);
+
+    float r_inv = 1.0f / r_k;
+    float r2_inv = r_inv * r_inv;
+    float r4_inv = r2_inv * r2_inv;
+    float sigma_ratio = r2 / fmaxf(1e-8f, sigma);
+    v3 n = normalize3(p);
+    v3 r_hat = {-n.x, -n.y, -n.z};
+    v3 acc = scale3(r_hat, M * r2_inv * sigma_ratio + 3.0f * M * fmaxf(0.0f, L2_eff) * r4_inv * sigma_ratio);
+
+    float r3_p_a2r = r_k * r2 + a2 * r_k;
+    float drag = 2.0f * M * a / fmaxf(1e-8f, r3_p_a2r);
+    v3 yhat = {0.0f, 1.0f, 0.0f};
+    acc = add3(acc, scale3(cross3(yhat, v), drag));
+    *omega = 2.0f * M * a / fmaxf(1e-8f, r3_p_a2r);
+    return acc;
+}
+
+/* chunks/blackbody.ts:9-34 */
+static void gl_blackbody(float temp, float rgb[3]) {
+    float t = fmaxf(temp, 1.0f) / 100.0f;
+    float r, g, b;
+    if (t <= 66.0f) {
+        r = 255.0f;
+        g = 99.4708025861f * logf(t) - 161.1195681661f;
+        if (t <= 19.0f) b = 0.0f;
+        else b = 138.5177312231f * logf(t - 10.0f) - 305.0447927307f;
+    } else {
+        r = 329.698727446f * powf(t - 60.0f, -0.1332047592f);
+        g = 288.1221695283f * powf(t - 60.0f, -0.0755148492f);
+        b = 255.0f;
+    }
+    rgb[0] = powf(fmaxf(r / 255.0f, 0.0f), 2.2f);
+    rgb[1] = powf(fmaxf(g / 255.0f, 0.0f), 2.2f);
+    rgb[2] = powf(fmaxf(b / 255.0f, 0.0f), 2.2f);
+}
+
+/* chunks/common.ts:44-47 : mat2(c,-s,s,c), and `v.xy *= m` is row-vector * matrix */
+static void gl_rot_apply(float ang, float *x, float *y) {
+    float s = sinf(ang), c = cosf(ang);
+    float nx = *x * c + *y * (-s);
+    float ny = *x * s + *y * c;
+    *x = nx;
+    *y = ny;
+}
+
+/* chunks/disk.ts:16-115 */
+static void gl_sample_disk(const orc_glsl_params *U, v3 p, v3 p_prev, v3 v, float isco, float M,
+                           float a, float dt, float color[3], float *alpha) {
+    int crossed = (p_prev.y * p.y < 0.0f);
+    v3 sp = p;
+    if (crossed) {
+        float t = fabsf(p_prev.y) / fmaxf(0.0001f, fabsf(p_prev.y) + fabsf(p.y));
+        sp.x = p_prev.x * (1.0f - t) + p.x * t; /* mix */
+        sp.y = p_prev.y * (1.0f - t) + p.y * t;
+        sp.z = p_prev.z * (1.0f - t) + p.z * t;
+    }
+    float sampleR = length3(sp);
+    float effH = fminf(U->disk_scale_height, 0.45f); /* physics.config.ts:49 */
+    float diskHeight = sampleR * effH;
+    float diskInner = isco;
+    float diskOuter = fmaxf(M * U->disk_size, diskInner * 1.1f);
+    if (!((fabsf(sp.y) < diskHeight || crossed) && sampleR > diskInner && sampleR < diskOuter)) return;
+
+    float turbulence = U->turbulence;
+    float samplesDiskHeight = sampleR * effH;
+    float heightFalloff = expf(-fabsf(sp.y) / fmaxf(0.001f, samplesDiskHeight * 0.25f));
+    float radialFalloff = smoothstepf(diskOuter, diskInner, sampleR);
+    float baseDensity = turbulence * heightFalloff * radialFalloff;
+    if (!(baseDensity > 0.001f)) return;
+
+    float r2 = sampleR * sampleR;
+    float sqrt_M = sqrtf(M);
+    float signSpin = signf(U->spin + 1e-8f);
+    float Omega = (signSpin * sqrt_M) / (sampleR * sqrtf(sampleR) + a * sqrt_M);
+    float g_tt = -(1.0f - 2.0f * M / sampleR);
+    float g_tphi = -2.0f * M * a / sampleR;
+    float g_phiphi = r2 + a * a + 2.0f * M * a * a / sampleR;
+    float u_t_sq = -(g_tt + 2.0f * Omega * g_tphi + Omega * Omega * g_phiphi);
+    float u_t = 1.0f / sqrtf(fmaxf(1e-6f, u_t_sq));
+    float L_photon = p.z * v.x - p.x * v.z;
+    float delta = 1.0f / fmaxf(0.01f, u_t * (1.0f - Omega * L_photon));
+    float beaming = fmaxf(0.01f, powf(delta, 3.5f));
+    float isco_r = clampf(isco / sampleR, 0.0f, 1.0f);
+    float nt_factor = fmaxf(0.0f, 1.0f - sqrtf(isco_r));
+    float radialTempGradient = powf(isco_r, 0.75f) * powf(nt_factor, 0.25f);
+    float temperature = U->disk_temp * radialTempGradient * delta;
+    float bb[3];
+    gl_blackbody(temperature, bb);
+    float density = baseDensity * U->disk_density * 0.12f * dt;
+    for (int c = 0; c < 3; c++) color[c] += bb[c] * beaming * density * (1.0f - *alpha);
+    *alpha += density;
+}
+
+static float aces(float c) { /* chunks/common.ts:50-57 */
+    const float A = 2.51f, B = 0.03f, C = 2.43f, D = 0.59f, E = 0.14f;
+    return clampf((c * (A * c + B)) / (c * (C * c + D) + E), 0.0f, 1.0f);
+}
+
+/* fragment.glsl.ts:40-221 (+ 276, 327-333), fallback camera (u_camPos = 0, renderer.ts:313) */
+uint32_t orc_glsl_pixel(const orc_glsl_params *U, uint32_t ix, uint32_t iy, float rgba[4]) {
+    float resx = (float)U->width, resy = (float)U->height;
+    float minRes = fminf(resx, resy);
+    /* gl_FragCoord = pixel centre, origin bottom-left; iy counts image rows from the top */
+    float fcx = (float)ix + 0.5f, fcy = (float)(U->height - 1u - iy) + 0.5f;
+    float uvx = (fcx - 0.5f * resx) / minRes, uvy = (fcy - 0.5f * resy) / minRes;
+
+    v3 ro = {0.0f, 0.0f, -U->zoom};
+    v3 rd = {uvx, uvy, 1.5f};
+    rd = normalize3(rd);
+    float ax = (U->mouse[1] - 0.5f) * GL_PI, ay = (U->mouse[0] - 0.5f) * GL_PI * 2.0f;
+    gl_rot_apply(ax, &ro.y, &ro.z);
+    gl_rot_apply(ax, &rd.y, &rd.z);
+    gl_rot_apply(ay, &ro.x, &ro.z);
+    gl_rot_apply(ay, &rd.x, &rd.z);
+
+    float M = U->mass;
+    float rs = M * 2.0f;
+    float a = U->spin * M;
+    float rh = gl_horizon(M, a);
+    float rph = gl_photon_sphere(M, a);
+    float isco = gl_isco(M, a);
+    (void)rs;
+
+    v3 p = ro, v = rd;
+    if (length3(ro) < rh * 1.5f) {
+        ro = scale3(scale3(normalize3(ro), rh), 1.5f); /* normalize(ro) * rh * 1.5 */
+        p = ro;
+    }
+    float color[3] = {0.0f, 0.0f, 0.0f};
+    float alpha = 0.0f;
+    int hitHorizon = 0;
+    float impactParam = length3(cross3(ro, rd));
+    int maxSteps = (int)fminf((float)U->max_ray_steps, 500.0f);
+    v3 p_prev = p;
+    if (impactParam < rh * 0.9f) hitHorizon = 1;
+    uint32_t steps = 0;
+
+    for (int i = 0; i < maxSteps; i++) {
+        p_prev = p;
+        float r = length3(p);
+        if (r < rh * GL_HORIZON_THRESHOLD) {
+            hitHorizon = 1;
+            break;
+        }
+        if (r > GL_MAX_DIST) break;
+
+        float distFactor = 1.0f + r * 0.05f;
+        float dt = clampf((r - rh) * 0.1f * distFactor, GL_MIN_STEP, GL_MAX_STEP * distFactor);
+        if (r > 30.0f) {
+            float farBoost = (r - 30.0f) * 0.08f;
+            dt = fmaxf(dt, GL_MIN_STEP + farBoost);
+            dt = fminf(dt, GL_MAX_STEP * 2.5f);
+        }
+        float sphereProx = fabsf(r - rph);
+        dt = fminf(dt, GL_MIN_STEP + sphereProx * 0.15f);
+        float hRefinement = smoothstepf(0.2f, 0.0f, fabsf(p.y));
+        float currentDt = dt * (1.0f - hRefinement * 0.7f);
+
+        float omega;
+        v3 accel = scale3(gl_kerr_accel(p, v, M, a, &omega), U->lensing_strength);
+        gl_rot_apply(omega * currentDt, &v.x, &v.z); /* ZAMO twist of the velocity */
+
+        p = add3(p, add3(scale3(v, currentDt), scale3(scale3(scale3(accel, 0.5f), currentDt), currentDt)));
+        float r_new = length3(p);
+        if (alpha < 0.95f) {
+            float om2;
+            v3 accel_new = scale3(gl_kerr_accel(p, v, M, a, &om2), U->lensing_strength);
+            v = add3(v, scale3(scale3(add3(accel, accel_new), 0.5f), currentDt));
+        }
+        v = normalize3(v);
+        steps++;
+
+        gl_sample_disk(U, p, p_prev, v, isco, M, a, currentDt, color, &alpha);
+        (void)r_new;
+        if (alpha > 0.99f) break;
+    }
+    (void)hitHorizon; /* background / glow terms are zero in this restatement */
+    for (int c = 0; c < 3; c++) {
+        float f = color[c];
+        if (U->tone_map) f = powf(fmaxf(aces(f), 0.0f), 0.4545f);
+        rgba[c] = f;
+    }
+    rgba[3] = 1.0f;
+    return steps;
+}
+
+void orc_glsl_frame(const orc_glsl_params *p, uint32_t sx, uint32_t sy, float *rgba,
+                    uint32_t *steps, int nthreads) {
+    if (sx == 0) sx = 1;
+    if (sy == 0) sy = 1;
+    if (nthreads < 1) nthreads = 1;
+    uint32_t nx = (p->width + sx - 1) / sx, ny = (p->height + sy - 1) / sy;
+    long long total = (long long)nx * ny;
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nthreads) if (nthreads > 1)
+    for (long long k = 0; k < total; k++) {
+        float px[4];
+        uint32_t st = orc_glsl_pixel(p, (uint32_t)(k % nx) * sx, (uint32_t)(k / nx) * sy, px);
+        if (rgba) memcpy(&rgba[k * 4], px, sizeof px);
+        if (steps) steps[k] = st;
+    }
+}
