@@ -92,8 +92,28 @@ def timing():
                   f"init {st.init_ms:.2f} integ {st.integrate_ms:.2f} shade {st.shade_ms:.2f} total {st.total_ms:.2f} ms -> {st.accepted_steps/dt/1e6:.0f} Mray-steps/s  frac={(st.accepted_steps*144+n*96)/dt/8e12:.3f}", flush=True)
     eng.close()
 
+def shader_timing():
+    eng = bh.PhysicsEngine(1.0, 0.999)
+    for (W, H, ms) in ((1920, 1080, 512), (3840, 2160, 512), (7680, 4320, 1024)):
+        n = W * H
+        rgba = torch.zeros(n, 4, dtype=torch.float32, device="cuda:0")
+        cam = bh.camera_look_at(EYE3, aspect=W / H)
+        for name, fn, gp in (("wgsl-symplectic-f32", eng.render_frame_wgsl, bh.wgsl_params(W, H, cam, 1.0, 0.999, max_steps=ms)),
+                             ("glsl-verlet-f32", eng.render_frame_glsl, bh.glsl_params(W, H, 1.0, 0.999, max_ray_steps=ms))):
+            fn(gp, rgba); torch.cuda.synchronize()
+            t = time.time(); reps = 5
+            for _ in range(reps):
+                tot = fn(gp, rgba)
+            torch.cuda.synchronize(); dt = (time.time() - t) / reps
+            print(f"{name} {W}x{H} max_steps={ms}: {dt*1e3:.2f} ms/frame, {tot/1e6:.1f} M steps, {tot/dt/1e6:.0f} Mray-steps/s, "
+                  f"frac(72 B/step + 16 B/ray)={(tot*72+n*16)/dt/8e12:.3f}", flush=True)
+    eng.close()
+
+EYE3 = (60.0 * np.sin(np.deg2rad(97.0)), 60.0 * np.cos(np.deg2rad(97.0)), 0.0)
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["batch", "frame", "timing"]
     if "batch" in what: batch_check()
     if "frame" in what: frame_check()
     if "timing" in what: timing()
+    if "shader" in what: shader_timing()

@@ -67,3 +67,34 @@ for label, items in pm.items():
     for it in items:
         if "integrate" in it["kernel"] or "finalize" in it["kernel"] or "init_from" in it["kernel"]:
             print(label, it)
+
+# HBM traffic of the dominant kernel per launch (bench.py reads profiles/traffic.json)
+def _avg(label, counter):
+    for it in pm.get(label, []):
+        if "integrate_segment_kernel" in it["kernel"] and it["counter"] == counter:
+            return it["avg"]
+    return None
+
+f, w = _avg("pmc_fetch", "FETCH_SIZE"), _avg("pmc_write", "WRITE_SIZE")
+if f is not None and w is not None:
+    # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  gfx950 correction
+    # (/opt/skills/guides/MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 64 B per 128-B request
+    # on coalesced streaming reads -> x2.  Cross-check: 8 355 840 slots x 92 B read = 0.769 GB,
+    # x 76 B written = 0.635 GB.
+    traffic = {
+        "kernel": "integrate_segment_kernel<KerrSchild,FAST,RKF45>",
+        "command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline",
+        "fetch_size_kib_raw_avg_per_launch": f,
+        "write_size_kib_avg_per_launch": w,
+        "fetch_correction": 2.0,
+        "hbm_bytes_per_launch": int((2.0 * f + w) * 1024),
+        "expected_from_layout_bytes": 8355840 * (92 + 76),
+    }
+    f2, w2 = _avg("pmc_fetch_k16", "FETCH_SIZE"), _avg("pmc_write_k16", "WRITE_SIZE")
+    if f2 is not None and w2 is not None:
+        traffic["segment_tries_16"] = {"fetch_size_kib_raw_avg_per_launch": f2,
+                                       "write_size_kib_avg_per_launch": w2,
+                                       "hbm_bytes_per_launch": int((2.0 * f2 + w2) * 1024),
+                                       "launches_per_frame": 32}
+    open(os.path.join(DST, "traffic.json"), "w").write(json.dumps(traffic, indent=1))
+    print(json.dumps(traffic, indent=1))
