@@ -98,8 +98,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ  # under torchrun even a 1-rank job walks the RCCL path
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
@@ -115,21 +118,24 @@ def main():
     rp = D.rank_params(params, world, rank)
     n_local = eng.frame_ray_count(rp)
     stream = torch.cuda.current_stream().cuda_stream
-    bufs = [torch.empty((n_local, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+    # all buffers live outside the frame loop: the padded send buffer doubles as the render
+    # target, rank 0 additionally holds the receive slots and the assembled image
+    tg = D.TileGather(params, world, rank, 4, torch.float32, torch.device("cuda", local_rank)) \
+        if use_dist else None
+    buf = tg.local_view(n_local) if tg else torch.empty((n_local, 4), dtype=torch.float32, device="cuda")
 
     def dev_unpack(rparams, r, packed, image):
         eng.unpack_tiles_device(rparams, r, packed, image, 16, stream)
 
     def one_frame(i):
-        buf = bufs[i & 1]
         eng.render_frame_device(cam, rp, rgba=buf, stream=stream)
         st = eng.frame_stats(stream)
-        if world > 1:
-            D.gather_tiles(buf, params, world, rank, None, dev_unpack)
+        if tg:
+            tg.run(dev_unpack, force_collective=True)  # the one exchange: gather tiles -> rank 0
         return st
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -149,7 +155,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     agg = torch.tensor([elapsed, float(steps_local), float(n_local)], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         tmax = agg[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(agg[1:], op=dist.ReduceOp.SUM)
@@ -192,7 +198,7 @@ def main():
         print(json.dumps(line), flush=True)
 
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

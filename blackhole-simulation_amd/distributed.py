@@ -35,34 +35,53 @@ def rank_params(params, world, rank):
     return p
 
 
+class TileGather:
+    """Pre-allocated buffers for the per-frame gather: the padded send buffer, rank 0's
+    receive slots and the assembled image are created once, outside the frame loop."""
+
+    def __init__(self, params, world, rank, channels, dtype, device, group=None):
+        import torch
+        self.params, self.world, self.rank, self.group = params, world, rank, group
+        self.n_max = max_tiles_per_rank(params.width, params.height, world) * TILE * TILE
+        self.send = torch.zeros((self.n_max, channels), dtype=dtype, device=device)
+        self.parts = None
+        self.image = None
+        if rank == 0:
+            self.parts = [torch.empty((self.n_max, channels), dtype=dtype, device=device)
+                          for _ in range(world)]
+            self.image = torch.zeros((params.height, params.width, channels), dtype=dtype, device=device)
+        self.rparams = [rank_params(params, world, r) for r in range(world)]
+
+    def local_view(self, n_local):
+        """Render directly into the (padded) send buffer: no staging copy."""
+        return self.send[:n_local]
+
+    def run(self, unpack, force_collective=False):
+        import torch.distributed as dist
+        collective = self.world > 1 or force_collective  # force: 1-rank dry run of the RCCL call
+        if collective:
+            dist.gather(self.send, self.parts if self.rank == 0 else None, dst=0, group=self.group)
+        if self.rank != 0:
+            return None
+        parts = self.parts if collective else [self.send]
+        for r in range(self.world):
+            unpack(self.rparams[r], r, parts[r], self.image)
+        return self.image
+
+
 def gather_tiles(local_packed, params, world, rank, group=None, unpack=None):
-    """Gather every rank's packed tiles on rank 0 and de-interleave them.
+    """One-shot form of TileGather (allocates per call): gather every rank's packed tiles on
+    rank 0 and de-interleave them.
 
     local_packed: tensor [n_tiles_local * 4096, C] (this rank's tiles, tile order).
     unpack(rank_params, r, packed_tensor, image_tensor): scatters rank r's tiles into
     the row-major image (device kernel or host memcpy, chosen by the caller).
     Returns the [H, W, C] image on rank 0, None elsewhere.
     """
-    import torch
-    import torch.distributed as dist
-
-    chans = local_packed.shape[1]
-    n_max = max_tiles_per_rank(params.width, params.height, world) * TILE * TILE
-    send = local_packed
-    if local_packed.shape[0] != n_max:  # ranks differ by at most one tile: pad to equal size
-        send = torch.zeros((n_max, chans), dtype=local_packed.dtype, device=local_packed.device)
-        send[: local_packed.shape[0]] = local_packed
-    if world == 1:
-        parts = [send]
-    else:
-        parts = ([torch.empty_like(send) for _ in range(world)] if rank == 0 else None)
-        dist.gather(send, parts, dst=0, group=group)
-    if rank != 0:
-        return None
-    image = torch.zeros((params.height, params.width, chans), dtype=send.dtype, device=send.device)
-    for r in range(world):
-        unpack(rank_params(params, world, r), r, parts[r], image)
-    return image
+    tg = TileGather(params, world, rank, local_packed.shape[1], local_packed.dtype,
+                    local_packed.device, group)
+    tg.send[: local_packed.shape[0]] = local_packed
+    return tg.run(unpack)
 
 
 def host_unpack(rparams, r, packed, image):

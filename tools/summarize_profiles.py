@@ -16,25 +16,32 @@ def q(db, sql):
 
 
 def short(name):
-    if "integrate_segment_kernel" in name:
-        return "integrate_segment_kernel" + name[name.index("<"):name.index(">") + 1] if "<" in name else name
-    return name.split("(")[0]
+    n = name.replace("void ", "").replace("(anonymous namespace)::", "")
+    depth = 0
+    for k, ch in enumerate(n):  # cut the argument list, keep template arguments
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            return n[:k]
+    return n
 
 
 def trace_summary(dbpath, label):
     rows = q(dbpath, "select name, total_calls, total_duration, average, percentage from top_kernels")
     lines = ["# rocprofv3 --kernel-trace --stats  (%s)" % label,
-             "%-110s %8s %14s %14s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "pct")]
+             "%-60s %8s %14s %14s %7s" % ("kernel", "calls", "total_us", "avg_us", "pct")]
     for n, c, t, a, p in rows:
-        lines.append("%-110s %8d %14d %14.1f %7.2f" % (short(n)[:110], c, t, a, p))
+        lines.append("%-60s %8d %14.1f %14.2f %7.2f" % (short(n)[:60], c, t, a, p))
     reg = q(dbpath, "select name, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, scratch_size, "
                     "workgroup_x, min(grid_x), max(grid_x), count(*), avg(duration), min(duration), max(duration) "
                     "from kernels group by name")
     lines.append("")
-    lines.append("%-80s %5s %5s %5s %7s %7s %5s %10s %10s %6s %12s %12s %12s" % (
+    lines.append("%-44s %5s %5s %5s %7s %7s %5s %10s %10s %6s %12s %12s %12s" % (
         "kernel", "vgpr", "agpr", "sgpr", "lds", "scratch", "wg", "grid_min", "grid_max", "n", "avg_ns", "min_ns", "max_ns"))
     for r in reg:
-        lines.append("%-80s %5d %5d %5d %7d %7d %5d %10d %10d %6d %12.0f %12d %12d" % ((short(r[0])[:80],) + tuple(r[1:])))
+        lines.append("%-44s %5d %5d %5d %7d %7d %5d %10d %10d %6d %12.0f %12d %12d" % ((short(r[0])[:44],) + tuple(r[1:])))
     return "\n".join(lines) + "\n", rows
 
 
