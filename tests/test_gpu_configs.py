@@ -1,0 +1,103 @@
+"""One GPU test per BASELINE.json config that is not already the subject of
+tests/test_gpu_parity.py (C3 and C5 live there: test_4k_* and
+test_4k_strided_subset_vs_oracle).  Sizes the oracle finishes in seconds get a direct
+comparison; full sizes are checked through size-independent properties."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+EYE = (60.0 * np.sin(np.deg2rad(97.0)), 60.0 * np.cos(np.deg2rad(97.0)), 0.0)
+
+
+def rel_err(a, b):
+    return (np.abs(a - b) / np.maximum(1.0, np.abs(b))).max(axis=1)
+
+
+def test_config1_256x256_schwarzschild_symplectic(engine_mod, oracle):
+    """C1: single 256x256 frame, a = 0, fixed-step implicit midpoint h = 0.05, <= 1024 steps
+    (gravitas-core IntegrationMethod::Symplectic, integrator.rs:209-226), through the C ABI.
+    a = 0 runs on the Kerr-Schild metric (the reference's `Schwarzschild` struct has a sign
+    defect)."""
+    import torch
+    bh = engine_mod
+    W = H = 256
+    n = W * H
+    with bh.PhysicsEngine(1.0, 0.0) as e:
+        cam = bh.camera_look_at(EYE, aspect=1.0)
+        p = bh.render_params(W, H, method=bh.METHOD_SYMPLECTIC, step_size=0.05, max_steps=1024,
+                             shading=0, arith=bh.ARITH_STRICT)
+        fs = torch.zeros(n, 8, dtype=torch.float64, device="cuda:0")
+        steps = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+        term = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
+        e.render_frame_device(cam, p, None, fs, steps, term)
+        st = e.frame_stats()
+    ocam = oracle.camera_look_at(EYE, aspect=1.0)
+    fp = oracle.frame_params(W, H, spin=0.0, shading=0,
+                             opt=oracle.options(method=oracle.METHOD_SYMPLECTIC, step_size=0.05,
+                                                max_steps=1024))
+    ref = oracle.render_frame(ocam, fp, None, nthreads=8)
+    assert st.accepted_steps == ref["stats"].accepted_steps == n * 1024  # h = 0.05: nobody gets anywhere
+    assert np.array_equal(term.cpu().numpy(), ref["term"]) and np.all(ref["term"] == 3)
+    assert np.array_equal(steps.cpu().numpy().astype(np.uint32), ref["steps"])
+    err = rel_err(fs.cpu().numpy(), ref["states"])
+    assert err.max() <= 1e-9   # 1024 tiny steps far from the hole: rounding-level agreement
+
+
+def test_config2_1080p_fixed_step_f32(engine_mod, oracle):
+    """C2: 1920x1080, a = 0.999, 512 max steps, both f32 fixed-step loops.  Full size by
+    properties + a 1/36 strided subset against the f32 restatement."""
+    import torch
+    bh = engine_mod
+    W, H = 1920, 1080
+    n = W * H
+    with bh.PhysicsEngine(1.0, 0.999) as e:
+        cam = bh.camera_look_at(EYE, aspect=W / H)
+        rgba = torch.zeros(n, 4, dtype=torch.float32, device="cuda:0")
+        steps = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+        for name in ("wgsl", "glsl"):
+            if name == "wgsl":
+                gp = bh.wgsl_params(W, H, cam, 1.0, 0.999, max_steps=512)
+                tot = e.render_frame_wgsl(gp, rgba, steps)
+                ref_rgba, ref_steps = oracle.wgsl_frame(oracle.wgsl_params_from(gp), stride=(6, 6), nthreads=8)
+            else:
+                gp = bh.glsl_params(W, H, 1.0, 0.999, max_ray_steps=512)
+                tot = e.render_frame_glsl(gp, rgba, steps)
+                ref_rgba, ref_steps = oracle.glsl_frame(oracle.glsl_params_from(gp), stride=(6, 6), nthreads=8)
+            s = steps.cpu().numpy().reshape(H, W)
+            c = rgba.cpu().numpy().reshape(H, W, 4)
+            assert tot == int(s.sum()) and s.max() <= (512 if name == "wgsl" else 500) and s.min() >= 0
+            assert np.all(np.isfinite(c)) and np.all(c[..., 3] == 1.0) and c[..., :3].min() >= 0.0
+            ds = np.abs(s[::6, ::6].astype(np.int64) - ref_steps.astype(np.int64))
+            peak = ref_rgba[..., :3].max()
+            dc = np.abs(c[::6, ::6] - ref_rgba)[..., :3].max(-1) / peak
+            assert (ds == 0).mean() >= 0.99 and (dc <= 2e-3).mean() >= 0.99 and (dc <= 5e-2).mean() >= 0.999
+
+
+def test_config4_8k_tiled_over_8_ranks_fixed_1024(engine_mod):
+    """C4: 7680x4320 tiled across 8 ranks, fixed 1024 steps, f32.  One GPU plays the 8 ranks
+    in turn; the reassembled frame must equal the single-rank frame bitwise, and the tile
+    counts per rank must be balanced to within one tile."""
+    import torch
+    from blackhole_simulation_amd import distributed as D
+    bh = engine_mod
+    W, H, R = 7680, 4320, 8
+    with bh.PhysicsEngine(1.0, 0.999) as e:
+        cam = bh.camera_look_at(EYE, aspect=W / H)
+        gp = bh.wgsl_params(W, H, cam, 1.0, 0.999, max_steps=1024)
+        whole = torch.zeros(W * H, 4, dtype=torch.float32, device="cuda:0")
+        tot = e.render_frame_wgsl(gp, whole)
+        img = torch.zeros(H, W, 4, dtype=torch.float32, device="cuda:0")
+        rp = bh.render_params(W, H)
+        counts, tsum = [], 0
+        for r in range(R):
+            gpr = bh.wgsl_params(W, H, cam, 1.0, 0.999, max_steps=1024, tile_world=R, tile_rank=r)
+            nt = len(D.tiles_of_rank(W, H, R, r))
+            counts.append(nt)
+            buf = torch.zeros(nt * 4096, 4, dtype=torch.float32, device="cuda:0")
+            tsum += e.render_frame_wgsl(gpr, buf)
+            e.unpack_tiles_device(D.rank_params(rp, R, r), r, buf, img, 16)
+        torch.cuda.synchronize()
+        assert max(counts) - min(counts) <= 1 and sum(counts) == D.tiles_total(W, H)
+        assert tsum == tot
+        assert torch.equal(img.reshape(-1, 4), whole)
