@@ -53,7 +53,15 @@ __device__ __forceinline__ double signum_rs(double x) {
 // candidate into `n` and returns the error estimate (max-abs over t,r,theta,phi).
 template <int KIND, int ARITH>
 __device__ __forceinline__ double rkf45_try(const Hole<double> &bh, const RayRegs &y, double h,
-                                            RayRegs &n) {
+                                            RayRegs &n, const KsRayConsts &rc) {
+    // right-hand side at a stage point; the FAST Kerr-Schild form takes the per-ray
+    // constant products (rc) instead of recomputing them six times a try
+    auto f = [&](double r_, double th_, double pr_, double pth_) {
+        if constexpr (kGeomCache<KIND, ARITH>)
+            return rhs_ks_geom(bh, ks_geom(bh, r_, th_), r_, rc, pr_, pth_);
+        else
+            return rhs<KIND, ARITH>(bh, r_, th_, y.pt, pr_, pth_, y.pph);
+    };
     // stage scale factors, same expressions as integrator.rs:119-160
     double s21, s31, s32, s41, s42, s43, s51, s52, s53, s54, s61, s62, s63, s64, s65;
     if constexpr (ARITH == GRV_ARITH_STRICT) {
@@ -96,7 +104,7 @@ __device__ __forceinline__ double rkf45_try(const Hole<double> &bh, const RayReg
 
     Deriv<double> k1;
     if constexpr (kGeomCache<KIND, ARITH>)
-        k1 = rhs_ks_geom(bh, y.geom, y.r, y.pt, y.pr, y.pth, y.pph);
+        k1 = rhs_ks_geom(bh, y.geom, y.r, rc, y.pr, y.pth);
     else
         k1 = rhs<KIND, ARITH>(bh, y.r, y.th, y.pt, y.pr, y.pth, y.pph);
     // t and phi never feed back into the right-hand side: keep only their running
@@ -125,39 +133,36 @@ __device__ __forceinline__ double rkf45_try(const Hole<double> &bh, const RayReg
         else return y0 + (a1 * s61 + a2 * s62 + a3 * s63 + a4 * s64 + a5 * s65);
     };
 
-    const Deriv<double> k2 = rhs<KIND, ARITH>(bh, y.r + k1.dr * s21, y.th + k1.dth * s21, y.pt,
-                                              y.pr + k1.dpr * s21, y.pth + k1.dpth * s21, y.pph);
+    const Deriv<double> k2 =
+        f(y.r + k1.dr * s21, y.th + k1.dth * s21, y.pr + k1.dpr * s21, y.pth + k1.dpth * s21);
 
-    const Deriv<double> k3 = rhs<KIND, ARITH>(bh, st2(y.r, k1.dr, k2.dr), st2(y.th, k1.dth, k2.dth),
-                                              y.pt, st2(y.pr, k1.dpr, k2.dpr),
-                                              st2(y.pth, k1.dpth, k2.dpth), y.pph);
+    const Deriv<double> k3 = f(st2(y.r, k1.dr, k2.dr), st2(y.th, k1.dth, k2.dth),
+                               st2(y.pr, k1.dpr, k2.dpr), st2(y.pth, k1.dpth, k2.dpth));
     a5_t = a5_t + c3 * k3.dt;
     a5_ph = a5_ph + c3 * k3.dph;
     ae_t = ae_t + e3 * k3.dt;
     ae_ph = ae_ph + e3 * k3.dph;
 
-    const Deriv<double> k4 = rhs<KIND, ARITH>(
-        bh, st3(y.r, k1.dr, k2.dr, k3.dr), st3(y.th, k1.dth, k2.dth, k3.dth), y.pt,
-        st3(y.pr, k1.dpr, k2.dpr, k3.dpr), st3(y.pth, k1.dpth, k2.dpth, k3.dpth), y.pph);
+    const Deriv<double> k4 =
+        f(st3(y.r, k1.dr, k2.dr, k3.dr), st3(y.th, k1.dth, k2.dth, k3.dth),
+          st3(y.pr, k1.dpr, k2.dpr, k3.dpr), st3(y.pth, k1.dpth, k2.dpth, k3.dpth));
     a5_t = a5_t + c4 * k4.dt;
     a5_ph = a5_ph + c4 * k4.dph;
     ae_t = ae_t + e4 * k4.dt;
     ae_ph = ae_ph + e4 * k4.dph;
 
-    const Deriv<double> k5 = rhs<KIND, ARITH>(
-        bh, st4(y.r, k1.dr, k2.dr, k3.dr, k4.dr), st4(y.th, k1.dth, k2.dth, k3.dth, k4.dth), y.pt,
-        st4(y.pr, k1.dpr, k2.dpr, k3.dpr, k4.dpr), st4(y.pth, k1.dpth, k2.dpth, k3.dpth, k4.dpth),
-        y.pph);
+    const Deriv<double> k5 =
+        f(st4(y.r, k1.dr, k2.dr, k3.dr, k4.dr), st4(y.th, k1.dth, k2.dth, k3.dth, k4.dth),
+          st4(y.pr, k1.dpr, k2.dpr, k3.dpr, k4.dpr), st4(y.pth, k1.dpth, k2.dpth, k3.dpth, k4.dpth));
     a5_t = a5_t - c5 * k5.dt;
     a5_ph = a5_ph - c5 * k5.dph;
     ae_t = ae_t + e5 * k5.dt;
     ae_ph = ae_ph + e5 * k5.dph;
 
-    const Deriv<double> k6 = rhs<KIND, ARITH>(
-        bh, st5(y.r, k1.dr, k2.dr, k3.dr, k4.dr, k5.dr),
-        st5(y.th, k1.dth, k2.dth, k3.dth, k4.dth, k5.dth), y.pt,
-        st5(y.pr, k1.dpr, k2.dpr, k3.dpr, k4.dpr, k5.dpr),
-        st5(y.pth, k1.dpth, k2.dpth, k3.dpth, k4.dpth, k5.dpth), y.pph);
+    const Deriv<double> k6 = f(st5(y.r, k1.dr, k2.dr, k3.dr, k4.dr, k5.dr),
+                               st5(y.th, k1.dth, k2.dth, k3.dth, k4.dth, k5.dth),
+                               st5(y.pr, k1.dpr, k2.dpr, k3.dpr, k4.dpr, k5.dpr),
+                               st5(y.pth, k1.dpth, k2.dpth, k3.dpth, k4.dpth, k5.dpth));
     a5_t = a5_t + c6 * k6.dt;
     a5_ph = a5_ph + c6 * k6.dph;
     ae_t = ae_t + c6 * k6.dt;
@@ -341,6 +346,7 @@ __global__ __launch_bounds__(kBlock) void integrate_segment_kernel(
 
     RayRegs y;
     y.flags = 0;
+    y.pt = y.pph = 0.0;
     if (have) load_ray(ws, slot, y);
     const Hole<double> bh{P.M, P.a, P.a2};
 
@@ -348,6 +354,7 @@ __global__ __launch_bounds__(kBlock) void integrate_segment_kernel(
     if constexpr (kGeomCache<KIND, ARITH>) {
         if (live) y.geom = ks_geom(bh, y.r, y.th); // state came from HBM: rebuild the cache
     }
+    const KsRayConsts rc = ks_ray_consts(bh, y.pt, y.pph); // p_t, p_phi never change
     for (uint32_t it = 0; it < P.max_tries; ++it) {
         if (__ballot(live) == 0ull) break; // whole wave finished: early out
         if (live) {
@@ -355,7 +362,7 @@ __global__ __launch_bounds__(kBlock) void integrate_segment_kernel(
             bool stepped;
             if constexpr (METHOD == GRV_METHOD_RKF45) {
                 RayRegs n;
-                const double err = rkf45_try<KIND, ARITH>(bh, y, y.h, n);
+                const double err = rkf45_try<KIND, ARITH>(bh, y, y.h, n, rc);
                 y.tries += 1;
                 const bool forced = (y.flags & kFlagForced) != 0u;
                 double ratio;

@@ -353,37 +353,58 @@ __device__ __forceinline__ KsGeom ks_geom(const Hole<double> &bh, double r, doub
     return g;
 }
 
+// per-ray products of the constants of motion, formed once per launch
+struct KsRayConsts {
+    double pt, pph;
+    double pt2;       // p_t^2
+    double m2pt;      // -2 p_t
+    double pph2;      // p_phi^2
+    double a_pph;     // a p_phi
+    double two_a_pph; // 2 a p_phi
+};
+__device__ __forceinline__ KsRayConsts ks_ray_consts(const Hole<double> &bh, double p_t, double p_ph) {
+    KsRayConsts c;
+    c.pt = p_t;
+    c.pph = p_ph;
+    c.pt2 = p_t * p_t;
+    c.m2pt = -2.0 * p_t;
+    c.pph2 = p_ph * p_ph;
+    c.a_pph = bh.a * p_ph;
+    c.two_a_pph = 2.0 * c.a_pph;
+    return c;
+}
+
 __device__ __forceinline__ Deriv<double> rhs_ks_geom(const Hole<double> &bh, const KsGeom &g,
-                                                     double r, double p_t, double p_r,
-                                                     double p_th, double p_ph) {
+                                                     double r, const KsRayConsts &c, double p_r,
+                                                     double p_th) {
     const double m = bh.M, a = bh.a, a2 = bh.a2;
     const double sigma = g.sigma, delta = g.delta, inv_ss = g.inv_ss;
     const double isig = inv_ss * g.sin2; // 1/Sigma
     const double isin2 = inv_ss * sigma; // 1/sin^2
     const double isig2 = isig * isig;
 
-    const double two_mr_isig = 2.0 * m * r * isig;
+    const double two_mr_isig = (2.0 * m) * r * isig;
     Deriv<double> d;
-    d.dt = two_mr_isig * (p_r - p_t) - p_t;                     // g^tt p_t + g^tr p_r
-    d.dr = two_mr_isig * p_t + (delta * p_r + a * p_ph) * isig; // g^tr p_t + g^rr p_r + g^rph p_ph
+    d.dt = two_mr_isig * (p_r - c.pt) - c.pt;                              // g^tt p_t + g^tr p_r
+    d.dr = fma(fma(delta, p_r, c.a_pph), isig, two_mr_isig * c.pt);        // g^tr p_t + g^rr p_r + g^rph p_ph
     d.dth = isig * p_th;
-    d.dph = (a * isig) * p_r + inv_ss * p_ph;
+    d.dph = isig * fma(c.pph, isin2, a * p_r);                             // g^rph p_r + g^phph p_ph
 
-    const double two_r = 2.0 * r;
-    const double dsig_dth = -2.0 * a2 * g.sc;
-    const double pt_mix = p_t * (p_t - 2.0 * p_r); // p_t^2 - 2 p_t p_r
-    const double pph2_isin2 = p_ph * p_ph * isin2;
+    const double two_r = r + r;
+    const double dsig_dth = (-2.0 * a2) * g.sc;
+    const double pt_mix = fma(c.m2pt, p_r, c.pt2); // p_t^2 - 2 p_t p_r
+    const double pph2_isin2 = c.pph2 * isin2;
     const double pr2 = p_r * p_r;
     const double pth2 = p_th * p_th;
-    const double apr_pph2 = 2.0 * a * p_r * p_ph;
+    const double apr_pph2 = c.two_a_pph * p_r;
 
     // 2 Sigma^2 dH/dr
-    const double ar = -2.0 * m * (sigma - two_r * r) * pt_mix +
+    const double ar = (-2.0 * m) * (sigma - two_r * r) * pt_mix +
                       ((two_r - 2.0 * m) * sigma - delta * two_r) * pr2 -
                       two_r * (pth2 + pph2_isin2 + apr_pph2);
     // 2 Sigma^2 dH/dtheta
     const double ath =
-        dsig_dth * (2.0 * m * r * pt_mix - delta * pr2 - pth2 - apr_pph2 - pph2_isin2) -
+        dsig_dth * ((2.0 * m) * r * pt_mix - delta * pr2 - pth2 - apr_pph2 - pph2_isin2) -
         2.0 * sigma * g.sc * pph2_isin2 * isin2;
     const double half_isig2 = 0.5 * isig2;
     d.dpr = -(half_isig2 * ar);
@@ -394,7 +415,7 @@ __device__ __forceinline__ Deriv<double> rhs_ks_geom(const Hole<double> &bh, con
 template <typename T = double>
 __device__ __forceinline__ Deriv<T> rhs_ks_fast(const Hole<T> &bh, T r, T theta, T p_t, T p_r,
                                                 T p_th, T p_ph) {
-    return rhs_ks_geom(bh, ks_geom(bh, r, theta), r, p_t, p_r, p_th, p_ph);
+    return rhs_ks_geom(bh, ks_geom(bh, r, theta), r, ks_ray_consts(bh, p_t, p_ph), p_r, p_th);
 }
 
 __device__ __forceinline__ GInv<double> ginv_from_geom(const Hole<double> &bh, const KsGeom &g,
