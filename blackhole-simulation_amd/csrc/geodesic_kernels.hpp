@@ -36,7 +36,9 @@ struct RayRegs {
     double h;
     double drift;
     uint32_t steps, tries, flags;
-    KsGeom geom; // FAST Kerr-Schild only: geometry at (r, th), reused by stage 1 of a try
+    uint32_t phase; // steps % renorm_interval, carried incrementally (no division in the loop)
+    Deriv<double> k1; // FAST Kerr-Schild only: right-hand side at the current state, formed by
+                      // the post-step bookkeeping and reused as stage 1 of the next try
 };
 
 template <int KIND, int ARITH> constexpr bool kGeomCache = (KIND == GRV_METRIC_KERR_KS && ARITH == GRV_ARITH_FAST);
@@ -49,11 +51,12 @@ __device__ __forceinline__ double signum_rs(double x) {
     return (x != x) ? x : (signbit(x) ? -1.0 : 1.0);
 }
 
-// One Fehlberg 4(5) evaluation on the reduced state.  Writes the 5th-order
-// candidate into `n` and returns the error estimate (max-abs over t,r,theta,phi).
+// One Fehlberg 4(5) evaluation on the reduced state.  Writes the 5th-order weighted
+// stage sums into `inc` (the candidate is y + h * inc, formed by the caller only if the
+// try is accepted, in place) and returns the error estimate (max-abs over t,r,theta,phi).
 template <int KIND, int ARITH>
 __device__ __forceinline__ double rkf45_try(const Hole<double> &bh, const RayRegs &y, double h,
-                                            RayRegs &n, const KsRayConsts &rc) {
+                                            Deriv<double> &inc, const KsRayConsts &rc) {
     // right-hand side at a stage point; the FAST Kerr-Schild form takes the per-ray
     // constant products (rc) instead of recomputing them six times a try
     auto f = [&](double r_, double th_, double pr_, double pth_) {
@@ -104,7 +107,7 @@ __device__ __forceinline__ double rkf45_try(const Hole<double> &bh, const RayReg
 
     Deriv<double> k1;
     if constexpr (kGeomCache<KIND, ARITH>)
-        k1 = rhs_ks_geom(bh, y.geom, y.r, rc, y.pr, y.pth);
+        k1 = y.k1;
     else
         k1 = rhs<KIND, ARITH>(bh, y.r, y.th, y.pt, y.pr, y.pth, y.pph);
     // t and phi never feed back into the right-hand side: keep only their running
@@ -168,13 +171,12 @@ __device__ __forceinline__ double rkf45_try(const Hole<double> &bh, const RayReg
     ae_t = ae_t + c6 * k6.dt;
     ae_ph = ae_ph + c6 * k6.dph;
 
-    n = y;
-    n.t = y.t + h * a5_t;
-    n.ph = y.ph + h * a5_ph;
-    n.r = y.r + h * (c1 * k1.dr + c3 * k3.dr + c4 * k4.dr - c5 * k5.dr + c6 * k6.dr);
-    n.th = y.th + h * (c1 * k1.dth + c3 * k3.dth + c4 * k4.dth - c5 * k5.dth + c6 * k6.dth);
-    n.pr = y.pr + h * (c1 * k1.dpr + c3 * k3.dpr + c4 * k4.dpr - c5 * k5.dpr + c6 * k6.dpr);
-    n.pth = y.pth + h * (c1 * k1.dpth + c3 * k3.dpth + c4 * k4.dpth - c5 * k5.dpth + c6 * k6.dpth);
+    inc.dt = a5_t;
+    inc.dph = a5_ph;
+    inc.dr = c1 * k1.dr + c3 * k3.dr + c4 * k4.dr - c5 * k5.dr + c6 * k6.dr;
+    inc.dth = c1 * k1.dth + c3 * k3.dth + c4 * k4.dth - c5 * k5.dth + c6 * k6.dth;
+    inc.dpr = c1 * k1.dpr + c3 * k3.dpr + c4 * k4.dpr - c5 * k5.dpr + c6 * k6.dpr;
+    inc.dpth = c1 * k1.dpth + c3 * k3.dpth + c4 * k4.dpth - c5 * k5.dpth + c6 * k6.dpth;
 
     const double err_r = h * (e1 * k1.dr + e3 * k3.dr + e4 * k4.dr + e5 * k5.dr + c6 * k6.dr);
     const double err_th = h * (e1 * k1.dth + e3 * k3.dth + e4 * k4.dth + e5 * k5.dth + c6 * k6.dth);
@@ -242,13 +244,7 @@ __device__ __forceinline__ bool ray_live(const RayRegs &y) {
 template <int KIND, int ARITH = GRV_ARITH_STRICT>
 __device__ __forceinline__ void ray_begin(const Hole<double> &bh, RayRegs &y,
                                           const SegmentParams &P, bool adaptive) {
-    GInv<double> g;
-    if constexpr (kGeomCache<KIND, ARITH>) {
-        y.geom = ks_geom(bh, y.r, y.th);
-        g = ginv_from_geom(bh, y.geom, y.r);
-    } else {
-        g = contravariant_at<KIND, ARITH, double>(bh, y.r, y.th);
-    }
+    const GInv<double> g = contravariant_at<KIND, ARITH, double>(bh, y.r, y.th);
     y.pr = renormalized_pr<KIND, ARITH, double>(g, y.pt, y.pr, y.pth, y.pph);
     if (adaptive) y.h = clamp_rs(y.h, -10.0, 10.0);
     uint32_t term = GRV_TERM_NONE;
@@ -264,19 +260,26 @@ __device__ __forceinline__ void ray_begin(const Hole<double> &bh, RayRegs &y,
 template <int KIND, int ARITH>
 __device__ __forceinline__ void after_step(const Hole<double> &bh, RayRegs &y, double r_prev,
                                            double th_prev, const SegmentParams &P,
-                                           const RayWorkspace &ws, uint32_t slot) {
-    GInv<double> g;
+                                           const RayWorkspace &ws, uint32_t slot,
+                                           const KsRayConsts &rc) {
+    const bool renorm = P.renorm_interval != 0 && y.phase == 0u; // steps % interval == 0
+    double hv;
     if constexpr (kGeomCache<KIND, ARITH>) {
-        y.geom = ks_geom(bh, y.r, y.th); // also stage 1 of the next try
-        g = ginv_from_geom(bh, y.geom, y.r);
+        // one geometry evaluation serves the projection, H and stage 1 of the next try
+        const KsGeom geom = ks_geom(bh, y.r, y.th);
+        if (renorm)
+            y.pr = renormalized_pr<KIND, ARITH, double>(ginv_from_geom(bh, geom, y.r), y.pt, y.pr,
+                                                        y.pth, y.pph);
+        y.k1 = rhs_ks_geom(bh, geom, y.r, rc, y.pr, y.pth, &hv);
+        hv = fabs(hv);
     } else {
-        g = contravariant_at<KIND, ARITH, double>(bh, y.r, y.th);
+        const GInv<double> g = contravariant_at<KIND, ARITH, double>(bh, y.r, y.th);
+        if (renorm) y.pr = renormalized_pr<KIND, ARITH, double>(g, y.pt, y.pr, y.pth, y.pph);
+        hv = fabs(hamiltonian_of<KIND, double>(g, y.pt, y.pr, y.pth, y.pph));
     }
-    if (P.renorm_interval != 0 && (y.steps % P.renorm_interval) == 0)
-        y.pr = renormalized_pr<KIND, ARITH, double>(g, y.pt, y.pr, y.pth, y.pph);
-    const double hv = fabs(hamiltonian_of<KIND, double>(g, y.pt, y.pr, y.pth, y.pph));
     if (hv > y.drift) y.drift = hv;
     y.steps += 1;
+    y.phase = (y.phase + 1u == P.renorm_interval) ? 0u : y.phase + 1u;
 
     uint32_t term = GRV_TERM_NONE;
     if (P.shading) {
@@ -348,21 +351,24 @@ __global__ __launch_bounds__(kBlock) void integrate_segment_kernel(
     y.flags = 0;
     y.pt = y.pph = 0.0;
     if (have) load_ray(ws, slot, y);
-    const Hole<double> bh{P.M, P.a, P.a2};
+    const Hole<double> bh{P.M, P.a, P.a2, 2.0 * P.M};
 
     bool live = have && ray_live(y);
-    if constexpr (kGeomCache<KIND, ARITH>) {
-        if (live) y.geom = ks_geom(bh, y.r, y.th); // state came from HBM: rebuild the cache
-    }
+    y.phase = P.renorm_interval ? y.steps % P.renorm_interval : 1u;
     const KsRayConsts rc = ks_ray_consts(bh, y.pt, y.pph); // p_t, p_phi never change
+    if constexpr (kGeomCache<KIND, ARITH>) {
+        // state came from HBM: rebuild the stage-1 cache
+        if (live) y.k1 = rhs_ks_geom(bh, ks_geom(bh, y.r, y.th), y.r, rc, y.pr, y.pth);
+    }
     for (uint32_t it = 0; it < P.max_tries; ++it) {
         if (__ballot(live) == 0ull) break; // whole wave finished: early out
         if (live) {
             const double r_prev = y.r, th_prev = y.th;
             bool stepped;
             if constexpr (METHOD == GRV_METHOD_RKF45) {
-                RayRegs n;
-                const double err = rkf45_try<KIND, ARITH>(bh, y, y.h, n, rc);
+                Deriv<double> inc;
+                const double h = y.h;
+                const double err = rkf45_try<KIND, ARITH>(bh, y, h, inc, rc);
                 y.tries += 1;
                 const bool forced = (y.flags & kFlagForced) != 0u;
                 double ratio;
@@ -370,39 +376,37 @@ __global__ __launch_bounds__(kBlock) void integrate_segment_kernel(
                     ratio = err * P.inv_tolerance; // err == 0 -> 0 without the special case
                 else
                     ratio = (err == 0.0) ? 0.0 : err / P.tolerance;
-                if (forced) {
-                    // integrator.rs:99-104: the forced minimum step is taken unconditionally
-                    // and its own size is handed back as the next h.
-                    const double hk = y.h;
-                    n.h = hk;
-                    n.tries = y.tries;
-                    n.flags = y.flags & ~kFlagForced;
-                    y = n;
-                    stepped = true;
-                } else if (ratio <= 1.0) {
-                    double growth;
-                    if constexpr (ARITH == GRV_ARITH_FAST)
-                        growth = (ratio < 1e-4) ? 5.0 : 0.9 * fast_pow_m1_5(ratio);
-                    else
-                        growth = (ratio < 1e-4) ? 5.0 : 0.9 * pow(ratio, -0.2);
-                    const double next_h = y.h * fmin(growth, 5.0);
-                    n.h = clamp_rs(next_h, -10.0, 10.0);
-                    n.tries = y.tries;
-                    y = n;
-                    stepped = true;
+                // integrator.rs:99-104: the forced minimum step is taken unconditionally and
+                // its own size is handed back as the next h.
+                stepped = forced || ratio <= 1.0;
+                if (stepped) {
+                    y.t = y.t + h * inc.dt;
+                    y.r = y.r + h * inc.dr;
+                    y.th = y.th + h * inc.dth;
+                    y.ph = y.ph + h * inc.dph;
+                    y.pr = y.pr + h * inc.dpr;
+                    y.pth = y.pth + h * inc.dpth;
+                    if (!forced) {
+                        double growth;
+                        if constexpr (ARITH == GRV_ARITH_FAST)
+                            growth = (ratio < 1e-4) ? 5.0 : 0.9 * fast_pow_m1_5(ratio);
+                        else
+                            growth = (ratio < 1e-4) ? 5.0 : 0.9 * pow(ratio, -0.2);
+                        y.h = clamp_rs(h * fmin(growth, 5.0), -10.0, 10.0);
+                    }
+                    y.flags &= ~kFlagForced;
                 } else {
                     double shrink;
                     if constexpr (ARITH == GRV_ARITH_FAST)
                         shrink = 0.9 * fast_pow_m1_4(ratio);
                     else
                         shrink = 0.9 * pow(ratio, -0.25);
-                    double hn = y.h * fmax(shrink, 0.1);
+                    double hn = h * fmax(shrink, 0.1);
                     if (fabs(hn) < 1e-5) {
                         hn = 1e-5 * signum_rs(hn);
                         y.flags |= kFlagForced;
                     }
                     y.h = hn;
-                    stepped = false;
                 }
             } else if constexpr (METHOD == GRV_METHOD_RK4) {
                 rk4_step<KIND, ARITH>(bh, y, P.step_size);
@@ -414,7 +418,7 @@ __global__ __launch_bounds__(kBlock) void integrate_segment_kernel(
                 stepped = true;
             }
             if (stepped) {
-                after_step<KIND, ARITH>(bh, y, r_prev, th_prev, P, ws, slot);
+                after_step<KIND, ARITH>(bh, y, r_prev, th_prev, P, ws, slot, rc);
                 live = ray_live(y);
             }
         }
@@ -471,7 +475,7 @@ __global__ __launch_bounds__(kBlock) void init_from_states_kernel(
     y.steps = 0;
     y.tries = 0;
     y.flags = kFlagValid;
-    const Hole<double> bh{P.M, P.a, P.a2};
+    const Hole<double> bh{P.M, P.a, P.a2, 2.0 * P.M};
     ray_begin<KIND>(bh, y, P, adaptive != 0);
     store_ray(ws, i, y);
     ws.pt[i] = y.pt;
@@ -562,7 +566,7 @@ __global__ __launch_bounds__(kBlock) void init_from_pixels_kernel(RayWorkspace w
     y.pth = pth_far * r0 * r0;
     y.pph = pph_far * r0 * r0 * st * st;
     y.flags = kFlagValid;
-    const Hole<double> bh{P.M, P.a, P.a2};
+    const Hole<double> bh{P.M, P.a, P.a2, 2.0 * P.M};
     ray_begin<KIND>(bh, y, P, adaptive != 0);
     store_ray(ws, slot, y);
     ws.pt[slot] = y.pt;

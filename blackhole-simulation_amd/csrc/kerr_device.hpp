@@ -28,6 +28,7 @@ template <typename T> struct Hole {
     T M;  // mass
     T a;  // spin * mass
     T a2; // a * a
+    T two_m; // 2 M
 };
 
 template <typename T> struct Deriv {
@@ -347,8 +348,9 @@ __device__ __forceinline__ KsGeom ks_geom(const Hole<double> &bh, double r, doub
     g.polar = s2 < 1e-20;
     g.sin2 = fmax(s2, 1e-12);
     g.sc = odd ? -prod : prod;
-    g.sigma = fma(bh.a2, 1.0 - g.sin2, r * r);
-    g.delta = fma(r, r - 2.0 * bh.M, bh.a2);
+    const double r2a2 = fma(r, r, bh.a2);
+    g.sigma = fma(-bh.a2, g.sin2, r2a2); // r^2 + a^2 (1 - sin^2)
+    g.delta = fma(-bh.two_m, r, r2a2);
     g.inv_ss = fast_rcp(g.sigma * g.sin2);
     return g;
 }
@@ -374,41 +376,42 @@ __device__ __forceinline__ KsRayConsts ks_ray_consts(const Hole<double> &bh, dou
     return c;
 }
 
+// `ham` (optional) receives H = N / (2 Sigma) = (W - Sigma p_t^2) / (2 Sigma) of the same point,
+// i.e. invariants/mod.rs:25-37 from the bracket the forces already need.
 __device__ __forceinline__ Deriv<double> rhs_ks_geom(const Hole<double> &bh, const KsGeom &g,
                                                      double r, const KsRayConsts &c, double p_r,
-                                                     double p_th) {
-    const double m = bh.M, a = bh.a, a2 = bh.a2;
+                                                     double p_th, double *ham = nullptr) {
+    // With N = 2 Sigma H the two force terms share one bracket W = N + Sigma p_t^2:
+    //   W = Delta p_r^2 + p_th^2 + p_ph^2/sin^2 + 2 a p_r p_ph - 2Mr (p_t^2 - 2 p_t p_r)
+    //   2 Sigma^2 dH/dr  = Sigma ((2r-2M) p_r^2 - 2M (p_t^2 - 2 p_t p_r)) - 2r W
+    //   2 Sigma^2 dH/dth = 2 sin cos (a^2 W - Sigma p_ph^2 / sin^4)
+    // (the Sigma p_t^2 pieces of N and of dN cancel identically).
     const double sigma = g.sigma, delta = g.delta, inv_ss = g.inv_ss;
     const double isig = inv_ss * g.sin2; // 1/Sigma
     const double isin2 = inv_ss * sigma; // 1/sin^2
-    const double isig2 = isig * isig;
+    const double two_mr = bh.two_m * r;
+    const double pt_mix = fma(c.m2pt, p_r, c.pt2); // p_t^2 - 2 p_t p_r
 
-    const double two_mr_isig = (2.0 * m) * r * isig;
     Deriv<double> d;
-    d.dt = two_mr_isig * (p_r - c.pt) - c.pt;                              // g^tt p_t + g^tr p_r
-    d.dr = fma(fma(delta, p_r, c.a_pph), isig, two_mr_isig * c.pt);        // g^tr p_t + g^rr p_r + g^rph p_ph
+    d.dt = fma(two_mr * isig, p_r - c.pt, -c.pt);                     // g^tt p_t + g^tr p_r
+    d.dr = isig * fma(two_mr, c.pt, fma(delta, p_r, c.a_pph));        // g^tr p_t + g^rr p_r + g^rph p_ph
     d.dth = isig * p_th;
-    d.dph = isig * fma(c.pph, isin2, a * p_r);                             // g^rph p_r + g^phph p_ph
+    d.dph = isig * fma(c.pph, isin2, bh.a * p_r);                     // g^rph p_r + g^phph p_ph
+
+    const double q = c.pph2 * isin2; // p_ph^2 / sin^2
+    const double pr2 = p_r * p_r;
+    double w = fma(c.two_a_pph, p_r, -(two_mr * pt_mix));
+    w = w + q;
+    w = fma(p_th, p_th, w);
+    w = fma(delta, pr2, w);
 
     const double two_r = r + r;
-    const double dsig_dth = (-2.0 * a2) * g.sc;
-    const double pt_mix = fma(c.m2pt, p_r, c.pt2); // p_t^2 - 2 p_t p_r
-    const double pph2_isin2 = c.pph2 * isin2;
-    const double pr2 = p_r * p_r;
-    const double pth2 = p_th * p_th;
-    const double apr_pph2 = c.two_a_pph * p_r;
-
-    // 2 Sigma^2 dH/dr
-    const double ar = (-2.0 * m) * (sigma - two_r * r) * pt_mix +
-                      ((two_r - 2.0 * m) * sigma - delta * two_r) * pr2 -
-                      two_r * (pth2 + pph2_isin2 + apr_pph2);
-    // 2 Sigma^2 dH/dtheta
-    const double ath =
-        dsig_dth * ((2.0 * m) * r * pt_mix - delta * pr2 - pth2 - apr_pph2 - pph2_isin2) -
-        2.0 * sigma * g.sc * pph2_isin2 * isin2;
-    const double half_isig2 = 0.5 * isig2;
-    d.dpr = -(half_isig2 * ar);
-    d.dpth = g.polar ? 0.0 : -(half_isig2 * ath);
+    const double ar = fma(-two_r, w, sigma * fma(two_r - bh.two_m, pr2, -(bh.two_m * pt_mix)));
+    const double ath_half = g.sc * fma(bh.a2, w, -(sigma * (q * isin2)));
+    const double isig2 = isig * isig;
+    d.dpr = -(0.5 * isig2) * ar;
+    d.dpth = g.polar ? 0.0 : -(isig2 * ath_half);
+    if (ham) *ham = (0.5 * isig) * fma(-sigma, c.pt2, w);
     return d;
 }
 
