@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "control_plane.hpp"
+#include "spacetime_viz.hpp"
 #include "engine_types.hpp"
 
 using namespace grvhip;
@@ -118,6 +119,7 @@ struct grv_engine {
     hipEvent_t ev[8] = {};
     bool ev_ok = false;
 
+    std::vector<float> disk_lut = std::vector<float>(512, 0.0f); // lut_buffer (lib.rs:50, 65-66)
     std::vector<float> sab;
     float *sab_ext = nullptr; // attach_sab (lib.rs:74)
     CameraFilter camera, last_good_camera;
@@ -363,6 +365,30 @@ int run_shader_frame(grv_engine *e, uint32_t width, uint32_t height, uint32_t tw
 // ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
+// ---- helpers of the spacetime read-outs (spacetime_viz.hip) ----
+namespace {
+VizHole viz_hole(const grv_engine *e) { return VizHole{e->mass, e->spin, e->spin_c * e->mass}; }
+
+// run one of the grid kernels into the staging buffer and copy n_floats back
+template <typename Launch>
+int viz_grid(grv_engine *e, size_t n_a, size_t n_b, float *out, Launch &&launch) {
+    if (!e) return GRV_ERR_INVALID;
+    if (n_a == 0 || n_b == 0) return GRV_OK; // empty loops upstream
+    if (!out) return fail(e, GRV_ERR_INVALID, "null output");
+    if (n_a > 0xFFFFu * 16u || n_b > 0xFFFFu * 16u || n_a * n_b > (size_t)1 << 28)
+        return fail(e, GRV_ERR_INVALID, "grid %zu x %zu too large", n_a, n_b);
+    GRV_HIP(e, hipSetDevice(e->device));
+    const size_t bytes = n_a * n_b * 3 * sizeof(float);
+    int rc = ensure_stage(e, bytes);
+    if (rc != GRV_OK) return rc;
+    float *d_out = static_cast<float *>(e->stage_mem);
+    GRV_HIP(e, launch(d_out));
+    GRV_HIP(e, hipDeviceSynchronize());
+    GRV_HIP(e, hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost));
+    return GRV_OK;
+}
+} // namespace
+
 extern "C" {
 
 int grv_abi_version(void) { return GRV_ABI_VERSION; }
@@ -955,7 +981,53 @@ int grv_generate_disk_lut(grv_engine *e, float *out512) {
     GRV_HIP(e, launch_disk_temperature_lut(d_out, d_tmp, w, e->mass, e->spin_c, nullptr));
     GRV_HIP(e, hipDeviceSynchronize());
     GRV_HIP(e, hipMemcpy(out512, d_out, w * sizeof(float), hipMemcpyDeviceToHost));
+    std::memcpy(e->disk_lut.data(), out512, w * sizeof(float)); // self.lut_buffer = ... (lib.rs:108)
     return GRV_OK;
+}
+
+const float *grv_get_disk_lut_ptr(const grv_engine *e) { return e ? e->disk_lut.data() : nullptr; }
+
+// ---- spacetime read-outs (spacetime_viz.hip) ----
+
+double grv_compute_kretschner(const grv_engine *e, double r, double theta) {
+    return e ? viz_kretschner(viz_hole(e), r, theta) : NAN;
+}
+double grv_compute_light_cone_tilt(const grv_engine *e, double r, double theta) {
+    return e ? viz_light_cone_tilt(viz_hole(e), r, theta) : NAN;
+}
+double grv_compute_frame_drag_omega(const grv_engine *e, double r, double theta) {
+    return e ? viz_frame_drag_omega(viz_hole(e), r, theta) : NAN;
+}
+double grv_compute_flamm_height(const grv_engine *e, double r) {
+    return e ? viz_flamm_height(r, e->mass) : NAN;
+}
+double grv_compute_proper_distance(const grv_engine *e, double r1, double r2, size_t n_steps) {
+    return e ? viz_proper_distance(viz_hole(e), r1, r2, n_steps) : NAN;
+}
+
+int grv_generate_field(grv_engine *e, int field, double r_min, double r_max, size_t n_radial,
+                       size_t n_polar, float *out) {
+    if (e && (field < GRV_FIELD_CURVATURE || field > GRV_FIELD_FRAME_DRAG))
+        return fail(e, GRV_ERR_INVALID, "unknown field %d", field);
+    return viz_grid(e, n_radial, n_polar, out, [&](float *d) {
+        return launch_viz_field(field, viz_hole(e), r_min, r_max, (uint32_t)n_radial,
+                                (uint32_t)n_polar, d, nullptr);
+    });
+}
+
+int grv_generate_embedding_mesh(grv_engine *e, double r_min, double r_max, size_t n_radial,
+                                size_t n_angular, float *out) {
+    return viz_grid(e, n_radial, n_angular, out, [&](float *d) {
+        return launch_embedding_mesh(viz_hole(e), r_min, r_max, (uint32_t)n_radial,
+                                     (uint32_t)n_angular, d, nullptr);
+    });
+}
+
+int grv_generate_ergosphere_mesh(grv_engine *e, size_t n_polar, size_t n_azimuthal, float *out) {
+    return viz_grid(e, n_polar, n_azimuthal, out, [&](float *d) {
+        return launch_ergosphere_mesh(viz_hole(e), (uint32_t)n_polar, (uint32_t)n_azimuthal, d,
+                                      nullptr);
+    });
 }
 
 void grv_get_sab_layout(size_t out5[5]) {

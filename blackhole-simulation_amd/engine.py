@@ -175,6 +175,22 @@ def load_library():
     L.grv_compute_shadow_radius.argtypes = [p]
     L.grv_compute_shadow_shift.restype = i
     L.grv_compute_shadow_shift.argtypes = [p, d, p]
+    L.grv_get_disk_lut_ptr.restype = p
+    L.grv_get_disk_lut_ptr.argtypes = [p]
+    for name in ("grv_compute_kretschner", "grv_compute_light_cone_tilt",
+                 "grv_compute_frame_drag_omega"):
+        getattr(L, name).restype = d
+        getattr(L, name).argtypes = [p, d, d]
+    L.grv_compute_flamm_height.restype = d
+    L.grv_compute_flamm_height.argtypes = [p, d]
+    L.grv_compute_proper_distance.restype = d
+    L.grv_compute_proper_distance.argtypes = [p, d, d, sz]
+    L.grv_generate_field.restype = i
+    L.grv_generate_field.argtypes = [p, i, d, d, sz, sz, p]
+    L.grv_generate_embedding_mesh.restype = i
+    L.grv_generate_embedding_mesh.argtypes = [p, d, d, sz, sz, p]
+    L.grv_generate_ergosphere_mesh.restype = i
+    L.grv_generate_ergosphere_mesh.argtypes = [p, sz, sz, p]
     L.grv_attach_sab.restype = i
     L.grv_attach_sab.argtypes = [p, p]
     L.grv_set_camera_state.argtypes = [p, d, d, d]
@@ -421,6 +437,55 @@ class PhysicsEngine:
         out = np.zeros(2, np.float32)
         self._check(self._lib.grv_compute_shadow_shift(self._h, float(theta_obs), _np_ptr(out)),
                     "compute_shadow_shift")
+        return out
+
+    def get_disk_lut_view(self):
+        """Float32 view of the engine-owned disk LUT (get_disk_lut_ptr, lib.rs:112)."""
+        ptr = self._lib.grv_get_disk_lut_ptr(self._h)
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(512,))
+
+    # ---- spacetime read-outs: lib.rs:139-159, 214-306 ----
+    def compute_kretschner(self, r, theta):
+        return self._lib.grv_compute_kretschner(self._h, float(r), float(theta))
+
+    def compute_light_cone_tilt(self, r, theta):
+        return self._lib.grv_compute_light_cone_tilt(self._h, float(r), float(theta))
+
+    def compute_frame_drag_omega(self, r, theta):
+        return self._lib.grv_compute_frame_drag_omega(self._h, float(r), float(theta))
+
+    def compute_flamm_height(self, r):
+        return self._lib.grv_compute_flamm_height(self._h, float(r))
+
+    def compute_proper_distance(self, r1, r2, n_steps):
+        return self._lib.grv_compute_proper_distance(self._h, float(r1), float(r2), int(n_steps))
+
+    def _field(self, kind, r_min, r_max, n_radial, n_polar, what):
+        out = np.zeros(3 * n_radial * n_polar, np.float32)
+        self._check(self._lib.grv_generate_field(self._h, kind, float(r_min), float(r_max),
+                                                 int(n_radial), int(n_polar), _np_ptr(out)), what)
+        return out
+
+    def generate_curvature_field(self, r_min, r_max, n_radial, n_polar):
+        return self._field(0, r_min, r_max, n_radial, n_polar, "generate_curvature_field")
+
+    def generate_tilt_field(self, r_min, r_max, n_radial, n_polar):
+        return self._field(1, r_min, r_max, n_radial, n_polar, "generate_tilt_field")
+
+    def generate_frame_drag_field(self, r_min, r_max, n_radial, n_polar):
+        return self._field(2, r_min, r_max, n_radial, n_polar, "generate_frame_drag_field")
+
+    def generate_embedding_mesh(self, r_min, r_max, n_radial, n_angular):
+        out = np.zeros(3 * n_radial * n_angular, np.float32)
+        self._check(self._lib.grv_generate_embedding_mesh(
+            self._h, float(r_min), float(r_max), int(n_radial), int(n_angular), _np_ptr(out)),
+            "generate_embedding_mesh")
+        return out
+
+    def generate_ergosphere_mesh(self, n_polar, n_azimuthal):
+        out = np.zeros(3 * n_polar * n_azimuthal, np.float32)
+        self._check(self._lib.grv_generate_ergosphere_mesh(
+            self._h, int(n_polar), int(n_azimuthal), _np_ptr(out)), "generate_ergosphere_mesh")
         return out
 
     # ---- SAB protocol: lib.rs:74, 116-126, 308-409 ----

@@ -233,6 +233,29 @@ size_t grv_compute_shadow_curve(const grv_engine *e, double theta_obs, size_t n_
 double grv_compute_shadow_radius(const grv_engine *e);
 int grv_compute_shadow_shift(const grv_engine *e, double theta_obs, float out2[2]);
 
+/* get_disk_lut_ptr lib.rs:112-114: the engine-owned copy of the last generate_disk_lut
+ * result (512 floats, zeros before the first call) */
+const float *grv_get_disk_lut_ptr(const grv_engine *e);
+
+/* ---- spacetime read-outs (viz helpers beside the path): lib.rs:139-159, 214-306 over
+ * gravitas-core/src/spacetime/{curvature,lightcone,frame_drag,embedding}.rs ---- */
+double grv_compute_kretschner(const grv_engine *e, double r, double theta);       /* lib.rs:214 */
+double grv_compute_light_cone_tilt(const grv_engine *e, double r, double theta);  /* lib.rs:239 */
+double grv_compute_frame_drag_omega(const grv_engine *e, double r, double theta); /* lib.rs:268 */
+double grv_compute_flamm_height(const grv_engine *e, double r);                   /* lib.rs:297 */
+double grv_compute_proper_distance(const grv_engine *e, double r1, double r2, size_t n_steps); /* :303 */
+#define GRV_FIELD_CURVATURE 0  /* generate_curvature_field  lib.rs:220-236 */
+#define GRV_FIELD_TILT 1       /* generate_tilt_field       lib.rs:245-265 */
+#define GRV_FIELD_FRAME_DRAG 2 /* generate_frame_drag_field lib.rs:274-294 */
+/* (r, theta, value) f32 triples, radial index slowest; `out` holds 3*n_radial*n_polar floats */
+int grv_generate_field(grv_engine *e, int field, double r_min, double r_max, size_t n_radial,
+                       size_t n_polar, float *out);
+/* generate_embedding_mesh lib.rs:139-150: xyz f32 vertices, 3*n_radial*n_angular floats */
+int grv_generate_embedding_mesh(grv_engine *e, double r_min, double r_max, size_t n_radial,
+                                size_t n_angular, float *out);
+/* generate_ergosphere_mesh lib.rs:153-157: xyz f32 vertices, 3*n_polar*n_azimuthal floats */
+int grv_generate_ergosphere_mesh(grv_engine *e, size_t n_polar, size_t n_azimuthal, float *out);
+
 /* ---- SAB protocol: lib.rs:36-40, 74, 116-126, 308-419 (offsets in f32 elements) ---- */
 const float *grv_get_sab_ptr(const grv_engine *e);
 void grv_get_sab_layout(size_t out5[5]);

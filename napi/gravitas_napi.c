@@ -26,6 +26,7 @@
 
 #define ARENA_BYTES (1u << 20)
 #define SAB_BYTES (2048u * 4u)
+#define LUT_BYTES (512u * 4u)
 
 static uint8_t *g_arena = NULL;
 static size_t g_arena_used = 0;
@@ -34,6 +35,7 @@ static napi_ref g_arena_ref = NULL;
 typedef struct {
     grv_engine *h;
     size_t sab_off;
+    size_t lut_off; /* 512-float disk LUT copy (get_disk_lut_ptr, lib.rs:112) */
 } engine_box;
 
 #define NAPI_OK(call)                                                        \
@@ -106,9 +108,10 @@ static napi_value engine_new(napi_env env, napi_callback_info info) {
         return NULL;
     }
     (void)get_arena(env);
-    if (g_arena && g_arena_used + SAB_BYTES <= ARENA_BYTES) {
+    if (g_arena && g_arena_used + SAB_BYTES + LUT_BYTES <= ARENA_BYTES) {
         box->sab_off = g_arena_used;
-        g_arena_used += SAB_BYTES;
+        box->lut_off = g_arena_used + SAB_BYTES;
+        g_arena_used += SAB_BYTES + LUT_BYTES;
         grv_attach_sab(box->h, (float *)(g_arena + box->sab_off)); /* attach_sab lib.rs:74 */
     }
     NAPI_OK(napi_wrap(env, self, box, engine_finalize, NULL, NULL));
@@ -227,6 +230,7 @@ static napi_value m_generate_disk_lut(napi_env env, napi_callback_info info) {
     void *dst;
     NAPI_OK(napi_create_arraybuffer(env, 512 * sizeof(float), &dst, &ab));
     grv_generate_disk_lut(b->h, (float *)dst);
+    if (g_arena && b->lut_off) memcpy(g_arena + b->lut_off, dst, LUT_BYTES); /* self.lut_buffer */
     NAPI_OK(napi_create_typedarray(env, napi_float32_array, 512, ab, 0, &ta));
     return ta;
 }
@@ -240,7 +244,7 @@ static napi_value m_compute_shadow_curve(napi_env env, napi_callback_info info) 
     uint32_t n = 0;
     napi_get_value_uint32(env, argv[1], &n);
     if (n > 4096) n = 4096;
-    float *tmp = (float *)malloc((size_t)2 * (n + 4) * sizeof(float));
+    float *tmp = (float *)malloc(((size_t)4 * n + 8) * sizeof(float)); /* n or 2n (alpha, beta) pairs */
     size_t m = grv_compute_shadow_curve(b->h, arg_f64(env, argv[0]), n, tmp);
     napi_value ab, ta;
     void *dst;
@@ -316,6 +320,222 @@ static napi_value m_get_sab_layout(napi_env env, napi_callback_info info) { /* l
     return arr;
 }
 
+
+/* ---- remaining wasm-bindgen methods: lib.rs:112-114, 139-159, 178-195, 214-306 ---- */
+static napi_value f32_array(napi_env env, const float *src, size_t n) {
+    napi_value ab, ta;
+    void *dst;
+    if (napi_create_arraybuffer(env, n * sizeof(float), &dst, &ab) != napi_ok) return NULL;
+    if (n && src) memcpy(dst, src, n * sizeof(float));
+    if (napi_create_typedarray(env, napi_float32_array, n, ab, 0, &ta) != napi_ok) return NULL;
+    return ta;
+}
+
+static uint32_t arg_u32(napi_env env, napi_value v) {
+    uint32_t u = 0;
+    napi_get_value_uint32(env, v, &u);
+    return u;
+}
+
+static napi_value m_compute_shadow_shift(napi_env env, napi_callback_info info) { /* lib.rs:178 */
+    size_t argc = 1;
+    napi_value argv[1];
+    engine_box *b = unwrap(env, info, &argc, argv);
+    if (!b) return NULL;
+    float mm[2] = {0.0f, 0.0f};
+    grv_compute_shadow_shift(b->h, arg_f64(env, argv[0]), mm);
+    return f32_array(env, mm, 2);
+}
+
+#define SCALAR2(name, fn)                                                                  \
+    static napi_value name(napi_env env, napi_callback_info info) {                        \
+        size_t argc = 2;                                                                   \
+        napi_value argv[2];                                                                \
+        engine_box *b = unwrap(env, info, &argc, argv);                                    \
+        return b ? mk_f64(env, fn(b->h, arg_f64(env, argv[0]), arg_f64(env, argv[1]))) : NULL; \
+    }
+SCALAR2(m_compute_kretschner, grv_compute_kretschner)             /* lib.rs:214 */
+SCALAR2(m_compute_light_cone_tilt, grv_compute_light_cone_tilt)   /* lib.rs:239 */
+SCALAR2(m_compute_frame_drag_omega, grv_compute_frame_drag_omega) /* lib.rs:268 */
+
+static napi_value m_compute_flamm_height(napi_env env, napi_callback_info info) { /* lib.rs:297 */
+    size_t argc = 1;
+    napi_value argv[1];
+    engine_box *b = unwrap(env, info, &argc, argv);
+    return b ? mk_f64(env, grv_compute_flamm_height(b->h, arg_f64(env, argv[0]))) : NULL;
+}
+
+static napi_value m_compute_proper_distance(napi_env env, napi_callback_info info) { /* lib.rs:303 */
+    size_t argc = 3;
+    napi_value argv[3];
+    engine_box *b = unwrap(env, info, &argc, argv);
+    return b ? mk_f64(env, grv_compute_proper_distance(b->h, arg_f64(env, argv[0]),
+                                                       arg_f64(env, argv[1]), arg_u32(env, argv[2])))
+             : NULL;
+}
+
+/* generate_{curvature,tilt,frame_drag}_field(rMin, rMax, nRadial, nPolar) -> Float32Array[3*nr*np] */
+static napi_value field_common(napi_env env, napi_callback_info info, int field) {
+    size_t argc = 4;
+    napi_value argv[4];
+    engine_box *b = unwrap(env, info, &argc, argv);
+    if (!b) return NULL;
+    const uint32_t nr = arg_u32(env, argv[2]), np = arg_u32(env, argv[3]);
+    const size_t n = (size_t)3 * nr * np;
+    float *tmp = (float *)malloc((n ? n : 1) * sizeof(float));
+    if (grv_generate_field(b->h, field, arg_f64(env, argv[0]), arg_f64(env, argv[1]), nr, np, tmp) !=
+        GRV_OK) {
+        free(tmp);
+        napi_throw_error(env, NULL, grv_last_error(b->h));
+        return NULL;
+    }
+    napi_value ta = f32_array(env, tmp, n);
+    free(tmp);
+    return ta;
+}
+static napi_value m_generate_curvature_field(napi_env env, napi_callback_info info) { /* lib.rs:220 */
+    return field_common(env, info, GRV_FIELD_CURVATURE);
+}
+static napi_value m_generate_tilt_field(napi_env env, napi_callback_info info) { /* lib.rs:245 */
+    return field_common(env, info, GRV_FIELD_TILT);
+}
+static napi_value m_generate_frame_drag_field(napi_env env, napi_callback_info info) { /* lib.rs:274 */
+    return field_common(env, info, GRV_FIELD_FRAME_DRAG);
+}
+
+/* generate_embedding_mesh(rMin, rMax, nRadial, nAngular)  lib.rs:139 ; physics-bridge.ts:315 */
+static napi_value m_generate_embedding_mesh(napi_env env, napi_callback_info info) {
+    size_t argc = 4;
+    napi_value argv[4];
+    engine_box *b = unwrap(env, info, &argc, argv);
+    if (!b) return NULL;
+    const uint32_t nr = arg_u32(env, argv[2]), na = arg_u32(env, argv[3]);
+    const size_t n = (size_t)3 * nr * na;
+    float *tmp = (float *)malloc((n ? n : 1) * sizeof(float));
+    if (grv_generate_embedding_mesh(b->h, arg_f64(env, argv[0]), arg_f64(env, argv[1]), nr, na, tmp) !=
+        GRV_OK) {
+        free(tmp);
+        napi_throw_error(env, NULL, grv_last_error(b->h));
+        return NULL;
+    }
+    napi_value ta = f32_array(env, tmp, n);
+    free(tmp);
+    return ta;
+}
+
+/* generate_ergosphere_mesh(nPolar, nAzimuthal)  lib.rs:153 ; physics-bridge.ts:333 */
+static napi_value m_generate_ergosphere_mesh(napi_env env, napi_callback_info info) {
+    size_t argc = 2;
+    napi_value argv[2];
+    engine_box *b = unwrap(env, info, &argc, argv);
+    if (!b) return NULL;
+    const uint32_t np = arg_u32(env, argv[0]), na = arg_u32(env, argv[1]);
+    const size_t n = (size_t)3 * np * na;
+    float *tmp = (float *)malloc((n ? n : 1) * sizeof(float));
+    if (grv_generate_ergosphere_mesh(b->h, np, na, tmp) != GRV_OK) {
+        free(tmp);
+        napi_throw_error(env, NULL, grv_last_error(b->h));
+        return NULL;
+    }
+    napi_value ta = f32_array(env, tmp, n);
+    free(tmp);
+    return ta;
+}
+
+/* get_disk_lut_ptr() lib.rs:112: byte offset of the engine's 512-float LUT copy in the arena
+ * (refreshed by generate_disk_lut) */
+static napi_value m_get_disk_lut_ptr(napi_env env, napi_callback_info info) {
+    size_t argc = 0;
+    engine_box *b = unwrap(env, info, &argc, NULL);
+    if (!b) return NULL;
+    napi_value v;
+    napi_create_uint32(env, (uint32_t)b->lut_off, &v);
+    return v;
+}
+
+static double obj_f64(napi_env env, napi_value obj, const char *key, double dflt) {
+    bool has = false;
+    napi_value v;
+    if (napi_has_named_property(env, obj, key, &has) != napi_ok || !has) return dflt;
+    if (napi_get_named_property(env, obj, key, &v) != napi_ok) return dflt;
+    napi_valuetype t;
+    if (napi_typeof(env, v, &t) != napi_ok || t != napi_number) return dflt;
+    return arg_f64(env, v);
+}
+
+static void obj_vec3(napi_env env, napi_value obj, const char *key, double out[3]) {
+    bool has = false;
+    napi_value arr, e;
+    if (napi_has_named_property(env, obj, key, &has) != napi_ok || !has) return;
+    if (napi_get_named_property(env, obj, key, &arr) != napi_ok) return;
+    for (uint32_t i = 0; i < 3; i++)
+        if (napi_get_element(env, arr, i, &e) == napi_ok) out[i] = arg_f64(env, e);
+}
+
+/* renderFrame({width, height, eye:[x,y,z], target?, up?, fovY?, maxSteps?, tolerance?, shading?,
+ *              arith?: "fast"|"strict"}) -> {rgba: Float32Array[w*h*4], width, height, rays,
+ *              acceptedSteps, launches}
+ * The frame the reference only produces in its WebGPU compute pass (compute.wgsl.ts:147-258),
+ * integrated by the f64 RKF45 kernel; pixel->ray of compute.wgsl.ts:159-187. */
+static napi_value m_render_frame(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    engine_box *b = unwrap(env, info, &argc, argv);
+    if (!b) return NULL;
+    napi_valuetype t;
+    if (argc < 1 || napi_typeof(env, argv[0], &t) != napi_ok || t != napi_object) {
+        napi_throw_type_error(env, NULL, "renderFrame expects an options object");
+        return NULL;
+    }
+    const uint32_t w = (uint32_t)obj_f64(env, argv[0], "width", 256);
+    const uint32_t h = (uint32_t)obj_f64(env, argv[0], "height", 256);
+    if (w == 0 || h == 0 || (uint64_t)w * h > (1ull << 27)) {
+        napi_throw_range_error(env, NULL, "renderFrame: width/height out of range");
+        return NULL;
+    }
+    double eye[3] = {0.0, 0.0, 60.0}, target[3] = {0.0, 0.0, 0.0}, up[3] = {0.0, 1.0, 0.0};
+    obj_vec3(env, argv[0], "eye", eye);
+    obj_vec3(env, argv[0], "target", target);
+    obj_vec3(env, argv[0], "up", up);
+    GrvCamera cam;
+    /* fovY in degrees (WebGPUCanvas.tsx:143-151 uses 60); the C ABI takes radians */
+    grv_camera_look_at(eye, target, up, obj_f64(env, argv[0], "fovY", 60.0) * (3.14159265358979323846 / 180.0),
+                       (double)w / (double)h, &cam);
+    GrvRenderParams p;
+    grv_render_params_default(w, h, &p);
+    p.opt.max_steps = (uint64_t)obj_f64(env, argv[0], "maxSteps", (double)p.opt.max_steps);
+    p.opt.tolerance = obj_f64(env, argv[0], "tolerance", p.opt.tolerance);
+    p.shading = (int32_t)obj_f64(env, argv[0], "shading", (double)p.shading);
+    bool has = false;
+    if (napi_has_named_property(env, argv[0], "arith", &has) == napi_ok && has) {
+        napi_value v;
+        char buf[16] = {0};
+        size_t len = 0;
+        if (napi_get_named_property(env, argv[0], "arith", &v) == napi_ok &&
+            napi_get_value_string_utf8(env, v, buf, sizeof buf, &len) == napi_ok)
+            p.opt.arith = strcmp(buf, "strict") == 0 ? GRV_ARITH_STRICT : GRV_ARITH_FAST;
+    }
+    const size_t n = (size_t)w * h * 4;
+    napi_value ab, rgba, out;
+    void *dst;
+    NAPI_OK(napi_create_arraybuffer(env, n * sizeof(float), &dst, &ab));
+    GrvFrameStats st;
+    memset(&st, 0, sizeof st);
+    if (grv_render_frame(b->h, &cam, &p, (float *)dst, &st) != GRV_OK) {
+        napi_throw_error(env, NULL, grv_last_error(b->h));
+        return NULL;
+    }
+    NAPI_OK(napi_create_typedarray(env, napi_float32_array, n, ab, 0, &rgba));
+    NAPI_OK(napi_create_object(env, &out));
+    NAPI_OK(napi_set_named_property(env, out, "rgba", rgba));
+    NAPI_OK(napi_set_named_property(env, out, "width", mk_f64(env, w)));
+    NAPI_OK(napi_set_named_property(env, out, "height", mk_f64(env, h)));
+    NAPI_OK(napi_set_named_property(env, out, "rays", mk_f64(env, (double)st.rays)));
+    NAPI_OK(napi_set_named_property(env, out, "acceptedSteps", mk_f64(env, (double)st.accepted_steps)));
+    NAPI_OK(napi_set_named_property(env, out, "launches", mk_f64(env, (double)st.launches)));
+    return out;
+}
+
 static napi_value m_free(napi_env env, napi_callback_info info) { /* wasm-bindgen's .free() */
     size_t argc = 0;
     napi_value self;
@@ -371,6 +591,20 @@ static napi_value module_init(napi_env env, napi_value exports) {
         METHOD("tick_sab", m_tick_sab),
         METHOD("get_sab_ptr", m_get_sab_ptr),
         METHOD("get_sab_layout", m_get_sab_layout),
+        METHOD("compute_shadow_shift", m_compute_shadow_shift),
+        METHOD("get_disk_lut_ptr", m_get_disk_lut_ptr),
+        METHOD("generate_embedding_mesh", m_generate_embedding_mesh),
+        METHOD("generate_ergosphere_mesh", m_generate_ergosphere_mesh),
+        METHOD("compute_kretschner", m_compute_kretschner),
+        METHOD("generate_curvature_field", m_generate_curvature_field),
+        METHOD("compute_light_cone_tilt", m_compute_light_cone_tilt),
+        METHOD("generate_tilt_field", m_generate_tilt_field),
+        METHOD("compute_frame_drag_omega", m_compute_frame_drag_omega),
+        METHOD("generate_frame_drag_field", m_generate_frame_drag_field),
+        METHOD("compute_flamm_height", m_compute_flamm_height),
+        METHOD("compute_proper_distance", m_compute_proper_distance),
+        METHOD("renderFrame", m_render_frame),
+        METHOD("render_frame", m_render_frame),
         METHOD("free", m_free),
     };
     napi_value cls, fn;

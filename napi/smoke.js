@@ -19,7 +19,25 @@ const wasm = require(path.join(__dirname, "blackhole_physics.node"));
     lut0: Array.from(engine.generate_spectrum_lut(8, 2, 1e5).slice(28, 32)),
     disk_lut_len: engine.generate_disk_lut().length,
     shadow_pts: engine.compute_shadow_curve(Math.PI / 2, 32).length / 2,
+    shadow_shift: Array.from(engine.compute_shadow_shift(Math.PI / 2)),
+    disk_lut_max: Math.max.apply(null, Array.from(
+      new Float32Array(mod.memory.buffer, engine.get_disk_lut_ptr(), 512))),
+    embedding_len: engine.generate_embedding_mesh(2.5, 30, 24, 16).length,   // physics-bridge.ts:315
+    ergosphere_len: engine.generate_ergosphere_mesh(17, 12).length,          // physics-bridge.ts:333
+    kretschner: engine.compute_kretschner(6.0, Math.PI / 2),
+    tilt: engine.compute_light_cone_tilt(6.0, Math.PI / 2),
+    omega: engine.compute_frame_drag_omega(6.0, Math.PI / 2),
+    flamm: engine.compute_flamm_height(100.0),
+    proper: engine.compute_proper_distance(4.0, 20.0, 500),
+    curvature_len: engine.generate_curvature_field(2.2, 40, 8, 5).length,
+    tilt_len: engine.generate_tilt_field(2.2, 40, 8, 5).length,
+    drag_len: engine.generate_frame_drag_field(2.2, 40, 8, 5).length,
   };
+  // the frame surface: f64 RKF45 kernel behind renderFrame (SURVEY F2)
+  const frame = engine.renderFrame({ width: 96, height: 54, eye: [59.55, -7.31, 0.0], maxSteps: 2048 });
+  let lit = 0;
+  for (let i = 0; i < frame.rgba.length; i += 4) if (frame.rgba[i] + frame.rgba[i + 1] + frame.rgba[i + 2] > 0) lit++;
+  res.frame = { rays: frame.rays, acceptedSteps: frame.acceptedSteps, lit: lit, alpha0: frame.rgba[3] };
   console.log(JSON.stringify(res));
   engine.free();
 })().catch((e) => { console.error("FAILED", e); process.exit(1); });

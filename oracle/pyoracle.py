@@ -180,6 +180,20 @@ def lib():
         L.orc_sab_engine_init.argtypes = [C.POINTER(SabEngine), d, d]
         L.orc_camera_update.argtypes = [C.POINTER(CameraState), d, d, d, d]
         L.orc_tick_sab.argtypes = [C.POINTER(SabEngine), d]
+        for name in ("orc_kretschner_kerr", "orc_light_cone_tilt_bl", "orc_frame_dragging_omega"):
+            getattr(L, name).restype = d
+            getattr(L, name).argtypes = [d, d, d, d]
+        L.orc_ergosphere_radius.restype = d
+        L.orc_ergosphere_radius.argtypes = [d, d, d]
+        L.orc_flamm_height.restype = d
+        L.orc_flamm_height.argtypes = [d, d]
+        L.orc_kerr_embedding_height.restype = d
+        L.orc_kerr_embedding_height.argtypes = [d, d, C.c_size_t, d, d]
+        L.orc_proper_distance.restype = d
+        L.orc_proper_distance.argtypes = [d, d, C.c_size_t, d, d]
+        L.orc_scalar_field.argtypes = [i, d, d, d, d, C.c_size_t, C.c_size_t, p]
+        L.orc_embedding_mesh.argtypes = [d, d, d, d, C.c_size_t, C.c_size_t, p]
+        L.orc_ergosphere_mesh.argtypes = [d, d, C.c_size_t, C.c_size_t, p]
         _lib = L
     return _lib
 
@@ -325,6 +339,25 @@ def bardeen_shadow(mass, spin, theta_obs, n_points):
     out = np.zeros(4 * n_points + 4, np.float64)
     n = lib().orc_bardeen_shadow(mass, spin, theta_obs, n_points, _ptr(out))
     return out[:2 * n].reshape(n, 2).copy()
+
+
+def scalar_field(kind, mass, spin, r_min, r_max, n_radial, n_polar):
+    """kind: 0 Kretschner, 1 light-cone tilt, 2 frame-drag omega -> (r, theta, value) f32 triples"""
+    out = np.zeros(3 * n_radial * n_polar, np.float32)
+    lib().orc_scalar_field(kind, mass, spin, r_min, r_max, n_radial, n_polar, _ptr(out))
+    return out
+
+
+def embedding_mesh(mass, spin, r_min, r_max, n_radial, n_angular):
+    out = np.zeros(3 * n_radial * n_angular, np.float32)
+    lib().orc_embedding_mesh(mass, spin, r_min, r_max, n_radial, n_angular, _ptr(out))
+    return out
+
+
+def ergosphere_mesh(mass, spin, n_polar, n_azimuthal):
+    out = np.zeros(3 * n_polar * n_azimuthal, np.float32)
+    lib().orc_ergosphere_mesh(mass, spin, n_polar, n_azimuthal, _ptr(out))
+    return out
 
 
 def sab_engine(mass, spin):

@@ -1,0 +1,109 @@
+"""The N-API addon (napi/gravitas_napi.c) presents the wasm-bindgen surface of
+gravitas-wasm/src/lib.rs:56-465 to the reference's TypeScript (src/engine/physics-bridge.ts,
+src/workers/physics.worker.ts).  CPU: it loads in Node and exports every method the
+reference's FFI has; GPU: napi/smoke.js walks the worker's call sequence and its numbers are
+checked against the oracle."""
+import json
+import math
+import os
+import re
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ADDON = os.path.join(ROOT, "napi", "blackhole_physics.node")
+NODE = shutil.which("node")
+
+# every `pub fn` of `#[wasm_bindgen] impl PhysicsEngine` (lib.rs:56-465) except attach_sab,
+# whose raw-pointer argument has no JS meaning (the addon attaches its arena block itself)
+WASM_METHODS = [
+    "update_params", "compute_horizon", "compute_isco", "compute_photon_sphere", "compute_dilation",
+    "generate_disk_lut", "get_disk_lut_ptr", "get_sab_ptr", "set_camera_state", "set_auto_spin",
+    "generate_spectrum_lut", "generate_embedding_mesh", "generate_ergosphere_mesh",
+    "compute_shadow_curve", "compute_shadow_radius", "compute_shadow_shift", "compute_disk_flux",
+    "compute_g_factor", "compute_kretschner", "generate_curvature_field", "compute_light_cone_tilt",
+    "generate_tilt_field", "compute_frame_drag_omega", "generate_frame_drag_field",
+    "compute_flamm_height", "compute_proper_distance", "tick_sab", "get_sab_layout",
+    "integrate_ray_relativistic",
+    # names BASELINE.json's north_star uses for the path
+    "integratePhotonGeodesic", "renderFrame", "free",
+]
+
+pytestmark = pytest.mark.skipif(NODE is None or not os.path.exists(ADDON),
+                                reason="node or the built addon is not available")
+
+
+def _node(script, timeout=120):
+    return subprocess.run([NODE, "-e", script], capture_output=True, text=True, timeout=timeout,
+                          cwd=ROOT)
+
+
+def test_addon_loads_and_exports_the_wasm_bindgen_surface():
+    r = _node("const m=require(%r);console.log(JSON.stringify({k:Object.keys(m),"
+              "p:Object.getOwnPropertyNames(m.PhysicsEngine.prototype),d:typeof m.default}))" % ADDON)
+    assert r.returncode == 0, r.stderr
+    got = json.loads(r.stdout)
+    assert {"PhysicsEngine", "default", "init_hooks"} <= set(got["k"]) and got["d"] == "function"
+    missing = [m for m in WASM_METHODS if m not in got["p"]]
+    assert not missing, missing
+
+
+def test_method_list_is_the_reference_ffi(oracle):
+    """WASM_METHODS above is checked against the reference source when it is mounted."""
+    src = "/root/reference/physics-engine/gravitas-wasm/src/lib.rs"
+    if not os.path.exists(src):
+        pytest.skip("reference not mounted")
+    names = re.findall(r"pub fn (\w+)\(", open(src).read())
+    want = set(names) - {"init_hooks", "new", "attach_sab"}
+    assert want <= set(WASM_METHODS), want - set(WASM_METHODS)
+
+
+def test_no_device_is_an_exception_not_a_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    r = _node("const m=require(%r);try{new m.PhysicsEngine(1,0.9);console.log('created')}"
+              "catch(e){console.log('threw:'+e.message)}" % ADDON)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.startswith("threw:") and "no HIP device" in r.stdout
+
+
+@pytest.mark.gpu
+def test_smoke_js_matches_oracle(oracle):
+    r = subprocess.run([NODE, os.path.join(ROOT, "napi", "smoke.js")], capture_output=True, text=True,
+                       timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr + r.stdout
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    L = oracle.lib()
+    m = oracle.metric(oracle.KERR_BL, 1.0, 0.9)
+    assert abs(res["horizon"] - L.orc_event_horizon(m)) < 1e-12
+    assert abs(res["isco"] - L.orc_isco(m, 0)) < 1e-12
+    assert res["layout"] == [0, 64, 128, 256, 2048]
+    assert abs(res["sab_horizon"] - res["horizon"]) < 1e-6 and abs(res["sab_isco"] - res["isco"]) < 1e-6
+    assert res["sab_points"] >= 32
+    ref = oracle.integrate_ray_relativistic(1.0, 0.9, [0, 20, math.pi / 2, 0, -1, -1, 0, 3.5], 10000,
+                                            1e-8, True)
+    assert np.allclose(res["ray"], ref, rtol=1e-6, atol=1e-6)
+    assert res["echo"] == [1, 2, 3]                                  # lib.rs:429-431
+    lut = oracle.blackbody_lut(8, 2, 1e5).reshape(-1)
+    assert np.allclose(res["lut0"], lut[28:32], rtol=1e-5)
+    assert res["disk_lut_len"] == 512 and res["disk_lut_max"] == 1.0
+    assert res["shadow_pts"] in (32, 64)
+    sh = oracle.bardeen_shadow(1.0, 0.9, math.pi / 2, 32)[:, 0]
+    assert np.allclose(res["shadow_shift"], [sh.min(), sh.max()], atol=1e-5)
+    assert res["embedding_len"] == 3 * 24 * 16 and res["ergosphere_len"] == 3 * 17 * 12
+    assert abs(res["kretschner"] - L.orc_kretschner_kerr(6.0, math.pi / 2, 1.0, 0.9)) < 1e-12
+    assert abs(res["tilt"] - L.orc_light_cone_tilt_bl(6.0, math.pi / 2, 1.0, 0.9)) < 1e-12
+    assert abs(res["omega"] - L.orc_frame_dragging_omega(6.0, math.pi / 2, 1.0, 0.9)) < 1e-12
+    assert abs(res["flamm"] - L.orc_flamm_height(100.0, 1.0)) < 1e-12
+    assert abs(res["proper"] - L.orc_proper_distance(4.0, 20.0, 500, 1.0, 0.9)) < 1e-10
+    assert res["curvature_len"] == res["tilt_len"] == res["drag_len"] == 3 * 8 * 5
+    # renderFrame: same frame through the oracle (96x54, a = 0.9, camera of smoke.js)
+    cam = oracle.camera_look_at((59.55, -7.31, 0.0), aspect=96 / 54)
+    fr = oracle.render_frame(cam, oracle.frame_params(96, 54, spin=0.9), None, nthreads=4)
+    assert res["frame"]["rays"] == 96 * 54 and res["frame"]["alpha0"] == 1.0
+    assert res["frame"]["acceptedSteps"] == int(fr["steps"].sum())
+    assert res["frame"]["lit"] == int((fr["rgba"].reshape(-1, 4)[:, :3].sum(axis=1) > 0).sum())
