@@ -119,6 +119,7 @@ struct grv_engine {
     hipEvent_t ev[8] = {};
     bool ev_ok = false;
 
+    uint8_t *d_noise = nullptr; // [2][256*256] R planes: u_noiseTex, u_blueNoiseTex
     std::vector<float> disk_lut = std::vector<float>(512, 0.0f); // lut_buffer (lib.rs:50, 65-66)
     std::vector<float> sab;
     float *sab_ext = nullptr; // attach_sab (lib.rs:74)
@@ -431,6 +432,7 @@ void grv_engine_destroy(grv_engine *e) {
     if (e->ws_mem) (void)hipFree(e->ws_mem);
     if (e->stage_mem) (void)hipFree(e->stage_mem);
     if (e->d_lut) (void)hipFree(e->d_lut);
+    if (e->d_noise) (void)hipFree(e->d_noise);
     if (e->d_counters) (void)hipFree(e->d_counters);
     if (e->d_stats) (void)hipFree(e->d_stats);
     if (e->h_counters) (void)hipHostFree(e->h_counters);
@@ -772,10 +774,44 @@ void grv_glsl_params_default(uint32_t width, uint32_t height, double mass, doubl
     p->disk_temp = (float)(9500.0 * std::pow(mass, -0.25)); // renderer.ts:352-356
     p->lensing_strength = 1.0f;                   // renderer.ts:340
     p->time = 0.0f;
-    p->turbulence = 0.75f;
+    p->turbulence = -1.0f;                        // sample the noise texture (disk.ts:55)
     p->max_ray_steps = 256;                       // simulation.config.ts:205-211 (ultra)
     p->tone_map = 0;
     p->tile_world = 1;
+    p->features = GRV_GLSL_FEATURES_DEFAULT;
+    p->quality = 1;
+    p->cam_quat[3] = 1.0f;                        // renderer.ts:315-316
+}
+
+void grv_seeded_noise_rgba8(uint32_t seed, uint32_t size, uint8_t *rgba) {
+    if (!rgba) return;
+    // xorshift32 stream; byte = floor(u * 255), u in [0, 1), as createNoiseTexture forms it
+    uint32_t x = seed ? seed : 0x9E3779B9u;
+    const size_t n = (size_t)size * size * 4u;
+    for (size_t i = 0; i < n; ++i) {
+        x ^= x << 13;
+        x ^= x >> 17;
+        x ^= x << 5;
+        rgba[i] = (uint8_t)std::floor((double)(x >> 8) / 16777216.0 * 255.0);
+    }
+}
+
+int grv_set_glsl_noise(grv_engine *e, const uint8_t *noise_rgba, const uint8_t *blue_rgba) {
+    if (!e) return GRV_ERR_INVALID;
+    GRV_HIP(e, hipSetDevice(e->device));
+    constexpr size_t kPlane = 256 * 256;
+    if (!e->d_noise) {
+        GRV_HIP(e, hipMalloc(reinterpret_cast<void **>(&e->d_noise), 2 * kPlane));
+        GRV_HIP(e, hipMemset(e->d_noise, 0, 2 * kPlane));
+    }
+    std::vector<uint8_t> plane(kPlane);
+    const uint8_t *src[2] = {noise_rgba, blue_rgba};
+    for (int t = 0; t < 2; ++t) {
+        if (!src[t]) continue;
+        for (size_t i = 0; i < kPlane; ++i) plane[i] = src[t][4 * i]; // .r
+        GRV_HIP(e, hipMemcpy(e->d_noise + t * kPlane, plane.data(), kPlane, hipMemcpyHostToDevice));
+    }
+    return GRV_OK;
 }
 
 
@@ -818,10 +854,28 @@ int grv_render_frame_glsl(grv_engine *e, const GrvGlslParams *p, float *d_rgba, 
     P.turbulence = p->turbulence;
     P.max_ray_steps = p->max_ray_steps;
     P.tone_map = p->tone_map;
+    P.features = p->features;
+    P.quality = p->quality;
+    P.show_redshift = p->show_redshift;
+    P.show_kerr_shadow = p->show_kerr_shadow;
+    P.debug = p->debug;
+    std::memcpy(P.cam_pos, p->cam_pos, sizeof P.cam_pos);
+    std::memcpy(P.cam_quat, p->cam_quat, sizeof P.cam_quat);
+    P.shadow_count = p->shadow_count;
+    std::memcpy(P.shadow_curve, p->shadow_curve, sizeof P.shadow_curve);
+    if (!e->d_noise) { // first GLSL frame of this engine: the seeded default textures
+        std::vector<uint8_t> a(256 * 256 * 4), b(256 * 256 * 4);
+        grv_seeded_noise_rgba8(1u, 256, a.data());
+        grv_seeded_noise_rgba8(2u, 256, b.data());
+        int rc = grv_set_glsl_noise(e, a.data(), b.data());
+        if (rc != GRV_OK) return rc;
+    }
+    P.noise_r = e->d_noise;
+    P.blue_r = e->d_noise + 256 * 256;
     hipStream_t s = static_cast<hipStream_t>(stream);
     return run_shader_frame(e, p->width, p->height, p->tile_world, p->tile_rank, total_steps, s,
                             [&](const FrameGeom &G, uint32_t n, unsigned long long *tot) {
-                                return launch_glsl_verlet(G, P, d_rgba, d_steps, tot, n, s);
+                                return launch_glsl_fragment(G, P, d_rgba, d_steps, tot, n, s);
                             });
 }
 

@@ -84,6 +84,14 @@ struct GlslParams {
     float disk_size, disk_scale_height, disk_density, disk_temp;
     float lensing_strength, time, turbulence;
     int32_t max_ray_steps, tone_map;
+    uint32_t features; // GRV_GLSL_* bits
+    int32_t quality;   // 0: RAY_QUALITY_LOW/OFF indicator path
+    float show_redshift, show_kerr_shadow, debug;
+    float cam_pos[3], cam_quat[4];
+    float shadow_count;
+    float shadow_curve[64][2];
+    const uint8_t *noise_r; // 256x256 R channel of u_noiseTex (device)
+    const uint8_t *blue_r;  // 256x256 R channel of u_blueNoiseTex (device)
 };
 
 struct FrameStatsDev {
@@ -114,7 +122,7 @@ hipError_t launch_unpack_tiles(const FrameGeom &G, const void *packed, void *ima
 hipError_t launch_wgsl_symplectic(const FrameGeom &G, const WgslParams &P, float *out_rgba,
                                   uint32_t *out_steps, unsigned long long *total_steps,
                                   uint32_t n_slots, hipStream_t s);
-hipError_t launch_glsl_verlet(const FrameGeom &G, const GlslParams &P, float *out_rgba,
+hipError_t launch_glsl_fragment(const FrameGeom &G, const GlslParams &P, float *out_rgba,
                               uint32_t *out_steps, unsigned long long *total_steps,
                               uint32_t n_slots, hipStream_t s);
 hipError_t launch_spectrum_lut(float *out, uint32_t width, uint32_t height, double max_temp,

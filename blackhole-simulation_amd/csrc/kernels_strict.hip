@@ -134,11 +134,11 @@ hipError_t launch_wgsl_symplectic(const FrameGeom &G, const WgslParams &P, float
     return hipGetLastError();
 }
 
-hipError_t launch_glsl_verlet(const FrameGeom &G, const GlslParams &P, float *out_rgba,
+hipError_t launch_glsl_fragment(const FrameGeom &G, const GlslParams &P, float *out_rgba,
                               uint32_t *out_steps, unsigned long long *total_steps,
                               uint32_t n_slots, hipStream_t s) {
     if (n_slots == 0) return hipSuccess;
-    hipLaunchKernelGGL(glsl_verlet_kernel, dim3((n_slots + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
+    hipLaunchKernelGGL(glsl_fragment_kernel, dim3((n_slots + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
                        G, P, reinterpret_cast<float4 *>(out_rgba), out_steps, total_steps, n_slots);
     return hipGetLastError();
 }

@@ -72,7 +72,18 @@ class GlslParams(C.Structure):
                 ("disk_density", C.c_float), ("disk_temp", C.c_float),
                 ("lensing_strength", C.c_float), ("time", C.c_float), ("turbulence", C.c_float),
                 ("max_ray_steps", C.c_int32), ("tone_map", C.c_int32),
-                ("tile_world", C.c_uint32), ("tile_rank", C.c_uint32)]
+                ("tile_world", C.c_uint32), ("tile_rank", C.c_uint32),
+                ("features", C.c_uint32), ("quality", C.c_int32),
+                ("show_redshift", C.c_float), ("show_kerr_shadow", C.c_float),
+                ("debug", C.c_float), ("cam_pos", C.c_float * 3), ("cam_quat", C.c_float * 4),
+                ("shadow_count", C.c_float), ("shadow_curve", (C.c_float * 2) * 64)]
+
+
+# ShaderManager #defines as GlslParams.features bits (include/gravitas_abi.h)
+GLSL_LENSING, GLSL_DISK, GLSL_DOPPLER, GLSL_STARS = 1, 2, 4, 8
+GLSL_PHOTON_GLOW, GLSL_JETS, GLSL_REDSHIFT, GLSL_DITHER = 16, 32, 64, 128
+GLSL_FEATURES_DEFAULT = (GLSL_LENSING | GLSL_DISK | GLSL_DOPPLER | GLSL_STARS | GLSL_PHOTON_GLOW
+                         | GLSL_JETS | GLSL_DITHER)
 
 
 class FrameBuffers(C.Structure):
@@ -165,6 +176,9 @@ def load_library():
     L.grv_render_frame_wgsl.argtypes = [p, C.POINTER(WgslParams), p, p, C.POINTER(C.c_uint64), p]
     L.grv_render_frame_glsl.restype = i
     L.grv_render_frame_glsl.argtypes = [p, C.POINTER(GlslParams), p, p, C.POINTER(C.c_uint64), p]
+    L.grv_seeded_noise_rgba8.argtypes = [C.c_uint32, C.c_uint32, p]
+    L.grv_set_glsl_noise.restype = i
+    L.grv_set_glsl_noise.argtypes = [p, p, p]
     L.grv_generate_disk_lut.restype = i
     L.grv_generate_disk_lut.argtypes = [p, p]
     L.grv_compute_disk_flux.restype = d
@@ -255,11 +269,28 @@ def wgsl_params(width, height, camera, mass=1.0, spin=0.999, **kw):
     return p
 
 
+def seeded_noise_rgba8(seed, size=256):
+    """Deterministic stand-in for createNoiseTexture's Math.random() bytes (RGBA8)."""
+    out = np.zeros(size * size * 4, np.uint8)
+    load_library().grv_seeded_noise_rgba8(int(seed), int(size), _np_ptr(out))
+    return out
+
+
 def glsl_params(width, height, mass=1.0, spin=0.999, **kw):
     p = GlslParams()
     load_library().grv_glsl_params_default(width, height, mass, spin, C.byref(p))
     for k, v in kw.items():
-        setattr(p, k, v)
+        if k == "shadow_curve":  # (n, 2) array of (alpha, beta); also sets shadow_count
+            v = np.asarray(v, np.float32).reshape(-1, 2)[:64]
+            for j in range(len(v)):
+                p.shadow_curve[j][0], p.shadow_curve[j][1] = float(v[j, 0]), float(v[j, 1])
+            p.shadow_count = float(len(v))
+        elif k in ("cam_pos", "cam_quat", "mouse"):
+            arr = getattr(p, k)
+            for j, x in enumerate(v):
+                arr[j] = float(x)
+        else:
+            setattr(p, k, v)
     return p
 
 
@@ -397,6 +428,14 @@ class PhysicsEngine:
             self._h, C.byref(params), _dev_ptr(rgba), _dev_ptr(steps), C.byref(tot),
             C.c_void_p(stream) if stream else None), "render_frame_glsl")
         return tot.value
+
+    def set_glsl_noise(self, noise_rgba8=None, blue_rgba8=None):
+        """Override the shader's 256x256 RGBA8 noise / blue-noise textures (None keeps one)."""
+        for a in (noise_rgba8, blue_rgba8):
+            if a is not None and (a.dtype != np.uint8 or a.size != 256 * 256 * 4):
+                raise ValueError("textures are 256x256 RGBA8")
+        self._check(self._lib.grv_set_glsl_noise(self._h, _np_ptr(noise_rgba8), _np_ptr(blue_rgba8)),
+                    "set_glsl_noise")
 
     def frame_stats(self, stream=None):
         st = FrameStats()

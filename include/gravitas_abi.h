@@ -183,18 +183,50 @@ typedef struct { /* src/shaders/compute.wgsl.ts + types.wgsl.ts:6-30 */
     uint32_t tile_world, tile_rank;
 } GrvWgslParams;
 
-typedef struct { /* src/shaders/blackhole/chunks/common.ts:8-35 uniforms used by the march */
+/* ShaderManager's #defines (src/shaders/manager.ts:61-82) as GrvGlslParams.features bits */
+#define GRV_GLSL_LENSING 1u     /* ENABLE_LENSING */
+#define GRV_GLSL_DISK 2u        /* ENABLE_DISK */
+#define GRV_GLSL_DOPPLER 4u     /* ENABLE_DOPPLER */
+#define GRV_GLSL_STARS 8u       /* ENABLE_STARS */
+#define GRV_GLSL_PHOTON_GLOW 16u /* ENABLE_PHOTON_GLOW */
+#define GRV_GLSL_JETS 32u       /* ENABLE_JETS (only with DISK, manager.ts:72-73) */
+#define GRV_GLSL_REDSHIFT 64u   /* ENABLE_REDSHIFT */
+#define GRV_GLSL_DITHER 128u    /* blue-noise start offset, fragment.glsl.ts:104-108 (always on upstream) */
+/* the reference's default preset "high-quality" (src/configs/simulation.config.ts:48-60, 77-78) */
+#define GRV_GLSL_FEATURES_DEFAULT \
+    (GRV_GLSL_LENSING | GRV_GLSL_DISK | GRV_GLSL_DOPPLER | GRV_GLSL_STARS | GRV_GLSL_PHOTON_GLOW | \
+     GRV_GLSL_JETS | GRV_GLSL_DITHER)
+
+typedef struct { /* src/shaders/blackhole/chunks/common.ts:8-35 uniforms */
     uint32_t width, height;
     float mass;              /* u_mass */
     float spin;              /* u_spin as uploaded: spin * mass (src/rendering/webgl/renderer.ts:326) */
     float zoom;              /* u_zoom = zoom * 2 (renderer.ts:327) */
     float mouse[2];          /* u_mouse */
     float disk_size, disk_scale_height, disk_density, disk_temp, lensing_strength, time;
-    float turbulence;        /* stands in for the two unseeded noise() fetches of disk.ts:55 */
+    float turbulence;        /* >= 0: stands in for noise()*0.5 + noise()*0.25 of disk.ts:55;
+                                < 0: the two fetches from the engine's noise texture */
     int32_t max_ray_steps;   /* u_maxRaySteps (shader clamps to 500, fragment.glsl.ts:115) */
     int32_t tone_map;        /* 0: ENABLE_LINEAR_OUTPUT, 1: ACES + gamma (fragment.glsl.ts:327-331) */
     uint32_t tile_world, tile_rank;
+    uint32_t features;       /* GRV_GLSL_* */
+    int32_t quality;         /* 0: RAY_QUALITY_OFF/LOW indicator path (fragment.glsl.ts:76-88), else march */
+    float show_redshift;     /* u_show_redshift */
+    float show_kerr_shadow;  /* u_show_kerr_shadow */
+    float debug;             /* u_debug */
+    float cam_pos[3];        /* u_camPos; |.| <= 0.001 selects the mouse camera (renderer.ts:312-316) */
+    float cam_quat[4];       /* u_camQuat xyzw */
+    float shadow_count;      /* u_shadowCount */
+    float shadow_curve[64][2]; /* u_shadowCurve (alpha, beta) from compute_shadow_curve */
 } GrvGlslParams;
+
+/* The shader's two 256x256 RGBA8 textures (u_noiseTex LINEAR/REPEAT, u_blueNoiseTex
+ * NEAREST/REPEAT; only .r is sampled).  Upstream fills them with Math.random()
+ * (src/utils/webgl-utils.ts:259-305, not reproducible); an engine starts with seeded ones
+ * (grv_seeded_noise_rgba8, seeds 1 and 2).  Pass the `data` arrays createNoiseTexture /
+ * createBlueNoiseTexture would upload to override; NULL keeps the current plane. */
+void grv_seeded_noise_rgba8(uint32_t seed, uint32_t size, uint8_t *rgba);
+int grv_set_glsl_noise(grv_engine *e, const uint8_t *noise_rgba8_256, const uint8_t *blue_rgba8_256);
 
 void grv_wgsl_params_default(uint32_t width, uint32_t height, const GrvCamera *cam, double mass,
                              double spin, GrvWgslParams *p);

@@ -79,7 +79,12 @@ class GlslParams(C.Structure):
                 ("disk_size", C.c_float), ("disk_scale_height", C.c_float),
                 ("disk_density", C.c_float), ("disk_temp", C.c_float),
                 ("lensing_strength", C.c_float), ("time", C.c_float), ("turbulence", C.c_float),
-                ("max_ray_steps", C.c_int32), ("tone_map", C.c_int32)]
+                ("max_ray_steps", C.c_int32), ("tone_map", C.c_int32),
+                ("features", C.c_uint32), ("quality", C.c_int32),
+                ("show_redshift", C.c_float), ("show_kerr_shadow", C.c_float),
+                ("debug", C.c_float), ("cam_pos", C.c_float * 3), ("cam_quat", C.c_float * 4),
+                ("shadow_count", C.c_float), ("shadow_curve", (C.c_float * 2) * 64),
+                ("noise_r", C.c_void_p), ("blue_r", C.c_void_p)]
 
 
 def build(force=False):
@@ -177,6 +182,7 @@ def lib():
         L.orc_bardeen_shadow.argtypes = [d, d, d, C.c_size_t, p]
         L.orc_wgsl_frame.argtypes = [C.POINTER(WgslParams), C.c_uint32, C.c_uint32, p, p, i]
         L.orc_glsl_frame.argtypes = [C.POINTER(GlslParams), C.c_uint32, C.c_uint32, p, p, i]
+        L.orc_seeded_noise_rgba8.argtypes = [C.c_uint32, C.c_uint32, p]
         L.orc_sab_engine_init.argtypes = [C.POINTER(SabEngine), d, d]
         L.orc_camera_update.argtypes = [C.POINTER(CameraState), d, d, d, d]
         L.orc_tick_sab.argtypes = [C.POINTER(SabEngine), d]
@@ -385,14 +391,35 @@ def wgsl_params_from(gp):
     return o
 
 
-def glsl_params_from(gp):
+def seeded_noise_rgba8(seed, size=256):
+    out = np.zeros(size * size * 4, np.uint8)
+    lib().orc_seeded_noise_rgba8(int(seed), int(size), _ptr(out))
+    return out
+
+
+def glsl_params_from(gp, noise_rgba8=None, blue_rgba8=None):
+    """Oracle uniforms from the engine-side GrvGlslParams mirror.  Textures default to the
+    seeded planes an engine starts with (seeds 1 and 2)."""
     o = GlslParams()
     for f, _ in GlslParams._fields_:
+        if f in ("noise_r", "blue_r"):
+            continue
         v = getattr(gp, f)
-        if f == "mouse":
-            o.mouse[0], o.mouse[1] = v[0], v[1]
+        if f in ("mouse", "cam_pos", "cam_quat"):
+            dst = getattr(o, f)
+            for j in range(len(dst)):
+                dst[j] = v[j]
+        elif f == "shadow_curve":
+            for j in range(64):
+                o.shadow_curve[j][0], o.shadow_curve[j][1] = v[j][0], v[j][1]
         else:
             setattr(o, f, v)
+    noise = seeded_noise_rgba8(1) if noise_rgba8 is None else np.asarray(noise_rgba8, np.uint8)
+    blue = seeded_noise_rgba8(2) if blue_rgba8 is None else np.asarray(blue_rgba8, np.uint8)
+    o._planes = (np.ascontiguousarray(noise.reshape(-1, 4)[:, 0]),
+                 np.ascontiguousarray(blue.reshape(-1, 4)[:, 0]))  # keep alive
+    o.noise_r = o._planes[0].ctypes.data
+    o.blue_r = o._planes[1].ctypes.data
     return o
 
 

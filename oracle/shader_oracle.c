@@ -6,10 +6,12 @@
  * shader's evaluation order.  Deliberately fixed (the reference is not
  * reproducible there):
  *   - WGSL star hash (compute.wgsl.ts:201-204): omitted, background = 0;
- *   - GLSL blue-noise dither (fragment.glsl.ts:105-108): bNoise = 0;
- *   - GLSL disk turbulence (disk.ts:55): the two noise() fetches are replaced by the
- *     caller's `turbulence` value (0.75 = a uniform texture of 1.0);
- *   - GLSL jets / stars / photon-ring glow / ergosphere glow: not part of a16/a17.
+ *   - GLSL noise textures (webgl-utils.ts:259-305 fills them with Math.random()): the caller
+ *     supplies the two 256x256 R channels (orc_seeded_noise_rgba8 makes seeded ones);
+ *     hash() = texture(u_noiseTex, (uv+0.5)/256).r with LINEAR/REPEAT is evaluated with f32
+ *     bilinear weights (GPU samplers use fixed-point weights: not specified, not reproducible);
+ *   - `turbulence >= 0` replaces the two noise() fetches of disk.ts:55 by that value
+ *     (0.75 = a uniform texture of 1.0); ORC_GLSL_DITHER off = bNoise 0.
  * GLSL built-ins: normalize(v) = v / sqrt(dot(v,v)); smoothstep, clamp, mix, sign as in
  * the GLSL ES 3.00 specification.
  */
@@ -324,9 +326,95 @@ static void gl_rot_apply(float ang, float *x, float *y) {
     *y = ny;
 }
 
+/* ---- chunks/noise.ts ---- */
+static float gl_fract(float x) { return x - floorf(x); }
+static float gl_mix(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+
+static float tex_r(const uint8_t *t, int x, int y) { /* REPEAT wrap, UNORM8 */
+    return (float)t[(size_t)(y & 255) * 256u + (size_t)(x & 255)] / 255.0f;
+}
+/* texture(u_noiseTex, (uv + 0.5) / 256.0).r, LINEAR + REPEAT (GLSL ES 3.00 / GL ES 3.0 8.14) */
+static float gl_hash_uv(const orc_glsl_params *U, float uvx, float uvy) {
+    float s = (uvx + 0.5f) / 256.0f, t = (uvy + 0.5f) / 256.0f;
+    float u = s * 256.0f - 0.5f, v = t * 256.0f - 0.5f;
+    float fu = floorf(u), fv = floorf(v);
+    float a = u - fu, b = v - fv;
+    int i0 = (int)fmodf(fu, 256.0f), j0 = (int)fmodf(fv, 256.0f); /* & 255 wraps negatives */
+    const uint8_t *T = U->noise_r;
+    float t00 = tex_r(T, i0, j0), t10 = tex_r(T, i0 + 1, j0);
+    float t01 = tex_r(T, i0, j0 + 1), t11 = tex_r(T, i0 + 1, j0 + 1);
+    return (1.0f - a) * (1.0f - b) * t00 + a * (1.0f - b) * t10 + (1.0f - a) * b * t01 + a * b * t11;
+}
+static float gl_hash(const orc_glsl_params *U, v3 p) { /* noise.ts:3-9 */
+    return gl_hash_uv(U, p.x + p.z * 37.0f, p.y + p.z * 37.0f);
+}
+static float gl_noise(const orc_glsl_params *U, v3 p) { /* noise.ts:11-21 */
+    v3 i = {floorf(p.x), floorf(p.y), floorf(p.z)};
+    v3 f = {gl_fract(p.x), gl_fract(p.y), gl_fract(p.z)};
+    f.x = f.x * f.x * (3.0f - 2.0f * f.x);
+    f.y = f.y * f.y * (3.0f - 2.0f * f.y);
+    f.z = f.z * f.z * (3.0f - 2.0f * f.z);
+#define H(dx, dy, dz) gl_hash(U, (v3){i.x + dx, i.y + dy, i.z + dz})
+    float r = gl_mix(gl_mix(gl_mix(H(0, 0, 0), H(1, 0, 0), f.x), gl_mix(H(0, 1, 0), H(1, 1, 0), f.x), f.y),
+                     gl_mix(gl_mix(H(0, 0, 1), H(1, 0, 1), f.x), gl_mix(H(0, 1, 1), H(1, 1, 1), f.x), f.y),
+                     f.z);
+#undef H
+    return r;
+}
+static float gl_fbm(const orc_glsl_params *U, v3 p) { /* noise.ts:23-33 */
+    float f = 0.0f, amp = 0.5f;
+    for (int i = 0; i < 4; i++) {
+        f += amp * gl_noise(U, p);
+        p = scale3(p, 2.0f);
+        amp *= 0.5f;
+    }
+    return f;
+}
+
+/* chunks/blackbody.ts:36-46 */
+static void gl_star_color(float bv, float c[3]) {
+    float t = clampf(bv, -0.4f, 2.0f);
+    if (t < 0.0f) { c[0] = 0.6f; c[1] = 0.7f; c[2] = 1.0f; }
+    else if (t < 0.3f) { c[0] = 0.85f; c[1] = 0.88f; c[2] = 1.0f; }
+    else if (t < 0.6f) { c[0] = 1.0f; c[1] = 0.96f; c[2] = 0.9f; }
+    else if (t < 1.0f) { c[0] = 1.0f; c[1] = 0.85f; c[2] = 0.6f; }
+    else { c[0] = 1.0f; c[1] = 0.6f; c[2] = 0.4f; }
+}
+
+/* chunks/background.ts:3-30 */
+static void gl_starfield(const orc_glsl_params *U, v3 dir, float stars[3]) {
+    stars[0] = stars[1] = stars[2] = 0.0f;
+    v3 cell = {floorf(dir.x * 200.0f), floorf(dir.y * 200.0f), floorf(dir.z * 200.0f)};
+    float starNoise = gl_hash(U, cell);
+    if (starNoise > 0.998f) {
+        float brightness = powf(starNoise, 10.0f) * 2.0f;
+        float bv = gl_hash(U, (v3){cell.x + 127.1f, cell.y + 127.1f, cell.z + 127.1f}) * 2.4f - 0.4f;
+        float twinkle = 0.85f + 0.15f * sinf(U->time * (3.0f + gl_hash(U, (v3){cell.x + 73.7f, cell.y + 73.7f, cell.z + 73.7f}) * 2.0f));
+        float sc[3];
+        gl_star_color(bv, sc);
+        for (int c = 0; c < 3; c++) stars[c] = sc[c] * brightness * twinkle;
+    }
+    cell = (v3){floorf(dir.x * 500.0f), floorf(dir.y * 500.0f), floorf(dir.z * 500.0f)};
+    starNoise = gl_hash(U, cell);
+    if (starNoise > 0.996f) {
+        float brightness = powf(starNoise, 20.0f) * 1.5f;
+        float bv = gl_hash(U, (v3){cell.x + 217.3f, cell.y + 217.3f, cell.z + 217.3f}) * 2.4f - 0.4f;
+        float sc[3];
+        gl_star_color(bv, sc);
+        for (int c = 0; c < 3; c++) stars[c] += sc[c] * brightness;
+    }
+    float tt = U->time * 0.01f;
+    float nebula = gl_fbm(U, (v3){dir.x * 2.0f + tt, dir.y * 2.0f + tt, dir.z * 2.0f + tt}) * 0.03f;
+    float ln = fabsf(nebula); /* length(float) */
+    stars[0] += nebula * 0.2f + 0.05f * ln;
+    stars[1] += nebula * 0.3f + 0.02f * ln;
+    stars[2] += nebula * 0.5f + 0.05f * ln;
+}
+
 /* chunks/disk.ts:16-115 */
 static void gl_sample_disk(const orc_glsl_params *U, v3 p, v3 p_prev, v3 v, float isco, float M,
                            float a, float dt, float color[3], float *alpha) {
+    if (!(U->show_redshift < 0.5f)) return;
     int crossed = (p_prev.y * p.y < 0.0f);
     v3 sp = p;
     if (crossed) {
@@ -343,6 +431,20 @@ static void gl_sample_disk(const orc_glsl_params *U, v3 p, v3 p_prev, v3 v, floa
     if (!((fabsf(sp.y) < diskHeight || crossed) && sampleR > diskInner && sampleR < diskOuter)) return;
 
     float turbulence = U->turbulence;
+    if (turbulence < 0.0f) { /* disk.ts:43-55 */
+        float sqrt_M_phase = sqrtf(M);
+        float signSpinPhase = signf(U->spin + 1e-8f);
+        float OmegaPhase = (signSpinPhase * sqrt_M_phase) / (sampleR * sqrtf(sampleR) + a * sqrt_M_phase);
+        float rotAngle = OmegaPhase * U->time * 0.12f * 10.0f;
+        v3 np = sp;
+        /* mat2(cos, -sin, sin, cos); noiseP.xz *= rotPhase (row vector * matrix) */
+        float cs = cosf(rotAngle), sn = sinf(rotAngle);
+        float nx = np.x * cs + np.z * (-sn), nz = np.x * sn + np.z * cs;
+        np.x = nx;
+        np.z = nz;
+        np = scale3(np, 0.75f);
+        turbulence = gl_noise(U, np) * 0.5f + gl_noise(U, scale3(np, 2.5f)) * 0.25f;
+    }
     float samplesDiskHeight = sampleR * effH;
     float heightFalloff = expf(-fabsf(sp.y) / fmaxf(0.001f, samplesDiskHeight * 0.25f));
     float radialFalloff = smoothstepf(diskOuter, diskInner, sampleR);
@@ -360,7 +462,7 @@ static void gl_sample_disk(const orc_glsl_params *U, v3 p, v3 p_prev, v3 v, floa
     float u_t = 1.0f / sqrtf(fmaxf(1e-6f, u_t_sq));
     float L_photon = p.z * v.x - p.x * v.z;
     float delta = 1.0f / fmaxf(0.01f, u_t * (1.0f - Omega * L_photon));
-    float beaming = fmaxf(0.01f, powf(delta, 3.5f));
+    float beaming = (U->features & ORC_GLSL_DOPPLER) ? fmaxf(0.01f, powf(delta, 3.5f)) : 1.0f;
     float isco_r = clampf(isco / sampleR, 0.0f, 1.0f);
     float nt_factor = fmaxf(0.0f, 1.0f - sqrtf(isco_r));
     float radialTempGradient = powf(isco_r, 0.75f) * powf(nt_factor, 0.25f);
@@ -372,27 +474,75 @@ static void gl_sample_disk(const orc_glsl_params *U, v3 p, v3 p_prev, v3 v, floa
     *alpha += density;
 }
 
+/* chunks/disk.ts:117-155 */
+static void gl_sample_jets(const orc_glsl_params *U, v3 p, v3 v, float rh, float dt, float color[3],
+                           float *alpha) {
+    float jetVerticalPos = fabsf(p.y);
+    if (!(jetVerticalPos > rh * 1.8f && jetVerticalPos < GL_MAX_DIST * 0.8f)) return;
+    float jetRadialDist = sqrtf(p.x * p.x + p.z * p.z);
+    float jetWidth = 1.0f + jetVerticalPos * 0.15f;
+    if (!(jetRadialDist < jetWidth * 2.0f)) return;
+    float radialFalloff = expf(-(jetRadialDist * jetRadialDist) / (jetWidth * 0.5f));
+    float lengthFalloff = expf(-jetVerticalPos * 0.05f);
+    float flowCombined = p.y * 2.0f - U->time * 8.0f;
+    v3 uvJet = {p.x, flowCombined, p.z};
+    float noiseVal = gl_noise(U, scale3(uvJet, 0.5f)) * 0.6f + gl_noise(U, scale3(uvJet, 1.5f)) * 0.4f;
+    float jetDensity = radialFalloff * lengthFalloff * fmaxf(0.0f, noiseVal - 0.2f);
+    if (!(jetDensity > 0.001f)) return;
+    float jetVel = 0.92f * signf(p.y);
+    v3 jetVelVec = {0.0f, jetVel, 0.0f};
+    v3 nv = normalize3(jetVelVec);
+    float cosThetaJet = dot3(nv, (v3){-v.x, -v.y, -v.z});
+    float betaJet = fabsf(jetVel);
+    float gammaJet = 1.0f / sqrtf(1.0f - betaJet * betaJet);
+    float deltaJet = 1.0f / (gammaJet * (1.0f - betaJet * cosThetaJet));
+    float beamingJet = powf(deltaJet, 3.5f);
+    const float base[3] = {0.4f, 0.7f, 1.0f};
+    for (int c = 0; c < 3; c++) color[c] += base[c] * jetDensity * 0.05f * beamingJet * dt * (1.0f - *alpha);
+    *alpha += jetDensity * 0.05f * dt;
+}
+
 static float aces(float c) { /* chunks/common.ts:50-57 */
     const float A = 2.51f, B = 0.03f, C = 2.43f, D = 0.59f, E = 0.14f;
     return clampf((c * (A * c + B)) / (c * (C * c + D) + E), 0.0f, 1.0f);
 }
 
-/* fragment.glsl.ts:40-221 (+ 276, 327-333), fallback camera (u_camPos = 0, renderer.ts:313) */
+static v3 gl_qrot(const float q[4], v3 v) { /* common.ts:74-76 */
+    v3 qv = {q[0], q[1], q[2]};
+    v3 t = add3(cross3(qv, v), scale3(v, q[3]));
+    return add3(v, scale3(cross3(qv, t), 2.0f));
+}
+
+/* fragment.glsl.ts:40-334 (the whole main()) */
 uint32_t orc_glsl_pixel(const orc_glsl_params *U, uint32_t ix, uint32_t iy, float rgba[4]) {
+    const uint32_t F = U->features;
     float resx = (float)U->width, resy = (float)U->height;
     float minRes = fminf(resx, resy);
     /* gl_FragCoord = pixel centre, origin bottom-left; iy counts image rows from the top */
     float fcx = (float)ix + 0.5f, fcy = (float)(U->height - 1u - iy) + 0.5f;
     float uvx = (fcx - 0.5f * resx) / minRes, uvy = (fcy - 0.5f * resy) / minRes;
+    rgba[3] = 1.0f;
+    if (U->debug > 0.5f) {
+        rgba[0] = uvx + 0.5f;
+        rgba[1] = uvy + 0.5f;
+        rgba[2] = 0.0f;
+        return 0;
+    }
 
-    v3 ro = {0.0f, 0.0f, -U->zoom};
-    v3 rd = {uvx, uvy, 1.5f};
-    rd = normalize3(rd);
-    float ax = (U->mouse[1] - 0.5f) * GL_PI, ay = (U->mouse[0] - 0.5f) * GL_PI * 2.0f;
-    gl_rot_apply(ax, &ro.y, &ro.z);
-    gl_rot_apply(ax, &rd.y, &rd.z);
-    gl_rot_apply(ay, &ro.x, &ro.z);
-    gl_rot_apply(ay, &rd.x, &rd.z);
+    v3 ro, rd;
+    v3 cp = {U->cam_pos[0], U->cam_pos[1], U->cam_pos[2]};
+    if (length3(cp) > 0.001f) {
+        ro = cp;
+        rd = gl_qrot(U->cam_quat, normalize3((v3){uvx, uvy, 1.2f}));
+    } else {
+        ro = (v3){0.0f, 0.0f, -U->zoom};
+        rd = normalize3((v3){uvx, uvy, 1.5f});
+        float ax = (U->mouse[1] - 0.5f) * GL_PI, ay = (U->mouse[0] - 0.5f) * GL_PI * 2.0f;
+        gl_rot_apply(ax, &ro.y, &ro.z);
+        gl_rot_apply(ax, &rd.y, &rd.z);
+        gl_rot_apply(ay, &ro.x, &ro.z);
+        gl_rot_apply(ay, &rd.x, &rd.z);
+    }
 
     float M = U->mass;
     float rs = M * 2.0f;
@@ -400,7 +550,21 @@ uint32_t orc_glsl_pixel(const orc_glsl_params *U, uint32_t ix, uint32_t iy, floa
     float rh = gl_horizon(M, a);
     float rph = gl_photon_sphere(M, a);
     float isco = gl_isco(M, a);
-    (void)rs;
+    float absA = fabsf(U->spin);
+
+    if (U->quality == 0) { /* fragment.glsl.ts:76-88 */
+        float bg[3];
+        gl_starfield(U, rd, bg);
+        float d = length3(cross3(ro, rd));
+        float shadow = smoothstepf(rh * 1.2f, rh * 0.9f, d);
+        float glow = expf(-fabsf(d - rph) * 12.0f) * 0.8f;
+        const float glowCol[3] = {0.3f * glow, 0.6f * glow, 1.0f * glow};
+        float diskMask = smoothstepf(isco * 2.0f, isco * 1.0f, d) * (1.0f - smoothstepf(isco * 1.0f, isco * 0.8f, d));
+        const float diskCol[3] = {1.0f * diskMask * 0.6f, 0.7f * diskMask * 0.6f, 0.3f * diskMask * 0.6f};
+        for (int c = 0; c < 3; c++)
+            rgba[c] = powf(bg[c] * (1.0f - shadow) + glowCol[c] + diskCol[c], 0.4545f);
+        return 0;
+    }
 
     v3 p = ro, v = rd;
     if (length3(ro) < rh * 1.5f) {
@@ -410,7 +574,17 @@ uint32_t orc_glsl_pixel(const orc_glsl_params *U, uint32_t ix, uint32_t iy, floa
     float color[3] = {0.0f, 0.0f, 0.0f};
     float alpha = 0.0f;
     int hitHorizon = 0;
+    float maxRedshift = 0.0f;
+
+    /* blue-noise dither: texture(u_blueNoiseTex, gl_FragCoord.xy / 256).r, NEAREST + REPEAT */
+    float bNoise = 0.0f;
+    if (F & ORC_GLSL_DITHER) bNoise = tex_r(U->blue_r, (int)floorf(fcx), (int)floorf(fcy));
+    p = add3(p, scale3(scale3(v, bNoise), GL_MIN_STEP));
+
+    int photonCrossings = 0;
+    float prevY = p.y;
     float impactParam = length3(cross3(ro, rd));
+    int redshiftInitialized = 0;
     int maxSteps = (int)fminf((float)U->max_ray_steps, 500.0f);
     v3 p_prev = p;
     if (impactParam < rh * 0.9f) hitHorizon = 1;
@@ -437,13 +611,15 @@ uint32_t orc_glsl_pixel(const orc_glsl_params *U, uint32_t ix, uint32_t iy, floa
         float hRefinement = smoothstepf(0.2f, 0.0f, fabsf(p.y));
         float currentDt = dt * (1.0f - hRefinement * 0.7f);
 
-        float omega;
-        v3 accel = scale3(gl_kerr_accel(p, v, M, a, &omega), U->lensing_strength);
-        gl_rot_apply(omega * currentDt, &v.x, &v.z); /* ZAMO twist of the velocity */
-
+        v3 accel = {0.0f, 0.0f, 0.0f};
+        if (F & ORC_GLSL_LENSING) {
+            float omega;
+            accel = scale3(gl_kerr_accel(p, v, M, a, &omega), U->lensing_strength);
+            gl_rot_apply(omega * currentDt, &v.x, &v.z); /* ZAMO twist of the velocity */
+        }
         p = add3(p, add3(scale3(v, currentDt), scale3(scale3(scale3(accel, 0.5f), currentDt), currentDt)));
         float r_new = length3(p);
-        if (alpha < 0.95f) {
+        if ((F & ORC_GLSL_LENSING) && alpha < 0.95f) {
             float om2;
             v3 accel_new = scale3(gl_kerr_accel(p, v, M, a, &om2), U->lensing_strength);
             v = add3(v, scale3(scale3(add3(accel, accel_new), 0.5f), currentDt));
@@ -451,18 +627,126 @@ uint32_t orc_glsl_pixel(const orc_glsl_params *U, uint32_t ix, uint32_t iy, floa
         v = normalize3(v);
         steps++;
 
-        gl_sample_disk(U, p, p_prev, v, isco, M, a, currentDt, color, &alpha);
-        (void)r_new;
-        if (alpha > 0.99f) break;
+        if (prevY * p.y < 0.0f && r_new < rph * 2.0f && r_new > rh)
+            photonCrossings = photonCrossings + 1 < 3 ? photonCrossings + 1 : 3;
+        if (U->show_redshift > 0.5f) {
+            float potential = sqrtf(fmaxf(0.0f, 1.0f - rs / r_new));
+            if (!redshiftInitialized) {
+                maxRedshift = potential;
+                redshiftInitialized = 1;
+            } else
+                maxRedshift = fminf(maxRedshift, potential);
+        }
+        prevY = p.y;
+
+        if (F & ORC_GLSL_DISK) {
+            gl_sample_disk(U, p, p_prev, v, isco, M, a, currentDt, color, &alpha);
+            if (alpha > 0.99f) break;
+        }
+        /* jets take the un-refined dt and the pre-step r (fragment.glsl.ts:219) */
+        if ((F & ORC_GLSL_JETS) && (F & ORC_GLSL_DISK)) gl_sample_jets(U, p, v, rh, dt, color, &alpha);
     }
-    (void)hitHorizon; /* background / glow terms are zero in this restatement */
+
+    if ((F & ORC_GLSL_REDSHIFT) && U->show_redshift > 0.5f) { /* fragment.glsl.ts:224-237 */
+        float val = hitHorizon ? 0.0f : maxRedshift;
+        float h[3] = {0.0f, 0.0f, 0.0f};
+        const float c1[3] = {1.0f, 0.0f, 0.0f}, c2[3] = {1.0f, 1.0f, 0.0f}, c3[3] = {0.0f, 0.0f, 1.0f};
+        float t1 = smoothstepf(0.0f, 0.3f, val), t2 = smoothstepf(0.3f, 0.7f, val), t3 = smoothstepf(0.7f, 1.0f, val);
+        for (int c = 0; c < 3; c++) {
+            h[c] = gl_mix(0.0f, c1[c], t1);
+            h[c] = gl_mix(h[c], c2[c], t2);
+            h[c] = gl_mix(h[c], c3[c], t3);
+            rgba[c] = h[c];
+        }
+        return steps;
+    }
+
+    float background[3] = {0.0f, 0.0f, 0.0f};
+    if (F & ORC_GLSL_STARS) gl_starfield(U, v, background);
+
+    float photonColor = 0.0f;
+    if ((F & ORC_GLSL_PHOTON_GLOW) && !hitHorizon) { /* fragment.glsl.ts:246-258 */
+        float distToPhotonRing = fabsf(length3(p) - rph);
+        float directRing = expf(-distToPhotonRing * 40.0f) * 1.8f * U->lensing_strength;
+        float higherOrderRing = 0.0f;
+        if (photonCrossings > 0) {
+            float ringSharpness = 60.0f + (float)photonCrossings * 30.0f;
+            float ringBrightness = expf(-(float)photonCrossings * 1.0f) * 1.2f;
+            higherOrderRing = expf(-distToPhotonRing * ringSharpness) * ringBrightness * U->lensing_strength;
+        }
+        photonColor = 1.0f * (directRing + higherOrderRing);
+    }
+
+    float ergo[3] = {0.0f, 0.0f, 0.0f};
+    if (absA > 0.1f && !hitHorizon) { /* fragment.glsl.ts:261-268 */
+        float rFinal = length3(p);
+        float cosTheta = p.y / fmaxf(rFinal, 0.001f);
+        float r_ergo = M + sqrtf(fmaxf(0.0f, M * M - a * a * cosTheta * cosTheta));
+        float ergoGlow = expf(-fabsf(rFinal - r_ergo) * 20.0f) * 0.35f * absA;
+        ergo[0] = 0.3f * ergoGlow;
+        ergo[1] = 0.35f * ergoGlow;
+        ergo[2] = 0.9f * ergoGlow;
+    }
+    if (hitHorizon) background[0] = background[1] = background[2] = 0.0f;
+
+    float fin[3];
+    for (int c = 0; c < 3; c++)
+        fin[c] = background[c] * (1.0f - alpha) + color[c] + photonColor * (1.0f - alpha) + ergo[c] * (1.0f - alpha);
+
+    if (U->show_kerr_shadow > 0.5f) { /* fragment.glsl.ts:279-324 */
+        v3 spin_axis = {0.0f, 1.0f, 0.0f};
+        v3 cam_dir = normalize3(ro);
+        v3 sky_right = normalize3(cross3(spin_axis, cam_dir));
+        v3 sky_up = cross3(cam_dir, sky_right);
+        v3 impact_vec = scale3(cross3(cam_dir, rd), length3(ro));
+        float alpha_s = -dot3(impact_vec, sky_up);
+        float beta_s = dot3(impact_vec, sky_right);
+        float minDist = 1e10f;
+        int count = (int)U->shadow_count;
+        for (int j = 0; j < 63; j++) {
+            if (j >= count - 1) break;
+            float p1x = U->shadow_curve[j][0], p1y = U->shadow_curve[j][1];
+            float p2x = U->shadow_curve[j + 1][0], p2y = U->shadow_curve[j + 1][1];
+            float pax = alpha_s - p1x, pay = beta_s - p1y, bax = p2x - p1x, bay = p2y - p1y;
+            float h = clampf((pax * bax + pay * bay) / (bax * bax + bay * bay), 0.0f, 1.0f);
+            float dx = pax - bax * h, dy = pay - bay * h;
+            minDist = fminf(minDist, sqrtf(dx * dx + dy * dy));
+        }
+        if (count > 2) {
+            float pfx = U->shadow_curve[0][0], pfy = U->shadow_curve[0][1];
+            float plx = U->shadow_curve[count - 1][0], ply = U->shadow_curve[count - 1][1];
+            float pax = alpha_s - plx, pay = beta_s - ply, bax = pfx - plx, bay = pfy - ply;
+            float h = clampf((pax * bax + pay * bay) / (bax * bax + bay * bay), 0.0f, 1.0f);
+            float dx = pax - bax * h, dy = pay - bay * h;
+            minDist = fminf(minDist, sqrtf(dx * dx + dy * dy));
+        }
+        float thickness = M * 0.045f;
+        if (minDist < thickness) {
+            float edge = smoothstepf(thickness, thickness * 0.5f, minDist);
+            const float green[3] = {0.0f, 1.0f, 0.0f};
+            for (int c = 0; c < 3; c++) fin[c] = gl_mix(fin[c], green[c], 1.0f * edge);
+        }
+    }
+
     for (int c = 0; c < 3; c++) {
-        float f = color[c];
+        float f = fin[c];
         if (U->tone_map) f = powf(fmaxf(aces(f), 0.0f), 0.4545f);
         rgba[c] = f;
     }
-    rgba[3] = 1.0f;
     return steps;
+}
+
+/* xorshift32 byte stream, value = floor(u * 255) with u in [0, 1) as createNoiseTexture does */
+void orc_seeded_noise_rgba8(uint32_t seed, uint32_t size, uint8_t *rgba) {
+    uint32_t x = seed ? seed : 0x9E3779B9u;
+    const size_t n = (size_t)size * size * 4u;
+    for (size_t i = 0; i < n; i++) {
+        x ^= x << 13;
+        x ^= x >> 17;
+        x ^= x << 5;
+        double u = (double)(x >> 8) / 16777216.0;
+        rgba[i] = (uint8_t)floor(u * 255.0);
+    }
 }
 
 void orc_glsl_frame(const orc_glsl_params *p, uint32_t sx, uint32_t sy, float *rgba,

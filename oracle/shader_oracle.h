@@ -33,7 +33,17 @@ uint32_t orc_wgsl_pixel(const orc_wgsl_params *p, uint32_t ix, uint32_t iy, floa
 void orc_wgsl_frame(const orc_wgsl_params *p, uint32_t stride_x, uint32_t stride_y, float *rgba,
                     uint32_t *steps, int nthreads);
 
-/* uniforms of the GLSL fragment shader (chunks/common.ts:8-35) that the march uses */
+/* ShaderManager #defines (src/shaders/manager.ts:61-82) as bits */
+#define ORC_GLSL_LENSING 1u
+#define ORC_GLSL_DISK 2u
+#define ORC_GLSL_DOPPLER 4u
+#define ORC_GLSL_STARS 8u
+#define ORC_GLSL_PHOTON_GLOW 16u
+#define ORC_GLSL_JETS 32u       /* only effective with DISK (manager.ts:72-73) */
+#define ORC_GLSL_REDSHIFT 64u
+#define ORC_GLSL_DITHER 128u    /* blue-noise start offset (fragment.glsl.ts:104-108); always on upstream */
+
+/* uniforms of the GLSL fragment shader (chunks/common.ts:8-35) */
 typedef struct {
     uint32_t width, height;
     float mass;              /* u_mass */
@@ -45,11 +55,24 @@ typedef struct {
     float disk_density;      /* u_disk_density */
     float disk_temp;         /* u_disk_temp */
     float lensing_strength;  /* u_lensing_strength */
-    float time;              /* u_time (only rotates the turbulence phase) */
-    float turbulence;        /* value standing in for noise()*0.5 + noise()*0.25 (unseeded texture) */
+    float time;              /* u_time */
+    float turbulence;        /* >= 0: stands in for noise()*0.5 + noise()*0.25 of disk.ts:55;
+                                < 0: the two noise() fetches from the noise texture */
     int32_t max_ray_steps;   /* u_maxRaySteps, clamped to 500 in the shader */
     int32_t tone_map;        /* 0 = ENABLE_LINEAR_OUTPUT, 1 = ACES + gamma */
+    uint32_t features;       /* ORC_GLSL_* */
+    int32_t quality;         /* 0 = RAY_QUALITY_OFF/LOW indicator path (fragment.glsl.ts:76-88) */
+    float show_redshift, show_kerr_shadow, debug; /* u_show_redshift, u_show_kerr_shadow, u_debug */
+    float cam_pos[3], cam_quat[4];                /* u_camPos, u_camQuat (xyzw) */
+    float shadow_count;                           /* u_shadowCount */
+    float shadow_curve[64][2];                    /* u_shadowCurve */
+    const uint8_t *noise_r;  /* 256x256 R channel of u_noiseTex (LINEAR, REPEAT) */
+    const uint8_t *blue_r;   /* 256x256 R channel of u_blueNoiseTex (NEAREST, REPEAT) */
 } orc_glsl_params;
+
+/* deterministic stand-in for createNoiseTexture's Math.random() bytes
+ * (src/utils/webgl-utils.ts:259-305: floor(random * 255), RGBA8, 256x256): xorshift32 stream */
+void orc_seeded_noise_rgba8(uint32_t seed, uint32_t size, uint8_t *rgba);
 
 uint32_t orc_glsl_pixel(const orc_glsl_params *p, uint32_t ix, uint32_t iy, float rgba[4]);
 void orc_glsl_frame(const orc_glsl_params *p, uint32_t stride_x, uint32_t stride_y, float *rgba,

@@ -67,7 +67,10 @@ def test_config2_1080p_fixed_step_f32(engine_mod, oracle):
             s = steps.cpu().numpy().reshape(H, W)
             c = rgba.cpu().numpy().reshape(H, W, 4)
             assert tot == int(s.sum()) and s.max() <= (512 if name == "wgsl" else 500) and s.min() >= 0
-            assert np.all(np.isfinite(c)) and np.all(c[..., 3] == 1.0) and c[..., :3].min() >= 0.0
+            assert np.all(np.isfinite(c)) and np.all(c[..., 3] == 1.0)
+            # linear GLSL output may dip below 0 behind an over-dense disk: the shader lets the
+            # accumulated alpha pass 1 and composites background * (1 - alpha) (fragment.glsl.ts:276)
+            assert name == "glsl" or c[..., :3].min() >= 0.0
             ds = np.abs(s[::6, ::6].astype(np.int64) - ref_steps.astype(np.int64))
             peak = ref_rgba[..., :3].max()
             dc = np.abs(c[::6, ::6] - ref_rgba)[..., :3].max(-1) / peak

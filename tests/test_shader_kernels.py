@@ -26,12 +26,18 @@ def test_wgsl_oracle_frame_is_sane(oracle, engine_mod):
 
 def test_glsl_oracle_frame_is_sane(oracle, engine_mod):
     W, H = 96, 54
-    gp = engine_mod.glsl_params(W, H, 1.0, 0.9, max_ray_steps=256)
+    # march + disk only (no stars/nebula): the sky is black, the disk is lit
+    gp = engine_mod.glsl_params(W, H, 1.0, 0.9, max_ray_steps=256, features=7, turbulence=0.75)
     rgba, steps = oracle.glsl_frame(oracle.glsl_params_from(gp), nthreads=4)
     assert np.all(np.isfinite(rgba)) and np.all(rgba[..., 3] == 1.0)
     assert steps.max() <= 256
     lit = rgba[..., :3].sum(-1) > 0
     assert 0.02 < lit.mean() < 0.9
+    # reference default preset: the nebula term lights every escaping ray
+    gpd = engine_mod.glsl_params(W, H, 1.0, 0.9, max_ray_steps=256)
+    assert gpd.features == engine_mod.GLSL_FEATURES_DEFAULT and gpd.quality == 1
+    full, _ = oracle.glsl_frame(oracle.glsl_params_from(gpd), nthreads=4)
+    assert np.all(np.isfinite(full)) and (full[..., :3].sum(-1) > 0).mean() > lit.mean()
     # shader cap: u_maxRaySteps above 500 is clamped (fragment.glsl.ts:115)
     gp2 = engine_mod.glsl_params(32, 18, 1.0, 0.9, max_ray_steps=4000)
     _, st2 = oracle.glsl_frame(oracle.glsl_params_from(gp2))
@@ -40,6 +46,58 @@ def test_glsl_oracle_frame_is_sane(oracle, engine_mod):
     gp3 = engine_mod.glsl_params(32, 18, 1.0, 0.9, tone_map=1)
     r3, _ = oracle.glsl_frame(oracle.glsl_params_from(gp3))
     assert r3[..., :3].max() <= 1.0
+
+
+def test_glsl_oracle_compositing_terms(oracle, engine_mod):
+    """each ShaderManager #define changes exactly the term it gates."""
+    bh = engine_mod
+    W, H = 96, 54
+    base = bh.GLSL_LENSING | bh.GLSL_DISK | bh.GLSL_DOPPLER
+
+    def frame(**kw):
+        gp = bh.glsl_params(W, H, 1.0, 0.9, max_ray_steps=256, **kw)
+        return oracle.glsl_frame(oracle.glsl_params_from(gp), nthreads=4)
+    plain, st_plain = frame(features=base, turbulence=0.75)
+    # the seeded textures agree between the product helper and the oracle helper
+    assert np.array_equal(bh.seeded_noise_rgba8(1), oracle.seeded_noise_rgba8(1))
+    assert bh.seeded_noise_rgba8(2).max() <= 254            # floor(u * 255), webgl-utils.ts:264-266
+    # stars: the march is unchanged; rays that saw no disk gain the sky.  (Behind the disk the
+    # term is background * (1 - alpha) and the shader lets alpha pass 1: fragment.glsl.ts:276.)
+    sky = plain[..., :3].sum(-1) == 0
+    stars, st = frame(features=base | bh.GLSL_STARS, turbulence=0.75)
+    assert np.array_equal(st, st_plain) and (stars[sky][:, :3] >= 0).all()
+    assert (stars[sky][:, :3] > 0).any()
+    # photon glow adds light to disk-free rays only; jets add emission above/below the hole
+    glow, _ = frame(features=base | bh.GLSL_PHOTON_GLOW, turbulence=0.75)
+    assert (glow[sky][:, :3] >= 0).all()
+    jets, _ = frame(features=base | bh.GLSL_JETS, turbulence=0.75)
+    assert jets[..., 2].sum() > plain[..., 2].sum()
+    # jets without a disk are suppressed (manager.ts:72-73)
+    nodisk, _ = frame(features=bh.GLSL_LENSING | bh.GLSL_JETS, turbulence=0.75)
+    nodisk2, _ = frame(features=bh.GLSL_LENSING, turbulence=0.75)
+    assert np.array_equal(nodisk, nodisk2)
+    # texture turbulence modulates the disk, dither moves the start point by < MIN_STEP
+    tex, _ = frame(features=base)
+    assert not np.array_equal(tex, plain) and np.isfinite(tex).all()
+    # redshift overlay replaces the image by the heat map; the disk is skipped (disk.ts:21)
+    red, _ = frame(features=base | bh.GLSL_REDSHIFT, show_redshift=1.0, turbulence=0.75)
+    assert set(np.unique(red[..., 3])) == {1.0} and red[..., :3].max() <= 1.0 + 1e-6
+    assert (red[..., 1] <= red[..., 0] + red[..., 2] + 1e-6).all()
+    # Kerr shadow guide paints green along the Bardeen curve
+    curve = oracle.bardeen_shadow(1.0, 0.9, np.deg2rad(97.0), 32)
+    guide, _ = frame(features=base, turbulence=0.75, show_kerr_shadow=1.0, shadow_curve=curve[:64])
+    changed = np.abs(guide - plain)[..., :3].max(-1) > 0
+    assert 0 < changed.mean() < 0.1
+    assert (guide[changed][:, 1] >= plain[changed][:, 1]).all()
+    # low-quality indicator path does not march; debug path shows uv
+    low, st_low = frame(features=base | bh.GLSL_STARS, quality=0)
+    assert st_low.max() == 0 and np.isfinite(low).all() and low[..., :3].max() > 0
+    dbg, _ = frame(debug=1.0)
+    assert abs(dbg[0, 0, 1] - (0.5 - 0.5 / H + 0.5)) < 1e-6 and np.all(dbg[..., 2] == 0)
+    # SAB camera path (u_camPos != 0): looking from +z at the hole still finds the disk
+    cam, _ = frame(features=base, turbulence=0.75, cam_pos=(0.0, 6.0, -60.0),
+                   cam_quat=(np.sin(0.05), 0.0, 0.0, np.cos(0.05)))
+    assert (cam[..., :3].sum(-1) > 0).mean() > 0.01
 
 
 def _compare(got_rgba, got_steps, ref_rgba, ref_steps):
@@ -71,11 +129,18 @@ def test_wgsl_kernel_matches_oracle(engine_mod, oracle, spin, max_steps):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("spin,tone", [(0.999, 0), (0.9, 1)])
-def test_glsl_kernel_matches_oracle(engine_mod, oracle, spin, tone):
+@pytest.mark.parametrize("spin,tone,kw", [
+    (0.999, 0, dict(features=7, turbulence=0.75)),            # a16/a17 only: march + disk Doppler
+    (0.9, 1, dict()),                                           # reference default preset, textures
+    (0.9, 0, dict(time=3.7)),                                   # animated: phase rotation, twinkle, jets
+    (-0.7, 1, dict(features=7 | 64, show_redshift=1.0)),        # redshift overlay, retrograde spin
+    (0.9, 0, dict(quality=0)),                                  # RAY_QUALITY_LOW indicator path
+    (0.9, 1, dict(cam_pos=(0.0, 6.0, -60.0), cam_quat=(0.05, 0.0, 0.0, 0.99875))),  # SAB camera
+])
+def test_glsl_kernel_matches_oracle(engine_mod, oracle, spin, tone, kw):
     import torch
     W, H = 480, 270
-    gp = engine_mod.glsl_params(W, H, 1.0, spin, max_ray_steps=512, tone_map=tone)
+    gp = engine_mod.glsl_params(W, H, 1.0, spin, max_ray_steps=512, tone_map=tone, **kw)
     n = W * H
     with engine_mod.PhysicsEngine(1.0, spin) as e:
         rgba = torch.zeros(n, 4, dtype=torch.float32, device="cuda:0")
@@ -84,6 +149,25 @@ def test_glsl_kernel_matches_oracle(engine_mod, oracle, spin, tone):
     ref_rgba, ref_steps = oracle.glsl_frame(oracle.glsl_params_from(gp), nthreads=8)
     assert tot == int(steps.sum().item())
     _compare(rgba.cpu().numpy().reshape(H, W, 4), steps.cpu().numpy().reshape(H, W), ref_rgba, ref_steps)
+
+
+@pytest.mark.gpu
+def test_glsl_kernel_shadow_guide_and_custom_textures(engine_mod, oracle):
+    import torch
+    W, H = 320, 180
+    curve = oracle.bardeen_shadow(1.0, 0.9, np.deg2rad(97.0), 32)
+    gp = engine_mod.glsl_params(W, H, 1.0, 0.9, max_ray_steps=300, show_kerr_shadow=1.0,
+                                shadow_curve=curve[:64], tone_map=1)
+    noise, blue = engine_mod.seeded_noise_rgba8(77), engine_mod.seeded_noise_rgba8(78)
+    with engine_mod.PhysicsEngine(1.0, 0.9) as e:
+        e.set_glsl_noise(noise, blue)
+        rgba = torch.zeros(W * H, 4, dtype=torch.float32, device="cuda:0")
+        steps = torch.zeros(W * H, dtype=torch.int32, device="cuda:0")
+        e.render_frame_glsl(gp, rgba, steps)
+    ref_rgba, ref_steps = oracle.glsl_frame(oracle.glsl_params_from(gp, noise, blue), nthreads=8)
+    _compare(rgba.cpu().numpy().reshape(H, W, 4), steps.cpu().numpy().reshape(H, W), ref_rgba, ref_steps)
+    green = (ref_rgba[..., 1] > 0.9) & (ref_rgba[..., 0] < 0.2)
+    assert green.any()
 
 
 @pytest.mark.gpu
