@@ -12,5 +12,5 @@ from .engine import (  # noqa: F401
     RenderParams, WgslParams, build_library, camera_look_at, glsl_params, library_path,
     load_library, render_params, seeded_noise_rgba8, unpack_tiles, wgsl_params,
     GLSL_LENSING, GLSL_DISK, GLSL_DOPPLER, GLSL_STARS, GLSL_PHOTON_GLOW, GLSL_JETS, GLSL_REDSHIFT,
-    GLSL_DITHER, GLSL_FEATURES_DEFAULT,
+    GLSL_DITHER, GLSL_FEATURES_DEFAULT, AtaaParams, BloomParams, TaaParams,
 )

@@ -119,6 +119,8 @@ struct grv_engine {
     hipEvent_t ev[8] = {};
     bool ev_ok = false;
 
+    void *post_mem = nullptr; // bloom render targets (bright, blur ping/pong)
+    size_t post_bytes = 0;
     uint8_t *d_noise = nullptr; // [2][256*256] R planes: u_noiseTex, u_blueNoiseTex
     std::vector<float> disk_lut = std::vector<float>(512, 0.0f); // lut_buffer (lib.rs:50, 65-66)
     std::vector<float> sab;
@@ -433,6 +435,7 @@ void grv_engine_destroy(grv_engine *e) {
     if (e->stage_mem) (void)hipFree(e->stage_mem);
     if (e->d_lut) (void)hipFree(e->d_lut);
     if (e->d_noise) (void)hipFree(e->d_noise);
+    if (e->post_mem) (void)hipFree(e->post_mem);
     if (e->d_counters) (void)hipFree(e->d_counters);
     if (e->d_stats) (void)hipFree(e->d_stats);
     if (e->h_counters) (void)hipHostFree(e->h_counters);
@@ -877,6 +880,69 @@ int grv_render_frame_glsl(grv_engine *e, const GrvGlslParams *p, float *d_rgba, 
                             [&](const FrameGeom &G, uint32_t n, unsigned long long *tot) {
                                 return launch_glsl_fragment(G, P, d_rgba, d_steps, tot, n, s);
                             });
+}
+
+float grv_taa_effective_blend(float blend_factor, float v) {
+    if (v > 0.001f) return std::fmax(0.05f, std::fmin(0.9f, 0.9f - v * 6.0f));
+    return blend_factor;
+}
+
+int grv_post_taa_resolve(grv_engine *e, const GrvTaaParams *p, const float *d_current,
+                         const float *d_history, float *d_out, void *stream) {
+    if (!e) return GRV_ERR_INVALID;
+    if (!p || !d_current || !d_history || !d_out) return fail(e, GRV_ERR_INVALID, "null argument");
+    if (d_out == d_current || d_out == d_history) return fail(e, GRV_ERR_INVALID, "taa: out aliases an input");
+    GRV_HIP(e, hipSetDevice(e->device));
+    GRV_HIP(e, launch_taa_resolve(p->width, p->height, d_current, d_history, p->blend_factor,
+                                  p->camera_moving, p->half_storage, d_out, static_cast<hipStream_t>(stream)));
+    return GRV_OK;
+}
+
+int grv_post_ataa_resolve(grv_engine *e, const GrvAtaaParams *p, const float *d_current,
+                          const float *d_history, float *d_out, void *stream) {
+    if (!e) return GRV_ERR_INVALID;
+    if (!p || !d_current || !d_history || !d_out) return fail(e, GRV_ERR_INVALID, "null argument");
+    if (d_out == d_current || d_out == d_history) return fail(e, GRV_ERR_INVALID, "ataa: out aliases an input");
+    AtaaCameraHost cam;
+    std::memcpy(cam.inv_view, p->inv_view, sizeof cam.inv_view);
+    std::memcpy(cam.inv_proj, p->inv_proj, sizeof cam.inv_proj);
+    std::memcpy(cam.prev_view_proj, p->prev_view_proj, sizeof cam.prev_view_proj);
+    std::memcpy(cam.position, p->position, sizeof cam.position);
+    GRV_HIP(e, hipSetDevice(e->device));
+    GRV_HIP(e, launch_ataa_resolve(p->width, p->height, cam, d_current, d_history, p->half_storage, d_out,
+                                   static_cast<hipStream_t>(stream)));
+    return GRV_OK;
+}
+
+void grv_bloom_params_default(uint32_t width, uint32_t height, GrvBloomParams *p) {
+    if (!p) return;
+    p->width = width;
+    p->height = height;
+    p->intensity = 0.5f; // bloom.ts:34-39
+    p->threshold = 0.8f;
+    p->blur_passes = 2;
+    p->half_storage = 1;
+}
+
+int grv_post_bloom(grv_engine *e, const GrvBloomParams *p, const float *d_scene, float *d_out,
+                   void *stream) {
+    if (!e) return GRV_ERR_INVALID;
+    if (!p || !d_scene || !d_out) return fail(e, GRV_ERR_INVALID, "null argument");
+    if (p->blur_passes < 0 || p->blur_passes > 64) return fail(e, GRV_ERR_INVALID, "blur_passes out of range");
+    if (d_out == d_scene) return fail(e, GRV_ERR_INVALID, "bloom: out aliases the scene");
+    GRV_HIP(e, hipSetDevice(e->device));
+    const size_t need = bloom_scratch_floats(p->width, p->height) * sizeof(float);
+    if (need > e->post_bytes) {
+        if (e->post_mem) (void)hipFree(e->post_mem);
+        e->post_mem = nullptr;
+        e->post_bytes = 0;
+        GRV_HIP(e, hipMalloc(&e->post_mem, need));
+        e->post_bytes = need;
+    }
+    GRV_HIP(e, launch_bloom(p->width, p->height, d_scene, p->threshold, p->intensity, p->blur_passes,
+                            p->half_storage, static_cast<float *>(e->post_mem), d_out,
+                            static_cast<hipStream_t>(stream)));
+    return GRV_OK;
 }
 
 int grv_unpack_tiles_device(grv_engine *e, const GrvRenderParams *p, uint32_t rank,

@@ -127,6 +127,19 @@ hipError_t launch_glsl_fragment(const FrameGeom &G, const GlslParams &P, float *
                               uint32_t n_slots, hipStream_t s);
 hipError_t launch_spectrum_lut(float *out, uint32_t width, uint32_t height, double max_temp,
                                hipStream_t s);
+// ---- post chain (post_kernels.hpp, in kernels_strict.hip) ----
+struct AtaaCameraHost {
+    float inv_view[16], inv_proj[16], prev_view_proj[16], position[3];
+};
+hipError_t launch_taa_resolve(uint32_t w, uint32_t h, const float *current, const float *history,
+                              float blend_factor, int camera_moving, int half_storage, float *out,
+                              hipStream_t s);
+hipError_t launch_ataa_resolve(uint32_t w, uint32_t h, const AtaaCameraHost &cam, const float *current,
+                               const float *history, int half_storage, float *out, hipStream_t s);
+// scratch: (w/2*h/2 + 2*(w/4*h/4)) float4
+hipError_t launch_bloom(uint32_t w, uint32_t h, const float *scene, float threshold, float intensity,
+                        int blur_passes, int half_storage, float *scratch, float *out, hipStream_t s);
+size_t bloom_scratch_floats(uint32_t w, uint32_t h);
 // ---- launcher (kernels_fast.hip: -ffp-contract=fast) ----
 hipError_t launch_segment_fast(int kind, int method, const RayWorkspace &ws,
                                const SegmentParams &P, const uint32_t *live_in, uint32_t n_live,

@@ -1,0 +1,228 @@
+// post_kernels.hpp -- the reference's post chain as HIP kernels, compiled
+// in the -ffp-contract=off unit so operation order is the shaders':
+//   taa_resolve_kernel   src/shaders/postprocess/reprojection.glsl.ts:44-116
+//                        (driven by src/rendering/reprojection.ts:196-262, renderScale = 1)
+//   ataa_resolve_kernel  src/shaders/postprocess/ataa.wgsl.ts:29-86
+//   bloom_*_kernel       src/shaders/postprocess/bloom.glsl.ts:35-127, pass sequence
+//                        src/rendering/bloom.ts:443-583
+// Images are RGBA f32 (float4), row-major, resident in HBM.  All five kernels are
+// HBM-streaming stencils: one thread per output pixel, a wave covers a 64x1 row segment so
+// every fetch of a row is one coalesced 1 KiB transaction; the 3x3 / 9-tap neighbourhoods
+// re-read lines that are still in L2 (4 MiB per XCD holds ~60 rows of a 4K frame).
+// Texture fetches: GL LINEAR + CLAMP_TO_EDGE with f32 weights.  Render targets are RGBA16F
+// upstream: with half_storage every stored channel is rounded through binary16 (RNE).
+#pragma once
+
+#include <hip/hip_fp16.h>
+
+#include "engine_types.hpp"
+
+namespace {
+
+using namespace grvhip;
+
+__device__ __forceinline__ float post_store(float v, int half) {
+    return half ? __half2float(__float2half_rn(v)) : v;
+}
+__device__ __forceinline__ float post_clamp(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+__device__ __forceinline__ int post_clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
+__device__ __forceinline__ float post_mix(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+
+// texture(tex, uv): LINEAR + CLAMP_TO_EDGE
+__device__ __forceinline__ float4 post_sample(const float4 *__restrict__ tex, uint32_t w, uint32_t h,
+                                              float u, float v) {
+    const float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+    const float fx = floorf(x), fy = floorf(y);
+    const float a = x - fx, b = y - fy;
+    const int i0 = post_clampi((int)fx, 0, (int)w - 1), i1 = post_clampi((int)fx + 1, 0, (int)w - 1);
+    const int j0 = post_clampi((int)fy, 0, (int)h - 1), j1 = post_clampi((int)fy + 1, 0, (int)h - 1);
+    const float4 t00 = tex[(size_t)j0 * w + i0], t10 = tex[(size_t)j0 * w + i1];
+    const float4 t01 = tex[(size_t)j1 * w + i0], t11 = tex[(size_t)j1 * w + i1];
+    const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    return make_float4(w00 * t00.x + w10 * t10.x + w01 * t01.x + w11 * t11.x,
+                       w00 * t00.y + w10 * t10.y + w01 * t01.y + w11 * t11.y,
+                       w00 * t00.z + w10 * t10.z + w01 * t01.z + w11 * t11.z,
+                       w00 * t00.w + w10 * t10.w + w01 * t01.w + w11 * t11.w);
+}
+
+struct YCC {
+    float y, co, cg;
+};
+__device__ __forceinline__ YCC to_ycocg(float r, float g, float b) {
+    return YCC{r * 0.25f + g * 0.5f + b * 0.25f, r * 0.5f + g * 0.0f + b * -0.5f,
+               r * -0.25f + g * 0.5f + b * -0.25f};
+}
+__device__ __forceinline__ float4 from_ycocg(YCC c, int half) {
+    return make_float4(post_store(c.y + c.co - c.cg, half), post_store(c.y + c.cg, half),
+                       post_store(c.y - c.co - c.cg, half), 1.0f);
+}
+
+// first and second moments of the 3x3 YCoCg neighbourhood
+struct Moments {
+    float m1[3], m2[3];
+    __device__ __forceinline__ void add(YCC s) {
+        m1[0] += s.y;
+        m1[1] += s.co;
+        m1[2] += s.cg;
+        m2[0] += s.y * s.y;
+        m2[1] += s.co * s.co;
+        m2[2] += s.cg * s.cg;
+    }
+    __device__ __forceinline__ void mean_std(float mean[3], float sd[3]) const {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            mean[c] = m1[c] / 9.0f;
+            sd[c] = sqrtf(fmaxf(m2[c] / 9.0f - mean[c] * mean[c], 0.0f));
+        }
+    }
+};
+
+__device__ __forceinline__ bool post_pixel(uint32_t w, uint32_t h, uint32_t &px, uint32_t &py) {
+    px = blockIdx.x * blockDim.x + threadIdx.x;
+    py = blockIdx.y;
+    return px < w && py < h;
+}
+
+__global__ __launch_bounds__(256) void taa_resolve_kernel(uint32_t w, uint32_t h,
+                                                          const float4 *__restrict__ current,
+                                                          const float4 *__restrict__ history,
+                                                          float blend_factor, int camera_moving,
+                                                          int half_storage, float4 *__restrict__ out) {
+    uint32_t px, py;
+    if (!post_pixel(w, h, px, py)) return;
+    const float tx = 1.0f / (float)w, ty = 1.0f / (float)h;
+    const float u = ((float)px + 0.5f) / (float)w, v = ((float)py + 0.5f) / (float)h;
+    const float4 cur = post_sample(current, w, h, u, v);
+    Moments M{{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+    for (int y = -1; y <= 1; ++y)
+        for (int x = -1; x <= 1; ++x) {
+            const float4 s = post_sample(current, w, h, u + (float)x * tx, v + (float)y * ty);
+            M.add(to_ycocg(s.x, s.y, s.z));
+        }
+    float mean[3], sd[3];
+    M.mean_std(mean, sd);
+    const float4 h4 = post_sample(history, w, h, u, v);
+    YCC hy = to_ycocg(h4.x, h4.y, h4.z);
+    hy.y = post_clamp(hy.y, mean[0] - 1.5f * sd[0], mean[0] + 1.5f * sd[0]);
+    hy.co = post_clamp(hy.co, mean[1] - 1.5f * sd[1], mean[1] + 1.5f * sd[1]);
+    hy.cg = post_clamp(hy.cg, mean[2] - 1.5f * sd[2], mean[2] + 1.5f * sd[2]);
+    const float varianceWeight = 1.0f - post_clamp(sd[0] * 4.0f, 0.0f, 0.55f);
+    const float alpha = camera_moving ? 0.0f : blend_factor * varianceWeight;
+    const YCC cy = to_ycocg(cur.x, cur.y, cur.z);
+    out[(size_t)py * w + px] = from_ycocg(
+        YCC{post_mix(cy.y, hy.y, alpha), post_mix(cy.co, hy.co, alpha), post_mix(cy.cg, hy.cg, alpha)},
+        half_storage);
+}
+
+struct AtaaCamera { // CameraUniforms fields the resolve pass reads (types.wgsl.ts:6-17)
+    float inv_view[16], inv_proj[16], prev_view_proj[16], position[3];
+};
+__device__ __forceinline__ void post_m4v4(const float *m, float x, float y, float z, float w, float o[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = m[0 + r] * x + m[4 + r] * y + m[8 + r] * z + m[12 + r] * w;
+}
+
+__global__ __launch_bounds__(256) void ataa_resolve_kernel(uint32_t w, uint32_t h, AtaaCamera cam,
+                                                           const float4 *__restrict__ current,
+                                                           const float4 *__restrict__ history,
+                                                           int half_storage, float4 *__restrict__ out) {
+    uint32_t px, py;
+    if (!post_pixel(w, h, px, py)) return;
+    const float u = ((float)px + 0.5f) / (float)w, v = ((float)py + 0.5f) / (float)h;
+    const float4 c4 = current[(size_t)py * w + px];
+    const YCC center = to_ycocg(c4.x, c4.y, c4.z);
+    Moments M{{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int sx = post_clampi((int)px + dx, 0, (int)w - 1), sy = post_clampi((int)py + dy, 0, (int)h - 1);
+            const float4 s = current[(size_t)sy * w + sx];
+            M.add(to_ycocg(s.x, s.y, s.z));
+        }
+    float mean[3], sd[3];
+    M.mean_std(mean, sd);
+    const float ndcx = u * 2.0f - 1.0f, ndcy = v * 2.0f - 1.0f;
+    float vt[4], wd[4], pc[4];
+    post_m4v4(cam.inv_proj, ndcx, -ndcy, 1.0f, 1.0f, vt);
+    float vx = vt[0] / vt[3], vy = vt[1] / vt[3], vz = vt[2] / vt[3];
+    const float len = sqrtf(vx * vx + vy * vy + vz * vz);
+    vx /= len;
+    vy /= len;
+    vz /= len;
+    post_m4v4(cam.inv_view, vx, vy, vz, 0.0f, wd);
+    const float depth = 12.0f; // reprojectDepth, ataa.wgsl.ts:68
+    post_m4v4(cam.prev_view_proj, cam.position[0] + wd[0] * depth, cam.position[1] + wd[1] * depth,
+              cam.position[2] + wd[2] * depth, 1.0f, pc);
+    const float pu = (pc[0] / pc[3]) * 0.5f + 0.5f, pv = (pc[1] / pc[3]) * -0.5f + 0.5f;
+    const float4 h4 = post_sample(history, w, h, pu, pv);
+    YCC hy = to_ycocg(h4.x, h4.y, h4.z);
+    hy.y = post_clamp(hy.y, mean[0] - 2.0f * sd[0], mean[0] + 2.0f * sd[0]);
+    hy.co = post_clamp(hy.co, mean[1] - 2.0f * sd[1], mean[1] + 2.0f * sd[1]);
+    hy.cg = post_clamp(hy.cg, mean[2] - 2.0f * sd[2], mean[2] + 2.0f * sd[2]);
+    out[(size_t)py * w + px] = from_ycocg(YCC{post_mix(center.y, hy.y, 0.92f), post_mix(center.co, hy.co, 0.92f),
+                                              post_mix(center.cg, hy.cg, 0.92f)},
+                                          half_storage);
+}
+
+// bloom.glsl.ts:35-58: dst (dw x dh) <- bright pixels of src (w x h)
+__global__ __launch_bounds__(256) void bloom_bright_kernel(uint32_t w, uint32_t h,
+                                                           const float4 *__restrict__ src, uint32_t dw,
+                                                           uint32_t dh, float threshold, int half_storage,
+                                                           float4 *__restrict__ dst) {
+    uint32_t px, py;
+    if (!post_pixel(dw, dh, px, py)) return;
+    const float4 c = post_sample(src, w, h, ((float)px + 0.5f) / (float)dw, ((float)py + 0.5f) / (float)dh);
+    const float lum = c.x * 0.299f + c.y * 0.587f + c.z * 0.114f;
+    dst[(size_t)py * dw + px] =
+        lum > threshold ? make_float4(post_store(c.x, half_storage), post_store(c.y, half_storage),
+                                      post_store(c.z, half_storage), post_store(c.w, half_storage))
+                        : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+// bloom.glsl.ts:64-89: 9-tap separable Gaussian; u_resolution = destination size
+__global__ __launch_bounds__(256) void bloom_blur_kernel(uint32_t sw, uint32_t sh,
+                                                         const float4 *__restrict__ src, uint32_t dw,
+                                                         uint32_t dh, int vertical, int half_storage,
+                                                         float4 *__restrict__ dst) {
+    uint32_t px, py;
+    if (!post_pixel(dw, dh, px, py)) return;
+    const float wts[5] = {0.227027f, 0.1945946f, 0.1216216f, 0.054054f, 0.016216f};
+    const float tx = 1.0f / (float)dw, ty = 1.0f / (float)dh;
+    const float u = ((float)px + 0.5f) / (float)dw, v = ((float)py + 0.5f) / (float)dh;
+    const float4 c0 = post_sample(src, sw, sh, u, v);
+    float r = c0.x * wts[0], g = c0.y * wts[0], b = c0.z * wts[0];
+#pragma unroll
+    for (int i = 1; i < 5; ++i) {
+        const float ox = (vertical ? 0.0f : 1.0f) * tx * (float)i, oy = (vertical ? 1.0f : 0.0f) * ty * (float)i;
+        const float4 p = post_sample(src, sw, sh, u + ox, v + oy);
+        const float4 m = post_sample(src, sw, sh, u - ox, v - oy);
+        r += p.x * wts[i];
+        r += m.x * wts[i];
+        g += p.y * wts[i];
+        g += m.y * wts[i];
+        b += p.z * wts[i];
+        b += m.z * wts[i];
+    }
+    dst[(size_t)py * dw + px] =
+        make_float4(post_store(r, half_storage), post_store(g, half_storage), post_store(b, half_storage), 1.0f);
+}
+
+__device__ __forceinline__ float post_aces(float c) {
+    return post_clamp((c * (2.51f * c + 0.03f)) / (c * (2.43f * c + 0.59f) + 0.14f), 0.0f, 1.0f);
+}
+
+// bloom.glsl.ts:95-127: scene + bloom * intensity -> ACES -> gamma (the backbuffer)
+__global__ __launch_bounds__(256) void bloom_combine_kernel(uint32_t w, uint32_t h,
+                                                            const float4 *__restrict__ scene, uint32_t bw,
+                                                            uint32_t bh, const float4 *__restrict__ bloom,
+                                                            float intensity, float4 *__restrict__ out) {
+    uint32_t px, py;
+    if (!post_pixel(w, h, px, py)) return;
+    const float u = ((float)px + 0.5f) / (float)w, v = ((float)py + 0.5f) / (float)h;
+    const float4 s = post_sample(scene, w, h, u, v);
+    const float4 b = post_sample(bloom, bw, bh, u, v);
+    out[(size_t)py * w + px] = make_float4(powf(post_aces(s.x + b.x * intensity), 0.4545f),
+                                           powf(post_aces(s.y + b.y * intensity), 0.4545f),
+                                           powf(post_aces(s.z + b.z * intensity), 0.4545f), 1.0f);
+}
+
+} // namespace

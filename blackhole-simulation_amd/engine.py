@@ -86,6 +86,22 @@ GLSL_FEATURES_DEFAULT = (GLSL_LENSING | GLSL_DISK | GLSL_DOPPLER | GLSL_STARS | 
                          | GLSL_JETS | GLSL_DITHER)
 
 
+class TaaParams(C.Structure):  # reprojection.glsl.ts uniforms
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("blend_factor", C.c_float),
+                ("camera_moving", C.c_int32), ("half_storage", C.c_int32)]
+
+
+class AtaaParams(C.Structure):  # ataa.wgsl.ts CameraUniforms subset
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("inv_view", C.c_float * 16),
+                ("inv_proj", C.c_float * 16), ("prev_view_proj", C.c_float * 16),
+                ("position", C.c_float * 3), ("half_storage", C.c_int32)]
+
+
+class BloomParams(C.Structure):  # bloom.ts BloomConfig
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("intensity", C.c_float),
+                ("threshold", C.c_float), ("blur_passes", C.c_int32), ("half_storage", C.c_int32)]
+
+
 class FrameBuffers(C.Structure):
     _fields_ = [("rgba", C.c_void_p), ("final_state", C.c_void_p), ("steps", C.c_void_p),
                 ("termination", C.c_void_p), ("drift", C.c_void_p)]
@@ -176,6 +192,15 @@ def load_library():
     L.grv_render_frame_wgsl.argtypes = [p, C.POINTER(WgslParams), p, p, C.POINTER(C.c_uint64), p]
     L.grv_render_frame_glsl.restype = i
     L.grv_render_frame_glsl.argtypes = [p, C.POINTER(GlslParams), p, p, C.POINTER(C.c_uint64), p]
+    L.grv_post_taa_resolve.restype = i
+    L.grv_post_taa_resolve.argtypes = [p, C.POINTER(TaaParams), p, p, p, p]
+    L.grv_taa_effective_blend.restype = C.c_float
+    L.grv_taa_effective_blend.argtypes = [C.c_float, C.c_float]
+    L.grv_post_ataa_resolve.restype = i
+    L.grv_post_ataa_resolve.argtypes = [p, C.POINTER(AtaaParams), p, p, p, p]
+    L.grv_bloom_params_default.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(BloomParams)]
+    L.grv_post_bloom.restype = i
+    L.grv_post_bloom.argtypes = [p, C.POINTER(BloomParams), p, p, p]
     L.grv_seeded_noise_rgba8.argtypes = [C.c_uint32, C.c_uint32, p]
     L.grv_set_glsl_noise.restype = i
     L.grv_set_glsl_noise.argtypes = [p, p, p]
@@ -436,6 +461,27 @@ class PhysicsEngine:
                 raise ValueError("textures are 256x256 RGBA8")
         self._check(self._lib.grv_set_glsl_noise(self._h, _np_ptr(noise_rgba8), _np_ptr(blue_rgba8)),
                     "set_glsl_noise")
+
+    # ---- post chain (reprojection.ts / ataa.wgsl.ts / bloom.ts): device RGBA f32 images ----
+    def post_taa_resolve(self, width, height, current, history, out, blend_factor=0.75,
+                         camera_moving=False, half_storage=True, stream=None):
+        p = TaaParams(width, height, blend_factor, 1 if camera_moving else 0, 1 if half_storage else 0)
+        self._check(self._lib.grv_post_taa_resolve(self._h, C.byref(p), _dev_ptr(current),
+                                                   _dev_ptr(history), _dev_ptr(out), stream),
+                    "post_taa_resolve")
+
+    def post_ataa_resolve(self, params, current, history, out, stream=None):
+        self._check(self._lib.grv_post_ataa_resolve(self._h, C.byref(params), _dev_ptr(current),
+                                                    _dev_ptr(history), _dev_ptr(out), stream),
+                    "post_ataa_resolve")
+
+    def post_bloom(self, width, height, scene, out, stream=None, **kw):
+        p = BloomParams()
+        self._lib.grv_bloom_params_default(width, height, C.byref(p))
+        for k, v in kw.items():
+            setattr(p, k, v)
+        self._check(self._lib.grv_post_bloom(self._h, C.byref(p), _dev_ptr(scene), _dev_ptr(out),
+                                             stream), "post_bloom")
 
     def frame_stats(self, stream=None):
         st = FrameStats()

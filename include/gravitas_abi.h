@@ -239,6 +239,42 @@ int grv_render_frame_wgsl(grv_engine *e, const GrvWgslParams *p, float *d_rgba, 
 int grv_render_frame_glsl(grv_engine *e, const GrvGlslParams *p, float *d_rgba, uint32_t *d_steps,
                           uint64_t *total_steps, void *stream);
 
+/* ---- post chain: device RGBA f32 images [height][width][4], row-major ----
+ * Texture fetches are GL LINEAR + CLAMP_TO_EDGE with f32 weights; half_storage != 0 rounds every
+ * stored channel through binary16 as the reference's RGBA16F render targets do. */
+typedef struct { /* src/shaders/postprocess/reprojection.glsl.ts:44-116 uniforms */
+    uint32_t width, height;
+    float blend_factor;     /* u_blendFactor: 0.75 from src/rendering/webgl/renderer.ts:383 */
+    int32_t camera_moving;  /* u_cameraMoving */
+    int32_t half_storage;
+} GrvTaaParams;
+/* ReprojectionManager.resolve (src/rendering/reprojection.ts:196-262): out = history-blended frame */
+int grv_post_taa_resolve(grv_engine *e, const GrvTaaParams *p, const float *d_current,
+                         const float *d_history, float *d_out, void *stream);
+/* effective blend of resolve(): clamp(0.9 - 6 v, 0.05, 0.9) when v > 0.001 (reprojection.ts:241-245) */
+float grv_taa_effective_blend(float blend_factor, float camera_velocity_magnitude);
+
+typedef struct { /* src/shaders/postprocess/ataa.wgsl.ts:29-86 (CameraUniforms, types.wgsl.ts:6-17) */
+    uint32_t width, height;
+    float inv_view[16], inv_proj[16], prev_view_proj[16], position[3]; /* column-major */
+    int32_t half_storage;
+} GrvAtaaParams;
+int grv_post_ataa_resolve(grv_engine *e, const GrvAtaaParams *p, const float *d_current,
+                          const float *d_history, float *d_out, void *stream);
+
+typedef struct { /* src/rendering/bloom.ts:23-39 BloomConfig */
+    uint32_t width, height;
+    float intensity;      /* 0.5 */
+    float threshold;      /* 0.8 */
+    int32_t blur_passes;  /* 2 */
+    int32_t half_storage;
+} GrvBloomParams;
+void grv_bloom_params_default(uint32_t width, uint32_t height, GrvBloomParams *p);
+/* BloomManager.applyBloomToTexture (bloom.ts:443-583, renderScale 1): bright pass at w/2 x h/2,
+ * blur_passes x (H, V) 9-tap Gaussian at w/4 x h/4, combine + ACES + gamma at w x h */
+int grv_post_bloom(grv_engine *e, const GrvBloomParams *p, const float *d_scene, float *d_out,
+                   void *stream);
+
 /* camera helpers (gl-matrix lookAt/perspective as src/components/canvas/WebGPUCanvas.tsx:143-157) */
 void grv_camera_look_at(const double eye[3], const double target[3], const double up[3],
                         double fovy_rad, double aspect, GrvCamera *cam);

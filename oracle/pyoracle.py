@@ -183,6 +183,11 @@ def lib():
         L.orc_wgsl_frame.argtypes = [C.POINTER(WgslParams), C.c_uint32, C.c_uint32, p, p, i]
         L.orc_glsl_frame.argtypes = [C.POINTER(GlslParams), C.c_uint32, C.c_uint32, p, p, i]
         L.orc_seeded_noise_rgba8.argtypes = [C.c_uint32, C.c_uint32, p]
+        L.orc_round_to_half.restype = C.c_float
+        L.orc_round_to_half.argtypes = [C.c_float]
+        L.orc_taa_resolve.argtypes = [C.c_uint32, C.c_uint32, p, p, C.c_float, i, i, p]
+        L.orc_ataa_resolve.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(AtaaCamera), p, p, i, p]
+        L.orc_bloom.argtypes = [C.c_uint32, C.c_uint32, p, C.c_float, C.c_float, i, i, p]
         L.orc_sab_engine_init.argtypes = [C.POINTER(SabEngine), d, d]
         L.orc_camera_update.argtypes = [C.POINTER(CameraState), d, d, d, d]
         L.orc_tick_sab.argtypes = [C.POINTER(SabEngine), d]
@@ -389,6 +394,37 @@ def wgsl_params_from(gp):
     o.jitter[0], o.jitter[1] = gp.jitter[0], gp.jitter[1]
     o.max_steps = gp.max_steps
     return o
+
+
+class AtaaCamera(C.Structure):
+    _fields_ = [("inv_view", C.c_float * 16), ("inv_proj", C.c_float * 16),
+                ("prev_view_proj", C.c_float * 16), ("position", C.c_float * 3)]
+
+
+def taa_resolve(current, history, blend_factor=0.75, camera_moving=False, half_storage=True):
+    h, w, _ = current.shape
+    out = np.zeros_like(current)
+    lib().orc_taa_resolve(w, h, _ptr(np.ascontiguousarray(current, np.float32)),
+                          _ptr(np.ascontiguousarray(history, np.float32)), blend_factor,
+                          1 if camera_moving else 0, 1 if half_storage else 0, _ptr(out))
+    return out
+
+
+def ataa_resolve(cam, current, history, half_storage=True):
+    h, w, _ = current.shape
+    out = np.zeros_like(current)
+    lib().orc_ataa_resolve(w, h, C.byref(cam), _ptr(np.ascontiguousarray(current, np.float32)),
+                           _ptr(np.ascontiguousarray(history, np.float32)), 1 if half_storage else 0,
+                           _ptr(out))
+    return out
+
+
+def bloom(scene, threshold=0.8, intensity=0.5, blur_passes=2, half_storage=True):
+    h, w, _ = scene.shape
+    out = np.zeros_like(scene)
+    lib().orc_bloom(w, h, _ptr(np.ascontiguousarray(scene, np.float32)), threshold, intensity,
+                    blur_passes, 1 if half_storage else 0, _ptr(out))
+    return out
 
 
 def seeded_noise_rgba8(seed, size=256):
