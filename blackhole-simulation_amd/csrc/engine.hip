@@ -822,6 +822,8 @@ int grv_render_frame_wgsl(grv_engine *e, const GrvWgslParams *p, float *d_rgba, 
                           uint64_t *total_steps, void *stream) {
     if (!e) return GRV_ERR_INVALID;
     if (!p || !d_rgba) return fail(e, GRV_ERR_INVALID, "null argument");
+    if (p->arith != GRV_ARITH_STRICT && p->arith != GRV_ARITH_FAST)
+        return fail(e, GRV_ERR_INVALID, "invalid arith %d", p->arith);
     WgslParams P{};
     std::memcpy(P.inv_view, p->inv_view, sizeof P.inv_view);
     std::memcpy(P.inv_proj, p->inv_proj, sizeof P.inv_proj);
@@ -834,7 +836,9 @@ int grv_render_frame_wgsl(grv_engine *e, const GrvWgslParams *p, float *d_rgba, 
     hipStream_t s = static_cast<hipStream_t>(stream);
     return run_shader_frame(e, p->width, p->height, p->tile_world, p->tile_rank, total_steps, s,
                             [&](const FrameGeom &G, uint32_t n, unsigned long long *tot) {
-                                return launch_wgsl_symplectic(G, P, d_rgba, d_steps, tot, n, s);
+                                return p->arith == GRV_ARITH_FAST
+                                           ? launch_wgsl_symplectic_fast(G, P, d_rgba, d_steps, tot, n, s)
+                                           : launch_wgsl_symplectic(G, P, d_rgba, d_steps, tot, n, s);
                             });
 }
 

@@ -2,6 +2,7 @@
 // Instantiates the segment kernel with the shared-reciprocal Kerr-Schild
 // right-hand side (kerr_device.hpp: rhs_ks_fast) and FMA contraction.
 #include "geodesic_kernels.hpp"
+#include "wgsl_fast_kernel.hpp"
 
 namespace grvhip {
 
@@ -37,6 +38,15 @@ hipError_t launch_segment_fast(int kind, int method, const RayWorkspace &ws,
     case GRV_METRIC_SCHWARZSCHILD: return by_method<GRV_METRIC_SCHWARZSCHILD>(method, ws, P, live_in, n_live, live_out, live_out_count, s);
     default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t launch_wgsl_symplectic_fast(const FrameGeom &G, const WgslParams &P, float *out_rgba,
+                                       uint32_t *out_steps, unsigned long long *total_steps,
+                                       uint32_t n_slots, hipStream_t s) {
+    if (n_slots == 0) return hipSuccess;
+    hipLaunchKernelGGL(wgsl_symplectic_fast_kernel, dim3((n_slots + kBlock - 1) / kBlock), dim3(kBlock),
+                       0, s, G, P, reinterpret_cast<float4 *>(out_rgba), out_steps, total_steps, n_slots);
+    return hipGetLastError();
 }
 
 } // namespace grvhip

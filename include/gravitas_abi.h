@@ -181,6 +181,8 @@ typedef struct { /* src/shaders/compute.wgsl.ts + types.wgsl.ts:6-30 */
     float jitter[2];         /* halton(frame)-0.5 in pixels (compute.wgsl.ts:154-157); 0 = none */
     int32_t max_steps;       /* override MAX_STEPS, default 150 (compute.wgsl.ts:13) */
     uint32_t tile_world, tile_rank;
+    int32_t arith;           /* GRV_ARITH_STRICT: the shader's operation order;
+                                GRV_ARITH_FAST: same equations, shared reciprocal + FMA (f32 rounding only) */
 } GrvWgslParams;
 
 /* ShaderManager's #defines (src/shaders/manager.ts:61-82) as GrvGlslParams.features bits */

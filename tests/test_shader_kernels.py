@@ -111,12 +111,13 @@ def _compare(got_rgba, got_steps, ref_rgba, ref_steps):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("arith", [0, 1])  # shader operation order / FAST contract (f32 rounding only)
 @pytest.mark.parametrize("spin,max_steps", [(0.999, 512), (0.5, 150)])
-def test_wgsl_kernel_matches_oracle(engine_mod, oracle, spin, max_steps):
+def test_wgsl_kernel_matches_oracle(engine_mod, oracle, spin, max_steps, arith):
     import torch
     W, H = 480, 270
     cam = engine_mod.camera_look_at(EYE, aspect=W / H)
-    gp = engine_mod.wgsl_params(W, H, cam, 1.0, spin, max_steps=max_steps)
+    gp = engine_mod.wgsl_params(W, H, cam, 1.0, spin, max_steps=max_steps, arith=arith)
     gp.jitter[0], gp.jitter[1] = 0.0, -1.0 / 6.0        # frame-0 Halton jitter
     n = W * H
     with engine_mod.PhysicsEngine(1.0, spin) as e:

@@ -39,10 +39,10 @@ def run(name, W, H, make, call, reps=10, world=1):
                       "algorithmic_GBps_72B": round(tot * 72 / ms / 1e6, 1)}), flush=True)
 
 
-def wgsl(max_steps):
+def wgsl(max_steps, arith=0):
     def make(W, H):
         cam = bh.camera_look_at(EYE, aspect=W / H)
-        return bh.wgsl_params(W, H, cam, 1.0, 0.999, max_steps=max_steps)
+        return bh.wgsl_params(W, H, cam, 1.0, 0.999, max_steps=max_steps, arith=arith)
     return make
 
 
@@ -54,8 +54,11 @@ if __name__ == "__main__":
     cw = lambda e, gp, rgba: e.render_frame_wgsl(gp, rgba)  # noqa: E731
     cg = lambda e, gp, rgba: e.render_frame_glsl(gp, rgba)  # noqa: E731
     run("C2 wgsl symplectic f32, 512 steps", 1920, 1080, wgsl(512), cw)
+    run("C2 wgsl symplectic f32 FAST, 512 steps", 1920, 1080, wgsl(512, 1), cw)
     run("C2 glsl verlet f32 (march+disk), 512->500 steps", 1920, 1080, glsl(512, features=7, turbulence=0.75), cg)
     run("C2 glsl full default preset, 512->500 steps", 1920, 1080, glsl(512), cg)
     run("C4 share wgsl, 8K / 8 ranks, 1024 steps", 7680, 4320, wgsl(1024), cw, reps=5, world=8)
+    run("C4 share wgsl FAST, 8K / 8 ranks, 1024 steps", 7680, 4320, wgsl(1024, 1), cw, reps=5, world=8)
     run("C4 share glsl full, 8K / 8 ranks, 1024->500 steps", 7680, 4320, glsl(1024), cg, reps=5, world=8)
     run("4K wgsl, 150 steps (shader default)", 3840, 2160, wgsl(150), cw)
+    run("4K wgsl FAST, 150 steps (shader default)", 3840, 2160, wgsl(150, 1), cw)
