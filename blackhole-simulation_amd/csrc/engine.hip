@@ -846,6 +846,8 @@ int grv_render_frame_glsl(grv_engine *e, const GrvGlslParams *p, float *d_rgba, 
                           uint64_t *total_steps, void *stream) {
     if (!e) return GRV_ERR_INVALID;
     if (!p || !d_rgba) return fail(e, GRV_ERR_INVALID, "null argument");
+    if (p->arith != GRV_ARITH_STRICT && p->arith != GRV_ARITH_FAST)
+        return fail(e, GRV_ERR_INVALID, "invalid arith %d", p->arith);
     GlslParams P{};
     P.mass = p->mass;
     P.spin = p->spin;
@@ -882,7 +884,9 @@ int grv_render_frame_glsl(grv_engine *e, const GrvGlslParams *p, float *d_rgba, 
     hipStream_t s = static_cast<hipStream_t>(stream);
     return run_shader_frame(e, p->width, p->height, p->tile_world, p->tile_rank, total_steps, s,
                             [&](const FrameGeom &G, uint32_t n, unsigned long long *tot) {
-                                return launch_glsl_fragment(G, P, d_rgba, d_steps, tot, n, s);
+                                return p->arith == GRV_ARITH_FAST
+                                           ? launch_glsl_fragment_fast(G, P, d_rgba, d_steps, tot, n, s)
+                                           : launch_glsl_fragment(G, P, d_rgba, d_steps, tot, n, s);
                             });
 }
 

@@ -141,6 +141,9 @@ hipError_t launch_bloom(uint32_t w, uint32_t h, const float *scene, float thresh
                         int blur_passes, int half_storage, float *scratch, float *out, hipStream_t s);
 size_t bloom_scratch_floats(uint32_t w, uint32_t h);
 // ---- launcher (kernels_fast.hip: -ffp-contract=fast) ----
+hipError_t launch_glsl_fragment_fast(const FrameGeom &G, const GlslParams &P, float *out_rgba,
+                                     uint32_t *out_steps, unsigned long long *total_steps,
+                                     uint32_t n_slots, hipStream_t s);
 hipError_t launch_wgsl_symplectic_fast(const FrameGeom &G, const WgslParams &P, float *out_rgba,
                                        uint32_t *out_steps, unsigned long long *total_steps,
                                        uint32_t n_slots, hipStream_t s);

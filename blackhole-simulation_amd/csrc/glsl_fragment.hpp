@@ -1,0 +1,548 @@
+// glsl_fragment.hpp -- the reference's WebGL fragment shader as a HIP kernel:
+// src/shaders/blackhole/fragment.glsl.ts:40-334 (the whole main()) with chunks/metric.ts,
+// chunks/disk.ts, chunks/noise.ts, chunks/background.ts, chunks/blackbody.ts [SURVEY a16, a17,
+// 8f-3].  ShaderManager's #defines (manager.ts:61-82) are GlslParams::features bits.
+//
+// Two arithmetic contracts, one per translation unit:
+//   STRICT (kernels_strict.hip, -ffp-contract=off): the shader's operation order, IEEE divide /
+//          sqrt, OCML sinf / cosf;
+//   FAST   (kernels_fast.hip, -ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt):
+//          the same expressions with FMA contraction, v_rcp_f32 / v_sqrt_f32 based divide and
+//          sqrt, and a polynomial sin / cos for the ZAMO twist.  f32 rounding differences only.
+//
+// Not reproducible in the reference and therefore fixed here: the two noise
+// textures are Math.random() upstream -- here they are engine-owned seeded 256x256 byte planes
+// (grv_set_glsl_noise), sampled with f32 weights.
+// One thread per pixel, registers only; a wave is one 8x8 pixel block.
+#pragma once
+
+#include "shader_common.hpp"
+
+namespace {
+
+// ===========================================================================
+// GLSL fragment march
+// ===========================================================================
+// chunks/metric.ts:96-149
+__device__ __forceinline__ F3 glsl_kerr_accel(F3 p, F3 v, float M, float a, float &omega) {
+    const float a2 = a * a;
+    const float rho2 = dot_f3(p, p);
+    const float diff = rho2 - a2;
+    const float disc = diff * diff + 4.0f * a2 * p.y * p.y;
+    const float r2 = 0.5f * (diff + sqrtf(fmaxf(0.0f, disc)));
+    const float r_k = sqrtf(fmaxf(1e-8f, r2));
+    const float sigma = r2 + a2 * (p.y * p.y / fmaxf(1e-8f, r2));
+    const F3 L = cross_f3(p, v);
+    const float Ly = L.y;
+    const float Ly_eff = Ly - a;
+    const float L2_eff = Ly_eff * Ly_eff + (dot_f3(L, L) - Ly * Ly);
+    const float r_inv = 1.0f / r_k;
+    const float r2_inv = r_inv * r_inv;
+    const float r4_inv = r2_inv * r2_inv;
+    const float sigma_ratio = r2 / fmaxf(1e-8f, sigma);
+    const F3 n = normalize_f3(p);
+    const F3 r_hat{-n.x, -n.y, -n.z};
+    F3 acc = scale_f3(r_hat, M * r2_inv * sigma_ratio + 3.0f * M * fmaxf(0.0f, L2_eff) * r4_inv * sigma_ratio);
+    const float r3_p_a2r = r_k * r2 + a2 * r_k;
+    const float drag = 2.0f * M * a / fmaxf(1e-8f, r3_p_a2r);
+    acc = add_f3(acc, scale_f3(cross_f3(F3{0.0f, 1.0f, 0.0f}, v), drag));
+    omega = 2.0f * M * a / fmaxf(1e-8f, r3_p_a2r);
+    return acc;
+}
+
+// sin / cos of the FAST contract: two-term Cody-Waite reduction by pi/2 + cephes minimax
+// polynomials on [-pi/4, pi/4] (~1 ulp f32 for the O(1) angles of the march)
+__device__ __forceinline__ void glsl_fast_sincos(float ang, float &s, float &c) {
+    const float j = rintf(ang * 0.636619772367581343f);
+    float x = fmaf(-j, 1.57079637050628662109375f, ang);
+    x = fmaf(-j, -4.37113900018624283e-8f, x);
+    const float z = x * x;
+    float ps = fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = fmaf(z, ps, -1.6666654611e-1f);
+    const float sr = fmaf(x * z, ps, x);
+    float pc = fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = fmaf(z, pc, 4.166664568298827e-2f);
+    const float cr = fmaf(z * z, pc, fmaf(z, -0.5f, 1.0f));
+    const int q = (int)j;
+    const float s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;
+    s = (q & 2) ? -s0 : s0;
+    c = ((q + 1) & 2) ? -c0 : c0;
+}
+
+// pow / exp / log: OCML in the STRICT contract; v_log_f32 / v_exp_f32 (base 2, ~1 ulp each)
+// in the FAST contract.  pow(0, y > 0) = exp2(-inf) = 0 in both.
+template <int ARITH> __device__ __forceinline__ float pow_d(float x, float y) {
+    if constexpr (ARITH == GRV_ARITH_FAST) return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
+    else return powf(x, y);
+}
+template <int ARITH> __device__ __forceinline__ float exp_d(float x) {
+    if constexpr (ARITH == GRV_ARITH_FAST) return __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
+    else return expf(x);
+}
+template <int ARITH> __device__ __forceinline__ float log_d(float x) {
+    if constexpr (ARITH == GRV_ARITH_FAST) return __builtin_amdgcn_logf(x) * 0.693147180559945309f;
+    else return logf(x);
+}
+
+// chunks/common.ts:44-47 : `v.ab *= rot(ang)`
+template <int ARITH>
+__device__ __forceinline__ void glsl_rot(float ang, float &x, float &y) {
+    float s, c;
+    if constexpr (ARITH == GRV_ARITH_FAST) {
+        glsl_fast_sincos(ang, s, c);
+    } else {
+        s = sinf(ang);
+        c = cosf(ang);
+    }
+    const float nx = x * c + y * (-s);
+    const float ny = x * s + y * c;
+    x = nx;
+    y = ny;
+}
+
+// chunks/blackbody.ts:9-34
+template <int ARITH>
+__device__ __forceinline__ void glsl_blackbody(float temp, float rgb[3]) {
+    const float t = fmaxf(temp, 1.0f) / 100.0f;
+    float r, g, b;
+    if (t <= 66.0f) {
+        r = 255.0f;
+        g = 99.4708025861f * log_d<ARITH>(t) - 161.1195681661f;
+        b = (t <= 19.0f) ? 0.0f : 138.5177312231f * log_d<ARITH>(t - 10.0f) - 305.0447927307f;
+    } else {
+        r = 329.698727446f * pow_d<ARITH>(t - 60.0f, -0.1332047592f);
+        g = 288.1221695283f * pow_d<ARITH>(t - 60.0f, -0.0755148492f);
+        b = 255.0f;
+    }
+    rgb[0] = pow_d<ARITH>(fmaxf(r / 255.0f, 0.0f), 2.2f);
+    rgb[1] = pow_d<ARITH>(fmaxf(g / 255.0f, 0.0f), 2.2f);
+    rgb[2] = pow_d<ARITH>(fmaxf(b / 255.0f, 0.0f), 2.2f);
+}
+
+// ---- chunks/noise.ts: the 256x256 R channels live in HBM/L2 (64 KiB each) ----
+__device__ __forceinline__ float glsl_texel(const uint8_t *__restrict__ t, int x, int y) {
+    return (float)t[(uint32_t)(y & 255) * 256u + (uint32_t)(x & 255)] / 255.0f; // REPEAT, UNORM8
+}
+// texture(u_noiseTex, (uv + 0.5) / 256.0).r with LINEAR + REPEAT, f32 weights
+__device__ __forceinline__ float glsl_hash_uv(const uint8_t *__restrict__ T, float uvx, float uvy) {
+    const float s = (uvx + 0.5f) / 256.0f, t = (uvy + 0.5f) / 256.0f;
+    const float u = s * 256.0f - 0.5f, v = t * 256.0f - 0.5f;
+    const float fu = floorf(u), fv = floorf(v);
+    const float a = u - fu, b = v - fv;
+    const int i0 = (int)fmodf(fu, 256.0f), j0 = (int)fmodf(fv, 256.0f);
+    // integer lattice points (every noise() corner) land on a texel centre: weights (1, 0, 0, 0),
+    // and 0 * texel is exactly 0 for UNORM8 data -- one fetch gives the bitwise same value
+    if (a == 0.0f && b == 0.0f) return glsl_texel(T, i0, j0);
+    const float t00 = glsl_texel(T, i0, j0), t10 = glsl_texel(T, i0 + 1, j0);
+    const float t01 = glsl_texel(T, i0, j0 + 1), t11 = glsl_texel(T, i0 + 1, j0 + 1);
+    return (1.0f - a) * (1.0f - b) * t00 + a * (1.0f - b) * t10 + (1.0f - a) * b * t01 + a * b * t11;
+}
+__device__ __forceinline__ float glsl_hash(const uint8_t *__restrict__ T, F3 p) { // noise.ts:3-9
+    return glsl_hash_uv(T, p.x + p.z * 37.0f, p.y + p.z * 37.0f);
+}
+__device__ __forceinline__ float mix_d(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+__device__ __forceinline__ float fract_d(float x) { return x - floorf(x); }
+__device__ float glsl_noise(const uint8_t *__restrict__ T, F3 p) { // noise.ts:11-21
+    const F3 i{floorf(p.x), floorf(p.y), floorf(p.z)};
+    F3 f{fract_d(p.x), fract_d(p.y), fract_d(p.z)};
+    f.x = f.x * f.x * (3.0f - 2.0f * f.x);
+    f.y = f.y * f.y * (3.0f - 2.0f * f.y);
+    f.z = f.z * f.z * (3.0f - 2.0f * f.z);
+    auto H = [&](float dx, float dy, float dz) { return glsl_hash(T, F3{i.x + dx, i.y + dy, i.z + dz}); };
+    return mix_d(mix_d(mix_d(H(0, 0, 0), H(1, 0, 0), f.x), mix_d(H(0, 1, 0), H(1, 1, 0), f.x), f.y),
+                 mix_d(mix_d(H(0, 0, 1), H(1, 0, 1), f.x), mix_d(H(0, 1, 1), H(1, 1, 1), f.x), f.y), f.z);
+}
+__device__ __forceinline__ float glsl_fbm(const uint8_t *__restrict__ T, F3 p) { // noise.ts:23-33
+    float f = 0.0f, amp = 0.5f;
+    for (int i = 0; i < 4; ++i) {
+        f += amp * glsl_noise(T, p);
+        p = scale_f3(p, 2.0f);
+        amp *= 0.5f;
+    }
+    return f;
+}
+
+// chunks/blackbody.ts:36-46
+__device__ __forceinline__ void glsl_star_color(float bv, float c[3]) {
+    const float t = clampf_d(bv, -0.4f, 2.0f);
+    if (t < 0.0f) { c[0] = 0.6f; c[1] = 0.7f; c[2] = 1.0f; }
+    else if (t < 0.3f) { c[0] = 0.85f; c[1] = 0.88f; c[2] = 1.0f; }
+    else if (t < 0.6f) { c[0] = 1.0f; c[1] = 0.96f; c[2] = 0.9f; }
+    else if (t < 1.0f) { c[0] = 1.0f; c[1] = 0.85f; c[2] = 0.6f; }
+    else { c[0] = 1.0f; c[1] = 0.6f; c[2] = 0.4f; }
+}
+
+// chunks/background.ts:3-30
+template <int ARITH>
+__device__ void glsl_starfield(const GlslParams &U, F3 dir, float stars[3]) {
+    const uint8_t *T = U.noise_r;
+    stars[0] = stars[1] = stars[2] = 0.0f;
+    F3 cell{floorf(dir.x * 200.0f), floorf(dir.y * 200.0f), floorf(dir.z * 200.0f)};
+    float starNoise = glsl_hash(T, cell);
+    if (starNoise > 0.998f) {
+        const float brightness = pow_d<ARITH>(starNoise, 10.0f) * 2.0f;
+        const float bv = glsl_hash(T, F3{cell.x + 127.1f, cell.y + 127.1f, cell.z + 127.1f}) * 2.4f - 0.4f;
+        const float twinkle =
+            0.85f + 0.15f * sinf(U.time * (3.0f + glsl_hash(T, F3{cell.x + 73.7f, cell.y + 73.7f, cell.z + 73.7f}) * 2.0f));
+        float sc[3];
+        glsl_star_color(bv, sc);
+        for (int c = 0; c < 3; ++c) stars[c] = sc[c] * brightness * twinkle;
+    }
+    cell = F3{floorf(dir.x * 500.0f), floorf(dir.y * 500.0f), floorf(dir.z * 500.0f)};
+    starNoise = glsl_hash(T, cell);
+    if (starNoise > 0.996f) {
+        const float brightness = pow_d<ARITH>(starNoise, 20.0f) * 1.5f;
+        const float bv = glsl_hash(T, F3{cell.x + 217.3f, cell.y + 217.3f, cell.z + 217.3f}) * 2.4f - 0.4f;
+        float sc[3];
+        glsl_star_color(bv, sc);
+        for (int c = 0; c < 3; ++c) stars[c] += sc[c] * brightness;
+    }
+    const float tt = U.time * 0.01f;
+    const float nebula = glsl_fbm(T, F3{dir.x * 2.0f + tt, dir.y * 2.0f + tt, dir.z * 2.0f + tt}) * 0.03f;
+    const float ln = fabsf(nebula);
+    stars[0] += nebula * 0.2f + 0.05f * ln;
+    stars[1] += nebula * 0.3f + 0.02f * ln;
+    stars[2] += nebula * 0.5f + 0.05f * ln;
+}
+
+// chunks/disk.ts:16-115
+template <int ARITH>
+__device__ __forceinline__ void glsl_sample_disk(const GlslParams &U, F3 p, F3 p_prev, F3 v,
+                                                 float isco, float M, float a, float dt,
+                                                 float col[3], float &alpha) {
+    if (!(U.show_redshift < 0.5f)) return;
+    const bool crossed = (p_prev.y * p.y < 0.0f);
+    F3 sp = p;
+    if (crossed) {
+        const float t = fabsf(p_prev.y) / fmaxf(0.0001f, fabsf(p_prev.y) + fabsf(p.y));
+        sp.x = p_prev.x * (1.0f - t) + p.x * t;
+        sp.y = p_prev.y * (1.0f - t) + p.y * t;
+        sp.z = p_prev.z * (1.0f - t) + p.z * t;
+    }
+    const float sampleR = length_f3(sp);
+    const float effH = fminf(U.disk_scale_height, 0.45f);
+    const float diskHeight = sampleR * effH;
+    const float diskInner = isco;
+    const float diskOuter = fmaxf(M * U.disk_size, diskInner * 1.1f);
+    if (!((fabsf(sp.y) < diskHeight || crossed) && sampleR > diskInner && sampleR < diskOuter)) return;
+    float turbulence = U.turbulence;
+    if (turbulence < 0.0f) { // disk.ts:43-55: Keplerian phase rotation of the noise field
+        const float sqrt_Mp = sqrtf(M);
+        const float signSpinPhase = sign_d(U.spin + 1e-8f);
+        const float OmegaPhase = (signSpinPhase * sqrt_Mp) / (sampleR * sqrtf(sampleR) + a * sqrt_Mp);
+        const float rotAngle = OmegaPhase * U.time * 0.12f * 10.0f;
+        const float cs = cosf(rotAngle), sn = sinf(rotAngle);
+        F3 np{sp.x * cs + sp.z * (-sn), sp.y, sp.x * sn + sp.z * cs};
+        np = scale_f3(np, 0.75f);
+        turbulence = glsl_noise(U.noise_r, np) * 0.5f + glsl_noise(U.noise_r, scale_f3(np, 2.5f)) * 0.25f;
+    }
+    const float heightFalloff = exp_d<ARITH>(-fabsf(sp.y) / fmaxf(0.001f, (sampleR * effH) * 0.25f));
+    const float radialFalloff = smoothstep_d(diskOuter, diskInner, sampleR);
+    const float baseDensity = turbulence * heightFalloff * radialFalloff;
+    if (!(baseDensity > 0.001f)) return;
+
+    const float r2 = sampleR * sampleR;
+    const float sqrt_M = sqrtf(M);
+    const float signSpin = sign_d(U.spin + 1e-8f);
+    const float Omega = (signSpin * sqrt_M) / (sampleR * sqrtf(sampleR) + a * sqrt_M);
+    const float g_tt = -(1.0f - 2.0f * M / sampleR);
+    const float g_tphi = -2.0f * M * a / sampleR;
+    const float g_phiphi = r2 + a * a + 2.0f * M * a * a / sampleR;
+    const float u_t_sq = -(g_tt + 2.0f * Omega * g_tphi + Omega * Omega * g_phiphi);
+    const float u_t = 1.0f / sqrtf(fmaxf(1e-6f, u_t_sq));
+    const float L_photon = p.z * v.x - p.x * v.z;
+    const float delta = 1.0f / fmaxf(0.01f, u_t * (1.0f - Omega * L_photon));
+    const float beaming = (U.features & GRV_GLSL_DOPPLER) ? fmaxf(0.01f, pow_d<ARITH>(delta, 3.5f)) : 1.0f;
+    const float isco_r = clampf_d(isco / sampleR, 0.0f, 1.0f);
+    const float nt_factor = fmaxf(0.0f, 1.0f - sqrtf(isco_r));
+    const float grad = pow_d<ARITH>(isco_r, 0.75f) * pow_d<ARITH>(nt_factor, 0.25f);
+    const float temperature = U.disk_temp * grad * delta;
+    float bb[3];
+    glsl_blackbody<ARITH>(temperature, bb);
+    const float density = baseDensity * U.disk_density * 0.12f * dt;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) col[c] += bb[c] * beaming * density * (1.0f - alpha);
+    alpha += density;
+}
+
+// chunks/disk.ts:117-155
+template <int ARITH>
+__device__ __forceinline__ void glsl_sample_jets(const GlslParams &U, F3 p, F3 v, float rh, float dt,
+                                                 float col[3], float &alpha) {
+    const float jetVerticalPos = fabsf(p.y);
+    if (!(jetVerticalPos > rh * 1.8f && jetVerticalPos < 10000.0f * 0.8f)) return;
+    const float jetRadialDist = sqrtf(p.x * p.x + p.z * p.z);
+    const float jetWidth = 1.0f + jetVerticalPos * 0.15f;
+    if (!(jetRadialDist < jetWidth * 2.0f)) return;
+    const float radialFalloff = exp_d<ARITH>(-(jetRadialDist * jetRadialDist) / (jetWidth * 0.5f));
+    const float lengthFalloff = exp_d<ARITH>(-jetVerticalPos * 0.05f);
+    const float flow = p.y * 2.0f - U.time * 8.0f;
+    const F3 uvJet{p.x, flow, p.z};
+    const float noiseVal = glsl_noise(U.noise_r, scale_f3(uvJet, 0.5f)) * 0.6f +
+                           glsl_noise(U.noise_r, scale_f3(uvJet, 1.5f)) * 0.4f;
+    const float jetDensity = radialFalloff * lengthFalloff * fmaxf(0.0f, noiseVal - 0.2f);
+    if (!(jetDensity > 0.001f)) return;
+    const float jetVel = 0.92f * sign_d(p.y);
+    const F3 nv = normalize_f3(F3{0.0f, jetVel, 0.0f});
+    const float cosThetaJet = dot_f3(nv, F3{-v.x, -v.y, -v.z});
+    const float betaJet = fabsf(jetVel);
+    const float gammaJet = 1.0f / sqrtf(1.0f - betaJet * betaJet);
+    const float deltaJet = 1.0f / (gammaJet * (1.0f - betaJet * cosThetaJet));
+    const float beamingJet = pow_d<ARITH>(deltaJet, 3.5f);
+    const float base[3] = {0.4f, 0.7f, 1.0f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) col[c] += base[c] * jetDensity * 0.05f * beamingJet * dt * (1.0f - alpha);
+    alpha += jetDensity * 0.05f * dt;
+}
+
+__device__ __forceinline__ float aces_d(float c) {
+    return clampf_d((c * (2.51f * c + 0.03f)) / (c * (2.43f * c + 0.59f) + 0.14f), 0.0f, 1.0f);
+}
+
+__device__ __forceinline__ F3 glsl_qrot(const float q[4], F3 v) { // common.ts:74-76
+    const F3 qv{q[0], q[1], q[2]};
+    const F3 t = add_f3(cross_f3(qv, v), scale_f3(v, q[3]));
+    return add_f3(v, scale_f3(cross_f3(qv, t), 2.0f));
+}
+
+// distance from (px, py) to the segment a-b (fragment.glsl.ts:303-308)
+__device__ __forceinline__ float glsl_seg_dist(float px, float py, float ax, float ay, float bx, float by) {
+    const float pax = px - ax, pay = py - ay, bax = bx - ax, bay = by - ay;
+    const float h = clampf_d((pax * bax + pay * bay) / (bax * bax + bay * bay), 0.0f, 1.0f);
+    const float dx = pax - bax * h, dy = pay - bay * h;
+    return sqrtf(dx * dx + dy * dy);
+}
+
+// fragment.glsl.ts:40-334 -- the whole main().  Returns the march steps taken.
+template <int ARITH>
+__device__ uint32_t glsl_fragment(const GlslParams &U, uint32_t width, uint32_t height, uint32_t X,
+                                  uint32_t Y, float o[3]) {
+    const uint32_t F = U.features;
+    const float PI = 3.14159265359f;
+    const float resx = (float)width, resy = (float)height;
+    const float minRes = fminf(resx, resy);
+    const float fcx = (float)X + 0.5f, fcy = (float)(height - 1u - Y) + 0.5f;
+    const float uvx = (fcx - 0.5f * resx) / minRes, uvy = (fcy - 0.5f * resy) / minRes;
+    if (U.debug > 0.5f) {
+        o[0] = uvx + 0.5f;
+        o[1] = uvy + 0.5f;
+        o[2] = 0.0f;
+        return 0;
+    }
+    F3 ro, rd;
+    if (length_f3(F3{U.cam_pos[0], U.cam_pos[1], U.cam_pos[2]}) > 0.001f) {
+        ro = F3{U.cam_pos[0], U.cam_pos[1], U.cam_pos[2]};
+        rd = glsl_qrot(U.cam_quat, normalize_f3(F3{uvx, uvy, 1.2f}));
+    } else {
+        ro = F3{0.0f, 0.0f, -U.zoom};
+        rd = normalize_f3(F3{uvx, uvy, 1.5f});
+        const float ax = (U.mouse[1] - 0.5f) * PI, ay = (U.mouse[0] - 0.5f) * PI * 2.0f;
+        glsl_rot<ARITH>(ax, ro.y, ro.z);
+        glsl_rot<ARITH>(ax, rd.y, rd.z);
+        glsl_rot<ARITH>(ay, ro.x, ro.z);
+        glsl_rot<ARITH>(ay, rd.x, rd.z);
+    }
+
+    const float M = U.mass;
+    const float rs = M * 2.0f;
+    const float a = U.spin * M;
+    const float rh = M + sqrtf(fmaxf(0.0f, M * M - a * a)); // metric.ts:13-15
+    // metric.ts:32-37
+    const float a_star = clampf_d(a / M, -0.9999f, 0.9999f);
+    const float rph = 2.0f * M * (1.0f + cosf((2.0f / 3.0f) * acosf(clampf_d(-a_star, -1.0f, 1.0f))));
+    // metric.ts:18-29
+    const float absS = fabsf(clampf_d(a / M, -0.9999f, 0.9999f));
+    const float z1 = 1.0f + pow_d<ARITH>(1.0f - absS * absS, 1.0f / 3.0f) *
+                                (pow_d<ARITH>(1.0f + absS, 1.0f / 3.0f) + pow_d<ARITH>(1.0f - absS, 1.0f / 3.0f));
+    const float z2 = sqrtf(3.0f * absS * absS + z1 * z1);
+    float sgnA = sign_d(a);
+    if (sgnA == 0.0f) sgnA = 1.0f;
+    const float isco = M * (3.0f + z2 - sgnA * sqrtf((3.0f - z1) * (3.0f + z1 + 2.0f * z2)));
+    const float absA = fabsf(U.spin);
+
+    if (U.quality == 0) { // RAY_QUALITY_LOW / OFF indicator path, fragment.glsl.ts:76-88
+        float bg[3];
+        glsl_starfield<ARITH>(U, rd, bg);
+        const float d = length_f3(cross_f3(ro, rd));
+        const float shadow = smoothstep_d(rh * 1.2f, rh * 0.9f, d);
+        const float glow = exp_d<ARITH>(-fabsf(d - rph) * 12.0f) * 0.8f;
+        const float glowCol[3] = {0.3f * glow, 0.6f * glow, 1.0f * glow};
+        const float diskMask =
+            smoothstep_d(isco * 2.0f, isco * 1.0f, d) * (1.0f - smoothstep_d(isco * 1.0f, isco * 0.8f, d));
+        const float diskCol[3] = {1.0f * diskMask * 0.6f, 0.7f * diskMask * 0.6f, 0.3f * diskMask * 0.6f};
+        for (int c = 0; c < 3; ++c) o[c] = pow_d<ARITH>(bg[c] * (1.0f - shadow) + glowCol[c] + diskCol[c], 0.4545f);
+        return 0;
+    }
+
+    F3 p = ro, v = rd;
+    if (length_f3(ro) < rh * 1.5f) {
+        ro = scale_f3(scale_f3(normalize_f3(ro), rh), 1.5f);
+        p = ro;
+    }
+    float col[3] = {0.0f, 0.0f, 0.0f};
+    float alpha = 0.0f;
+    bool hitHorizon = false;
+    float maxRedshift = 0.0f;
+    float bNoise = 0.0f; // fragment.glsl.ts:104-108, NEAREST + REPEAT
+    if (F & GRV_GLSL_DITHER) bNoise = glsl_texel(U.blue_r, (int)floorf(fcx), (int)floorf(fcy));
+    p = add_f3(p, scale_f3(scale_f3(v, bNoise), 0.01f));
+
+    int photonCrossings = 0;
+    float prevY = p.y;
+    const float impactParam = length_f3(cross_f3(ro, rd));
+    bool redshiftInit = false;
+    const int maxSteps = (int)fminf((float)U.max_ray_steps, 500.0f);
+    F3 p_prev = p;
+    if (impactParam < rh * 0.9f) hitHorizon = true;
+    uint32_t steps = 0;
+    const bool lensing = (F & GRV_GLSL_LENSING) != 0u, disk = (F & GRV_GLSL_DISK) != 0u;
+    const bool jets = disk && (F & GRV_GLSL_JETS) != 0u;
+
+    for (int i = 0; i < maxSteps; ++i) {
+        p_prev = p;
+        const float r = length_f3(p);
+        if (r < rh * 1.15f) {
+            hitHorizon = true;
+            break;
+        }
+        if (r > 10000.0f) break;
+        const float distFactor = 1.0f + r * 0.05f;
+        float dt = clampf_d((r - rh) * 0.1f * distFactor, 0.01f, 1.2f * distFactor);
+        if (r > 30.0f) {
+            const float farBoost = (r - 30.0f) * 0.08f;
+            dt = fmaxf(dt, 0.01f + farBoost);
+            dt = fminf(dt, 1.2f * 2.5f);
+        }
+        const float sphereProx = fabsf(r - rph);
+        dt = fminf(dt, 0.01f + sphereProx * 0.15f);
+        const float hRefinement = smoothstep_d(0.2f, 0.0f, fabsf(p.y));
+        const float cdt = dt * (1.0f - hRefinement * 0.7f);
+
+        F3 accel{0.0f, 0.0f, 0.0f};
+        if (lensing) {
+            float omega;
+            accel = scale_f3(glsl_kerr_accel(p, v, M, a, omega), U.lensing_strength);
+            glsl_rot<ARITH>(omega * cdt, v.x, v.z);
+        }
+        p = add_f3(p, add_f3(scale_f3(v, cdt), scale_f3(scale_f3(scale_f3(accel, 0.5f), cdt), cdt)));
+        const float r_new = length_f3(p);
+        if (lensing && alpha < 0.95f) {
+            float om2;
+            const F3 accel_new = scale_f3(glsl_kerr_accel(p, v, M, a, om2), U.lensing_strength);
+            v = add_f3(v, scale_f3(scale_f3(add_f3(accel, accel_new), 0.5f), cdt));
+        }
+        v = normalize_f3(v);
+        ++steps;
+
+        if (prevY * p.y < 0.0f && r_new < rph * 2.0f && r_new > rh)
+            photonCrossings = photonCrossings + 1 < 3 ? photonCrossings + 1 : 3;
+        if (U.show_redshift > 0.5f) {
+            const float potential = sqrtf(fmaxf(0.0f, 1.0f - rs / r_new));
+            if (!redshiftInit) {
+                maxRedshift = potential;
+                redshiftInit = true;
+            } else {
+                maxRedshift = fminf(maxRedshift, potential);
+            }
+        }
+        prevY = p.y;
+        if (disk) {
+            glsl_sample_disk<ARITH>(U, p, p_prev, v, isco, M, a, cdt, col, alpha);
+            if (alpha > 0.99f) break;
+        }
+        if (jets) glsl_sample_jets<ARITH>(U, p, v, rh, dt, col, alpha); // un-refined dt (fragment.glsl.ts:219)
+    }
+
+    if ((F & GRV_GLSL_REDSHIFT) && U.show_redshift > 0.5f) { // fragment.glsl.ts:224-237
+        const float val = hitHorizon ? 0.0f : maxRedshift;
+        const float c1[3] = {1.0f, 0.0f, 0.0f}, c2[3] = {1.0f, 1.0f, 0.0f}, c3[3] = {0.0f, 0.0f, 1.0f};
+        const float t1 = smoothstep_d(0.0f, 0.3f, val), t2 = smoothstep_d(0.3f, 0.7f, val),
+                    t3 = smoothstep_d(0.7f, 1.0f, val);
+        for (int c = 0; c < 3; ++c) {
+            float h = mix_d(0.0f, c1[c], t1);
+            h = mix_d(h, c2[c], t2);
+            o[c] = mix_d(h, c3[c], t3);
+        }
+        return steps;
+    }
+
+    float background[3] = {0.0f, 0.0f, 0.0f};
+    if (F & GRV_GLSL_STARS) glsl_starfield<ARITH>(U, v, background);
+
+    float photonColor = 0.0f;
+    if ((F & GRV_GLSL_PHOTON_GLOW) && !hitHorizon) { // fragment.glsl.ts:246-258
+        const float dring = fabsf(length_f3(p) - rph);
+        const float directRing = exp_d<ARITH>(-dring * 40.0f) * 1.8f * U.lensing_strength;
+        float higher = 0.0f;
+        if (photonCrossings > 0) {
+            const float sharp = 60.0f + (float)photonCrossings * 30.0f;
+            const float bright = exp_d<ARITH>(-(float)photonCrossings * 1.0f) * 1.2f;
+            higher = exp_d<ARITH>(-dring * sharp) * bright * U.lensing_strength;
+        }
+        photonColor = 1.0f * (directRing + higher);
+    }
+    float ergo[3] = {0.0f, 0.0f, 0.0f};
+    if (absA > 0.1f && !hitHorizon) { // fragment.glsl.ts:261-268
+        const float rFinal = length_f3(p);
+        const float cosTheta = p.y / fmaxf(rFinal, 0.001f);
+        const float r_ergo = M + sqrtf(fmaxf(0.0f, M * M - a * a * cosTheta * cosTheta));
+        const float g = exp_d<ARITH>(-fabsf(rFinal - r_ergo) * 20.0f) * 0.35f * absA;
+        ergo[0] = 0.3f * g;
+        ergo[1] = 0.35f * g;
+        ergo[2] = 0.9f * g;
+    }
+    if (hitHorizon) background[0] = background[1] = background[2] = 0.0f;
+    float fin[3];
+    for (int c = 0; c < 3; ++c)
+        fin[c] = background[c] * (1.0f - alpha) + col[c] + photonColor * (1.0f - alpha) + ergo[c] * (1.0f - alpha);
+
+    if (U.show_kerr_shadow > 0.5f) { // fragment.glsl.ts:279-324
+        const F3 cam_dir = normalize_f3(ro);
+        const F3 sky_right = normalize_f3(cross_f3(F3{0.0f, 1.0f, 0.0f}, cam_dir));
+        const F3 sky_up = cross_f3(cam_dir, sky_right);
+        const F3 impact = scale_f3(cross_f3(cam_dir, rd), length_f3(ro));
+        const float sa = -dot_f3(impact, sky_up), sb = dot_f3(impact, sky_right);
+        float minDist = 1e10f;
+        const int count = (int)U.shadow_count;
+        for (int j = 0; j < 63; ++j) {
+            if (j >= count - 1) break;
+            minDist = fminf(minDist, glsl_seg_dist(sa, sb, U.shadow_curve[j][0], U.shadow_curve[j][1],
+                                                   U.shadow_curve[j + 1][0], U.shadow_curve[j + 1][1]));
+        }
+        if (count > 2)
+            minDist = fminf(minDist, glsl_seg_dist(sa, sb, U.shadow_curve[count - 1][0],
+                                                   U.shadow_curve[count - 1][1], U.shadow_curve[0][0],
+                                                   U.shadow_curve[0][1]));
+        const float thickness = M * 0.045f;
+        if (minDist < thickness) {
+            const float edge = smoothstep_d(thickness, thickness * 0.5f, minDist);
+            const float green[3] = {0.0f, 1.0f, 0.0f};
+            for (int c = 0; c < 3; ++c) fin[c] = mix_d(fin[c], green[c], 1.0f * edge);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = U.tone_map ? pow_d<ARITH>(fmaxf(aces_d(fin[c]), 0.0f), 0.4545f) : fin[c];
+    return steps;
+}
+
+// one thread per pixel of this rank's tile set; a wave is one 8x8 pixel block
+template <int ARITH>
+__global__ __launch_bounds__(kBlock) void glsl_fragment_kernel(FrameGeom G, GlslParams U,
+                                                               float4 *__restrict__ out_rgba,
+                                                               uint32_t *__restrict__ out_steps,
+                                                               unsigned long long *total_steps,
+                                                               uint32_t n_slots) {
+    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t X = 0, Y = 0, oi = 0;
+    const bool valid = slot < n_slots && slot_to_pixel(G, slot, X, Y, oi);
+    uint32_t steps = 0;
+    if (valid) {
+        float o[3];
+        steps = glsl_fragment<ARITH>(U, G.width, G.height, X, Y, o);
+        if (out_rgba) out_rgba[oi] = make_float4(o[0], o[1], o[2], 1.0f);
+        if (out_steps) out_steps[oi] = steps;
+    }
+    add_steps(total_steps, steps);
+}
+
+} // namespace

@@ -3,6 +3,7 @@
 // right-hand side (kerr_device.hpp: rhs_ks_fast) and FMA contraction.
 #include "geodesic_kernels.hpp"
 #include "wgsl_fast_kernel.hpp"
+#include "glsl_fragment.hpp"
 
 namespace grvhip {
 
@@ -46,6 +47,16 @@ hipError_t launch_wgsl_symplectic_fast(const FrameGeom &G, const WgslParams &P, 
     if (n_slots == 0) return hipSuccess;
     hipLaunchKernelGGL(wgsl_symplectic_fast_kernel, dim3((n_slots + kBlock - 1) / kBlock), dim3(kBlock),
                        0, s, G, P, reinterpret_cast<float4 *>(out_rgba), out_steps, total_steps, n_slots);
+    return hipGetLastError();
+}
+
+hipError_t launch_glsl_fragment_fast(const FrameGeom &G, const GlslParams &P, float *out_rgba,
+                                     uint32_t *out_steps, unsigned long long *total_steps,
+                                     uint32_t n_slots, hipStream_t s) {
+    if (n_slots == 0) return hipSuccess;
+    hipLaunchKernelGGL((glsl_fragment_kernel<GRV_ARITH_FAST>), dim3((n_slots + kBlock - 1) / kBlock),
+                       dim3(kBlock), 0, s, G, P, reinterpret_cast<float4 *>(out_rgba), out_steps,
+                       total_steps, n_slots);
     return hipGetLastError();
 }
 

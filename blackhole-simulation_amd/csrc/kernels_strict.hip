@@ -141,7 +141,7 @@ hipError_t launch_glsl_fragment(const FrameGeom &G, const GlslParams &P, float *
                               uint32_t *out_steps, unsigned long long *total_steps,
                               uint32_t n_slots, hipStream_t s) {
     if (n_slots == 0) return hipSuccess;
-    hipLaunchKernelGGL(glsl_fragment_kernel, dim3((n_slots + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
+    hipLaunchKernelGGL((glsl_fragment_kernel<GRV_ARITH_STRICT>), dim3((n_slots + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
                        G, P, reinterpret_cast<float4 *>(out_rgba), out_steps, total_steps, n_slots);
     return hipGetLastError();
 }

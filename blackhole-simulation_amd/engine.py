@@ -76,7 +76,8 @@ class GlslParams(C.Structure):
                 ("features", C.c_uint32), ("quality", C.c_int32),
                 ("show_redshift", C.c_float), ("show_kerr_shadow", C.c_float),
                 ("debug", C.c_float), ("cam_pos", C.c_float * 3), ("cam_quat", C.c_float * 4),
-                ("shadow_count", C.c_float), ("shadow_curve", (C.c_float * 2) * 64)]
+                ("shadow_count", C.c_float), ("shadow_curve", (C.c_float * 2) * 64),
+                ("arith", C.c_int32)]
 
 
 # ShaderManager #defines as GlslParams.features bits (include/gravitas_abi.h)

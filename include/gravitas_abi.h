@@ -220,6 +220,9 @@ typedef struct { /* src/shaders/blackhole/chunks/common.ts:8-35 uniforms */
     float cam_quat[4];       /* u_camQuat xyzw */
     float shadow_count;      /* u_shadowCount */
     float shadow_curve[64][2]; /* u_shadowCurve (alpha, beta) from compute_shadow_curve */
+    int32_t arith;           /* GRV_ARITH_STRICT: the shader's operation order, IEEE divide/sqrt;
+                                GRV_ARITH_FAST: FMA + reciprocal-based divide/sqrt + polynomial
+                                sin/cos (f32 rounding differences only) */
 } GrvGlslParams;
 
 /* The shader's two 256x256 RGBA8 textures (u_noiseTex LINEAR/REPEAT, u_blueNoiseTex

@@ -138,10 +138,11 @@ def test_wgsl_kernel_matches_oracle(engine_mod, oracle, spin, max_steps, arith):
     (0.9, 0, dict(quality=0)),                                  # RAY_QUALITY_LOW indicator path
     (0.9, 1, dict(cam_pos=(0.0, 6.0, -60.0), cam_quat=(0.05, 0.0, 0.0, 0.99875))),  # SAB camera
 ])
-def test_glsl_kernel_matches_oracle(engine_mod, oracle, spin, tone, kw):
+@pytest.mark.parametrize("arith", [0, 1])  # shader operation order / FAST contract
+def test_glsl_kernel_matches_oracle(engine_mod, oracle, spin, tone, kw, arith):
     import torch
     W, H = 480, 270
-    gp = engine_mod.glsl_params(W, H, 1.0, spin, max_ray_steps=512, tone_map=tone, **kw)
+    gp = engine_mod.glsl_params(W, H, 1.0, spin, max_ray_steps=512, tone_map=tone, arith=arith, **kw)
     n = W * H
     with engine_mod.PhysicsEngine(1.0, spin) as e:
         rgba = torch.zeros(n, 4, dtype=torch.float32, device="cuda:0")

@@ -57,8 +57,13 @@ if __name__ == "__main__":
     run("C2 wgsl symplectic f32 FAST, 512 steps", 1920, 1080, wgsl(512, 1), cw)
     run("C2 glsl verlet f32 (march+disk), 512->500 steps", 1920, 1080, glsl(512, features=7, turbulence=0.75), cg)
     run("C2 glsl full default preset, 512->500 steps", 1920, 1080, glsl(512), cg)
+    run("C2 glsl verlet f32 FAST (march+disk), 512->500 steps", 1920, 1080,
+        glsl(512, features=7, turbulence=0.75, arith=1), cg)
+    run("C2 glsl full default preset FAST, 512->500 steps", 1920, 1080, glsl(512, arith=1), cg)
     run("C4 share wgsl, 8K / 8 ranks, 1024 steps", 7680, 4320, wgsl(1024), cw, reps=5, world=8)
     run("C4 share wgsl FAST, 8K / 8 ranks, 1024 steps", 7680, 4320, wgsl(1024, 1), cw, reps=5, world=8)
     run("C4 share glsl full, 8K / 8 ranks, 1024->500 steps", 7680, 4320, glsl(1024), cg, reps=5, world=8)
+    run("C4 share glsl full FAST, 8K / 8 ranks, 1024->500 steps", 7680, 4320, glsl(1024, arith=1), cg,
+        reps=5, world=8)
     run("4K wgsl, 150 steps (shader default)", 3840, 2160, wgsl(150), cw)
     run("4K wgsl FAST, 150 steps (shader default)", 3840, 2160, wgsl(150, 1), cw)
