@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N > 1: wait for each frame's gather before integrating the next frame")
     args = ap.parse_args()
 
     import torch
@@ -122,19 +124,27 @@ def main():
     # target, rank 0 additionally holds the receive slots and the assembled image
     tg = D.TileGather(params, world, rank, 4, torch.float32, torch.device("cuda", local_rank)) \
         if use_dist else None
+    overlap = tg is not None and not args.no_overlap
+    if overlap:
+        tg.enable_pipeline()  # second send buffer: frame i's gather runs under frame i+1's kernels
     buf = tg.local_view(n_local) if tg else torch.empty((n_local, 4), dtype=torch.float32, device="cuda")
 
     def dev_unpack(rparams, r, packed, image):
         eng.unpack_tiles_device(rparams, r, packed, image, 16, stream)
 
     def one_frame(i):
-        eng.render_frame_device(cam, rp, rgba=buf, stream=stream)
+        target = tg.pipelined_view(i, n_local) if overlap else buf
+        eng.render_frame_device(cam, rp, rgba=target, stream=stream)
         st = eng.frame_stats(stream)
-        if tg:
+        if overlap:
+            tg.submit(i, dev_unpack, force_collective=True)  # finish frame i-1's exchange, start frame i's
+        elif tg:
             tg.run(dev_unpack, force_collective=True)  # the one exchange: gather tiles -> rank 0
         return st
 
     def fence():
+        if overlap:
+            tg.drain(dev_unpack)  # the last frame's exchange is inside the timed region
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -147,7 +157,7 @@ def main():
     integ_ms = 0.0
     launches = 0
     for i in range(args.steps):
-        st = one_frame(i)
+        st = one_frame(args.warmup + i)
         steps_local += st.accepted_steps
         integ_ms += st.integrate_ms
         launches += st.launches
@@ -189,7 +199,9 @@ def main():
                                    "Planck LUT 512x64 Tmax=1e5 redshift shading, camera r0=60M "
                                    "theta=97deg fov=60deg" % (W, H, args.width, args.height, world),
                        "arith": args.arith, "segment_tries": args.segment_tries or "auto",
-                       "partition": "64x64 tiles round-robin, one gather to rank 0" if world > 1 else "single GPU",
+                       "partition": ("64x64 tiles round-robin, one gather to rank 0 per frame%s"
+                                     % (", overlapped with the next frame" if overlap else ""))
+                       if world > 1 else "single GPU",
                        "rays": int(total_rays), "accepted_steps_per_frame": int(total_steps / args.steps)},
             "roofline": roofline,
         }

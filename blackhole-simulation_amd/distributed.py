@@ -57,13 +57,59 @@ class TileGather:
         return self.send[:n_local]
 
     def run(self, unpack, force_collective=False):
+        """Synchronous form: gather this frame's tiles now, de-interleave on rank 0."""
+        return self._unpack(unpack, self._gather(self.send, force_collective, False), self.send)
+
+    # ---- pipelined form: the gather of frame i runs while frame i+1 is integrated ----------
+    # Two send buffers alternate; the exchange is issued asynchronously (RCCL runs it on its own
+    # stream over xGMI) and waited for only after the next frame's kernels are in the queue, so
+    # the only exposed communication is the last frame's.  The data path still holds exactly one
+    # collective per frame.
+    def enable_pipeline(self):
+        import torch
+        if getattr(self, "sends", None) is None:
+            self.sends = [self.send, torch.zeros_like(self.send)]
+            self._pending = None  # (work, send buffer, collective?)
+        return self
+
+    def pipelined_view(self, frame_index, n_local):
+        """Render target for `frame_index` (no staging copy)."""
+        return self.sends[frame_index % 2][:n_local]
+
+    def submit(self, frame_index, unpack, force_collective=False):
+        """Call after frame `frame_index` was rendered into pipelined_view(frame_index): completes
+        the previous frame's exchange (its gather overlapped this frame's integration), then
+        starts this frame's.  Returns the previous frame's image on rank 0 (None on the first
+        call and on other ranks)."""
+        img = self.drain(unpack)
+        buf = self.sends[frame_index % 2]
+        self._pending = (self._gather(buf, force_collective, True), buf)
+        return img
+
+    def drain(self, unpack):
+        """Finish the outstanding exchange, if any."""
+        if self._pending is None:
+            return None
+        (work, collective), buf = self._pending
+        self._pending = None
+        if work is not None:
+            work.wait()
+        return self._unpack(unpack, (None, collective), buf)
+
+    def _gather(self, buf, force_collective, async_op):
         import torch.distributed as dist
         collective = self.world > 1 or force_collective  # force: 1-rank dry run of the RCCL call
+        work = None
         if collective:
-            dist.gather(self.send, self.parts if self.rank == 0 else None, dst=0, group=self.group)
+            work = dist.gather(buf, self.parts if self.rank == 0 else None, dst=0, group=self.group,
+                               async_op=async_op)
+        return work, collective
+
+    def _unpack(self, unpack, gathered, buf):
+        _, collective = gathered
         if self.rank != 0:
             return None
-        parts = self.parts if collective else [self.send]
+        parts = self.parts if collective else [buf]
         for r in range(self.world):
             unpack(self.rparams[r], r, parts[r], self.image)
         return self.image

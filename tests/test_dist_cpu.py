@@ -44,6 +44,26 @@ def _worker(rank, world, port, w, h, out_path):
             np.save(out_path, img.numpy())
         else:
             assert img is None
+        # pipelined form (bench.py's default for N > 1): frame i's gather is issued
+        # asynchronously and completed when frame i+1 is submitted; three frames whose fourth
+        # channel carries the frame number must come back in order and intact
+        tg = D.TileGather(p, world, rank, 4, torch.float32, torch.device("cpu")).enable_pipeline()
+        got = []
+        for f in range(3):
+            view = tg.pipelined_view(f, packed.shape[0])
+            view.copy_(packed)
+            view[:, 3] = float(f)
+            prev = tg.submit(f, D.host_unpack)
+            if prev is not None:
+                got.append(prev.clone())
+        last = tg.drain(D.host_unpack)
+        if rank == 0:
+            got.append(last.clone())
+            assert len(got) == 3 and tg.drain(D.host_unpack) is None
+            for f, im in enumerate(got):
+                assert torch.equal(im[..., :3], img[..., :3]) and bool((im[..., 3] == float(f)).all())
+        else:
+            assert last is None and not got
         dist.barrier()
     finally:
         dist.destroy_process_group()
