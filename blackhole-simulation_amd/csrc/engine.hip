@@ -494,8 +494,8 @@ int grv_integrate_batch_device(grv_engine *e, size_t n, const double *d_states,
     GRV_HIP(e, hipMemsetAsync(e->d_stats, 0, sizeof(FrameStatsDev), s));
     GRV_HIP(e, launch_init_states(opt->metric_kind, e->ws, P, d_states, opt->initial_step,
                                   opt->method == GRV_METHOD_RKF45, s));
-    // independent rays diverge freely in a batch: compact every 64 tries
-    rc = run_segments(e, *opt, P, 64, s, false);
+    // independent rays diverge freely in a batch: compact every 64 tries unless told otherwise
+    rc = run_segments(e, *opt, P, opt->segment_tries > 0 ? (uint32_t)opt->segment_tries : 64u, s, false);
     if (rc != GRV_OK) return rc;
     GRV_HIP(e, launch_finalize_batch(e->ws, d_out_states, d_steps, d_termination, d_drift,
                                      e->d_stats, s));

@@ -31,7 +31,7 @@ class Options(C.Structure):
     _fields_ = [("method", C.c_int32), ("metric_kind", C.c_int32), ("tolerance", C.c_double),
                 ("initial_step", C.c_double), ("max_steps", C.c_uint64),
                 ("escape_radius", C.c_double), ("renormalize_interval", C.c_uint64),
-                ("step_size", C.c_double), ("arith", C.c_int32), ("reserved", C.c_int32)]
+                ("step_size", C.c_double), ("arith", C.c_int32), ("segment_tries", C.c_int32)]
 
 
 class Camera(C.Structure):

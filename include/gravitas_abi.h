@@ -68,7 +68,8 @@ typedef struct {
     uint64_t renormalize_interval; /* 0 = never (Rust would panic) */
     double step_size;
     int32_t arith;                 /* GRV_ARITH_* */
-    int32_t reserved;
+    int32_t segment_tries;         /* batch calls: integrator tries per launch before live-ray
+                                      compaction; 0 = engine default (64) */
 } GrvOptions;
 
 /* f64 mirror of the CameraUniforms fields the compute kernel reads
