@@ -157,6 +157,7 @@ hipError_t launch_spectrum_lut(float *out, uint32_t width, uint32_t height, doub
 
 namespace {
 inline dim3 post_grid(uint32_t w, uint32_t h) { return dim3((w + 255u) / 256u, h); }
+inline dim3 tile_grid(uint32_t w, uint32_t h) { return dim3((w + kTileW - 1) / kTileW, (h + kTileH - 1) / kTileH); }
 inline uint32_t at_least_1(uint32_t x) { return x ? x : 1u; }
 } // namespace
 
@@ -164,7 +165,7 @@ hipError_t launch_taa_resolve(uint32_t w, uint32_t h, const float *current, cons
                               float blend_factor, int camera_moving, int half_storage, float *out,
                               hipStream_t s) {
     if (w == 0 || h == 0) return hipSuccess;
-    hipLaunchKernelGGL(taa_resolve_kernel, post_grid(w, h), dim3(256), 0, s, w, h,
+    hipLaunchKernelGGL(taa_resolve_kernel, tile_grid(w, h), dim3(kTileW, kTileH), 0, s, w, h,
                        reinterpret_cast<const float4 *>(current), reinterpret_cast<const float4 *>(history),
                        blend_factor, camera_moving, half_storage, reinterpret_cast<float4 *>(out));
     return hipGetLastError();
@@ -176,7 +177,7 @@ hipError_t launch_ataa_resolve(uint32_t w, uint32_t h, const AtaaCameraHost &cam
     AtaaCamera c;
     static_assert(sizeof(AtaaCamera) == sizeof(AtaaCameraHost), "camera blocks must match");
     std::memcpy(&c, &cam, sizeof c);
-    hipLaunchKernelGGL(ataa_resolve_kernel, post_grid(w, h), dim3(256), 0, s, w, h, c,
+    hipLaunchKernelGGL(ataa_resolve_kernel, tile_grid(w, h), dim3(kTileW, kTileH), 0, s, w, h, c,
                        reinterpret_cast<const float4 *>(current), reinterpret_cast<const float4 *>(history),
                        half_storage, reinterpret_cast<float4 *>(out));
     return hipGetLastError();

@@ -7,8 +7,9 @@
 //                        src/rendering/bloom.ts:443-583
 // Images are RGBA f32 (float4), row-major, resident in HBM.  All five kernels are
 // HBM-streaming stencils: one thread per output pixel, a wave covers a 64x1 row segment so
-// every fetch of a row is one coalesced 1 KiB transaction; the 3x3 / 9-tap neighbourhoods
-// re-read lines that are still in L2 (4 MiB per XCD holds ~60 rows of a 4K frame).
+// every fetch of a row is one coalesced 1 KiB transaction.  The TAA resolve stages the current
+// frame's 64x4 tile plus a 2-texel halo in LDS once (2.1 global fetches per pixel instead of
+// 44): its eleven bilinear taps then read LDS (0.26 -> 0.19 ms at 4K).
 // Texture fetches: GL LINEAR + CLAMP_TO_EDGE with f32 weights.  Render targets are RGBA16F
 // upstream: with half_storage every stored channel is rounded through binary16 (RNE).
 #pragma once
@@ -38,6 +39,53 @@ __device__ __forceinline__ float4 post_sample(const float4 *__restrict__ tex, ui
     const int j0 = post_clampi((int)fy, 0, (int)h - 1), j1 = post_clampi((int)fy + 1, 0, (int)h - 1);
     const float4 t00 = tex[(size_t)j0 * w + i0], t10 = tex[(size_t)j0 * w + i1];
     const float4 t01 = tex[(size_t)j1 * w + i0], t11 = tex[(size_t)j1 * w + i1];
+    const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    return make_float4(w00 * t00.x + w10 * t10.x + w01 * t01.x + w11 * t11.x,
+                       w00 * t00.y + w10 * t10.y + w01 * t01.y + w11 * t11.y,
+                       w00 * t00.z + w10 * t10.z + w01 * t01.z + w11 * t11.z,
+                       w00 * t00.w + w10 * t10.w + w01 * t01.w + w11 * t11.w);
+}
+
+// ---- LDS-staged tile of the current frame: 64x4 pixels + halo -------------------------------
+constexpr int kTileW = 64, kTileH = 4;
+template <int HALO> struct PostTile {
+    static constexpr int W = kTileW + 2 * HALO, H = kTileH + 2 * HALO;
+    float4 t[H][W]; // t[0][0] is image texel (blockIdx.x * 64 - HALO, blockIdx.y * 4 - HALO)
+};
+// fill with edge-clamped texels (CLAMP_TO_EDGE is applied when the tile is read back by
+// clamped image coordinates, so the halo only has to exist where the image does)
+template <int HALO>
+__device__ __forceinline__ void post_tile_load(PostTile<HALO> &T, const float4 *__restrict__ img,
+                                               uint32_t w, uint32_t h) {
+    const int tid = threadIdx.y * kTileW + threadIdx.x;
+    const int bx0 = (int)(blockIdx.x * kTileW) - HALO, by0 = (int)(blockIdx.y * kTileH) - HALO;
+    for (int k = tid; k < PostTile<HALO>::W * PostTile<HALO>::H; k += kTileW * kTileH) {
+        const int ly = k / PostTile<HALO>::W, lx = k % PostTile<HALO>::W;
+        const int gx = post_clampi(bx0 + lx, 0, (int)w - 1), gy = post_clampi(by0 + ly, 0, (int)h - 1);
+        T.t[ly][lx] = img[(size_t)gy * w + gx];
+    }
+    __syncthreads();
+}
+// texel (i, j) of the image (already clamped to the image) through the tile.  A tap at an offset
+// of at most HALO - 1 texels touches texels within HALO of the pixel (bilinear footprint), and
+// clamping to the image only moves a coordinate towards the pixel: always inside the window.
+template <int HALO>
+__device__ __forceinline__ float4 post_tile_texel(const PostTile<HALO> &T, const float4 *__restrict__,
+                                                  uint32_t, int i, int j) {
+    const int lx = i - ((int)(blockIdx.x * kTileW) - HALO), ly = j - ((int)(blockIdx.y * kTileH) - HALO);
+    return T.t[ly][lx];
+}
+// texture(tex, uv) LINEAR + CLAMP_TO_EDGE, texels through the tile: same arithmetic as post_sample
+template <int HALO>
+__device__ __forceinline__ float4 post_sample_tile(const PostTile<HALO> &T, const float4 *__restrict__ tex,
+                                                   uint32_t w, uint32_t h, float u, float v) {
+    const float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+    const float fx = floorf(x), fy = floorf(y);
+    const float a = x - fx, b = y - fy;
+    const int i0 = post_clampi((int)fx, 0, (int)w - 1), i1 = post_clampi((int)fx + 1, 0, (int)w - 1);
+    const int j0 = post_clampi((int)fy, 0, (int)h - 1), j1 = post_clampi((int)fy + 1, 0, (int)h - 1);
+    const float4 t00 = post_tile_texel(T, tex, w, i0, j0), t10 = post_tile_texel(T, tex, w, i1, j0);
+    const float4 t01 = post_tile_texel(T, tex, w, i0, j1), t11 = post_tile_texel(T, tex, w, i1, j1);
     const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
     return make_float4(w00 * t00.x + w10 * t10.x + w01 * t01.x + w11 * t11.x,
                        w00 * t00.y + w10 * t10.y + w01 * t01.y + w11 * t11.y,
@@ -88,15 +136,19 @@ __global__ __launch_bounds__(256) void taa_resolve_kernel(uint32_t w, uint32_t h
                                                           const float4 *__restrict__ history,
                                                           float blend_factor, int camera_moving,
                                                           int half_storage, float4 *__restrict__ out) {
-    uint32_t px, py;
-    if (!post_pixel(w, h, px, py)) return;
+    __shared__ PostTile<2> tile; // taps at +-1 texel may round one texel further out
+    post_tile_load(tile, current, w, h);
+    const uint32_t px = blockIdx.x * kTileW + threadIdx.x, py = blockIdx.y * kTileH + threadIdx.y;
+    if (px >= w || py >= h) return;
     const float tx = 1.0f / (float)w, ty = 1.0f / (float)h;
     const float u = ((float)px + 0.5f) / (float)w, v = ((float)py + 0.5f) / (float)h;
-    const float4 cur = post_sample(current, w, h, u, v);
+    const float4 cur = post_sample_tile(tile, current, w, h, u, v);
     Moments M{{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+#pragma unroll
     for (int y = -1; y <= 1; ++y)
+#pragma unroll
         for (int x = -1; x <= 1; ++x) {
-            const float4 s = post_sample(current, w, h, u + (float)x * tx, v + (float)y * ty);
+            const float4 s = post_sample_tile(tile, current, w, h, u + (float)x * tx, v + (float)y * ty);
             M.add(to_ycocg(s.x, s.y, s.z));
         }
     float mean[3], sd[3];
@@ -126,13 +178,16 @@ __global__ __launch_bounds__(256) void ataa_resolve_kernel(uint32_t w, uint32_t 
                                                            const float4 *__restrict__ current,
                                                            const float4 *__restrict__ history,
                                                            int half_storage, float4 *__restrict__ out) {
-    uint32_t px, py;
-    if (!post_pixel(w, h, px, py)) return;
+    // nine integer texel loads per pixel: rows stay in L1/L2, an LDS stage measured slower here
+    const uint32_t px = blockIdx.x * kTileW + threadIdx.x, py = blockIdx.y * kTileH + threadIdx.y;
+    if (px >= w || py >= h) return;
     const float u = ((float)px + 0.5f) / (float)w, v = ((float)py + 0.5f) / (float)h;
     const float4 c4 = current[(size_t)py * w + px];
     const YCC center = to_ycocg(c4.x, c4.y, c4.z);
     Moments M{{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+#pragma unroll
     for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
         for (int dx = -1; dx <= 1; ++dx) {
             const int sx = post_clampi((int)px + dx, 0, (int)w - 1), sy = post_clampi((int)py + dy, 0, (int)h - 1);
             const float4 s = current[(size_t)sy * w + sx];
