@@ -41,7 +41,7 @@ struct RayRegs {
                       // the post-step bookkeeping and reused as stage 1 of the next try
 };
 
-template <int KIND, int ARITH> constexpr bool kGeomCache = (KIND == GRV_METRIC_KERR_KS && ARITH == GRV_ARITH_FAST);
+template <int KIND, int ARITH> constexpr bool kStage1Cache = (KIND == GRV_METRIC_KERR_KS && ARITH == GRV_ARITH_FAST);
 
 __device__ __forceinline__ double clamp_rs(double x, double lo, double hi) {
     // Rust f64::clamp
@@ -60,7 +60,7 @@ __device__ __forceinline__ double rkf45_try(const Hole<double> &bh, const RayReg
     // right-hand side at a stage point; the FAST Kerr-Schild form takes the per-ray
     // constant products (rc) instead of recomputing them six times a try
     auto f = [&](double r_, double th_, double pr_, double pth_) {
-        if constexpr (kGeomCache<KIND, ARITH>)
+        if constexpr (kStage1Cache<KIND, ARITH>)
             return rhs_ks_geom(bh, ks_geom(bh, r_, th_), r_, rc, pr_, pth_);
         else
             return rhs<KIND, ARITH>(bh, r_, th_, y.pt, pr_, pth_, y.pph);
@@ -106,7 +106,7 @@ __device__ __forceinline__ double rkf45_try(const Hole<double> &bh, const RayReg
                      e4 = 28561.0 / 56430.0 - 2197.0 / 4104.0, e5 = -9.0 / 50.0 + 1.0 / 5.0;
 
     Deriv<double> k1;
-    if constexpr (kGeomCache<KIND, ARITH>)
+    if constexpr (kStage1Cache<KIND, ARITH>)
         k1 = y.k1;
     else
         k1 = rhs<KIND, ARITH>(bh, y.r, y.th, y.pt, y.pr, y.pth, y.pph);
@@ -264,7 +264,7 @@ __device__ __forceinline__ void after_step(const Hole<double> &bh, RayRegs &y, d
                                            const KsRayConsts &rc) {
     const bool renorm = P.renorm_interval != 0 && y.phase == 0u; // steps % interval == 0
     double hv;
-    if constexpr (kGeomCache<KIND, ARITH>) {
+    if constexpr (kStage1Cache<KIND, ARITH>) {
         // one geometry evaluation serves the projection, H and stage 1 of the next try
         const KsGeom geom = ks_geom(bh, y.r, y.th);
         if (renorm)
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(kBlock) void integrate_segment_kernel(
     bool live = have && ray_live(y);
     y.phase = P.renorm_interval ? y.steps % P.renorm_interval : 1u;
     const KsRayConsts rc = ks_ray_consts(bh, y.pt, y.pph); // p_t, p_phi never change
-    if constexpr (kGeomCache<KIND, ARITH>) {
+    if constexpr (kStage1Cache<KIND, ARITH>) {
         // state came from HBM: rebuild the stage-1 cache
         if (live) y.k1 = rhs_ks_geom(bh, ks_geom(bh, y.r, y.th), y.r, rc, y.pr, y.pth);
     }
