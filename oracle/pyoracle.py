@@ -88,13 +88,10 @@ class GlslParams(C.Structure):
 
 
 def build(force=False):
-    """Compile the oracle with its Makefile (gcc)."""
-    if force or not os.path.exists(_LIB_PATH) or any(
-            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-            for f in ("gravitas_oracle.c", "gravitas_oracle.h", "frame_oracle.c",
-                      "frame_oracle.h", "control_oracle.c", "control_oracle.h", "shader_oracle.c",
-                      "shader_oracle.h", "Makefile")):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    """Compile the oracle with its Makefile (gcc); make decides what is stale."""
+    if force:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "clean"])
+    subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _LIB_PATH
 
 

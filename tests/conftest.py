@@ -40,4 +40,8 @@ def oracle():
 @pytest.fixture(scope="session")
 def engine_mod():
     import blackhole_simulation_amd as bh
+    if not os.path.exists(bh.library_path()):
+        # a checkout without the built artefact (they are git-ignored): compile it with hipcc --
+        # the tests never fall back to anything else
+        bh.build_library()
     return bh

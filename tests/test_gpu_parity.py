@@ -26,9 +26,8 @@ def rel_err(a, b):
 
 
 @pytest.fixture(scope="module")
-def bh():
-    import blackhole_simulation_amd as m
-    return m
+def bh(engine_mod):
+    return engine_mod
 
 
 @pytest.fixture(scope="module")
