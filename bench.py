@@ -99,6 +99,12 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    if not os.path.exists(bh.library_path()):
+        if local_rank == 0:
+            bh.build_library()  # checkout without the built artefact: compile it (hipcc)
+        else:
+            while not os.path.exists(bh.library_path()):
+                time.sleep(1.0)
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or "RANK" in os.environ  # under torchrun even a 1-rank job walks the RCCL path
     if use_dist:
