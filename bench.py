@@ -29,12 +29,39 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 B_STEP, B_RAY = 144, 96  # algorithmic bytes: SURVEY.md 8(d) / DESIGN.md
 
 
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota
+    (a container on a 256-thread node is often limited to far fewer)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2: "<quota|max> <period>"
+            q, per = f.read().split()
+            if q != "max":
+                quota = int(q) / int(per)
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, \
+                    open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:  # cgroup v1
+                q, per = int(f.read()), int(g.read())
+                if q > 0:
+                    quota = q / per
+        except Exception:
+            pass
+    if quota:
+        n = min(n, max(1, int(quota)))
+    return max(1, n)
+
+
 def cpu_baseline(width, height, eye, target_seconds=15.0):
     """The oracle (C restatement of gravitas-core) timed on the host cores on a bounded,
     pixel-strided sample of the same workload.  Checker/baseline only."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     cam = po.camera_look_at(eye, aspect=width / height)
     fp = po.frame_params(width, height, spin=0.999)
     lut = po.blackbody_lut(fp.lut_width, fp.lut_height, fp.lut_max_temp)
