@@ -119,6 +119,13 @@ struct grv_engine {
     hipEvent_t ev[8] = {};
     bool ev_ok = false;
 
+    // renderer layer (grv_webgpu_render / grv_webgl_render): full-size RGBA f32 targets
+    struct Targets {
+        float *mem = nullptr; // [3][h][w][4]: scene / compute texture, history ping, history pong
+        uint32_t w = 0, h = 0;
+        uint32_t hist = 0;   // webgpu: currentHistoryIndex; webgl: currentWriteIndex
+        uint32_t frames = 0; // frameCount
+    } rt;
     void *post_mem = nullptr; // bloom render targets (bright, blur ping/pong)
     size_t post_bytes = 0;
     uint8_t *d_noise = nullptr; // [2][256*256] R planes: u_noiseTex, u_blueNoiseTex
@@ -436,6 +443,7 @@ void grv_engine_destroy(grv_engine *e) {
     if (e->d_lut) (void)hipFree(e->d_lut);
     if (e->d_noise) (void)hipFree(e->d_noise);
     if (e->post_mem) (void)hipFree(e->post_mem);
+    if (e->rt.mem) (void)hipFree(e->rt.mem);
     if (e->d_counters) (void)hipFree(e->d_counters);
     if (e->d_stats) (void)hipFree(e->d_stats);
     if (e->h_counters) (void)hipHostFree(e->h_counters);
@@ -942,6 +950,7 @@ int grv_post_bloom(grv_engine *e, const GrvBloomParams *p, const float *d_scene,
     const size_t need = bloom_scratch_floats(p->width, p->height) * sizeof(float);
     if (need > e->post_bytes) {
         if (e->post_mem) (void)hipFree(e->post_mem);
+    if (e->rt.mem) (void)hipFree(e->rt.mem);
         e->post_mem = nullptr;
         e->post_bytes = 0;
         GRV_HIP(e, hipMalloc(&e->post_mem, need));
@@ -950,6 +959,166 @@ int grv_post_bloom(grv_engine *e, const GrvBloomParams *p, const float *d_scene,
     GRV_HIP(e, launch_bloom(p->width, p->height, d_scene, p->threshold, p->intensity, p->blur_passes,
                             p->half_storage, static_cast<float *>(e->post_mem), d_out,
                             static_cast<hipStream_t>(stream)));
+    return GRV_OK;
+}
+
+// ---- renderer layer ----
+namespace {
+int ensure_targets(grv_engine *e, uint32_t w, uint32_t h, hipStream_t s) {
+    if (e->rt.mem && e->rt.w == w && e->rt.h == h) return GRV_OK;
+    if (e->rt.mem) (void)hipFree(e->rt.mem);
+    e->rt = grv_engine::Targets{};
+    const size_t bytes = (size_t)3 * w * h * 4 * sizeof(float);
+    GRV_HIP(e, hipMalloc(reinterpret_cast<void **>(&e->rt.mem), bytes));
+    GRV_HIP(e, hipMemsetAsync(e->rt.mem, 0, bytes, s)); // textures start zeroed
+    e->rt.w = w;
+    e->rt.h = h;
+    return GRV_OK;
+}
+int ensure_bloom_scratch(grv_engine *e, uint32_t w, uint32_t h, hipStream_t s) {
+    const size_t need = bloom_scratch_floats(w, h) * sizeof(float);
+    if (need <= e->post_bytes) return GRV_OK;
+    if (e->post_mem) (void)hipFree(e->post_mem);
+    e->post_mem = nullptr;
+    e->post_bytes = 0;
+    GRV_HIP(e, hipMalloc(&e->post_mem, need));
+    GRV_HIP(e, hipMemsetAsync(e->post_mem, 0, need, s));
+    e->post_bytes = need;
+    return GRV_OK;
+}
+// halton(index, base), compute.wgsl.ts:134-145, in f32
+float halton_f32(uint32_t index, uint32_t base) {
+    float result = 0.0f, f = 1.0f / (float)base;
+    for (uint32_t i = index; i > 0u; i /= base) {
+        result += f * (float)(i % base);
+        f = f / (float)base;
+    }
+    return result;
+}
+} // namespace
+
+void grv_renderer_reset(grv_engine *e) {
+    if (!e) return;
+    if (e->rt.mem) (void)hipFree(e->rt.mem);
+    e->rt = grv_engine::Targets{};
+}
+uint32_t grv_renderer_frame_count(const grv_engine *e) { return e ? e->rt.frames : 0u; }
+
+int grv_webgpu_render(grv_engine *e, const float *cu, const float *pp, int32_t max_steps, int32_t arith,
+                      float *d_screen, void *stream) {
+    if (!e) return GRV_ERR_INVALID;
+    if (!cu || !pp || !d_screen) return fail(e, GRV_ERR_INVALID, "null argument");
+    const uint32_t w = (uint32_t)pp[2], h = (uint32_t)pp[3]; // u32(physics.resolution), compute.wgsl.ts:149-150
+    if (w == 0 || h == 0 || (uint64_t)w * h > (1ull << 27)) return fail(e, GRV_ERR_INVALID, "bad resolution");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    GRV_HIP(e, hipSetDevice(e->device));
+    int rc = ensure_targets(e, w, h, s);
+    if (rc != GRV_OK) return rc;
+    const size_t plane = (size_t)w * h * 4;
+    float *compute_tex = e->rt.mem, *hist[2] = {e->rt.mem + plane, e->rt.mem + 2 * plane};
+    // Pass 1: main ray march.  CameraUniforms floats: inv_view 32..47, inv_proj 48..63,
+    // prev_view_proj 64..79, position 80..82 (types/webgpu.ts:95-116)
+    GrvWgslParams wp;
+    std::memset(&wp, 0, sizeof wp);
+    wp.width = w;
+    wp.height = h;
+    std::memcpy(wp.inv_view, cu + 32, sizeof wp.inv_view);
+    std::memcpy(wp.inv_proj, cu + 48, sizeof wp.inv_proj);
+    std::memcpy(wp.position, cu + 80, sizeof wp.position);
+    wp.mass = pp[0];
+    wp.spin = pp[1];
+    const uint32_t fi = e->rt.frames; // paramsWithFrame.frameIndex = this.frameCount
+    wp.jitter[0] = halton_f32((fi % 8u) + 1u, 2u) - 0.5f;
+    wp.jitter[1] = halton_f32((fi % 8u) + 1u, 3u) - 0.5f;
+    wp.max_steps = max_steps > 0 ? max_steps : 150;
+    wp.tile_world = 1;
+    wp.arith = arith;
+    rc = grv_render_frame_wgsl(e, &wp, compute_tex, nullptr, nullptr, stream);
+    if (rc != GRV_OK) return rc;
+    GRV_HIP(e, launch_post_quantize(compute_tex, w * h, s)); // texture_storage_2d<rgba16float>
+    // Pass 2: ATAA resolve, history ping-pong (renderer.ts:319-345, 385-395)
+    const uint32_t hi = e->rt.hist, nx = 1u - hi;
+    AtaaCameraHost cam;
+    std::memcpy(cam.inv_view, cu + 32, sizeof cam.inv_view);
+    std::memcpy(cam.inv_proj, cu + 48, sizeof cam.inv_proj);
+    std::memcpy(cam.prev_view_proj, cu + 64, sizeof cam.prev_view_proj);
+    std::memcpy(cam.position, cu + 80, sizeof cam.position);
+    GRV_HIP(e, launch_ataa_resolve(w, h, cam, compute_tex, hist[hi], 1, hist[nx], s));
+    // Pass 3: blit with Reinhard (renderer.ts:14-50, 397-411)
+    GRV_HIP(e, launch_blit_reinhard(w, h, hist[nx], d_screen, s));
+    e->rt.hist = nx;
+    e->rt.frames++;
+    return GRV_OK;
+}
+
+int grv_webgl_render(grv_engine *e, const GrvGlslParams *p, int32_t bloom_enabled, int32_t camera_moving,
+                     float *d_screen, void *stream) {
+    if (!e) return GRV_ERR_INVALID;
+    if (!p || !d_screen) return fail(e, GRV_ERR_INVALID, "null argument");
+    const uint32_t w = p->width, h = p->height;
+    if (w == 0 || h == 0 || (uint64_t)w * h > (1ull << 27)) return fail(e, GRV_ERR_INVALID, "bad resolution");
+    if (p->tile_world > 1) return fail(e, GRV_ERR_INVALID, "the renderer layer draws whole frames");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    GRV_HIP(e, hipSetDevice(e->device));
+    int rc = ensure_targets(e, w, h, s);
+    if (rc != GRV_OK) return rc;
+    rc = ensure_bloom_scratch(e, w, h, s);
+    if (rc != GRV_OK) return rc;
+    const size_t plane = (size_t)w * h * 4;
+    float *scene = e->rt.mem, *ping = e->rt.mem + plane, *pong = e->rt.mem + 2 * plane;
+    // scene pass into the RGBA16F scene target, linear output (manager.ts:84-86)
+    GrvGlslParams gp = *p;
+    gp.tone_map = 0;
+    rc = grv_render_frame_glsl(e, &gp, scene, nullptr, nullptr, stream);
+    if (rc != GRV_OK) return rc;
+    GRV_HIP(e, launch_post_quantize(scene, w * h, s));
+    // ReprojectionManager.resolve: write index 0 -> write pong, read ping (reprojection.ts:209-216)
+    float *write_tex = e->rt.hist == 0 ? pong : ping;
+    const float *read_tex = e->rt.hist == 0 ? ping : pong;
+    GRV_HIP(e, launch_taa_resolve(w, h, scene, read_tex, 0.75f, camera_moving, 1, write_tex, s));
+    e->rt.hist = 1u - e->rt.hist;
+    // bloom (features.bloom) or plain presentation: both are the combine pass (bloom.ts:443-632)
+    float *scratch = static_cast<float *>(e->post_mem);
+    if (bloom_enabled) {
+        GRV_HIP(e, launch_bloom(w, h, write_tex, 0.8f, 0.5f, 2, 1, scratch, d_screen, s));
+    } else {
+        // drawTextureToScreen: combine with intensity 0; the bloom input is a stale dummy upstream,
+        // here the (zero or last) bright-pass target, multiplied by 0 either way
+        GRV_HIP(e, launch_bloom(w, h, write_tex, 3.0e38f, 0.0f, 0, 1, scratch, d_screen, s));
+    }
+    e->rt.frames++;
+    return GRV_OK;
+}
+
+int grv_webgpu_render_host(grv_engine *e, const float *cu, const float *pp, int32_t max_steps,
+                           int32_t arith, float *screen) {
+    if (!e) return GRV_ERR_INVALID;
+    if (!cu || !pp || !screen) return fail(e, GRV_ERR_INVALID, "null argument");
+    const size_t bytes = (size_t)(uint32_t)pp[2] * (uint32_t)pp[3] * 4 * sizeof(float);
+    if (bytes == 0 || bytes > ((size_t)1 << 31)) return fail(e, GRV_ERR_INVALID, "bad resolution");
+    GRV_HIP(e, hipSetDevice(e->device));
+    int rc = ensure_stage(e, bytes);
+    if (rc != GRV_OK) return rc;
+    rc = grv_webgpu_render(e, cu, pp, max_steps, arith, static_cast<float *>(e->stage_mem), nullptr);
+    if (rc != GRV_OK) return rc;
+    GRV_HIP(e, hipDeviceSynchronize());
+    GRV_HIP(e, hipMemcpy(screen, e->stage_mem, bytes, hipMemcpyDeviceToHost));
+    return GRV_OK;
+}
+
+int grv_webgl_render_host(grv_engine *e, const GrvGlslParams *p, int32_t bloom_enabled,
+                          int32_t camera_moving, float *screen) {
+    if (!e) return GRV_ERR_INVALID;
+    if (!p || !screen) return fail(e, GRV_ERR_INVALID, "null argument");
+    const size_t bytes = (size_t)p->width * p->height * 4 * sizeof(float);
+    if (bytes == 0 || bytes > ((size_t)1 << 31)) return fail(e, GRV_ERR_INVALID, "bad resolution");
+    GRV_HIP(e, hipSetDevice(e->device));
+    int rc = ensure_stage(e, bytes);
+    if (rc != GRV_OK) return rc;
+    rc = grv_webgl_render(e, p, bloom_enabled, camera_moving, static_cast<float *>(e->stage_mem), nullptr);
+    if (rc != GRV_OK) return rc;
+    GRV_HIP(e, hipDeviceSynchronize());
+    GRV_HIP(e, hipMemcpy(screen, e->stage_mem, bytes, hipMemcpyDeviceToHost));
     return GRV_OK;
 }
 

@@ -140,6 +140,8 @@ hipError_t launch_ataa_resolve(uint32_t w, uint32_t h, const AtaaCameraHost &cam
 hipError_t launch_bloom(uint32_t w, uint32_t h, const float *scene, float threshold, float intensity,
                         int blur_passes, int half_storage, float *scratch, float *out, hipStream_t s);
 size_t bloom_scratch_floats(uint32_t w, uint32_t h);
+hipError_t launch_post_quantize(float *img, uint32_t n_px, hipStream_t s);
+hipError_t launch_blit_reinhard(uint32_t w, uint32_t h, const float *src, float *dst, hipStream_t s);
 // ---- launcher (kernels_fast.hip: -ffp-contract=fast) ----
 hipError_t launch_glsl_fragment_fast(const FrameGeom &G, const GlslParams &P, float *out_rgba,
                                      uint32_t *out_steps, unsigned long long *total_steps,

@@ -217,4 +217,18 @@ hipError_t launch_bloom(uint32_t w, uint32_t h, const float *scene, float thresh
     return hipGetLastError();
 }
 
+hipError_t launch_post_quantize(float *img, uint32_t n_px, hipStream_t s) {
+    if (n_px == 0) return hipSuccess;
+    hipLaunchKernelGGL(post_quantize_kernel, dim3((n_px + 255u) / 256u), dim3(256), 0, s,
+                       reinterpret_cast<float4 *>(img), n_px);
+    return hipGetLastError();
+}
+
+hipError_t launch_blit_reinhard(uint32_t w, uint32_t h, const float *src, float *dst, hipStream_t s) {
+    if (w == 0 || h == 0) return hipSuccess;
+    hipLaunchKernelGGL(blit_reinhard_kernel, post_grid(w, h), dim3(256), 0, s, w, h,
+                       reinterpret_cast<const float4 *>(src), reinterpret_cast<float4 *>(dst));
+    return hipGetLastError();
+}
+
 } // namespace grvhip

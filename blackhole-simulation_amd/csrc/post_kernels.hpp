@@ -280,4 +280,24 @@ __global__ __launch_bounds__(256) void bloom_combine_kernel(uint32_t w, uint32_t
                                            powf(post_aces(s.z + b.z * intensity), 0.4545f), 1.0f);
 }
 
+// A compute / fragment pass that writes an RGBA16F target: round the stored channels in place
+// (the march kernels keep f32 outputs; the renderer layer applies the storage format).
+__global__ __launch_bounds__(256) void post_quantize_kernel(float4 *__restrict__ img, uint32_t n_px) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_px) return;
+    const float4 c = img[k];
+    img[k] = make_float4(post_store(c.x, 1), post_store(c.y, 1), post_store(c.z, 1), post_store(c.w, 1));
+}
+
+// blit pass of the WebGPU renderer (src/rendering/webgpu/renderer.ts:14-50): the resolved
+// history sampled at the pixel centre, Reinhard c / (c + 1), alpha passed through
+__global__ __launch_bounds__(256) void blit_reinhard_kernel(uint32_t w, uint32_t h,
+                                                            const float4 *__restrict__ src,
+                                                            float4 *__restrict__ dst) {
+    uint32_t px, py;
+    if (!post_pixel(w, h, px, py)) return;
+    const float4 c = post_sample(src, w, h, ((float)px + 0.5f) / (float)w, ((float)py + 0.5f) / (float)h);
+    dst[(size_t)py * w + px] = make_float4(c.x / (c.x + 1.0f), c.y / (c.y + 1.0f), c.z / (c.z + 1.0f), c.w);
+}
+
 } // namespace

@@ -202,6 +202,13 @@ def load_library():
     L.grv_bloom_params_default.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(BloomParams)]
     L.grv_post_bloom.restype = i
     L.grv_post_bloom.argtypes = [p, C.POINTER(BloomParams), p, p, p]
+    L.grv_webgpu_render.restype = i
+    L.grv_webgpu_render.argtypes = [p, p, p, C.c_int32, C.c_int32, p, p]
+    L.grv_webgl_render.restype = i
+    L.grv_webgl_render.argtypes = [p, C.POINTER(GlslParams), C.c_int32, C.c_int32, p, p]
+    L.grv_renderer_reset.argtypes = [p]
+    L.grv_renderer_frame_count.restype = C.c_uint32
+    L.grv_renderer_frame_count.argtypes = [p]
     L.grv_seeded_noise_rgba8.argtypes = [C.c_uint32, C.c_uint32, p]
     L.grv_set_glsl_noise.restype = i
     L.grv_set_glsl_noise.argtypes = [p, p, p]
@@ -462,6 +469,28 @@ class PhysicsEngine:
                 raise ValueError("textures are 256x256 RGBA8")
         self._check(self._lib.grv_set_glsl_noise(self._h, _np_ptr(noise_rgba8), _np_ptr(blue_rgba8)),
                     "set_glsl_noise")
+
+    # ---- renderer layer: WebGPURenderer.render / WebGLRenderer.render ----
+    def webgpu_render(self, camera_uniforms, physics_params, screen, max_steps=150, arith=ARITH_STRICT,
+                      stream=None):
+        """camera_uniforms: float32[88] (352-byte CameraUniforms), physics_params: float32[8]
+        (32-byte PhysicsParams, frame_index as u32 bits); screen: device RGBA f32 [h, w, 4]."""
+        cu = np.ascontiguousarray(camera_uniforms, np.float32)
+        pp = np.ascontiguousarray(physics_params, np.float32)
+        assert cu.size == 88 and pp.size == 8
+        self._check(self._lib.grv_webgpu_render(self._h, _np_ptr(cu), _np_ptr(pp), int(max_steps),
+                                                int(arith), _dev_ptr(screen), stream), "webgpu_render")
+
+    def webgl_render(self, params, screen, bloom=True, camera_moving=False, stream=None):
+        self._check(self._lib.grv_webgl_render(self._h, C.byref(params), 1 if bloom else 0,
+                                               1 if camera_moving else 0, _dev_ptr(screen), stream),
+                    "webgl_render")
+
+    def renderer_reset(self):
+        self._lib.grv_renderer_reset(self._h)
+
+    def renderer_frame_count(self):
+        return int(self._lib.grv_renderer_frame_count(self._h))
 
     # ---- post chain (reprojection.ts / ataa.wgsl.ts / bloom.ts): device RGBA f32 images ----
     def post_taa_resolve(self, width, height, current, history, out, blend_factor=0.75,

@@ -281,6 +281,34 @@ void grv_bloom_params_default(uint32_t width, uint32_t height, GrvBloomParams *p
 int grv_post_bloom(grv_engine *e, const GrvBloomParams *p, const float *d_scene, float *d_out,
                    void *stream);
 
+/* ---- the reference's two renderers: the callers of the path ----
+ * Frame-to-frame state (history ping-pong, frame counter) lives in the engine, as it lives in
+ * the renderer objects upstream.  Output: device RGBA f32 [height][width][4], the image the
+ * renderer presents (8-bit swap-chain quantisation is not applied). */
+/* WebGPURenderer.render (src/rendering/webgpu/renderer.ts:280-411): compute march with the
+ * Halton jitter of its own frame counter (compute.wgsl.ts:134-157) -> rgba16float compute
+ * texture -> ATAA resolve against the history ping-pong -> Reinhard blit.
+ * camera_uniforms: the 352-byte CameraUniforms block, physics_params: the 32-byte PhysicsParams
+ * block exactly as writeCameraUniforms / writePhysicsParams fill them (src/types/webgpu.ts:67-116;
+ * frame_index in the block is overridden by the renderer's counter, renderer.ts:303).
+ * max_steps: the pipeline's MAX_STEPS override constant (renderer.ts:188, default 150). */
+int grv_webgpu_render(grv_engine *e, const float camera_uniforms[88], const float physics_params[8],
+                      int32_t max_steps, int32_t arith, float *d_screen, void *stream);
+/* WebGLRenderer.render (src/rendering/webgl/renderer.ts:173-422): fragment shader with
+ * ENABLE_LINEAR_OUTPUT into the RGBA16F scene target -> ReprojectionManager.resolve(scene, 0.75,
+ * cameraMoving) -> BloomManager.applyBloomToTexture (features.bloom) or drawTextureToScreen; both
+ * end in ACES + gamma (bloom.glsl.ts:117-123).  p->tone_map is ignored (the post chain owns it). */
+int grv_webgl_render(grv_engine *e, const GrvGlslParams *p, int32_t bloom_enabled,
+                     int32_t camera_moving, float *d_screen, void *stream);
+/* same, presenting into host memory (one PCIe copy of the final image; N-API / ctypes hosts) */
+int grv_webgpu_render_host(grv_engine *e, const float camera_uniforms[88], const float physics_params[8],
+                           int32_t max_steps, int32_t arith, float *screen);
+int grv_webgl_render_host(grv_engine *e, const GrvGlslParams *p, int32_t bloom_enabled,
+                          int32_t camera_moving, float *screen);
+/* drop the history textures and frame counters (renderer resize / re-creation) */
+void grv_renderer_reset(grv_engine *e);
+uint32_t grv_renderer_frame_count(const grv_engine *e);
+
 /* camera helpers (gl-matrix lookAt/perspective as src/components/canvas/WebGPUCanvas.tsx:143-157) */
 void grv_camera_look_at(const double eye[3], const double target[3], const double up[3],
                         double fovy_rad, double aspect, GrvCamera *cam);

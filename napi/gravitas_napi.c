@@ -536,6 +536,98 @@ static napi_value m_render_frame(napi_env env, napi_callback_info info) {
     return out;
 }
 
+/* renderWebGPUFrame(cameraUniforms: Float32Array(88), physicsParams: Float32Array(8),
+ *                   {maxSteps?, arith?}) -> Float32Array[w*h*4]
+ * WebGPURenderer.render (src/rendering/webgpu/renderer.ts:280-411) with the uniform blocks exactly
+ * as writeCameraUniforms / writePhysicsParams fill them; history and frame counter live in the engine. */
+static napi_value m_render_webgpu_frame(napi_env env, napi_callback_info info) {
+    size_t argc = 3;
+    napi_value argv[3];
+    engine_box *b = unwrap(env, info, &argc, argv);
+    if (!b) return NULL;
+    float *blocks[2] = {NULL, NULL};
+    const size_t want[2] = {88, 8};
+    for (int k = 0; k < 2; k++) {
+        napi_typedarray_type ty;
+        size_t len = 0;
+        void *data = NULL;
+        bool is_ta = false;
+        if (argc <= (size_t)k || napi_is_typedarray(env, argv[k], &is_ta) != napi_ok || !is_ta ||
+            napi_get_typedarray_info(env, argv[k], &ty, &len, &data, NULL, NULL) != napi_ok ||
+            ty != napi_float32_array || len < want[k]) {
+            napi_throw_type_error(env, NULL, "renderWebGPUFrame(Float32Array(88), Float32Array(8), opts?)");
+            return NULL;
+        }
+        blocks[k] = (float *)data;
+    }
+    int32_t max_steps = 150, arith = GRV_ARITH_STRICT;
+    napi_valuetype t;
+    if (argc > 2 && napi_typeof(env, argv[2], &t) == napi_ok && t == napi_object) {
+        max_steps = (int32_t)obj_f64(env, argv[2], "maxSteps", 150.0);
+        bool has = false;
+        char buf[16] = {0};
+        size_t len = 0;
+        napi_value v;
+        if (napi_has_named_property(env, argv[2], "arith", &has) == napi_ok && has &&
+            napi_get_named_property(env, argv[2], "arith", &v) == napi_ok &&
+            napi_get_value_string_utf8(env, v, buf, sizeof buf, &len) == napi_ok)
+            arith = strcmp(buf, "fast") == 0 ? GRV_ARITH_FAST : GRV_ARITH_STRICT;
+    }
+    const size_t n = (size_t)(uint32_t)blocks[1][2] * (uint32_t)blocks[1][3] * 4;
+    napi_value ab, ta;
+    void *dst;
+    NAPI_OK(napi_create_arraybuffer(env, n * sizeof(float), &dst, &ab));
+    if (grv_webgpu_render_host(b->h, blocks[0], blocks[1], max_steps, arith, (float *)dst) != GRV_OK) {
+        napi_throw_error(env, NULL, grv_last_error(b->h));
+        return NULL;
+    }
+    NAPI_OK(napi_create_typedarray(env, napi_float32_array, n, ab, 0, &ta));
+    return ta;
+}
+
+/* renderWebGLFrame({width, height, spin?, zoom?, mouse?, time?, maxRaySteps?, bloom?, cameraMoving?,
+ *                   arith?}) -> Float32Array[w*h*4]: WebGLRenderer.render's scene + TAA + bloom chain
+ * (src/rendering/webgl/renderer.ts:173-422) with the reference's default uniforms. */
+static napi_value m_render_webgl_frame(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    engine_box *b = unwrap(env, info, &argc, argv);
+    if (!b) return NULL;
+    napi_valuetype t;
+    if (argc < 1 || napi_typeof(env, argv[0], &t) != napi_ok || t != napi_object) {
+        napi_throw_type_error(env, NULL, "renderWebGLFrame expects an options object");
+        return NULL;
+    }
+    const uint32_t w = (uint32_t)obj_f64(env, argv[0], "width", 256), h = (uint32_t)obj_f64(env, argv[0], "height", 256);
+    if (w == 0 || h == 0 || (uint64_t)w * h > (1ull << 27)) {
+        napi_throw_range_error(env, NULL, "renderWebGLFrame: width/height out of range");
+        return NULL;
+    }
+    GrvGlslParams p;
+    grv_glsl_params_default(w, h, obj_f64(env, argv[0], "mass", 1.0), obj_f64(env, argv[0], "spin", 0.5), &p);
+    p.zoom = (float)obj_f64(env, argv[0], "zoom", p.zoom);
+    p.time = (float)obj_f64(env, argv[0], "time", 0.0);
+    p.max_ray_steps = (int32_t)obj_f64(env, argv[0], "maxRaySteps", p.max_ray_steps);
+    p.features = (uint32_t)obj_f64(env, argv[0], "features", (double)p.features);
+    double mouse[3] = {p.mouse[0], p.mouse[1], 0.0};
+    obj_vec3(env, argv[0], "mouse", mouse);
+    p.mouse[0] = (float)mouse[0];
+    p.mouse[1] = (float)mouse[1];
+    p.arith = obj_f64(env, argv[0], "fast", 0.0) != 0.0 ? GRV_ARITH_FAST : GRV_ARITH_STRICT;
+    const int bloom = obj_f64(env, argv[0], "bloom", 1.0) != 0.0;
+    const int moving = obj_f64(env, argv[0], "cameraMoving", 0.0) != 0.0;
+    const size_t n = (size_t)w * h * 4;
+    napi_value ab, ta;
+    void *dst;
+    NAPI_OK(napi_create_arraybuffer(env, n * sizeof(float), &dst, &ab));
+    if (grv_webgl_render_host(b->h, &p, bloom, moving, (float *)dst) != GRV_OK) {
+        napi_throw_error(env, NULL, grv_last_error(b->h));
+        return NULL;
+    }
+    NAPI_OK(napi_create_typedarray(env, napi_float32_array, n, ab, 0, &ta));
+    return ta;
+}
+
 static napi_value m_free(napi_env env, napi_callback_info info) { /* wasm-bindgen's .free() */
     size_t argc = 0;
     napi_value self;
@@ -605,6 +697,8 @@ static napi_value module_init(napi_env env, napi_value exports) {
         METHOD("compute_proper_distance", m_compute_proper_distance),
         METHOD("renderFrame", m_render_frame),
         METHOD("render_frame", m_render_frame),
+        METHOD("renderWebGPUFrame", m_render_webgpu_frame),
+        METHOD("renderWebGLFrame", m_render_webgl_frame),
         METHOD("free", m_free),
     };
     napi_value cls, fn;

@@ -38,6 +38,11 @@ const wasm = require(path.join(__dirname, "blackhole_physics.node"));
   let lit = 0;
   for (let i = 0; i < frame.rgba.length; i += 4) if (frame.rgba[i] + frame.rgba[i + 1] + frame.rgba[i + 2] > 0) lit++;
   res.frame = { rays: frame.rays, acceptedSteps: frame.acceptedSteps, lit: lit, alpha0: frame.rgba[3] };
+  // the renderers' frame surfaces (WebGLRenderer.render / WebGPURenderer.render)
+  const gl = engine.renderWebGLFrame({ width: 64, height: 36, spin: 0.9, maxRaySteps: 200 });
+  let glMax = 0;
+  for (let i = 0; i < gl.length; i += 4) glMax = Math.max(glMax, gl[i], gl[i + 1], gl[i + 2]);
+  res.webgl = { len: gl.length, max: glMax, alpha: gl[3] };
   console.log(JSON.stringify(res));
   engine.free();
 })().catch((e) => { console.error("FAILED", e); process.exit(1); });

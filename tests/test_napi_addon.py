@@ -30,6 +30,8 @@ WASM_METHODS = [
     "integrate_ray_relativistic",
     # names BASELINE.json's north_star uses for the path
     "integratePhotonGeodesic", "renderFrame", "free",
+    # the renderers' frame surfaces
+    "renderWebGPUFrame", "renderWebGLFrame",
 ]
 
 pytestmark = pytest.mark.skipif(NODE is None or not os.path.exists(ADDON),
@@ -101,6 +103,7 @@ def test_smoke_js_matches_oracle(oracle):
     assert abs(res["flamm"] - L.orc_flamm_height(100.0, 1.0)) < 1e-12
     assert abs(res["proper"] - L.orc_proper_distance(4.0, 20.0, 500, 1.0, 0.9)) < 1e-10
     assert res["curvature_len"] == res["tilt_len"] == res["drag_len"] == 3 * 8 * 5
+    assert res["webgl"]["len"] == 64 * 36 * 4 and res["webgl"]["alpha"] == 1.0 and 0.0 < res["webgl"]["max"] <= 1.0
     # renderFrame: same frame through the oracle (96x54, a = 0.9, camera of smoke.js)
     cam = oracle.camera_look_at((59.55, -7.31, 0.0), aspect=96 / 54)
     fr = oracle.render_frame(cam, oracle.frame_params(96, 54, spin=0.9), None, nthreads=4)
