@@ -23,6 +23,54 @@ namespace {
 // ===========================================================================
 // GLSL fragment march
 // ===========================================================================
+// hot-loop math of the two contracts: STRICT = the GLSL built-ins as written (IEEE divide and
+// sqrt); FAST = v_rcp_f32 / v_sqrt_f32 / v_rsq_f32 (1 ulp each, no denormal scaling)
+template <int ARITH> __device__ __forceinline__ float length_t(F3 a) {
+    if constexpr (ARITH == GRV_ARITH_FAST) return __builtin_amdgcn_sqrtf(dot_f3(a, a));
+    else return length_f3(a);
+}
+template <int ARITH> __device__ __forceinline__ F3 normalize_t(F3 a) {
+    if constexpr (ARITH == GRV_ARITH_FAST) return scale_f3(a, __builtin_amdgcn_rsqf(dot_f3(a, a)));
+    else return normalize_f3(a);
+}
+template <int ARITH> __device__ __forceinline__ float smoothstep_t(float e0, float e1, float x) {
+    if constexpr (ARITH == GRV_ARITH_FAST) {
+        const float t = clampf_d((x - e0) * __builtin_amdgcn_rcpf(e1 - e0), 0.0f, 1.0f);
+        return t * t * (3.0f - 2.0f * t);
+    } else {
+        return smoothstep_d(e0, e1, x);
+    }
+}
+
+// chunks/metric.ts:96-149 in the FAST contract: the same expressions with the reciprocals and
+// roots taken once (rsq of |p|^2 and of r_k^2, rcp of Sigma and of r_k^3 + a^2 r_k)
+__device__ __forceinline__ F3 glsl_kerr_accel_fast(F3 p, F3 v, float M, float a, float &omega) {
+    const float a2 = a * a;
+    const float rho2 = dot_f3(p, p);
+    const float diff = rho2 - a2;
+    const float py2 = p.y * p.y;
+    const float disc = fmaf(diff, diff, 4.0f * a2 * py2);
+    const float r2 = 0.5f * (diff + __builtin_amdgcn_sqrtf(fmaxf(0.0f, disc)));
+    const float r2c = fmaxf(1e-8f, r2);
+    const float inv_rk = __builtin_amdgcn_rsqf(r2c); // 1 / r_k
+    const float r_k = r2c * inv_rk;
+    const float sigma = fmaf(a2, py2 * (inv_rk * inv_rk), r2);
+    const F3 L = cross_f3(p, v);
+    const float Ly_eff = L.y - a;
+    const float L2_eff = fmaf(Ly_eff, Ly_eff, dot_f3(L, L) - L.y * L.y);
+    const float r2_inv = inv_rk * inv_rk;
+    const float sigma_ratio = r2 * __builtin_amdgcn_rcpf(fmaxf(1e-8f, sigma));
+    // M r^-2 S + 3 M max(0, L^2) r^-4 S
+    const float pull = M * r2_inv * sigma_ratio * fmaf(3.0f * fmaxf(0.0f, L2_eff), r2_inv, 1.0f);
+    const float s = -pull * __builtin_amdgcn_rsqf(rho2); // along -normalize(p)
+    const float drag = 2.0f * M * a * __builtin_amdgcn_rcpf(fmaxf(1e-8f, r_k * (r2 + a2)));
+    omega = drag;
+    // cross((0,1,0), v) = (v.z, 0, -v.x)
+    return F3{fmaf(p.x, s, v.z * drag), p.y * s, fmaf(p.z, s, -v.x * drag)};
+}
+template <int ARITH>
+__device__ __forceinline__ F3 glsl_accel(F3 p, F3 v, float M, float a, float &omega);
+
 // chunks/metric.ts:96-149
 __device__ __forceinline__ F3 glsl_kerr_accel(F3 p, F3 v, float M, float a, float &omega) {
     const float a2 = a * a;
@@ -48,6 +96,11 @@ __device__ __forceinline__ F3 glsl_kerr_accel(F3 p, F3 v, float M, float a, floa
     acc = add_f3(acc, scale_f3(cross_f3(F3{0.0f, 1.0f, 0.0f}, v), drag));
     omega = 2.0f * M * a / fmaxf(1e-8f, r3_p_a2r);
     return acc;
+}
+template <int ARITH>
+__device__ __forceinline__ F3 glsl_accel(F3 p, F3 v, float M, float a, float &omega) {
+    if constexpr (ARITH == GRV_ARITH_FAST) return glsl_kerr_accel_fast(p, v, M, a, omega);
+    else return glsl_kerr_accel(p, v, M, a, omega);
 }
 
 // sin / cos of the FAST contract: two-term Cody-Waite reduction by pi/2 + cephes minimax
@@ -129,7 +182,11 @@ __device__ __forceinline__ float glsl_hash_uv(const uint8_t *__restrict__ T, flo
     const float u = s * 256.0f - 0.5f, v = t * 256.0f - 0.5f;
     const float fu = floorf(u), fv = floorf(v);
     const float a = u - fu, b = v - fv;
-    const int i0 = (int)fmodf(fu, 256.0f), j0 = (int)fmodf(fv, 256.0f);
+    // REPEAT wrap of the texel index: (int)fu & 255 equals (int)fmod(fu, 256) & 255 whenever fu fits
+    // an int32 (two's complement), which every lattice coordinate of the shader does; the fmod form
+    // is kept for out-of-range coordinates only
+    const bool small = fabsf(fu) < 1.0e9f && fabsf(fv) < 1.0e9f;
+    const int i0 = small ? (int)fu : (int)fmodf(fu, 256.0f), j0 = small ? (int)fv : (int)fmodf(fv, 256.0f);
     // integer lattice points (every noise() corner) land on a texel centre: weights (1, 0, 0, 0),
     // and 0 * texel is exactly 0 for UNORM8 data -- one fetch gives the bitwise same value
     if (a == 0.0f && b == 0.0f) return glsl_texel(T, i0, j0);
@@ -219,7 +276,7 @@ __device__ __forceinline__ void glsl_sample_disk(const GlslParams &U, F3 p, F3 p
         sp.y = p_prev.y * (1.0f - t) + p.y * t;
         sp.z = p_prev.z * (1.0f - t) + p.z * t;
     }
-    const float sampleR = length_f3(sp);
+    const float sampleR = length_t<ARITH>(sp);
     const float effH = fminf(U.disk_scale_height, 0.45f);
     const float diskHeight = sampleR * effH;
     const float diskInner = isco;
@@ -400,7 +457,7 @@ __device__ uint32_t glsl_fragment(const GlslParams &U, uint32_t width, uint32_t 
 
     for (int i = 0; i < maxSteps; ++i) {
         p_prev = p;
-        const float r = length_f3(p);
+        const float r = length_t<ARITH>(p);
         if (r < rh * 1.15f) {
             hitHorizon = true;
             break;
@@ -415,23 +472,23 @@ __device__ uint32_t glsl_fragment(const GlslParams &U, uint32_t width, uint32_t 
         }
         const float sphereProx = fabsf(r - rph);
         dt = fminf(dt, 0.01f + sphereProx * 0.15f);
-        const float hRefinement = smoothstep_d(0.2f, 0.0f, fabsf(p.y));
+        const float hRefinement = smoothstep_t<ARITH>(0.2f, 0.0f, fabsf(p.y));
         const float cdt = dt * (1.0f - hRefinement * 0.7f);
 
         F3 accel{0.0f, 0.0f, 0.0f};
         if (lensing) {
             float omega;
-            accel = scale_f3(glsl_kerr_accel(p, v, M, a, omega), U.lensing_strength);
+            accel = scale_f3(glsl_accel<ARITH>(p, v, M, a, omega), U.lensing_strength);
             glsl_rot<ARITH>(omega * cdt, v.x, v.z);
         }
         p = add_f3(p, add_f3(scale_f3(v, cdt), scale_f3(scale_f3(scale_f3(accel, 0.5f), cdt), cdt)));
-        const float r_new = length_f3(p);
+        const float r_new = length_t<ARITH>(p);
         if (lensing && alpha < 0.95f) {
             float om2;
-            const F3 accel_new = scale_f3(glsl_kerr_accel(p, v, M, a, om2), U.lensing_strength);
+            const F3 accel_new = scale_f3(glsl_accel<ARITH>(p, v, M, a, om2), U.lensing_strength);
             v = add_f3(v, scale_f3(scale_f3(add_f3(accel, accel_new), 0.5f), cdt));
         }
-        v = normalize_f3(v);
+        v = normalize_t<ARITH>(v);
         ++steps;
 
         if (prevY * p.y < 0.0f && r_new < rph * 2.0f && r_new > rh)
