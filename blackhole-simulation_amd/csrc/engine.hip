@@ -1,30 +1,12 @@
-// engine.hip -- host side of libgravitas_hip.so: the C ABI of include/gravitas_abi.h
-// on top of the segment kernels.  One engine == one `PhysicsEngine`
-// (physics-engine/gravitas-wasm/src/lib.rs:42-54) bound to one HIP device.
-//
-// No CPU compute path exists here: every integrate / render / LUT entry point
-// launches HIP kernels and fails with a status code if the device is missing.
-#include <hip/hip_runtime.h>
+// engine.hip -- lifecycle, closed forms, batch / single-ray / frame entry points of the C ABI
+// (include/gravitas_abi.h) on top of the segment kernels.  See engine_internal.hpp.
+#include "engine_internal.hpp"
 
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <new>
-#include <string>
-#include <vector>
-
-#include "control_plane.hpp"
-#include "spacetime_viz.hpp"
-#include "engine_types.hpp"
-
-using namespace grvhip;
+namespace grvhost {
 
 // ---------------------------------------------------------------------------
 // closed forms (host scalars; gravitas-core/src/metric/{mod,kerr}.rs)
 // ---------------------------------------------------------------------------
-namespace {
 
 double clamp_rs(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
@@ -78,66 +60,11 @@ double g_factor(double r, double mass, double spin, double lambda) {
 }
 
 constexpr size_t kSabFloats = 2048; // lib.rs:67
-constexpr size_t kOffControl = 0, kOffCamera = 64, kOffPhysics = 128, kOffTelemetry = 256,
-                 kOffLuts = 2048; // lib.rs:36-40
 
-} // namespace
 
 // ---------------------------------------------------------------------------
-// engine object
+// shared host helpers
 // ---------------------------------------------------------------------------
-struct grv_engine {
-    int device = 0;
-    double mass = 1.0;
-    double spin = 0.0;   // as given (lib.rs:44-45)
-    double spin_c = 0.0; // clamped copy held by the metrics (kerr.rs:48-63)
-    int n_cu = 256;
-    std::string err;
-
-    // ray workspace (device)
-    void *ws_mem = nullptr;
-    size_t ws_slots = 0;
-    RayWorkspace ws{};
-    uint32_t *live[2] = {nullptr, nullptr};
-    uint32_t *d_counters = nullptr; // [0],[1] live counts (ping-pong)
-    FrameStatsDev *d_stats = nullptr;
-    uint32_t *h_counters = nullptr; // pinned
-    FrameStatsDev *h_stats = nullptr; // pinned
-
-    // staging buffers for host-pointer entry points
-    void *stage_mem = nullptr;
-    size_t stage_bytes = 0;
-
-    // cached spectrum LUT (device)
-    float *d_lut = nullptr;
-    uint32_t lut_w = 0, lut_h = 0;
-    double lut_tmax = 0.0;
-
-    // last-frame bookkeeping
-    uint32_t last_launches = 0;
-    float last_ms[5] = {0, 0, 0, 0, 0};
-    hipEvent_t ev[8] = {};
-    bool ev_ok = false;
-
-    // renderer layer (grv_webgpu_render / grv_webgl_render): full-size RGBA f32 targets
-    struct Targets {
-        float *mem = nullptr; // [3][h][w][4]: scene / compute texture, history ping, history pong
-        uint32_t w = 0, h = 0;
-        uint32_t hist = 0;   // webgpu: currentHistoryIndex; webgl: currentWriteIndex
-        uint32_t frames = 0; // frameCount
-    } rt;
-    void *post_mem = nullptr; // bloom render targets (bright, blur ping/pong)
-    size_t post_bytes = 0;
-    uint8_t *d_noise = nullptr; // [2][256*256] R planes: u_noiseTex, u_blueNoiseTex
-    std::vector<float> disk_lut = std::vector<float>(512, 0.0f); // lut_buffer (lib.rs:50, 65-66)
-    std::vector<float> sab;
-    float *sab_ext = nullptr; // attach_sab (lib.rs:74)
-    CameraFilter camera, last_good_camera;
-    float *sab_block() { return sab_ext ? sab_ext : sab.data(); }
-};
-
-namespace {
-
 int fail(grv_engine *e, int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
@@ -148,13 +75,7 @@ int fail(grv_engine *e, int code, const char *fmt, ...) {
     return code;
 }
 
-#define GRV_HIP(e, call)                                                                   \
-    do {                                                                                   \
-        hipError_t _st = (call);                                                           \
-        if (_st != hipSuccess)                                                             \
-            return fail((e), _st == hipErrorOutOfMemory ? GRV_ERR_OOM : GRV_ERR_HIP,        \
-                        "%s failed: %s", #call, hipGetErrorString(_st));                   \
-    } while (0)
+
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -343,62 +264,13 @@ void stats_to_abi(const grv_engine *e, const FrameStatsDev &d, GrvFrameStats *ou
     out->total_ms = e->last_ms[4];
 }
 
-} // namespace
+} // namespace grvhost
 
-namespace {
-template <typename Launch>
-int run_shader_frame(grv_engine *e, uint32_t width, uint32_t height, uint32_t tw, uint32_t tr,
-                     uint64_t *total_steps, hipStream_t s, Launch &&launch) {
-    if (width == 0 || height == 0) return fail(e, GRV_ERR_INVALID, "empty frame");
-    if (tw > 1 && tr >= tw) return fail(e, GRV_ERR_INVALID, "tile_rank >= tile_world");
-    GRV_HIP(e, hipSetDevice(e->device));
-    GrvRenderParams q{};
-    q.width = width;
-    q.height = height;
-    q.tile_world = tw;
-    q.tile_rank = tr;
-    FrameGeom G;
-    frame_geometry(q, G);
-    const size_t slots = (size_t)G.n_tiles_local * 4096u;
-    GRV_HIP(e, hipMemsetAsync(e->d_stats, 0, sizeof(FrameStatsDev), s));
-    if (slots > 0x7FFFFFFFull) return fail(e, GRV_ERR_INVALID, "frame too large for one rank");
-    GRV_HIP(e, launch(G, (uint32_t)slots, &e->d_stats->accepted_steps));
-    if (total_steps) {
-        GRV_HIP(e, hipMemcpyAsync(e->h_stats, e->d_stats, sizeof(FrameStatsDev), hipMemcpyDeviceToHost, s));
-        GRV_HIP(e, hipStreamSynchronize(s));
-        *total_steps = e->h_stats->accepted_steps;
-    }
-    return GRV_OK;
-}
-} // namespace
+using namespace grvhost;
 
 // ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
-// ---- helpers of the spacetime read-outs (spacetime_viz.hip) ----
-namespace {
-VizHole viz_hole(const grv_engine *e) { return VizHole{e->mass, e->spin, e->spin_c * e->mass}; }
-
-// run one of the grid kernels into the staging buffer and copy n_floats back
-template <typename Launch>
-int viz_grid(grv_engine *e, size_t n_a, size_t n_b, float *out, Launch &&launch) {
-    if (!e) return GRV_ERR_INVALID;
-    if (n_a == 0 || n_b == 0) return GRV_OK; // empty loops upstream
-    if (!out) return fail(e, GRV_ERR_INVALID, "null output");
-    if (n_a > 0xFFFFu * 16u || n_b > 0xFFFFu * 16u || n_a * n_b > (size_t)1 << 28)
-        return fail(e, GRV_ERR_INVALID, "grid %zu x %zu too large", n_a, n_b);
-    GRV_HIP(e, hipSetDevice(e->device));
-    const size_t bytes = n_a * n_b * 3 * sizeof(float);
-    int rc = ensure_stage(e, bytes);
-    if (rc != GRV_OK) return rc;
-    float *d_out = static_cast<float *>(e->stage_mem);
-    GRV_HIP(e, launch(d_out));
-    GRV_HIP(e, hipDeviceSynchronize());
-    GRV_HIP(e, hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost));
-    return GRV_OK;
-}
-} // namespace
-
 extern "C" {
 
 int grv_abi_version(void) { return GRV_ABI_VERSION; }
@@ -748,380 +620,6 @@ int grv_unpack_tiles(const GrvRenderParams *p, uint32_t rank, const void *packed
     }
     return GRV_OK;
 }
-
-void grv_wgsl_params_default(uint32_t width, uint32_t height, const GrvCamera *cam, double mass,
-                             double spin, GrvWgslParams *p) {
-    if (!p) return;
-    std::memset(p, 0, sizeof *p);
-    p->width = width;
-    p->height = height;
-    if (cam) {
-        for (int k = 0; k < 16; ++k) {
-            p->inv_view[k] = (float)cam->inv_view[k];
-            p->inv_proj[k] = (float)cam->inv_proj[k];
-        }
-        for (int k = 0; k < 3; ++k) p->position[k] = (float)cam->position[k];
-    }
-    p->mass = (float)mass;
-    p->spin = (float)spin;
-    p->max_steps = 150; // compute.wgsl.ts:13
-    p->tile_world = 1;
-}
-
-void grv_glsl_params_default(uint32_t width, uint32_t height, double mass, double spin,
-                             GrvGlslParams *p) {
-    if (!p) return;
-    std::memset(p, 0, sizeof *p);
-    p->width = width;
-    p->height = height;
-    p->mass = (float)mass;
-    p->spin = (float)(spin * mass);              // renderer.ts:326
-    p->zoom = 30.0f * 2.0f;                       // simulation.config.ts:118-119, renderer.ts:327
-    p->mouse[0] = 0.5f;
-    p->mouse[1] = 97.0f / 180.0f;                 // simulation.config.ts:106-107
-    p->disk_size = 50.0f;                         // simulation.config.ts:138-139
-    p->disk_scale_height = 0.2f;                  // :147-148
-    p->disk_density = 4.0f;                       // :167-168
-    p->disk_temp = (float)(9500.0 * std::pow(mass, -0.25)); // renderer.ts:352-356
-    p->lensing_strength = 1.0f;                   // renderer.ts:340
-    p->time = 0.0f;
-    p->turbulence = -1.0f;                        // sample the noise texture (disk.ts:55)
-    p->max_ray_steps = 256;                       // simulation.config.ts:205-211 (ultra)
-    p->tone_map = 0;
-    p->tile_world = 1;
-    p->features = GRV_GLSL_FEATURES_DEFAULT;
-    p->quality = 1;
-    p->cam_quat[3] = 1.0f;                        // renderer.ts:315-316
-}
-
-void grv_seeded_noise_rgba8(uint32_t seed, uint32_t size, uint8_t *rgba) {
-    if (!rgba) return;
-    // xorshift32 stream; byte = floor(u * 255), u in [0, 1), as createNoiseTexture forms it
-    uint32_t x = seed ? seed : 0x9E3779B9u;
-    const size_t n = (size_t)size * size * 4u;
-    for (size_t i = 0; i < n; ++i) {
-        x ^= x << 13;
-        x ^= x >> 17;
-        x ^= x << 5;
-        rgba[i] = (uint8_t)std::floor((double)(x >> 8) / 16777216.0 * 255.0);
-    }
-}
-
-int grv_set_glsl_noise(grv_engine *e, const uint8_t *noise_rgba, const uint8_t *blue_rgba) {
-    if (!e) return GRV_ERR_INVALID;
-    GRV_HIP(e, hipSetDevice(e->device));
-    constexpr size_t kPlane = 256 * 256;
-    if (!e->d_noise) {
-        GRV_HIP(e, hipMalloc(reinterpret_cast<void **>(&e->d_noise), 2 * kPlane));
-        GRV_HIP(e, hipMemset(e->d_noise, 0, 2 * kPlane));
-    }
-    std::vector<uint8_t> plane(kPlane);
-    const uint8_t *src[2] = {noise_rgba, blue_rgba};
-    for (int t = 0; t < 2; ++t) {
-        if (!src[t]) continue;
-        for (size_t i = 0; i < kPlane; ++i) plane[i] = src[t][4 * i]; // .r
-        GRV_HIP(e, hipMemcpy(e->d_noise + t * kPlane, plane.data(), kPlane, hipMemcpyHostToDevice));
-    }
-    return GRV_OK;
-}
-
-
-int grv_render_frame_wgsl(grv_engine *e, const GrvWgslParams *p, float *d_rgba, uint32_t *d_steps,
-                          uint64_t *total_steps, void *stream) {
-    if (!e) return GRV_ERR_INVALID;
-    if (!p || !d_rgba) return fail(e, GRV_ERR_INVALID, "null argument");
-    if (p->arith != GRV_ARITH_STRICT && p->arith != GRV_ARITH_FAST)
-        return fail(e, GRV_ERR_INVALID, "invalid arith %d", p->arith);
-    WgslParams P{};
-    std::memcpy(P.inv_view, p->inv_view, sizeof P.inv_view);
-    std::memcpy(P.inv_proj, p->inv_proj, sizeof P.inv_proj);
-    std::memcpy(P.position, p->position, sizeof P.position);
-    P.mass = p->mass;
-    P.spin = p->spin;
-    P.jitter[0] = p->jitter[0];
-    P.jitter[1] = p->jitter[1];
-    P.max_steps = p->max_steps;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    return run_shader_frame(e, p->width, p->height, p->tile_world, p->tile_rank, total_steps, s,
-                            [&](const FrameGeom &G, uint32_t n, unsigned long long *tot) {
-                                return p->arith == GRV_ARITH_FAST
-                                           ? launch_wgsl_symplectic_fast(G, P, d_rgba, d_steps, tot, n, s)
-                                           : launch_wgsl_symplectic(G, P, d_rgba, d_steps, tot, n, s);
-                            });
-}
-
-int grv_render_frame_glsl(grv_engine *e, const GrvGlslParams *p, float *d_rgba, uint32_t *d_steps,
-                          uint64_t *total_steps, void *stream) {
-    if (!e) return GRV_ERR_INVALID;
-    if (!p || !d_rgba) return fail(e, GRV_ERR_INVALID, "null argument");
-    if (p->arith != GRV_ARITH_STRICT && p->arith != GRV_ARITH_FAST)
-        return fail(e, GRV_ERR_INVALID, "invalid arith %d", p->arith);
-    GlslParams P{};
-    P.mass = p->mass;
-    P.spin = p->spin;
-    P.zoom = p->zoom;
-    P.mouse[0] = p->mouse[0];
-    P.mouse[1] = p->mouse[1];
-    P.disk_size = p->disk_size;
-    P.disk_scale_height = p->disk_scale_height;
-    P.disk_density = p->disk_density;
-    P.disk_temp = p->disk_temp;
-    P.lensing_strength = p->lensing_strength;
-    P.time = p->time;
-    P.turbulence = p->turbulence;
-    P.max_ray_steps = p->max_ray_steps;
-    P.tone_map = p->tone_map;
-    P.features = p->features;
-    P.quality = p->quality;
-    P.show_redshift = p->show_redshift;
-    P.show_kerr_shadow = p->show_kerr_shadow;
-    P.debug = p->debug;
-    std::memcpy(P.cam_pos, p->cam_pos, sizeof P.cam_pos);
-    std::memcpy(P.cam_quat, p->cam_quat, sizeof P.cam_quat);
-    P.shadow_count = p->shadow_count;
-    std::memcpy(P.shadow_curve, p->shadow_curve, sizeof P.shadow_curve);
-    if (!e->d_noise) { // first GLSL frame of this engine: the seeded default textures
-        std::vector<uint8_t> a(256 * 256 * 4), b(256 * 256 * 4);
-        grv_seeded_noise_rgba8(1u, 256, a.data());
-        grv_seeded_noise_rgba8(2u, 256, b.data());
-        int rc = grv_set_glsl_noise(e, a.data(), b.data());
-        if (rc != GRV_OK) return rc;
-    }
-    P.noise_r = e->d_noise;
-    P.blue_r = e->d_noise + 256 * 256;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    return run_shader_frame(e, p->width, p->height, p->tile_world, p->tile_rank, total_steps, s,
-                            [&](const FrameGeom &G, uint32_t n, unsigned long long *tot) {
-                                return p->arith == GRV_ARITH_FAST
-                                           ? launch_glsl_fragment_fast(G, P, d_rgba, d_steps, tot, n, s)
-                                           : launch_glsl_fragment(G, P, d_rgba, d_steps, tot, n, s);
-                            });
-}
-
-float grv_taa_effective_blend(float blend_factor, float v) {
-    if (v > 0.001f) return std::fmax(0.05f, std::fmin(0.9f, 0.9f - v * 6.0f));
-    return blend_factor;
-}
-
-int grv_post_taa_resolve(grv_engine *e, const GrvTaaParams *p, const float *d_current,
-                         const float *d_history, float *d_out, void *stream) {
-    if (!e) return GRV_ERR_INVALID;
-    if (!p || !d_current || !d_history || !d_out) return fail(e, GRV_ERR_INVALID, "null argument");
-    if (d_out == d_current || d_out == d_history) return fail(e, GRV_ERR_INVALID, "taa: out aliases an input");
-    GRV_HIP(e, hipSetDevice(e->device));
-    GRV_HIP(e, launch_taa_resolve(p->width, p->height, d_current, d_history, p->blend_factor,
-                                  p->camera_moving, p->half_storage, d_out, static_cast<hipStream_t>(stream)));
-    return GRV_OK;
-}
-
-int grv_post_ataa_resolve(grv_engine *e, const GrvAtaaParams *p, const float *d_current,
-                          const float *d_history, float *d_out, void *stream) {
-    if (!e) return GRV_ERR_INVALID;
-    if (!p || !d_current || !d_history || !d_out) return fail(e, GRV_ERR_INVALID, "null argument");
-    if (d_out == d_current || d_out == d_history) return fail(e, GRV_ERR_INVALID, "ataa: out aliases an input");
-    AtaaCameraHost cam;
-    std::memcpy(cam.inv_view, p->inv_view, sizeof cam.inv_view);
-    std::memcpy(cam.inv_proj, p->inv_proj, sizeof cam.inv_proj);
-    std::memcpy(cam.prev_view_proj, p->prev_view_proj, sizeof cam.prev_view_proj);
-    std::memcpy(cam.position, p->position, sizeof cam.position);
-    GRV_HIP(e, hipSetDevice(e->device));
-    GRV_HIP(e, launch_ataa_resolve(p->width, p->height, cam, d_current, d_history, p->half_storage, d_out,
-                                   static_cast<hipStream_t>(stream)));
-    return GRV_OK;
-}
-
-void grv_bloom_params_default(uint32_t width, uint32_t height, GrvBloomParams *p) {
-    if (!p) return;
-    p->width = width;
-    p->height = height;
-    p->intensity = 0.5f; // bloom.ts:34-39
-    p->threshold = 0.8f;
-    p->blur_passes = 2;
-    p->half_storage = 1;
-}
-
-int grv_post_bloom(grv_engine *e, const GrvBloomParams *p, const float *d_scene, float *d_out,
-                   void *stream) {
-    if (!e) return GRV_ERR_INVALID;
-    if (!p || !d_scene || !d_out) return fail(e, GRV_ERR_INVALID, "null argument");
-    if (p->blur_passes < 0 || p->blur_passes > 64) return fail(e, GRV_ERR_INVALID, "blur_passes out of range");
-    if (d_out == d_scene) return fail(e, GRV_ERR_INVALID, "bloom: out aliases the scene");
-    GRV_HIP(e, hipSetDevice(e->device));
-    const size_t need = bloom_scratch_floats(p->width, p->height) * sizeof(float);
-    if (need > e->post_bytes) {
-        if (e->post_mem) (void)hipFree(e->post_mem);
-    if (e->rt.mem) (void)hipFree(e->rt.mem);
-        e->post_mem = nullptr;
-        e->post_bytes = 0;
-        GRV_HIP(e, hipMalloc(&e->post_mem, need));
-        e->post_bytes = need;
-    }
-    GRV_HIP(e, launch_bloom(p->width, p->height, d_scene, p->threshold, p->intensity, p->blur_passes,
-                            p->half_storage, static_cast<float *>(e->post_mem), d_out,
-                            static_cast<hipStream_t>(stream)));
-    return GRV_OK;
-}
-
-// ---- renderer layer ----
-namespace {
-int ensure_targets(grv_engine *e, uint32_t w, uint32_t h, hipStream_t s) {
-    if (e->rt.mem && e->rt.w == w && e->rt.h == h) return GRV_OK;
-    if (e->rt.mem) (void)hipFree(e->rt.mem);
-    e->rt = grv_engine::Targets{};
-    const size_t bytes = (size_t)3 * w * h * 4 * sizeof(float);
-    GRV_HIP(e, hipMalloc(reinterpret_cast<void **>(&e->rt.mem), bytes));
-    GRV_HIP(e, hipMemsetAsync(e->rt.mem, 0, bytes, s)); // textures start zeroed
-    e->rt.w = w;
-    e->rt.h = h;
-    return GRV_OK;
-}
-int ensure_bloom_scratch(grv_engine *e, uint32_t w, uint32_t h, hipStream_t s) {
-    const size_t need = bloom_scratch_floats(w, h) * sizeof(float);
-    if (need <= e->post_bytes) return GRV_OK;
-    if (e->post_mem) (void)hipFree(e->post_mem);
-    e->post_mem = nullptr;
-    e->post_bytes = 0;
-    GRV_HIP(e, hipMalloc(&e->post_mem, need));
-    GRV_HIP(e, hipMemsetAsync(e->post_mem, 0, need, s));
-    e->post_bytes = need;
-    return GRV_OK;
-}
-// halton(index, base), compute.wgsl.ts:134-145, in f32
-float halton_f32(uint32_t index, uint32_t base) {
-    float result = 0.0f, f = 1.0f / (float)base;
-    for (uint32_t i = index; i > 0u; i /= base) {
-        result += f * (float)(i % base);
-        f = f / (float)base;
-    }
-    return result;
-}
-} // namespace
-
-void grv_renderer_reset(grv_engine *e) {
-    if (!e) return;
-    if (e->rt.mem) (void)hipFree(e->rt.mem);
-    e->rt = grv_engine::Targets{};
-}
-uint32_t grv_renderer_frame_count(const grv_engine *e) { return e ? e->rt.frames : 0u; }
-
-int grv_webgpu_render(grv_engine *e, const float *cu, const float *pp, int32_t max_steps, int32_t arith,
-                      float *d_screen, void *stream) {
-    if (!e) return GRV_ERR_INVALID;
-    if (!cu || !pp || !d_screen) return fail(e, GRV_ERR_INVALID, "null argument");
-    const uint32_t w = (uint32_t)pp[2], h = (uint32_t)pp[3]; // u32(physics.resolution), compute.wgsl.ts:149-150
-    if (w == 0 || h == 0 || (uint64_t)w * h > (1ull << 27)) return fail(e, GRV_ERR_INVALID, "bad resolution");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    GRV_HIP(e, hipSetDevice(e->device));
-    int rc = ensure_targets(e, w, h, s);
-    if (rc != GRV_OK) return rc;
-    const size_t plane = (size_t)w * h * 4;
-    float *compute_tex = e->rt.mem, *hist[2] = {e->rt.mem + plane, e->rt.mem + 2 * plane};
-    // Pass 1: main ray march.  CameraUniforms floats: inv_view 32..47, inv_proj 48..63,
-    // prev_view_proj 64..79, position 80..82 (types/webgpu.ts:95-116)
-    GrvWgslParams wp;
-    std::memset(&wp, 0, sizeof wp);
-    wp.width = w;
-    wp.height = h;
-    std::memcpy(wp.inv_view, cu + 32, sizeof wp.inv_view);
-    std::memcpy(wp.inv_proj, cu + 48, sizeof wp.inv_proj);
-    std::memcpy(wp.position, cu + 80, sizeof wp.position);
-    wp.mass = pp[0];
-    wp.spin = pp[1];
-    const uint32_t fi = e->rt.frames; // paramsWithFrame.frameIndex = this.frameCount
-    wp.jitter[0] = halton_f32((fi % 8u) + 1u, 2u) - 0.5f;
-    wp.jitter[1] = halton_f32((fi % 8u) + 1u, 3u) - 0.5f;
-    wp.max_steps = max_steps > 0 ? max_steps : 150;
-    wp.tile_world = 1;
-    wp.arith = arith;
-    rc = grv_render_frame_wgsl(e, &wp, compute_tex, nullptr, nullptr, stream);
-    if (rc != GRV_OK) return rc;
-    GRV_HIP(e, launch_post_quantize(compute_tex, w * h, s)); // texture_storage_2d<rgba16float>
-    // Pass 2: ATAA resolve, history ping-pong (renderer.ts:319-345, 385-395)
-    const uint32_t hi = e->rt.hist, nx = 1u - hi;
-    AtaaCameraHost cam;
-    std::memcpy(cam.inv_view, cu + 32, sizeof cam.inv_view);
-    std::memcpy(cam.inv_proj, cu + 48, sizeof cam.inv_proj);
-    std::memcpy(cam.prev_view_proj, cu + 64, sizeof cam.prev_view_proj);
-    std::memcpy(cam.position, cu + 80, sizeof cam.position);
-    GRV_HIP(e, launch_ataa_resolve(w, h, cam, compute_tex, hist[hi], 1, hist[nx], s));
-    // Pass 3: blit with Reinhard (renderer.ts:14-50, 397-411)
-    GRV_HIP(e, launch_blit_reinhard(w, h, hist[nx], d_screen, s));
-    e->rt.hist = nx;
-    e->rt.frames++;
-    return GRV_OK;
-}
-
-int grv_webgl_render(grv_engine *e, const GrvGlslParams *p, int32_t bloom_enabled, int32_t camera_moving,
-                     float *d_screen, void *stream) {
-    if (!e) return GRV_ERR_INVALID;
-    if (!p || !d_screen) return fail(e, GRV_ERR_INVALID, "null argument");
-    const uint32_t w = p->width, h = p->height;
-    if (w == 0 || h == 0 || (uint64_t)w * h > (1ull << 27)) return fail(e, GRV_ERR_INVALID, "bad resolution");
-    if (p->tile_world > 1) return fail(e, GRV_ERR_INVALID, "the renderer layer draws whole frames");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    GRV_HIP(e, hipSetDevice(e->device));
-    int rc = ensure_targets(e, w, h, s);
-    if (rc != GRV_OK) return rc;
-    rc = ensure_bloom_scratch(e, w, h, s);
-    if (rc != GRV_OK) return rc;
-    const size_t plane = (size_t)w * h * 4;
-    float *scene = e->rt.mem, *ping = e->rt.mem + plane, *pong = e->rt.mem + 2 * plane;
-    // scene pass into the RGBA16F scene target, linear output (manager.ts:84-86)
-    GrvGlslParams gp = *p;
-    gp.tone_map = 0;
-    rc = grv_render_frame_glsl(e, &gp, scene, nullptr, nullptr, stream);
-    if (rc != GRV_OK) return rc;
-    GRV_HIP(e, launch_post_quantize(scene, w * h, s));
-    // ReprojectionManager.resolve: write index 0 -> write pong, read ping (reprojection.ts:209-216)
-    float *write_tex = e->rt.hist == 0 ? pong : ping;
-    const float *read_tex = e->rt.hist == 0 ? ping : pong;
-    GRV_HIP(e, launch_taa_resolve(w, h, scene, read_tex, 0.75f, camera_moving, 1, write_tex, s));
-    e->rt.hist = 1u - e->rt.hist;
-    // bloom (features.bloom) or plain presentation: both are the combine pass (bloom.ts:443-632)
-    float *scratch = static_cast<float *>(e->post_mem);
-    if (bloom_enabled) {
-        GRV_HIP(e, launch_bloom(w, h, write_tex, 0.8f, 0.5f, 2, 1, scratch, d_screen, s));
-    } else {
-        // drawTextureToScreen: combine with intensity 0; the bloom input is a stale dummy upstream,
-        // here the (zero or last) bright-pass target, multiplied by 0 either way
-        GRV_HIP(e, launch_bloom(w, h, write_tex, 3.0e38f, 0.0f, 0, 1, scratch, d_screen, s));
-    }
-    e->rt.frames++;
-    return GRV_OK;
-}
-
-int grv_webgpu_render_host(grv_engine *e, const float *cu, const float *pp, int32_t max_steps,
-                           int32_t arith, float *screen) {
-    if (!e) return GRV_ERR_INVALID;
-    if (!cu || !pp || !screen) return fail(e, GRV_ERR_INVALID, "null argument");
-    const size_t bytes = (size_t)(uint32_t)pp[2] * (uint32_t)pp[3] * 4 * sizeof(float);
-    if (bytes == 0 || bytes > ((size_t)1 << 31)) return fail(e, GRV_ERR_INVALID, "bad resolution");
-    GRV_HIP(e, hipSetDevice(e->device));
-    int rc = ensure_stage(e, bytes);
-    if (rc != GRV_OK) return rc;
-    rc = grv_webgpu_render(e, cu, pp, max_steps, arith, static_cast<float *>(e->stage_mem), nullptr);
-    if (rc != GRV_OK) return rc;
-    GRV_HIP(e, hipDeviceSynchronize());
-    GRV_HIP(e, hipMemcpy(screen, e->stage_mem, bytes, hipMemcpyDeviceToHost));
-    return GRV_OK;
-}
-
-int grv_webgl_render_host(grv_engine *e, const GrvGlslParams *p, int32_t bloom_enabled,
-                          int32_t camera_moving, float *screen) {
-    if (!e) return GRV_ERR_INVALID;
-    if (!p || !screen) return fail(e, GRV_ERR_INVALID, "null argument");
-    const size_t bytes = (size_t)p->width * p->height * 4 * sizeof(float);
-    if (bytes == 0 || bytes > ((size_t)1 << 31)) return fail(e, GRV_ERR_INVALID, "bad resolution");
-    GRV_HIP(e, hipSetDevice(e->device));
-    int rc = ensure_stage(e, bytes);
-    if (rc != GRV_OK) return rc;
-    rc = grv_webgl_render(e, p, bloom_enabled, camera_moving, static_cast<float *>(e->stage_mem), nullptr);
-    if (rc != GRV_OK) return rc;
-    GRV_HIP(e, hipDeviceSynchronize());
-    GRV_HIP(e, hipMemcpy(screen, e->stage_mem, bytes, hipMemcpyDeviceToHost));
-    return GRV_OK;
-}
-
 int grv_unpack_tiles_device(grv_engine *e, const GrvRenderParams *p, uint32_t rank,
                             const void *d_packed, void *d_image, size_t bpp, void *stream) {
     if (!e) return GRV_ERR_INVALID;
@@ -1182,158 +680,6 @@ void grv_camera_from_uniforms(const float *u, GrvCamera *cam) {
     for (int k = 0; k < 3; ++k) cam->position[k] = u[80 + k];
     cam->pixel_offset[0] = 0.0;
     cam->pixel_offset[1] = 0.0;
-}
-
-int grv_generate_spectrum_lut_device(grv_engine *e, size_t width, size_t height, double max_temp,
-                                     float *d_out, void *stream) {
-    if (!e) return GRV_ERR_INVALID;
-    if (!d_out || width == 0 || height == 0 || width * height > (1ull << 26))
-        return fail(e, GRV_ERR_INVALID, "bad LUT request");
-    GRV_HIP(e, hipSetDevice(e->device));
-    GRV_HIP(e, launch_spectrum_lut(d_out, (uint32_t)width, (uint32_t)height, max_temp,
-                                   static_cast<hipStream_t>(stream)));
-    return GRV_OK;
-}
-
-int grv_generate_spectrum_lut(grv_engine *e, size_t width, size_t height, double max_temp,
-                              float *out_host) {
-    if (!e) return GRV_ERR_INVALID;
-    if (!out_host || width == 0 || height == 0 || width * height > (1ull << 26))
-        return fail(e, GRV_ERR_INVALID, "bad LUT request");
-    GRV_HIP(e, hipSetDevice(e->device));
-    const size_t bytes = width * height * 4 * sizeof(float);
-    int rc = ensure_stage(e, bytes);
-    if (rc != GRV_OK) return rc;
-    rc = grv_generate_spectrum_lut_device(e, width, height, max_temp, static_cast<float *>(e->stage_mem), nullptr);
-    if (rc != GRV_OK) return rc;
-    GRV_HIP(e, hipDeviceSynchronize());
-    GRV_HIP(e, hipMemcpy(out_host, e->stage_mem, bytes, hipMemcpyDeviceToHost));
-    return GRV_OK;
-}
-
-const float *grv_get_sab_ptr(const grv_engine *e) { return e ? e->sab.data() : nullptr; }
-
-int grv_attach_sab(grv_engine *e, float *ptr) {
-    if (!e) return GRV_ERR_INVALID;
-    e->sab_ext = ptr;
-    return GRV_OK;
-}
-
-void grv_set_camera_state(grv_engine *e, double px, double py, double pz) {
-    if (!e) return;
-    e->camera.position[0] = px;
-    e->camera.position[1] = py;
-    e->camera.position[2] = pz;
-}
-
-void grv_set_auto_spin(grv_engine *e, int enabled) {
-    if (e) e->camera.auto_spin = enabled != 0;
-}
-
-int grv_tick_sab(grv_engine *e, double dt_override) {
-    if (!e) return GRV_ERR_INVALID;
-    tick_sab_host(e->sab_block(), e->mass, e->spin, e->spin_c, event_horizon(e->mass, e->spin_c),
-                  isco_prograde(e->mass, e->spin_c), e->camera, e->last_good_camera, dt_override);
-    return GRV_OK;
-}
-
-double grv_compute_disk_flux(const grv_engine *e, double r) {
-    return page_thorne_flux_host(r, e->mass, e->spin_c, 1.0);
-}
-
-double grv_compute_shadow_radius(const grv_engine *e) { return schwarzschild_shadow_radius_host(e->mass); }
-
-size_t grv_compute_shadow_curve(const grv_engine *e, double theta_obs, size_t n_points, float *out) {
-    if (!e || !out) return 0;
-    const std::vector<double> c = bardeen_shadow_host(e->mass, e->spin_c, theta_obs, n_points);
-    for (size_t i = 0; i < c.size(); ++i) out[i] = (float)c[i];
-    return c.size() / 2;
-}
-
-int grv_compute_shadow_shift(const grv_engine *e, double theta_obs, float out2[2]) {
-    if (!e || !out2) return GRV_ERR_INVALID;
-    const std::vector<double> c = bardeen_shadow_host(e->mass, e->spin_c, theta_obs, 32);
-    double lo = 0.0, hi = 0.0;
-    if (!c.empty()) {
-        lo = hi = c[0];
-        for (size_t i = 0; i < c.size(); i += 2) {
-            lo = c[i] < lo ? c[i] : lo;
-            hi = c[i] > hi ? c[i] : hi;
-        }
-    }
-    out2[0] = (float)lo;
-    out2[1] = (float)hi;
-    return GRV_OK;
-}
-
-int grv_generate_disk_lut(grv_engine *e, float *out512) {
-    if (!e) return GRV_ERR_INVALID;
-    if (!out512) return fail(e, GRV_ERR_INVALID, "null output");
-    GRV_HIP(e, hipSetDevice(e->device));
-    const uint32_t w = 512; // lut_width, lib.rs:65
-    int rc = ensure_stage(e, 4096 + w * sizeof(double));
-    if (rc != GRV_OK) return rc;
-    float *d_out = static_cast<float *>(e->stage_mem);
-    double *d_tmp = reinterpret_cast<double *>(static_cast<char *>(e->stage_mem) + 4096);
-    GRV_HIP(e, launch_disk_temperature_lut(d_out, d_tmp, w, e->mass, e->spin_c, nullptr));
-    GRV_HIP(e, hipDeviceSynchronize());
-    GRV_HIP(e, hipMemcpy(out512, d_out, w * sizeof(float), hipMemcpyDeviceToHost));
-    std::memcpy(e->disk_lut.data(), out512, w * sizeof(float)); // self.lut_buffer = ... (lib.rs:108)
-    return GRV_OK;
-}
-
-const float *grv_get_disk_lut_ptr(const grv_engine *e) { return e ? e->disk_lut.data() : nullptr; }
-
-// ---- spacetime read-outs (spacetime_viz.hip) ----
-
-double grv_compute_kretschner(const grv_engine *e, double r, double theta) {
-    return e ? viz_kretschner(viz_hole(e), r, theta) : NAN;
-}
-double grv_compute_light_cone_tilt(const grv_engine *e, double r, double theta) {
-    return e ? viz_light_cone_tilt(viz_hole(e), r, theta) : NAN;
-}
-double grv_compute_frame_drag_omega(const grv_engine *e, double r, double theta) {
-    return e ? viz_frame_drag_omega(viz_hole(e), r, theta) : NAN;
-}
-double grv_compute_flamm_height(const grv_engine *e, double r) {
-    return e ? viz_flamm_height(r, e->mass) : NAN;
-}
-double grv_compute_proper_distance(const grv_engine *e, double r1, double r2, size_t n_steps) {
-    return e ? viz_proper_distance(viz_hole(e), r1, r2, n_steps) : NAN;
-}
-
-int grv_generate_field(grv_engine *e, int field, double r_min, double r_max, size_t n_radial,
-                       size_t n_polar, float *out) {
-    if (e && (field < GRV_FIELD_CURVATURE || field > GRV_FIELD_FRAME_DRAG))
-        return fail(e, GRV_ERR_INVALID, "unknown field %d", field);
-    return viz_grid(e, n_radial, n_polar, out, [&](float *d) {
-        return launch_viz_field(field, viz_hole(e), r_min, r_max, (uint32_t)n_radial,
-                                (uint32_t)n_polar, d, nullptr);
-    });
-}
-
-int grv_generate_embedding_mesh(grv_engine *e, double r_min, double r_max, size_t n_radial,
-                                size_t n_angular, float *out) {
-    return viz_grid(e, n_radial, n_angular, out, [&](float *d) {
-        return launch_embedding_mesh(viz_hole(e), r_min, r_max, (uint32_t)n_radial,
-                                     (uint32_t)n_angular, d, nullptr);
-    });
-}
-
-int grv_generate_ergosphere_mesh(grv_engine *e, size_t n_polar, size_t n_azimuthal, float *out) {
-    return viz_grid(e, n_polar, n_azimuthal, out, [&](float *d) {
-        return launch_ergosphere_mesh(viz_hole(e), (uint32_t)n_polar, (uint32_t)n_azimuthal, d,
-                                      nullptr);
-    });
-}
-
-void grv_get_sab_layout(size_t out5[5]) {
-    if (!out5) return;
-    out5[0] = kOffControl;
-    out5[1] = kOffCamera;
-    out5[2] = kOffPhysics;
-    out5[3] = kOffTelemetry;
-    out5[4] = kOffLuts;
 }
 
 } // extern "C"

@@ -1,0 +1,135 @@
+// engine_internal.hpp -- the engine object and the host helpers shared by the translation
+// units that implement the C ABI of include/gravitas_abi.h:
+//   engine.hip          lifecycle, closed forms, batch / single-ray / frame entry points
+//   engine_shaders.hip  f32 shader frames, post chain, the two renderers
+//   engine_control.hip  LUTs, disk / shadow helpers, SAB protocol, spacetime read-outs
+// One engine == one `PhysicsEngine` (physics-engine/gravitas-wasm/src/lib.rs:42-54) bound to one
+// HIP device.  No CPU compute path exists: every integrate / render / LUT entry point launches
+// HIP kernels and fails with a status code if the device is missing.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "control_plane.hpp"
+#include "engine_types.hpp"
+#include "spacetime_viz.hpp"
+
+struct grv_engine {
+    int device = 0;
+    double mass = 1.0;
+    double spin = 0.0;   // as given (lib.rs:44-45)
+    double spin_c = 0.0; // clamped copy held by the metrics (kerr.rs:48-63)
+    int n_cu = 256;
+    std::string err;
+
+    // ray workspace (device)
+    void *ws_mem = nullptr;
+    size_t ws_slots = 0;
+    grvhip::RayWorkspace ws{};
+    uint32_t *live[2] = {nullptr, nullptr};
+    uint32_t *d_counters = nullptr; // [0],[1] live counts (ping-pong)
+    grvhip::FrameStatsDev *d_stats = nullptr;
+    uint32_t *h_counters = nullptr; // pinned
+    grvhip::FrameStatsDev *h_stats = nullptr; // pinned
+
+    // staging buffers for host-pointer entry points
+    void *stage_mem = nullptr;
+    size_t stage_bytes = 0;
+
+    // cached spectrum LUT (device)
+    float *d_lut = nullptr;
+    uint32_t lut_w = 0, lut_h = 0;
+    double lut_tmax = 0.0;
+
+    // last-frame bookkeeping
+    uint32_t last_launches = 0;
+    float last_ms[5] = {0, 0, 0, 0, 0};
+    hipEvent_t ev[8] = {};
+    bool ev_ok = false;
+
+    // renderer layer (grv_webgpu_render / grv_webgl_render): full-size RGBA f32 targets
+    struct Targets {
+        float *mem = nullptr; // [3][h][w][4]: scene / compute texture, history ping, history pong
+        uint32_t w = 0, h = 0;
+        uint32_t hist = 0;   // webgpu: currentHistoryIndex; webgl: currentWriteIndex
+        uint32_t frames = 0; // frameCount
+    } rt;
+    void *post_mem = nullptr; // bloom render targets (bright, blur ping/pong)
+    size_t post_bytes = 0;
+    uint8_t *d_noise = nullptr; // [2][256*256] R planes: u_noiseTex, u_blueNoiseTex
+    std::vector<float> disk_lut = std::vector<float>(512, 0.0f); // lut_buffer (lib.rs:50, 65-66)
+    std::vector<float> sab;
+    float *sab_ext = nullptr; // attach_sab (lib.rs:74)
+    grvhip::CameraFilter camera, last_good_camera;
+    float *sab_block() { return sab_ext ? sab_ext : sab.data(); }
+};
+
+namespace grvhost {
+
+using namespace grvhip;
+
+int fail(grv_engine *e, int code, const char *fmt, ...);
+
+#define GRV_HIP(e, call)                                                                   \
+    do {                                                                                   \
+        hipError_t _st = (call);                                                           \
+        if (_st != hipSuccess)                                                             \
+            return fail((e), _st == hipErrorOutOfMemory ? GRV_ERR_OOM : GRV_ERR_HIP,        \
+                        "%s failed: %s", #call, hipGetErrorString(_st));                   \
+    } while (0)
+
+// closed forms (host scalars; gravitas-core/src/metric/{mod,kerr}.rs)
+double event_horizon(double m, double spin);
+double isco_prograde(double m, double a_star);
+double photon_sphere(double m, double a_star);
+double dilation(double m, double a_star, double r);
+double g_factor(double r, double mass, double spin, double lambda);
+
+int ensure_workspace(grv_engine *e, size_t slots);
+int ensure_stage(grv_engine *e, size_t bytes);
+int ensure_lut(grv_engine *e, uint32_t w, uint32_t h, double tmax, hipStream_t s);
+SegmentParams make_segment_params(const grv_engine *e, const GrvOptions &o);
+bool options_valid(const GrvOptions &o);
+int run_segments(grv_engine *e, const GrvOptions &o, SegmentParams P, uint32_t seg_tries, hipStream_t s,
+                 bool profile);
+void frame_geometry(const GrvRenderParams &p, FrameGeom &G);
+void stats_to_abi(const grv_engine *e, const FrameStatsDev &d, GrvFrameStats *out);
+
+// SAB offsets in f32 elements (lib.rs:36-40)
+constexpr size_t kOffControl = 0, kOffCamera = 64, kOffPhysics = 128, kOffTelemetry = 256, kOffLuts = 2048;
+
+template <typename Launch>
+int run_shader_frame(grv_engine *e, uint32_t width, uint32_t height, uint32_t tw, uint32_t tr,
+                     uint64_t *total_steps, hipStream_t s, Launch &&launch) {
+    if (width == 0 || height == 0) return fail(e, GRV_ERR_INVALID, "empty frame");
+    if (tw > 1 && tr >= tw) return fail(e, GRV_ERR_INVALID, "tile_rank >= tile_world");
+    GRV_HIP(e, hipSetDevice(e->device));
+    GrvRenderParams q{};
+    q.width = width;
+    q.height = height;
+    q.tile_world = tw;
+    q.tile_rank = tr;
+    FrameGeom G;
+    frame_geometry(q, G);
+    const size_t slots = (size_t)G.n_tiles_local * 4096u;
+    GRV_HIP(e, hipMemsetAsync(e->d_stats, 0, sizeof(FrameStatsDev), s));
+    if (slots > 0x7FFFFFFFull) return fail(e, GRV_ERR_INVALID, "frame too large for one rank");
+    GRV_HIP(e, launch(G, (uint32_t)slots, &e->d_stats->accepted_steps));
+    if (total_steps) {
+        GRV_HIP(e, hipMemcpyAsync(e->h_stats, e->d_stats, sizeof(FrameStatsDev), hipMemcpyDeviceToHost, s));
+        GRV_HIP(e, hipStreamSynchronize(s));
+        *total_steps = e->h_stats->accepted_steps;
+    }
+    return GRV_OK;
+}
+
+} // namespace grvhost
