@@ -23,6 +23,7 @@ void grv_wgsl_params_default(uint32_t width, uint32_t height, const GrvCamera *c
     p->spin = (float)spin;
     p->max_steps = 150; // compute.wgsl.ts:13
     p->tile_world = 1;
+    p->stars = 1;
 }
 
 void grv_glsl_params_default(uint32_t width, uint32_t height, double mass, double spin,
@@ -98,6 +99,7 @@ int grv_render_frame_wgsl(grv_engine *e, const GrvWgslParams *p, float *d_rgba, 
     P.jitter[0] = p->jitter[0];
     P.jitter[1] = p->jitter[1];
     P.max_steps = p->max_steps;
+    P.stars = p->stars;
     hipStream_t s = static_cast<hipStream_t>(stream);
     return run_shader_frame(e, p->width, p->height, p->tile_world, p->tile_rank, total_steps, s,
                             [&](const FrameGeom &G, uint32_t n, unsigned long long *tot) {
@@ -290,6 +292,7 @@ int grv_webgpu_render(grv_engine *e, const float *cu, const float *pp, int32_t m
     wp.max_steps = max_steps > 0 ? max_steps : 150;
     wp.tile_world = 1;
     wp.arith = arith;
+    wp.stars = 1;
     rc = grv_render_frame_wgsl(e, &wp, compute_tex, nullptr, nullptr, stream);
     if (rc != GRV_OK) return rc;
     GRV_HIP(e, launch_post_quantize(compute_tex, w * h, s)); // texture_storage_2d<rgba16float>

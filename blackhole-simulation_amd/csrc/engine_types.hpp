@@ -77,6 +77,7 @@ struct WgslParams {
     float mass, spin;
     float jitter[2];
     int32_t max_steps;
+    int32_t stars; // escape-branch star hash on/off
 };
 struct GlslParams {
     float mass, spin, zoom;

@@ -13,8 +13,9 @@
 //       Kerr-shadow guide, ACES (fragment.glsl.ts:197-333).  ShaderManager's #defines
 //       (manager.ts:61-82) are GlslParams::features bits.
 //
-// Not reproducible in the reference and therefore fixed here: WGSL star hash
-// (omitted); the two GLSL noise textures are Math.random() upstream -- here they are
+// WGSL star hash (compute.wgsl.ts:201-204): restated with sinf; fract(sin * 43758.5) turns the
+// last ulp of sin into 5e-3, so a few star pixels can differ between libms (WgslParams::stars).
+// Not reproducible in the reference and therefore fixed here: the two GLSL noise textures are Math.random() upstream -- here they are
 // engine-owned seeded 256x256 byte planes (grv_set_glsl_noise), sampled with f32 weights.
 // One thread per pixel, registers only; a wave is one 8x8 pixel block (compute.wgsl.ts:147).
 #pragma once
@@ -179,7 +180,15 @@ __global__ __launch_bounds__(kBlock) void wgsl_symplectic_kernel(FrameGeom G, Wg
         for (int i = 0; i < P.max_steps; ++i) {
             const float r = s.r;
             if (r < rh * 1.001f) break;
-            if (r > 100.0f) break;
+            if (r > 100.0f) { // compute.wgsl.ts:199-206
+                if (P.stars) {
+                    const F3 vdir = normalize_f3(F3{s.pr, s.pth / r, s.pph / (r * safe_st)});
+                    const float sn = sinf(vdir.x * 12.9898f + vdir.y * 78.233f + vdir.z * 45.164f) * 43758.5453f;
+                    if (sn - floorf(sn) > 0.999f)
+                        for (int c = 0; c < 3; ++c) col[c] += 1.0f * (1.0f - alpha);
+                }
+                break;
+            }
             const float prev_theta = s.th;
             const float h = clampf_d((r - rh) * 0.15f, 0.05f, 1.0f);
             s = wgsl_symplectic(s, h, M, P.spin);

@@ -144,7 +144,16 @@ __global__ __launch_bounds__(kBlock) void wgsl_symplectic_fast_kernel(FrameGeom 
         float alpha = 0.0f;
         for (int i = 0; i < P.max_steps; ++i) {
             if (r < r_stop) break;
-            if (r > 100.0f) break;
+            if (r > 100.0f) { // star hash of the escape branch, compute.wgsl.ts:199-206
+                if (P.stars) {
+                    const float sx = p_r, sy = p_th / r, sz = p_ph / (r * fmaxf(st, 1e-4f));
+                    const float inv = __builtin_amdgcn_rsqf(sx * sx + sy * sy + sz * sz);
+                    const float sn = sinf((sx * 12.9898f + sy * 78.233f + sz * 45.164f) * inv) * 43758.5453f;
+                    if (sn - floorf(sn) > 0.999f)
+                        for (int k = 0; k < 3; ++k) col[k] += 1.0f * (1.0f - alpha);
+                }
+                break;
+            }
             const float r_before = r, th_before = th;
             const float h = fminf(fmaxf((r - rh) * 0.15f, 0.05f), 1.0f);
             const float hh = 0.5f * h;

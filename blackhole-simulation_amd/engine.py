@@ -62,7 +62,8 @@ class WgslParams(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("inv_view", C.c_float * 16),
                 ("inv_proj", C.c_float * 16), ("position", C.c_float * 3), ("mass", C.c_float),
                 ("spin", C.c_float), ("jitter", C.c_float * 2), ("max_steps", C.c_int32),
-                ("tile_world", C.c_uint32), ("tile_rank", C.c_uint32), ("arith", C.c_int32)]
+                ("tile_world", C.c_uint32), ("tile_rank", C.c_uint32), ("arith", C.c_int32),
+                ("stars", C.c_int32)]
 
 
 class GlslParams(C.Structure):

@@ -184,6 +184,7 @@ typedef struct { /* src/shaders/compute.wgsl.ts + types.wgsl.ts:6-30 */
     uint32_t tile_world, tile_rank;
     int32_t arith;           /* GRV_ARITH_STRICT: the shader's operation order;
                                 GRV_ARITH_FAST: same equations, shared reciprocal + FMA (f32 rounding only) */
+    int32_t stars;           /* 1 (default): the escape-branch star hash, compute.wgsl.ts:199-206 */
 } GrvWgslParams;
 
 /* ShaderManager's #defines (src/shaders/manager.ts:61-82) as GrvGlslParams.features bits */

@@ -70,7 +70,7 @@ class WgslParams(C.Structure):
     _fields_ = [("inv_view", C.c_float * 16), ("inv_proj", C.c_float * 16),
                 ("position", C.c_float * 3), ("mass", C.c_float), ("spin", C.c_float),
                 ("width", C.c_uint32), ("height", C.c_uint32), ("jitter", C.c_float * 2),
-                ("max_steps", C.c_int32)]
+                ("max_steps", C.c_int32), ("stars", C.c_int32)]
 
 
 class GlslParams(C.Structure):
@@ -390,6 +390,7 @@ def wgsl_params_from(gp):
     o.mass, o.spin, o.width, o.height = gp.mass, gp.spin, gp.width, gp.height
     o.jitter[0], o.jitter[1] = gp.jitter[0], gp.jitter[1]
     o.max_steps = gp.max_steps
+    o.stars = gp.stars
     return o
 
 

@@ -5,7 +5,9 @@
  * Restated as written: every formula of the cited shader lines, in f32, in the
  * shader's evaluation order.  Deliberately fixed (the reference is not
  * reproducible there):
- *   - WGSL star hash (compute.wgsl.ts:201-204): omitted, background = 0;
+ *   - WGSL star hash (compute.wgsl.ts:201-204): fract(sin(.) * 43758.5453) amplifies the last
+ *     ulp of sin by 4e4 -- restated with sinf, a handful of star pixels may flip between libms
+ *     (inside the statistical tolerance); `stars = 0` skips it;
  *   - GLSL noise textures (webgl-utils.ts:259-305 fills them with Math.random()): the caller
  *     supplies the two 256x256 R channels (orc_seeded_noise_rgba8 makes seeded ones);
  *     hash() = texture(u_noiseTex, (uv+0.5)/256).r with LINEAR/REPEAT is evaluated with f32
@@ -190,7 +192,17 @@ uint32_t orc_wgsl_pixel(const orc_wgsl_params *P, uint32_t ix, uint32_t iy, floa
     for (int i = 0; i < P->max_steps; i++) {
         float r = s.x[1];
         if (r < rh * 1.001f) break;
-        if (r > 100.0f) break; /* stars omitted */
+        if (r > 100.0f) { /* compute.wgsl.ts:199-206 */
+            if (P->stars) {
+                v3 vdir = {s.p[1], s.p[2] / r, s.p[3] / (r * safe_st)};
+                vdir = normalize3(vdir);
+                float sn = sinf(vdir.x * 12.9898f + vdir.y * 78.233f + vdir.z * 45.164f) * 43758.5453f;
+                float star = sn - floorf(sn); /* fract */
+                if (star > 0.999f)
+                    for (int c = 0; c < 3; c++) color[c] += 1.0f * (1.0f - alpha);
+            }
+            break;
+        }
         float prev_theta = s.x[2];
         float h = clampf((r - rh) * 0.15f, 0.05f, 1.0f);
         s = wgsl_symplectic(&s, h, M, P->spin);

@@ -26,6 +26,7 @@ typedef struct {
     uint32_t width, height;
     float jitter[2];    /* halton(frame)-0.5, in pixels (compute.wgsl.ts:154-157) */
     int32_t max_steps;  /* override MAX_STEPS (compute.wgsl.ts:13) */
+    int32_t stars;      /* 1: the escape-branch star hash of compute.wgsl.ts:201-204; 0: skipped */
 } orc_wgsl_params;
 
 /* one pixel; rgba[4]; returns the number of symplectic steps taken */

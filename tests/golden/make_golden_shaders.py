@@ -49,7 +49,7 @@ def post_image(seed=7, h=24, w=40, hdr=4.0):
 def main():
     out = {}
     cam = bh.camera_look_at(EYE, aspect=W / H)
-    gp = bh.wgsl_params(W, H, cam, 1.0, 0.999, max_steps=300)
+    gp = bh.wgsl_params(W, H, cam, 1.0, 0.999, max_steps=300, stars=0)
     gp.jitter[0], gp.jitter[1] = 0.0, -1.0 / 6.0
     rgba, steps = po.wgsl_frame(po.wgsl_params_from(gp), nthreads=4)
     out["wgsl_rgba"], out["wgsl_steps"] = rgba, steps

@@ -31,7 +31,7 @@ def _same_frame(rgba, steps, g_rgba, g_steps, exact):
 
 def test_oracle_reproduces_shader_golden(oracle, engine_mod, gold):
     cam = engine_mod.camera_look_at(G.EYE, aspect=G.W / G.H)
-    gp = engine_mod.wgsl_params(G.W, G.H, cam, 1.0, 0.999, max_steps=300)
+    gp = engine_mod.wgsl_params(G.W, G.H, cam, 1.0, 0.999, max_steps=300, stars=0)
     gp.jitter[0], gp.jitter[1] = 0.0, -1.0 / 6.0
     rgba, steps = oracle.wgsl_frame(oracle.wgsl_params_from(gp), nthreads=4)
     _same_frame(rgba, steps, gold["wgsl_rgba"], gold["wgsl_steps"], True)
@@ -66,7 +66,7 @@ def test_shader_kernels_against_golden(engine_mod, gold, arith):
         return rgba.cpu().numpy().reshape(G.H, G.W, 4), steps.cpu().numpy().reshape(G.H, G.W).astype(np.uint32)
     with engine_mod.PhysicsEngine(1.0, 0.9) as e:
         cam = engine_mod.camera_look_at(G.EYE, aspect=G.W / G.H)
-        gp = engine_mod.wgsl_params(G.W, G.H, cam, 1.0, 0.999, max_steps=300, arith=arith)
+        gp = engine_mod.wgsl_params(G.W, G.H, cam, 1.0, 0.999, max_steps=300, arith=arith, stars=0)
         gp.jitter[0], gp.jitter[1] = 0.0, -1.0 / 6.0
         e.render_frame_wgsl(gp, rgba, steps)
         _same_frame(*grab(), gold["wgsl_rgba"], gold["wgsl_steps"], False)

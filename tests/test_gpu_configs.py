@@ -57,7 +57,7 @@ def test_config2_1080p_fixed_step_f32(engine_mod, oracle):
         steps = torch.zeros(n, dtype=torch.int32, device="cuda:0")
         for name in ("wgsl", "glsl"):
             if name == "wgsl":
-                gp = bh.wgsl_params(W, H, cam, 1.0, 0.999, max_steps=512)
+                gp = bh.wgsl_params(W, H, cam, 1.0, 0.999, max_steps=512, stars=0)
                 tot = e.render_frame_wgsl(gp, rgba, steps)
                 ref_rgba, ref_steps = oracle.wgsl_frame(oracle.wgsl_params_from(gp), stride=(6, 6), nthreads=8)
             else:

@@ -14,7 +14,7 @@ EYE = (60.0 * np.sin(np.deg2rad(97.0)), 60.0 * np.cos(np.deg2rad(97.0)), 0.0)
 def test_wgsl_oracle_frame_is_sane(oracle, engine_mod):
     W, H = 96, 54
     cam = engine_mod.camera_look_at(EYE, aspect=W / H)
-    gp = engine_mod.wgsl_params(W, H, cam, 1.0, 0.9, max_steps=512)
+    gp = engine_mod.wgsl_params(W, H, cam, 1.0, 0.9, max_steps=512, stars=0)
     rgba, steps = oracle.wgsl_frame(oracle.wgsl_params_from(gp), nthreads=4)
     assert rgba.shape == (H, W, 4) and np.all(rgba[..., 3] == 1.0) and np.all(np.isfinite(rgba))
     assert steps.max() <= 512 and steps.min() >= 1
@@ -22,6 +22,25 @@ def test_wgsl_oracle_frame_is_sane(oracle, engine_mod):
     assert 0.02 < lit.mean() < 0.6               # the disk is visible, the sky is black
     # the image of an equatorial disk seen from 97 deg is brighter on the approaching side
     assert rgba[..., 0].max() > 0.1
+
+
+def test_wgsl_star_hash_density(oracle, engine_mod):
+    """compute.wgsl.ts:199-206: fract(sin(dot(v, k)) * 43758.5453) > 0.999 lights ~0.1 % of the
+    escaping rays.  The hash turns the last ulp of its argument into O(1), so the star *pattern*
+    cannot be compared between implementations -- its density can."""
+    W, H = 256, 144
+    cam = engine_mod.camera_look_at(EYE, aspect=W / H)
+    on = engine_mod.wgsl_params(W, H, cam, 1.0, 0.9, max_steps=512)
+    assert on.stars == 1                                        # the shader always has them
+    off = engine_mod.wgsl_params(W, H, cam, 1.0, 0.9, max_steps=512, stars=0)
+    a, sa = oracle.wgsl_frame(oracle.wgsl_params_from(on), nthreads=4)
+    b, sb = oracle.wgsl_frame(oracle.wgsl_params_from(off), nthreads=4)
+    assert np.array_equal(sa, sb)
+    star = (a[..., 0] - b[..., 0]) > 0.5
+    dark = b[..., :3].sum(-1) == 0
+    assert not (star & ~dark).any() or (a[star & ~dark] <= b[star & ~dark] + 1.0).all()
+    frac = star.sum() / max(dark.sum(), 1)
+    assert 2e-4 < frac < 4e-3, frac
 
 
 def test_glsl_oracle_frame_is_sane(oracle, engine_mod):
@@ -117,7 +136,7 @@ def test_wgsl_kernel_matches_oracle(engine_mod, oracle, spin, max_steps, arith):
     import torch
     W, H = 480, 270
     cam = engine_mod.camera_look_at(EYE, aspect=W / H)
-    gp = engine_mod.wgsl_params(W, H, cam, 1.0, spin, max_steps=max_steps, arith=arith)
+    gp = engine_mod.wgsl_params(W, H, cam, 1.0, spin, max_steps=max_steps, arith=arith, stars=0)
     gp.jitter[0], gp.jitter[1] = 0.0, -1.0 / 6.0        # frame-0 Halton jitter
     n = W * H
     with engine_mod.PhysicsEngine(1.0, spin) as e:
@@ -127,6 +146,27 @@ def test_wgsl_kernel_matches_oracle(engine_mod, oracle, spin, max_steps, arith):
     ref_rgba, ref_steps = oracle.wgsl_frame(oracle.wgsl_params_from(gp), nthreads=8)
     assert tot == int(steps.sum().item())
     _compare(rgba.cpu().numpy().reshape(H, W, 4), steps.cpu().numpy().reshape(H, W), ref_rgba, ref_steps)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arith", [0, 1])
+def test_wgsl_kernel_star_density(engine_mod, arith):
+    import torch
+    W, H = 960, 540
+    cam = engine_mod.camera_look_at(EYE, aspect=W / H)
+    out = {}
+    with engine_mod.PhysicsEngine(1.0, 0.9) as e:
+        for stars in (1, 0):
+            gp = engine_mod.wgsl_params(W, H, cam, 1.0, 0.9, max_steps=512, arith=arith, stars=stars)
+            rgba = torch.zeros(W * H, 4, dtype=torch.float32, device="cuda:0")
+            e.render_frame_wgsl(gp, rgba)
+            torch.cuda.synchronize()
+            out[stars] = rgba.cpu().numpy()
+    star = (out[1][:, 0] - out[0][:, 0]) > 0.5
+    dark = out[0][:, :3].sum(-1) == 0
+    frac = star.sum() / dark.sum()
+    assert 1e-4 < frac < 4e-3, frac        # sparse: of the order of 0.1 % of the dark sky
+    assert np.array_equal(out[1][~star], out[0][~star])
 
 
 @pytest.mark.gpu
