@@ -1,0 +1,112 @@
+/* Type declarations of the addon, shaped like the .d.ts wasm-pack emits for
+ * `#[wasm_bindgen] impl PhysicsEngine` (physics-engine/gravitas-wasm/src/lib.rs:56-465), plus the
+ * frame surfaces this engine adds.  Numbers are f64 on the Rust side unless noted. */
+
+export interface InitOutput {
+  /** one module-wide arena; `new Float32Array(memory.buffer, engine.get_sab_ptr(), 2048)` works as
+   *  with WebAssembly.Memory (src/workers/physics.worker.ts:61-68) */
+  readonly memory: { readonly buffer: ArrayBuffer };
+}
+
+export default function init(): Promise<InitOutput>;
+export function init_hooks(): void;
+
+export interface RenderFrameOptions {
+  width: number;
+  height: number;
+  /** camera position; looks at `target` (default origin) with `up` (default +y) */
+  eye?: [number, number, number];
+  target?: [number, number, number];
+  up?: [number, number, number];
+  /** vertical field of view in degrees (default 60, WebGPUCanvas.tsx:143-151) */
+  fovY?: number;
+  maxSteps?: number;
+  tolerance?: number;
+  /** 0 endpoints only, 1 thin-disk (T x g) Planck-LUT shading */
+  shading?: number;
+  arith?: "fast" | "strict";
+}
+
+export interface RenderFrameResult {
+  /** linear RGBA f32, row-major, top row first */
+  rgba: Float32Array;
+  width: number;
+  height: number;
+  rays: number;
+  acceptedSteps: number;
+  launches: number;
+}
+
+export interface WebGLFrameOptions {
+  width: number;
+  height: number;
+  mass?: number;
+  spin?: number;
+  zoom?: number;
+  mouse?: [number, number];
+  time?: number;
+  maxRaySteps?: number;
+  /** ShaderManager #defines as bits (include/gravitas_abi.h GRV_GLSL_*) */
+  features?: number;
+  bloom?: number;
+  cameraMoving?: number;
+  fast?: number;
+}
+
+export class PhysicsEngine {
+  constructor(mass: number, spin: number);
+  free(): void;
+
+  update_params(mass: number, spin: number): void;
+  compute_horizon(): number;
+  compute_isco(): number;
+  compute_photon_sphere(): number;
+  compute_dilation(r: number): number;
+  compute_g_factor(r: number, lambda: number): number;
+
+  /** lib.rs:422-464; input shorter than 8 is echoed */
+  integrate_ray_relativistic(
+    initial_state: Float64Array | number[], steps: number, tolerance: number, use_kerr_schild: boolean,
+  ): Float64Array;
+  /** the name BASELINE's north star uses for the same entry */
+  integratePhotonGeodesic(
+    initial_state: Float64Array | number[], steps: number, tolerance: number, use_kerr_schild: boolean,
+  ): Float64Array;
+
+  generate_disk_lut(): Float32Array;
+  get_disk_lut_ptr(): number;
+  generate_spectrum_lut(width: number, height: number, max_temp: number): Float32Array;
+
+  get_sab_ptr(): number;
+  get_sab_layout(): number[];
+  set_camera_state(px: number, py: number, pz: number, lx: number, ly: number, lz: number): void;
+  set_auto_spin(enabled: boolean): void;
+  tick_sab(dt_override: number): void;
+
+  compute_shadow_curve(theta_obs: number, n_points: number): Float32Array;
+  compute_shadow_radius(): number;
+  compute_shadow_shift(theta_obs: number): Float32Array;
+  compute_disk_flux(r: number): number;
+
+  generate_embedding_mesh(r_min: number, r_max: number, n_radial: number, n_angular: number): Float32Array;
+  generate_ergosphere_mesh(n_polar: number, n_azimuthal: number): Float32Array;
+  compute_kretschner(r: number, theta: number): number;
+  generate_curvature_field(r_min: number, r_max: number, n_radial: number, n_polar: number): Float32Array;
+  compute_light_cone_tilt(r: number, theta: number): number;
+  generate_tilt_field(r_min: number, r_max: number, n_radial: number, n_polar: number): Float32Array;
+  compute_frame_drag_omega(r: number, theta: number): number;
+  generate_frame_drag_field(r_min: number, r_max: number, n_radial: number, n_polar: number): Float32Array;
+  compute_flamm_height(r: number): number;
+  compute_proper_distance(r1: number, r2: number, n_steps: number): number;
+
+  /** f64 RKF45 frame (pixel -> ray of compute.wgsl.ts:159-187) */
+  renderFrame(options: RenderFrameOptions): RenderFrameResult;
+  render_frame(options: RenderFrameOptions): RenderFrameResult;
+  /** WebGPURenderer.render with the 352-byte / 32-byte uniform blocks (src/types/webgpu.ts:67-116) */
+  renderWebGPUFrame(
+    cameraUniforms: Float32Array, physicsParams: Float32Array,
+    options?: { maxSteps?: number; arith?: "fast" | "strict" },
+  ): Float32Array;
+  /** WebGLRenderer.render's scene + TAA + bloom chain */
+  renderWebGLFrame(options: WebGLFrameOptions): Float32Array;
+}

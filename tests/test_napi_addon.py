@@ -53,6 +53,18 @@ def test_addon_loads_and_exports_the_wasm_bindgen_surface():
     assert not missing, missing
 
 
+def test_type_declarations_match_the_addon():
+    """napi/shim/blackhole_physics.d.ts (what wasm-pack would emit) declares what the addon exports."""
+    dts = open(os.path.join(ROOT, "napi", "shim", "blackhole_physics.d.ts")).read()
+    cls = dts[dts.index("export class PhysicsEngine"):]
+    declared = set(re.findall(r"^  (\w+)\(", cls, flags=re.M)) - {"constructor"}
+    r = _node("const m=require(%r);console.log(JSON.stringify(Object.getOwnPropertyNames("
+              "m.PhysicsEngine.prototype)))" % ADDON)
+    assert r.returncode == 0, r.stderr
+    have = set(json.loads(r.stdout)) - {"constructor"}
+    assert declared == have, (declared ^ have)
+
+
 def test_method_list_is_the_reference_ffi(oracle):
     """WASM_METHODS above is checked against the reference source when it is mounted."""
     src = "/root/reference/physics-engine/gravitas-wasm/src/lib.rs"
