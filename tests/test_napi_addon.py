@@ -53,6 +53,21 @@ def test_addon_loads_and_exports_the_wasm_bindgen_surface():
     assert not missing, missing
 
 
+def test_esm_shim_reexports_the_addon(tmp_path):
+    """napi/shim/blackhole_physics.js is what replaces public/wasm/blackhole_physics.js: the
+    consumers' `import init, { PhysicsEngine } from "blackhole-physics"` must keep working."""
+    script = tmp_path / "t.mjs"
+    script.write_text(
+        'import init, { PhysicsEngine, init_hooks } from "%s";\n'
+        'init().then((mod) => console.log(JSON.stringify({i: typeof init, c: typeof PhysicsEngine,'
+        ' h: typeof init_hooks, m: mod.memory.buffer.byteLength})));\n'
+        % os.path.join(ROOT, "napi", "shim", "blackhole_physics.js"))
+    r = subprocess.run([NODE, str(script)], capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert r.returncode == 0, r.stderr
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    assert got["i"] == got["c"] == got["h"] == "function" and got["m"] >= 2048 * 4
+
+
 def test_type_declarations_match_the_addon():
     """napi/shim/blackhole_physics.d.ts (what wasm-pack would emit) declares what the addon exports."""
     dts = open(os.path.join(ROOT, "napi", "shim", "blackhole_physics.d.ts")).read()
