@@ -137,3 +137,23 @@ def test_smoke_js_matches_oracle(oracle):
     assert res["frame"]["rays"] == 96 * 54 and res["frame"]["alpha0"] == 1.0
     assert res["frame"]["acceptedSteps"] == int(fr["steps"].sum())
     assert res["frame"]["lit"] == int((fr["rgba"].reshape(-1, 4)[:, :3].sum(axis=1) > 0).sum())
+
+
+@pytest.mark.gpu
+def test_worker_and_bridge_sab_protocol(oracle):
+    """napi/worker_protocol.js speaks physics.worker.ts's writer and physics-bridge.ts's seqlock
+    reader against the addon; every published tick must equal the oracle's tick_sab block."""
+    r = subprocess.run([NODE, os.path.join(ROOT, "napi", "worker_protocol.js")], capture_output=True,
+                       text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr + r.stdout
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["torn"] == 0 and [t["seq"] for t in res["ticks"]] == [2, 4, 6, 8]
+    o = oracle.sab_engine(1.0, 0.9)
+    o.camera.auto_spin = 1
+    o.camera.position[0], o.camera.position[1], o.camera.position[2] = 3.0, 4.0, 12.0
+    for k, t in enumerate(res["ticks"]):
+        o.sab[1], o.sab[3] = 0.5 * k, -0.1
+        want = oracle.tick_sab(o, 0.016)
+        assert t["finite"] and t["inputs_consumed"]
+        assert np.allclose(t["camera"], want[64:76], rtol=1e-6, atol=1e-6)
+        assert np.allclose(t["physics"], want[128:256], rtol=1e-6, atol=1e-6)
