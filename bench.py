@@ -222,6 +222,10 @@ def main():
                     "avg_launch_ms": round(avg_launch_ms, 4),
                     "launches_per_frame": launches_per_frame,
                     "algorithmic_bytes_per_launch": int(per_frame_bytes / launches_per_frame)}
+        if traffic and "valu" in traffic and args.arith == "fast" and not args.segment_tries:
+            # the honest secondary picture (committed PMC pass): the register-resident kernel is
+            # bound by FP64 VALU issue, not by HBM
+            roofline["valu_issue_frac"] = traffic["valu"]["issue_frac"]
         line = {
             "metric": "Mray-steps/s", "value": round(value, 2), "unit": "Mray-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -103,5 +103,12 @@ if f is not None and w is not None:
                                        "write_size_kib_avg_per_launch": w2,
                                        "hbm_bytes_per_launch": int((2.0 * f2 + w2) * 1024),
                                        "launches_per_frame": 32}
+    # what actually bounds the kernel: FP64 VALU issue.  SQ_INSTS_VALU wave-instructions x 4 cycles
+    # over 1024 SIMDs, against the elapsed cycles per XCD (GRBM_GUI_ACTIVE is summed over 8 XCDs)
+    insts, gui = _avg("pmc_sq", "SQ_INSTS_VALU"), _avg("pmc_sq", "GRBM_GUI_ACTIVE")
+    if insts and gui:
+        traffic["valu"] = {"sq_insts_valu_per_launch": insts, "cycles_per_xcd": gui / 8.0,
+                           "issue_frac": round(insts * 4.0 / 1024.0 / (gui / 8.0), 4),
+                           "note": "wave64 VALU instructions x 4 cycles / 1024 SIMDs / elapsed cycles"}
     open(os.path.join(DST, "traffic.json"), "w").write(json.dumps(traffic, indent=1))
     print(json.dumps(traffic, indent=1))
