@@ -143,3 +143,90 @@ def test_symplectic_and_rk4_agree_with_rkf45(oracle):
     xa, xb = np.array(oracle.state_to_list(a.final_state)), np.array(oracle.state_to_list(b.final_state))
     assert a.steps_taken == n and b.steps_taken == n
     assert np.max(np.abs(xa - xb)) < 1e-4
+
+
+def test_fehlberg_tableau_orders(oracle):
+    """Oracle-independent pin of the stepper's tableau (integrator.rs:113-190): against an
+    independently integrated solution (scipy DOP853 on the complex-step Hamilton equations above)
+    the 5th-order update's local error falls as h^6 and the embedded 4(5) estimate as h^5.
+    A mistyped node or weight breaks the orders."""
+    from scipy.integrate import solve_ivp
+    import ctypes as C
+    M, a = 1.0, 0.9
+    m = oracle.metric(oracle.KERR_KS, M, a)
+    v = [0, 12.0, 1.2, 0.3, -1.0, -0.7, 1.5, 3.0]
+    s0 = oracle.make_state(v)
+    oracle.lib().orc_renormalize_null(C.byref(s0), C.byref(m))
+    y0 = [s0.x[0], s0.x[1], s0.x[2], s0.x[3], s0.p[1], s0.p[2]]
+    errs, ests = [], []
+    hs = [0.8, 0.4, 0.2]
+    for h in hs:
+        out = oracle.State()
+        est = oracle.lib().orc_rkf45_step(C.byref(s0), C.byref(m), h, C.byref(out))
+        sol = solve_ivp(_rhs, [0.0, h], y0, method="DOP853", rtol=1e-13, atol=1e-15, args=(M, a, v[4], v[7]))
+        ye = sol.y[:, -1]
+        got = [out.x[0], out.x[1], out.x[2], out.x[3], out.p[1], out.p[2]]
+        errs.append(max(abs(g - e) for g, e in zip(got, ye)))
+        ests.append(est)
+    order_sol = [np.log2(errs[i] / errs[i + 1]) for i in range(2)]
+    order_est = [np.log2(ests[i] / ests[i + 1]) for i in range(2)]
+    assert all(5.3 < o < 6.8 for o in order_sol), (errs, order_sol)     # local error O(h^6)
+    assert all(4.4 < o < 5.6 for o in order_est), (ests, order_est)     # estimate O(h^5)
+    # the estimate uses the coordinates only and bounds their true 4th-order error from above-ish
+    assert ests[-1] > errs[-1]
+
+
+def test_step_controller_constants(oracle):
+    """AdaptiveStepper (integrator.rs:53-107) pinned against its documented constants, with the
+    expected next step written here from SURVEY a10: safety 0.9, exponents -1/5 (accept) and -1/4
+    (reject), growth cap 5 (and 5 outright below ratio 1e-4), shrink floor 0.1, |h| <= 10,
+    forced step at 1e-5."""
+    import ctypes as C
+    L = oracle.lib()
+    m = oracle.metric(oracle.KERR_KS, 1.0, 0.9)
+    v = [0, 12.0, 1.2, 0.3, -1.0, -0.7, 1.5, 3.0]
+
+    def fresh():
+        s = oracle.make_state(v)
+        L.orc_renormalize_null(C.byref(s), C.byref(m))
+        return s
+
+    def err_of(h):
+        out = oracle.State()
+        return L.orc_rkf45_step(C.byref(fresh()), C.byref(m), h, C.byref(out)), out
+
+    tries = C.c_uint64(0)
+    # accepted at once: next = h * min(0.9 * ratio^-0.2, 5), clamped to 10
+    for h, tol in ((0.2, 1e-8), (0.05, 1e-8), (0.4, 1e-5), (3.0, 1e-1)):
+        err, out = err_of(h)
+        ratio = err / tol
+        assert ratio <= 1.0
+        growth = 5.0 if ratio < 1e-4 else 0.9 * ratio ** -0.2
+        want = max(-10.0, min(10.0, h * min(growth, 5.0)))
+        s = fresh()
+        tries.value = 0
+        nxt = L.orc_adaptive_step(C.byref(s), C.byref(m), h, tol, C.byref(tries))
+        assert tries.value == 1 and abs(nxt - want) <= 1e-15 * abs(want)
+        assert oracle.state_to_list(s) == oracle.state_to_list(out)      # the 5th-order candidate was taken
+    # h_try beyond the cap is clamped before the first try
+    s = fresh()
+    L.orc_adaptive_step(C.byref(s), C.byref(m), 50.0, 1e30, C.byref(tries))
+    _, out10 = err_of(10.0)
+    assert oracle.state_to_list(s) == oracle.state_to_list(out10)
+    # rejected once: h <- h * max(0.9 * ratio^-0.25, 0.1), then accepted from there
+    h, tol = 0.8, 1e-9
+    err, _ = err_of(h)
+    assert err / tol > 1.0
+    h2 = h * max(0.9 * (err / tol) ** -0.25, 0.1)
+    err2, out2 = err_of(h2)
+    if err2 / tol <= 1.0:
+        s = fresh()
+        tries.value = 0
+        L.orc_adaptive_step(C.byref(s), C.byref(m), h, tol, C.byref(tries))
+        assert tries.value == 2 and oracle.state_to_list(s) == oracle.state_to_list(out2)
+    # a tolerance nothing can meet: the step is forced at 1e-5 and handed back as the next h
+    s = fresh()
+    tries.value = 0
+    nxt = L.orc_adaptive_step(C.byref(s), C.byref(m), 0.5, 1e-300, C.byref(tries))
+    _, outmin = err_of(1e-5)
+    assert nxt == 1e-5 and oracle.state_to_list(s) == oracle.state_to_list(outmin) and tries.value >= 5
