@@ -454,7 +454,7 @@ void grv_render_params_default(uint32_t width, uint32_t height, GrvRenderParams 
     grv_options_default(&p->opt);
     p->opt.max_steps = 2048;
     p->shading = 1;
-    p->precision = 0;
+    p->reserved0 = 0;
     p->disk_inner = 0.0;
     p->disk_outer = 30.0;
     p->disk_temp = 9500.0;
@@ -475,7 +475,7 @@ int grv_render_frame_device(grv_engine *e, const GrvCamera *cam, const GrvRender
     if (!cam || !p || !out) return fail(e, GRV_ERR_INVALID, "null argument");
     if (!options_valid(p->opt)) return fail(e, GRV_ERR_INVALID, "invalid GrvOptions");
     if (p->width == 0 || p->height == 0) return fail(e, GRV_ERR_INVALID, "empty frame");
-    if (p->precision != 0) return fail(e, GRV_ERR_INVALID, "f32 frame kernels not built yet");
+    if (p->reserved0 != 0) return fail(e, GRV_ERR_INVALID, "reserved field must be 0");
     if (p->tile_world > 1 && p->tile_rank >= p->tile_world) return fail(e, GRV_ERR_INVALID, "tile_rank >= tile_world");
     hipStream_t s = static_cast<hipStream_t>(stream);
     GRV_HIP(e, hipSetDevice(e->device));

@@ -41,7 +41,7 @@ class Camera(C.Structure):
 
 class RenderParams(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("opt", Options),
-                ("shading", C.c_int32), ("precision", C.c_int32), ("disk_inner", C.c_double),
+                ("shading", C.c_int32), ("reserved0", C.c_int32), ("disk_inner", C.c_double),
                 ("disk_outer", C.c_double), ("disk_temp", C.c_double),
                 ("disk_opacity", C.c_double), ("exposure", C.c_double),
                 ("lut_width", C.c_uint32), ("lut_height", C.c_uint32),

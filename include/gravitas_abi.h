@@ -87,7 +87,7 @@ typedef struct {
     uint32_t width, height;
     GrvOptions opt;
     int32_t shading;      /* 0 endpoints only, 1 thin-disk (T x g) LUT shading */
-    int32_t precision;    /* 0 = f64 state, 1 = f32 state (fixed-step kernels only) */
+    int32_t reserved0;    /* must be 0 (the f32 marches have their own entry points below) */
     double disk_inner;    /* <= 0: prograde ISCO */
     double disk_outer;    /* src/shaders/compute.wgsl.ts:217 -> 30 M */
     double disk_temp;     /* K */
