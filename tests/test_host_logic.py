@@ -113,3 +113,19 @@ def test_unpack_places_pixels_row_major(engine_mod):
             packed[tl * 4096:(tl + 1) * 4096, 0] = blk.reshape(-1)
         img += engine_mod.unpack_tiles(rp, r, packed, 1, np.int32)
     assert np.array_equal(img[..., 0], truth)
+
+
+def test_bench_helpers():
+    """bench.py pieces that run without a GPU: the weak-scaling grid, the host-core count that
+    honours the cgroup quota, the committed PMC traffic record bench.py quotes."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert all(gx * gy == n for n, (gx, gy) in b.GRID.items()) and set(b.GRID) == {1, 2, 4, 8}
+    assert 1 <= b.usable_cores() <= (os.cpu_count() or 1)
+    assert (b.B_STEP, b.B_RAY, b.HBM_PEAK_GBS) == (144, 96, 8000.0)       # SURVEY 8(d), microarch guide
+    t = b.load_committed_traffic()
+    assert t and t["hbm_bytes_per_launch"] > 1e9 and 0.5 < t["valu"]["issue_frac"] <= 1.0
+    # measured HBM bytes agree with the layout's 92 B read + 76 B written per slot to 2 %
+    assert abs(t["hbm_bytes_per_launch"] / t["expected_from_layout_bytes"] - 1.0) < 0.02
