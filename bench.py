@@ -79,8 +79,12 @@ def cpu_baseline(width, height, eye, target_seconds=15.0):
     out = po.render_frame(cam, fp, lut, stride=(stride, stride), nthreads=cores, want_states=False)
     dt = time.time() - t
     st = out["stats"]
+    # the same path on one core (BASELINE.md section 4 asks for both), on a 1/1024 subset
+    t1 = time.time()
+    one = po.render_frame(cam, fp, lut, stride=(32, 32), nthreads=1, want_states=False)
+    one_rate = one["stats"].accepted_steps / max(time.time() - t1, 1e-3) / 1e6
     return {"value": round(st.accepted_steps / dt / 1e6, 4), "unit": "Mray-steps/s", "cores": cores,
-            "kind": "port",
+            "one_core_value": round(one_rate, 4), "kind": "port",
             "sample": "C restatement of gravitas-core (Rust toolchain unavailable), OpenMP over "
                       "rays, 1/%d pixel-strided subset of the %dx%d frame: %d rays, %d accepted "
                       "steps in %.1f s" % (stride * stride, width, height, st.rays,
