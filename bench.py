@@ -193,8 +193,10 @@ def main():
     steps_local = 0
     integ_ms = 0.0
     launches = 0
+    max_drift = 0.0
     for i in range(args.steps):
         st = one_frame(args.warmup + i)
+        max_drift = max(max_drift, st.max_drift)
         steps_local += st.accepted_steps
         integ_ms += st.integrate_ms
         launches += st.launches
@@ -243,7 +245,8 @@ def main():
                        "partition": ("64x64 tiles round-robin, one gather to rank 0 per frame%s"
                                      % (", overlapped with the next frame" if overlap else ""))
                        if world > 1 else "single GPU",
-                       "rays": int(total_rays), "accepted_steps_per_frame": int(total_steps / args.steps)},
+                       "rays": int(total_rays), "accepted_steps_per_frame": int(total_steps / args.steps),
+                       "max_hamiltonian_drift_rank0": max_drift},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
