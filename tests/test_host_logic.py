@@ -36,12 +36,16 @@ def test_no_device_fails_loudly(engine_mod):
 
 def test_package_has_no_oracle_dependency():
     """The product must never route through oracle/ (or any CPU fallback)."""
-    pkg = os.path.join(ROOT, "blackhole-simulation_amd")
-    for dirpath, _, files in os.walk(pkg):
-        for f in files:
-            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", ".c")) or f == "Makefile":
-                src = open(os.path.join(dirpath, f), errors="ignore").read()
-                assert "pyoracle" not in src and "gravitas_oracle" not in src and "orc_" not in src, f
+    for top in ("blackhole-simulation_amd", "napi", "tools", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", ".c", ".js", ".sh")) or f == "Makefile":
+                    src = open(os.path.join(dirpath, f), errors="ignore").read()
+                    assert "pyoracle" not in src and "gravitas_oracle" not in src and "orc_" not in src, f
+    # bench.py touches the oracle in its cpu_baseline leg only
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body = src[src.index("def cpu_baseline("):src.index("def load_committed_traffic(")]
+    assert "pyoracle" in body and "pyoracle" not in src.replace(body, "")
 
 
 def test_sab_layout(engine_mod):  # gravitas-wasm/src/lib.rs:36-40, 411-419
