@@ -1,4 +1,4 @@
-/* post_oracle.c -- see post_oracle.h.  Shader evaluation order, f32. */
+/* post_oracle.c -- see post_oracle.h.  TEST INFRASTRUCTURE ONLY.  Shader evaluation order, f32. */
 #include "post_oracle.h"
 
 #include <math.h>

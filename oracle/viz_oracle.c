@@ -1,4 +1,4 @@
-/* viz_oracle.c -- see viz_oracle.h.  Plain C, reference operation order. */
+/* viz_oracle.c -- see viz_oracle.h.  TEST INFRASTRUCTURE ONLY.  Plain C, reference operation order. */
 #include "viz_oracle.h"
 
 #include <math.h>
