@@ -2,7 +2,9 @@
  * viz_oracle.h -- CPU restatement of the spacetime read-outs the reference's FFI exposes next
  * to the path: gravitas-core/src/spacetime/{curvature,lightcone,frame_drag,
  * embedding}.rs behind gravitas-wasm/src/lib.rs:139-306.  TEST INFRASTRUCTURE ONLY.
- * Pinned by the reference's tests embedding.rs:113-129 (the only ones these files hold).
+ * Pinned by the reference's tests embedding.rs:113-129 (the only ones these files hold); the
+ * curvature, light-cone, frame-drag and mesh functions are "parity unpinned" upstream and are
+ * pinned here by closed forms (tests/test_spacetime_viz.py).
  * `spin` is the dimensionless a/M; functions that take the engine's Boyer-Lindquist Kerr
  * metric receive the spin already clamped to [-1, 1] (metric/kerr.rs:48-63).
  */
