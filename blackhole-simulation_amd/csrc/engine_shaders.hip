@@ -88,7 +88,7 @@ int grv_render_frame_wgsl(grv_engine *e, const GrvWgslParams *p, float *d_rgba, 
                           uint64_t *total_steps, void *stream) {
     if (!e) return GRV_ERR_INVALID;
     if (!p || !d_rgba) return fail(e, GRV_ERR_INVALID, "null argument");
-    if (p->arith != GRV_ARITH_STRICT && p->arith != GRV_ARITH_FAST)
+    if (p->arith < GRV_ARITH_STRICT || p->arith > GRV_ARITH_FAST_PACKED)
         return fail(e, GRV_ERR_INVALID, "invalid arith %d", p->arith);
     WgslParams P{};
     std::memcpy(P.inv_view, p->inv_view, sizeof P.inv_view);
@@ -103,6 +103,8 @@ int grv_render_frame_wgsl(grv_engine *e, const GrvWgslParams *p, float *d_rgba, 
     hipStream_t s = static_cast<hipStream_t>(stream);
     return run_shader_frame(e, p->width, p->height, p->tile_world, p->tile_rank, total_steps, s,
                             [&](const FrameGeom &G, uint32_t n, unsigned long long *tot) {
+                                if (p->arith == GRV_ARITH_FAST_PACKED)
+                                    return launch_wgsl_symplectic_pk(G, P, d_rgba, d_steps, tot, n, s);
                                 return p->arith == GRV_ARITH_FAST
                                            ? launch_wgsl_symplectic_fast(G, P, d_rgba, d_steps, tot, n, s)
                                            : launch_wgsl_symplectic(G, P, d_rgba, d_steps, tot, n, s);

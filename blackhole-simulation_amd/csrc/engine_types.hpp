@@ -147,6 +147,9 @@ hipError_t launch_blit_reinhard(uint32_t w, uint32_t h, const float *src, float 
 hipError_t launch_glsl_fragment_fast(const FrameGeom &G, const GlslParams &P, float *out_rgba,
                                      uint32_t *out_steps, unsigned long long *total_steps,
                                      uint32_t n_slots, hipStream_t s);
+hipError_t launch_wgsl_symplectic_pk(const FrameGeom &G, const WgslParams &P, float *out_rgba,
+                                     uint32_t *out_steps, unsigned long long *total_steps,
+                                     uint32_t n_slots, hipStream_t s);
 hipError_t launch_wgsl_symplectic_fast(const FrameGeom &G, const WgslParams &P, float *out_rgba,
                                        uint32_t *out_steps, unsigned long long *total_steps,
                                        uint32_t n_slots, hipStream_t s);

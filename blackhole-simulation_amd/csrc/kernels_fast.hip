@@ -3,6 +3,7 @@
 // right-hand side (kerr_device.hpp: rhs_ks_fast) and FMA contraction.
 #include "geodesic_kernels.hpp"
 #include "wgsl_fast_kernel.hpp"
+#include "wgsl_pk_kernel.hpp"
 #include "glsl_fragment.hpp"
 
 namespace grvhip {
@@ -57,6 +58,16 @@ hipError_t launch_glsl_fragment_fast(const FrameGeom &G, const GlslParams &P, fl
     hipLaunchKernelGGL((glsl_fragment_kernel<GRV_ARITH_FAST>), dim3((n_slots + kBlock - 1) / kBlock),
                        dim3(kBlock), 0, s, G, P, reinterpret_cast<float4 *>(out_rgba), out_steps,
                        total_steps, n_slots);
+    return hipGetLastError();
+}
+
+hipError_t launch_wgsl_symplectic_pk(const FrameGeom &G, const WgslParams &P, float *out_rgba,
+                                     uint32_t *out_steps, unsigned long long *total_steps,
+                                     uint32_t n_slots, hipStream_t s) {
+    if (n_slots == 0) return hipSuccess;
+    const uint32_t pairs = (n_slots + 1u) / 2u;
+    hipLaunchKernelGGL(wgsl_symplectic_pk_kernel, dim3((pairs + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
+                       G, P, reinterpret_cast<float4 *>(out_rgba), out_steps, total_steps, n_slots);
     return hipGetLastError();
 }
 

@@ -54,7 +54,9 @@ enum { GRV_METHOD_RKF45 = 0, GRV_METHOD_RK4 = 1, GRV_METHOD_SYMPLECTIC = 2 };
  *  STRICT: reference operation order, IEEE divide/sqrt, no FMA contraction;
  *  FAST  : algebraically identical right-hand side with shared reciprocals and
  *          FMA contraction (differs from STRICT by rounding only). */
-enum { GRV_ARITH_STRICT = 0, GRV_ARITH_FAST = 1 };
+enum { GRV_ARITH_STRICT = 0, GRV_ARITH_FAST = 1,
+       /* WGSL march only: the FAST contract with two rays per lane on the packed-f32 VALU ops */
+       GRV_ARITH_FAST_PACKED = 2 };
 
 /* gravitas-core/src/geodesic/integrator.rs:24-33 IntegrationOptions
  * (+ step_size carried by IntegrationMethod::{RK4,Symplectic}) */

@@ -66,10 +66,11 @@ def test_shader_kernels_against_golden(engine_mod, gold, arith):
         return rgba.cpu().numpy().reshape(G.H, G.W, 4), steps.cpu().numpy().reshape(G.H, G.W).astype(np.uint32)
     with engine_mod.PhysicsEngine(1.0, 0.9) as e:
         cam = engine_mod.camera_look_at(G.EYE, aspect=G.W / G.H)
-        gp = engine_mod.wgsl_params(G.W, G.H, cam, 1.0, 0.999, max_steps=300, arith=arith, stars=0)
-        gp.jitter[0], gp.jitter[1] = 0.0, -1.0 / 6.0
-        e.render_frame_wgsl(gp, rgba, steps)
-        _same_frame(*grab(), gold["wgsl_rgba"], gold["wgsl_steps"], False)
+        for wa in ((arith,) if arith == 0 else (1, 2)):     # 2: FAST with two rays per lane
+            gp = engine_mod.wgsl_params(G.W, G.H, cam, 1.0, 0.999, max_steps=300, arith=wa, stars=0)
+            gp.jitter[0], gp.jitter[1] = 0.0, -1.0 / 6.0
+            e.render_frame_wgsl(gp, rgba, steps)
+            _same_frame(*grab(), gold["wgsl_rgba"], gold["wgsl_steps"], False)
         for name in G.GLSL_CASES:
             p = G.glsl_case(name)
             p.arith = arith

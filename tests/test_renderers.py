@@ -55,7 +55,7 @@ def test_halton_sequence():  # compute.wgsl.ts:134-145
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("arith", [0, 1])
+@pytest.mark.parametrize("arith", [0, 1, 2])
 def test_webgpu_renderer_sequence(engine_mod, oracle, arith):
     import torch
     eyes = [(59.55, -7.31, 0.0), (59.4, -7.31, 3.0), (59.0, -7.0, 6.0)]

@@ -130,7 +130,7 @@ def _compare(got_rgba, got_steps, ref_rgba, ref_steps):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("arith", [0, 1])  # shader operation order / FAST contract (f32 rounding only)
+@pytest.mark.parametrize("arith", [0, 1, 2])  # shader order / FAST / FAST with two rays per lane (packed f32)
 @pytest.mark.parametrize("spin,max_steps", [(0.999, 512), (0.5, 150)])
 def test_wgsl_kernel_matches_oracle(engine_mod, oracle, spin, max_steps, arith):
     import torch
@@ -149,7 +149,7 @@ def test_wgsl_kernel_matches_oracle(engine_mod, oracle, spin, max_steps, arith):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("arith", [0, 1])
+@pytest.mark.parametrize("arith", [0, 1, 2])
 def test_wgsl_kernel_star_density(engine_mod, arith):
     import torch
     W, H = 960, 540
@@ -210,6 +210,34 @@ def test_glsl_kernel_shadow_guide_and_custom_textures(engine_mod, oracle):
     _compare(rgba.cpu().numpy().reshape(H, W, 4), steps.cpu().numpy().reshape(H, W), ref_rgba, ref_steps)
     green = (ref_rgba[..., 1] > 0.9) & (ref_rgba[..., 0] < 0.2)
     assert green.any()
+
+
+@pytest.mark.gpu
+def test_wgsl_packed_kernel_odd_sizes_and_tiles(engine_mod):
+    """Two rays per lane: odd slot counts, ragged frames and tile subsets must leave no pixel behind
+    and agree with the one-ray FAST kernel to rounding (same contract, same expressions)."""
+    import torch
+    for W, H, world in ((97, 61, 1), (200, 130, 3), (64, 64, 1)):
+        cam = engine_mod.camera_look_at(EYE, aspect=W / H)
+        with engine_mod.PhysicsEngine(1.0, 0.9) as e:
+            for r in range(world):
+                outs = {}
+                for arith in (1, 2):
+                    gp = engine_mod.wgsl_params(W, H, cam, 1.0, 0.9, max_steps=200, arith=arith, stars=0,
+                                                tile_world=world, tile_rank=r)
+                    tiles = ((W + 63) // 64) * ((H + 63) // 64)
+                    n = W * H if world == 1 else ((tiles - r + world - 1) // world) * 4096
+                    rgba = torch.full((n, 4), -7.0, dtype=torch.float32, device="cuda:0")
+                    steps = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+                    tot = e.render_frame_wgsl(gp, rgba, steps)
+                    torch.cuda.synchronize()
+                    outs[arith] = (rgba.cpu().numpy(), steps.cpu().numpy(), tot)
+                a, b = outs[1], outs[2]
+                assert a[2] == int(a[1].sum()) and b[2] == int(b[1].sum())
+                written = a[0][:, 3] == 1.0
+                assert np.array_equal(written, b[0][:, 3] == 1.0)           # the same pixels are covered
+                assert (np.abs(a[1].astype(np.int64) - b[1]) <= 1).mean() >= 0.995
+                assert np.abs(a[0][written] - b[0][written]).max() <= 5e-2 * max(a[0][written][:, :3].max(), 1e-9)
 
 
 @pytest.mark.gpu

@@ -55,6 +55,7 @@ if __name__ == "__main__":
     cg = lambda e, gp, rgba: e.render_frame_glsl(gp, rgba)  # noqa: E731
     run("C2 wgsl symplectic f32, 512 steps", 1920, 1080, wgsl(512), cw)
     run("C2 wgsl symplectic f32 FAST, 512 steps", 1920, 1080, wgsl(512, 1), cw)
+    run("C2 wgsl symplectic f32 FAST packed (2 rays/lane), 512 steps", 1920, 1080, wgsl(512, 2), cw)
     run("C2 glsl verlet f32 (march+disk), 512->500 steps", 1920, 1080, glsl(512, features=7, turbulence=0.75), cg)
     run("C2 glsl full default preset, 512->500 steps", 1920, 1080, glsl(512), cg)
     run("C2 glsl verlet f32 FAST (march+disk), 512->500 steps", 1920, 1080,
@@ -67,3 +68,4 @@ if __name__ == "__main__":
         reps=5, world=8)
     run("4K wgsl, 150 steps (shader default)", 3840, 2160, wgsl(150), cw)
     run("4K wgsl FAST, 150 steps (shader default)", 3840, 2160, wgsl(150, 1), cw)
+    run("4K wgsl FAST packed (2 rays/lane), 150 steps", 3840, 2160, wgsl(150, 2), cw)
