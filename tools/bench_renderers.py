@@ -45,10 +45,11 @@ if __name__ == "__main__":
         for W, H in ((1920, 1080), (3840, 2160)):
             screen = torch.zeros(H, W, 4, dtype=torch.float32, device="cuda:0")
             cu, pp = blocks(W, H, eye)
-            for arith, name in ((bh.ARITH_STRICT, "shader order"), (bh.ARITH_FAST, "fast")):
+            for arith, name in ((bh.ARITH_STRICT, "shader order"), (bh.ARITH_FAST, "fast"),
+                                (2, "fast, WebGPU march with two rays per lane")):
                 e.renderer_reset()
                 f1 = fps(lambda: e.webgpu_render(cu, pp, screen, max_steps=150, arith=arith), 20)
-                gp = bh.glsl_params(W, H, 1.0, 0.9, max_ray_steps=256, arith=arith)   # "ultra" budget
+                gp = bh.glsl_params(W, H, 1.0, 0.9, max_ray_steps=256, arith=min(arith, 1))   # "ultra" budget
                 e.renderer_reset()
                 f2 = fps(lambda: e.webgl_render(gp, screen, bloom=True), 20)
                 print(json.dumps({"width": W, "height": H, "arith": name,
