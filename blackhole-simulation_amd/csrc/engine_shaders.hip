@@ -170,8 +170,9 @@ int grv_post_taa_resolve(grv_engine *e, const GrvTaaParams *p, const float *d_cu
     if (!p || !d_current || !d_history || !d_out) return fail(e, GRV_ERR_INVALID, "null argument");
     if (d_out == d_current || d_out == d_history) return fail(e, GRV_ERR_INVALID, "taa: out aliases an input");
     GRV_HIP(e, hipSetDevice(e->device));
-    GRV_HIP(e, launch_taa_resolve(p->width, p->height, d_current, d_history, p->blend_factor,
-                                  p->camera_moving, p->half_storage, d_out, static_cast<hipStream_t>(stream)));
+    GRV_HIP(e, (p->arith == GRV_ARITH_FAST ? launch_taa_resolve_fast : launch_taa_resolve)(
+                   p->width, p->height, d_current, d_history, p->blend_factor, p->camera_moving,
+                   p->half_storage, d_out, static_cast<hipStream_t>(stream)));
     return GRV_OK;
 }
 
@@ -186,8 +187,9 @@ int grv_post_ataa_resolve(grv_engine *e, const GrvAtaaParams *p, const float *d_
     std::memcpy(cam.prev_view_proj, p->prev_view_proj, sizeof cam.prev_view_proj);
     std::memcpy(cam.position, p->position, sizeof cam.position);
     GRV_HIP(e, hipSetDevice(e->device));
-    GRV_HIP(e, launch_ataa_resolve(p->width, p->height, cam, d_current, d_history, p->half_storage, d_out,
-                                   static_cast<hipStream_t>(stream)));
+    GRV_HIP(e, (p->arith == GRV_ARITH_FAST ? launch_ataa_resolve_fast : launch_ataa_resolve)(
+                   p->width, p->height, cam, d_current, d_history, p->half_storage, d_out,
+                   static_cast<hipStream_t>(stream)));
     return GRV_OK;
 }
 
@@ -199,6 +201,7 @@ void grv_bloom_params_default(uint32_t width, uint32_t height, GrvBloomParams *p
     p->threshold = 0.8f;
     p->blur_passes = 2;
     p->half_storage = 1;
+    p->arith = GRV_ARITH_STRICT;
 }
 
 int grv_post_bloom(grv_engine *e, const GrvBloomParams *p, const float *d_scene, float *d_out,
@@ -217,9 +220,9 @@ int grv_post_bloom(grv_engine *e, const GrvBloomParams *p, const float *d_scene,
         GRV_HIP(e, hipMalloc(&e->post_mem, need));
         e->post_bytes = need;
     }
-    GRV_HIP(e, launch_bloom(p->width, p->height, d_scene, p->threshold, p->intensity, p->blur_passes,
-                            p->half_storage, static_cast<float *>(e->post_mem), d_out,
-                            static_cast<hipStream_t>(stream)));
+    GRV_HIP(e, (p->arith == GRV_ARITH_FAST ? launch_bloom_fast : launch_bloom)(
+                   p->width, p->height, d_scene, p->threshold, p->intensity, p->blur_passes, p->half_storage,
+                   static_cast<float *>(e->post_mem), d_out, static_cast<hipStream_t>(stream)));
     return GRV_OK;
 }
 
@@ -305,9 +308,11 @@ int grv_webgpu_render(grv_engine *e, const float *cu, const float *pp, int32_t m
     std::memcpy(cam.inv_proj, cu + 48, sizeof cam.inv_proj);
     std::memcpy(cam.prev_view_proj, cu + 64, sizeof cam.prev_view_proj);
     std::memcpy(cam.position, cu + 80, sizeof cam.position);
-    GRV_HIP(e, launch_ataa_resolve(w, h, cam, compute_tex, hist[hi], 1, hist[nx], s));
+    const bool fast_post = arith != GRV_ARITH_STRICT; // the post chain follows the march's contract
+    GRV_HIP(e, (fast_post ? launch_ataa_resolve_fast : launch_ataa_resolve)(w, h, cam, compute_tex, hist[hi], 1,
+                                                                             hist[nx], s));
     // Pass 3: blit with Reinhard (renderer.ts:14-50, 397-411)
-    GRV_HIP(e, launch_blit_reinhard(w, h, hist[nx], d_screen, s));
+    GRV_HIP(e, (fast_post ? launch_blit_reinhard_fast : launch_blit_reinhard)(w, h, hist[nx], d_screen, s));
     e->rt.hist = nx;
     e->rt.frames++;
     return GRV_OK;
@@ -337,16 +342,19 @@ int grv_webgl_render(grv_engine *e, const GrvGlslParams *p, int32_t bloom_enable
     // ReprojectionManager.resolve: write index 0 -> write pong, read ping (reprojection.ts:209-216)
     float *write_tex = e->rt.hist == 0 ? pong : ping;
     const float *read_tex = e->rt.hist == 0 ? ping : pong;
-    GRV_HIP(e, launch_taa_resolve(w, h, scene, read_tex, 0.75f, camera_moving, 1, write_tex, s));
+    const bool fast_post = p->arith == GRV_ARITH_FAST; // the post chain follows the march's contract
+    GRV_HIP(e, (fast_post ? launch_taa_resolve_fast : launch_taa_resolve)(w, h, scene, read_tex, 0.75f,
+                                                                         camera_moving, 1, write_tex, s));
     e->rt.hist = 1u - e->rt.hist;
     // bloom (features.bloom) or plain presentation: both are the combine pass (bloom.ts:443-632)
     float *scratch = static_cast<float *>(e->post_mem);
+    const auto bloom_fn = fast_post ? launch_bloom_fast : launch_bloom;
     if (bloom_enabled) {
-        GRV_HIP(e, launch_bloom(w, h, write_tex, 0.8f, 0.5f, 2, 1, scratch, d_screen, s));
+        GRV_HIP(e, bloom_fn(w, h, write_tex, 0.8f, 0.5f, 2, 1, scratch, d_screen, s));
     } else {
         // drawTextureToScreen: combine with intensity 0; the bloom input is a stale dummy upstream,
         // here the (zero or last) bright-pass target, multiplied by 0 either way
-        GRV_HIP(e, launch_bloom(w, h, write_tex, 3.0e38f, 0.0f, 0, 1, scratch, d_screen, s));
+        GRV_HIP(e, bloom_fn(w, h, write_tex, 3.0e38f, 0.0f, 0, 1, scratch, d_screen, s));
     }
     e->rt.frames++;
     return GRV_OK;

@@ -142,6 +142,15 @@ hipError_t launch_bloom(uint32_t w, uint32_t h, const float *scene, float thresh
                         int blur_passes, int half_storage, float *scratch, float *out, hipStream_t s);
 size_t bloom_scratch_floats(uint32_t w, uint32_t h);
 hipError_t launch_post_quantize(float *img, uint32_t n_px, hipStream_t s);
+// the same launchers in the FAST contract (kernels_fast.hip)
+hipError_t launch_taa_resolve_fast(uint32_t w, uint32_t h, const float *current, const float *history,
+                                   float blend_factor, int camera_moving, int half_storage, float *out,
+                                   hipStream_t s);
+hipError_t launch_ataa_resolve_fast(uint32_t w, uint32_t h, const AtaaCameraHost &cam, const float *current,
+                                    const float *history, int half_storage, float *out, hipStream_t s);
+hipError_t launch_bloom_fast(uint32_t w, uint32_t h, const float *scene, float threshold, float intensity,
+                             int blur_passes, int half_storage, float *scratch, float *out, hipStream_t s);
+hipError_t launch_blit_reinhard_fast(uint32_t w, uint32_t h, const float *src, float *dst, hipStream_t s);
 hipError_t launch_blit_reinhard(uint32_t w, uint32_t h, const float *src, float *dst, hipStream_t s);
 // ---- launcher (kernels_fast.hip: -ffp-contract=fast) ----
 hipError_t launch_glsl_fragment_fast(const FrameGeom &G, const GlslParams &P, float *out_rgba,

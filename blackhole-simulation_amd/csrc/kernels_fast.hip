@@ -4,7 +4,10 @@
 #include "geodesic_kernels.hpp"
 #include "wgsl_fast_kernel.hpp"
 #include "wgsl_pk_kernel.hpp"
+#include <cstring>
+
 #include "glsl_fragment.hpp"
+#include "post_kernels.hpp"
 
 namespace grvhip {
 
@@ -70,5 +73,14 @@ hipError_t launch_wgsl_symplectic_pk(const FrameGeom &G, const WgslParams &P, fl
                        G, P, reinterpret_cast<float4 *>(out_rgba), out_steps, total_steps, n_slots);
     return hipGetLastError();
 }
+
+namespace {
+inline uint32_t at_least_1(uint32_t x) { return x ? x : 1u; }
+} // namespace
+#define GRV_POST_ARITH GRV_ARITH_FAST
+#define GRV_POST_FN(name) name##_fast
+#include "post_launch.inc"
+#undef GRV_POST_ARITH
+#undef GRV_POST_FN
 
 } // namespace grvhip

@@ -156,65 +156,13 @@ hipError_t launch_spectrum_lut(float *out, uint32_t width, uint32_t height, doub
 }
 
 namespace {
-inline dim3 post_grid(uint32_t w, uint32_t h) { return dim3((w + 255u) / 256u, h); }
-inline dim3 tile_grid(uint32_t w, uint32_t h) { return dim3((w + kTileW - 1) / kTileW, (h + kTileH - 1) / kTileH); }
 inline uint32_t at_least_1(uint32_t x) { return x ? x : 1u; }
 } // namespace
-
-hipError_t launch_taa_resolve(uint32_t w, uint32_t h, const float *current, const float *history,
-                              float blend_factor, int camera_moving, int half_storage, float *out,
-                              hipStream_t s) {
-    if (w == 0 || h == 0) return hipSuccess;
-    hipLaunchKernelGGL(taa_resolve_kernel, tile_grid(w, h), dim3(kTileW, kTileH), 0, s, w, h,
-                       reinterpret_cast<const float4 *>(current), reinterpret_cast<const float4 *>(history),
-                       blend_factor, camera_moving, half_storage, reinterpret_cast<float4 *>(out));
-    return hipGetLastError();
-}
-
-hipError_t launch_ataa_resolve(uint32_t w, uint32_t h, const AtaaCameraHost &cam, const float *current,
-                               const float *history, int half_storage, float *out, hipStream_t s) {
-    if (w == 0 || h == 0) return hipSuccess;
-    AtaaCamera c;
-    static_assert(sizeof(AtaaCamera) == sizeof(AtaaCameraHost), "camera blocks must match");
-    std::memcpy(&c, &cam, sizeof c);
-    hipLaunchKernelGGL(ataa_resolve_kernel, tile_grid(w, h), dim3(kTileW, kTileH), 0, s, w, h, c,
-                       reinterpret_cast<const float4 *>(current), reinterpret_cast<const float4 *>(history),
-                       half_storage, reinterpret_cast<float4 *>(out));
-    return hipGetLastError();
-}
 
 size_t bloom_scratch_floats(uint32_t w, uint32_t h) {
     const size_t half = (size_t)at_least_1(w / 2) * at_least_1(h / 2);
     const size_t quarter = (size_t)at_least_1(w / 4) * at_least_1(h / 4);
     return 4 * (half + 2 * quarter);
-}
-
-// bloom.ts:443-583 with renderScale = 1: bright (w/2 x h/2) -> passes x (H, V) at w/4 x h/4 -> combine
-hipError_t launch_bloom(uint32_t w, uint32_t h, const float *scene, float threshold, float intensity,
-                        int blur_passes, int half_storage, float *scratch, float *out, hipStream_t s) {
-    if (w == 0 || h == 0) return hipSuccess;
-    const uint32_t hw = at_least_1(w / 2), hh = at_least_1(h / 2);
-    const uint32_t bw = at_least_1(w / 4), bh = at_least_1(h / 4);
-    float4 *bright = reinterpret_cast<float4 *>(scratch);
-    float4 *b1 = bright + (size_t)hw * hh;
-    float4 *b2 = b1 + (size_t)bw * bh;
-    const float4 *sc = reinterpret_cast<const float4 *>(scene);
-    hipLaunchKernelGGL(bloom_bright_kernel, post_grid(hw, hh), dim3(256), 0, s, w, h, sc, hw, hh, threshold,
-                       half_storage, bright);
-    const float4 *src = bright;
-    uint32_t sw = hw, sh = hh;
-    for (int i = 0; i < blur_passes; ++i) {
-        hipLaunchKernelGGL(bloom_blur_kernel, post_grid(bw, bh), dim3(256), 0, s, sw, sh, src, bw, bh, 0,
-                           half_storage, b1);
-        hipLaunchKernelGGL(bloom_blur_kernel, post_grid(bw, bh), dim3(256), 0, s, bw, bh,
-                           static_cast<const float4 *>(b1), bw, bh, 1, half_storage, b2);
-        src = b2;
-        sw = bw;
-        sh = bh;
-    }
-    hipLaunchKernelGGL(bloom_combine_kernel, post_grid(w, h), dim3(256), 0, s, w, h, sc, sw, sh, src,
-                       intensity, reinterpret_cast<float4 *>(out));
-    return hipGetLastError();
 }
 
 hipError_t launch_post_quantize(float *img, uint32_t n_px, hipStream_t s) {
@@ -224,11 +172,10 @@ hipError_t launch_post_quantize(float *img, uint32_t n_px, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_blit_reinhard(uint32_t w, uint32_t h, const float *src, float *dst, hipStream_t s) {
-    if (w == 0 || h == 0) return hipSuccess;
-    hipLaunchKernelGGL(blit_reinhard_kernel, post_grid(w, h), dim3(256), 0, s, w, h,
-                       reinterpret_cast<const float4 *>(src), reinterpret_cast<float4 *>(dst));
-    return hipGetLastError();
-}
+#define GRV_POST_ARITH GRV_ARITH_STRICT
+#define GRV_POST_FN(name) name
+#include "post_launch.inc"
+#undef GRV_POST_ARITH
+#undef GRV_POST_FN
 
 } // namespace grvhip

@@ -1,5 +1,7 @@
-// post_kernels.hpp -- the reference's post chain as HIP kernels, compiled
-// in the -ffp-contract=off unit so operation order is the shaders':
+// post_kernels.hpp -- the reference's post chain as HIP kernels.  Two arithmetic
+// contracts, one per translation unit, as for the shader marches: STRICT (kernels_strict.hip,
+// -ffp-contract=off: the shaders' operation order, IEEE divide / sqrt, OCML powf) and FAST
+// (kernels_fast.hip: FMA contraction, reciprocal-based divide / sqrt, v_log / v_exp gamma):
 //   taa_resolve_kernel   src/shaders/postprocess/reprojection.glsl.ts:44-116
 //                        (driven by src/rendering/reprojection.ts:196-262, renderScale = 1)
 //   ataa_resolve_kernel  src/shaders/postprocess/ataa.wgsl.ts:29-86
@@ -131,6 +133,7 @@ __device__ __forceinline__ bool post_pixel(uint32_t w, uint32_t h, uint32_t &px,
     return px < w && py < h;
 }
 
+template <int ARITH>
 __global__ __launch_bounds__(256) void taa_resolve_kernel(uint32_t w, uint32_t h,
                                                           const float4 *__restrict__ current,
                                                           const float4 *__restrict__ history,
@@ -174,6 +177,7 @@ __device__ __forceinline__ void post_m4v4(const float *m, float x, float y, floa
     for (int r = 0; r < 4; ++r) o[r] = m[0 + r] * x + m[4 + r] * y + m[8 + r] * z + m[12 + r] * w;
 }
 
+template <int ARITH>
 __global__ __launch_bounds__(256) void ataa_resolve_kernel(uint32_t w, uint32_t h, AtaaCamera cam,
                                                            const float4 *__restrict__ current,
                                                            const float4 *__restrict__ history,
@@ -219,6 +223,7 @@ __global__ __launch_bounds__(256) void ataa_resolve_kernel(uint32_t w, uint32_t 
 }
 
 // bloom.glsl.ts:35-58: dst (dw x dh) <- bright pixels of src (w x h)
+template <int ARITH>
 __global__ __launch_bounds__(256) void bloom_bright_kernel(uint32_t w, uint32_t h,
                                                            const float4 *__restrict__ src, uint32_t dw,
                                                            uint32_t dh, float threshold, int half_storage,
@@ -234,6 +239,7 @@ __global__ __launch_bounds__(256) void bloom_bright_kernel(uint32_t w, uint32_t 
 }
 
 // bloom.glsl.ts:64-89: 9-tap separable Gaussian; u_resolution = destination size
+template <int ARITH>
 __global__ __launch_bounds__(256) void bloom_blur_kernel(uint32_t sw, uint32_t sh,
                                                          const float4 *__restrict__ src, uint32_t dw,
                                                          uint32_t dh, int vertical, int half_storage,
@@ -261,11 +267,17 @@ __global__ __launch_bounds__(256) void bloom_blur_kernel(uint32_t sw, uint32_t s
         make_float4(post_store(r, half_storage), post_store(g, half_storage), post_store(b, half_storage), 1.0f);
 }
 
+// gamma: OCML powf in shader order; v_log_f32 / v_exp_f32 in the FAST contract
+template <int ARITH> __device__ __forceinline__ float post_pow(float x, float y) {
+    if constexpr (ARITH == GRV_ARITH_FAST) return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
+    else return powf(x, y);
+}
 __device__ __forceinline__ float post_aces(float c) {
     return post_clamp((c * (2.51f * c + 0.03f)) / (c * (2.43f * c + 0.59f) + 0.14f), 0.0f, 1.0f);
 }
 
 // bloom.glsl.ts:95-127: scene + bloom * intensity -> ACES -> gamma (the backbuffer)
+template <int ARITH>
 __global__ __launch_bounds__(256) void bloom_combine_kernel(uint32_t w, uint32_t h,
                                                             const float4 *__restrict__ scene, uint32_t bw,
                                                             uint32_t bh, const float4 *__restrict__ bloom,
@@ -275,9 +287,9 @@ __global__ __launch_bounds__(256) void bloom_combine_kernel(uint32_t w, uint32_t
     const float u = ((float)px + 0.5f) / (float)w, v = ((float)py + 0.5f) / (float)h;
     const float4 s = post_sample(scene, w, h, u, v);
     const float4 b = post_sample(bloom, bw, bh, u, v);
-    out[(size_t)py * w + px] = make_float4(powf(post_aces(s.x + b.x * intensity), 0.4545f),
-                                           powf(post_aces(s.y + b.y * intensity), 0.4545f),
-                                           powf(post_aces(s.z + b.z * intensity), 0.4545f), 1.0f);
+    out[(size_t)py * w + px] = make_float4(post_pow<ARITH>(post_aces(s.x + b.x * intensity), 0.4545f),
+                                           post_pow<ARITH>(post_aces(s.y + b.y * intensity), 0.4545f),
+                                           post_pow<ARITH>(post_aces(s.z + b.z * intensity), 0.4545f), 1.0f);
 }
 
 // A compute / fragment pass that writes an RGBA16F target: round the stored channels in place
@@ -291,6 +303,7 @@ __global__ __launch_bounds__(256) void post_quantize_kernel(float4 *__restrict__
 
 // blit pass of the WebGPU renderer (src/rendering/webgpu/renderer.ts:14-50): the resolved
 // history sampled at the pixel centre, Reinhard c / (c + 1), alpha passed through
+template <int ARITH>
 __global__ __launch_bounds__(256) void blit_reinhard_kernel(uint32_t w, uint32_t h,
                                                             const float4 *__restrict__ src,
                                                             float4 *__restrict__ dst) {

@@ -90,18 +90,19 @@ GLSL_FEATURES_DEFAULT = (GLSL_LENSING | GLSL_DISK | GLSL_DOPPLER | GLSL_STARS | 
 
 class TaaParams(C.Structure):  # reprojection.glsl.ts uniforms
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("blend_factor", C.c_float),
-                ("camera_moving", C.c_int32), ("half_storage", C.c_int32)]
+                ("camera_moving", C.c_int32), ("half_storage", C.c_int32), ("arith", C.c_int32)]
 
 
 class AtaaParams(C.Structure):  # ataa.wgsl.ts CameraUniforms subset
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("inv_view", C.c_float * 16),
                 ("inv_proj", C.c_float * 16), ("prev_view_proj", C.c_float * 16),
-                ("position", C.c_float * 3), ("half_storage", C.c_int32)]
+                ("position", C.c_float * 3), ("half_storage", C.c_int32), ("arith", C.c_int32)]
 
 
 class BloomParams(C.Structure):  # bloom.ts BloomConfig
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("intensity", C.c_float),
-                ("threshold", C.c_float), ("blur_passes", C.c_int32), ("half_storage", C.c_int32)]
+                ("threshold", C.c_float), ("blur_passes", C.c_int32), ("half_storage", C.c_int32),
+                ("arith", C.c_int32)]
 
 
 class FrameBuffers(C.Structure):
@@ -495,8 +496,9 @@ class PhysicsEngine:
 
     # ---- post chain (reprojection.ts / ataa.wgsl.ts / bloom.ts): device RGBA f32 images ----
     def post_taa_resolve(self, width, height, current, history, out, blend_factor=0.75,
-                         camera_moving=False, half_storage=True, stream=None):
-        p = TaaParams(width, height, blend_factor, 1 if camera_moving else 0, 1 if half_storage else 0)
+                         camera_moving=False, half_storage=True, stream=None, arith=ARITH_STRICT):
+        p = TaaParams(width, height, blend_factor, 1 if camera_moving else 0, 1 if half_storage else 0,
+                      int(arith))
         self._check(self._lib.grv_post_taa_resolve(self._h, C.byref(p), _dev_ptr(current),
                                                    _dev_ptr(history), _dev_ptr(out), stream),
                     "post_taa_resolve")

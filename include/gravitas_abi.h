@@ -256,6 +256,7 @@ typedef struct { /* src/shaders/postprocess/reprojection.glsl.ts:44-116 uniforms
     float blend_factor;     /* u_blendFactor: 0.75 from src/rendering/webgl/renderer.ts:383 */
     int32_t camera_moving;  /* u_cameraMoving */
     int32_t half_storage;
+    int32_t arith;          /* GRV_ARITH_STRICT (shader operation order) / GRV_ARITH_FAST */
 } GrvTaaParams;
 /* ReprojectionManager.resolve (src/rendering/reprojection.ts:196-262): out = history-blended frame */
 int grv_post_taa_resolve(grv_engine *e, const GrvTaaParams *p, const float *d_current,
@@ -267,6 +268,7 @@ typedef struct { /* src/shaders/postprocess/ataa.wgsl.ts:29-86 (CameraUniforms, 
     uint32_t width, height;
     float inv_view[16], inv_proj[16], prev_view_proj[16], position[3]; /* column-major */
     int32_t half_storage;
+    int32_t arith;
 } GrvAtaaParams;
 int grv_post_ataa_resolve(grv_engine *e, const GrvAtaaParams *p, const float *d_current,
                           const float *d_history, float *d_out, void *stream);
@@ -277,6 +279,7 @@ typedef struct { /* src/rendering/bloom.ts:23-39 BloomConfig */
     float threshold;      /* 0.8 */
     int32_t blur_passes;  /* 2 */
     int32_t half_storage;
+    int32_t arith;
 } GrvBloomParams;
 void grv_bloom_params_default(uint32_t width, uint32_t height, GrvBloomParams *p);
 /* BloomManager.applyBloomToTexture (bloom.ts:443-583, renderScale 1): bright pass at w/2 x h/2,

@@ -119,11 +119,52 @@ def test_bloom_properties(oracle):
 
 
 # ---- HIP kernels vs oracle (GPU box) ----------------------------------------------------------
-def _close(got, ref):
+def _close(got, ref, fast=False):
     d = np.abs(got - ref) / np.maximum(1.0, np.abs(ref))
     assert d.max() <= 1e-3, d.max()
     rel = np.abs(got - ref) / np.maximum(1e-6, np.abs(ref))
-    assert (rel <= 1e-6).mean() >= 0.999, (rel <= 1e-6).mean()
+    if fast:
+        # FMA, reciprocal-based divide / sqrt, exp2-log2 gamma.  The approximate divide also moves a
+        # texture coordinate by an ulp, i.e. the tap by ~1e-5 of a texel, which (with f32 bilinear
+        # weights) leaks that fraction of the neighbouring texel into the tap: O(1e-5) absolute on
+        # O(1) HDR values; the binary16 store then adds at most one half-ulp (2^-11 relative).
+        ad = np.abs(got - ref)
+        ok = ad <= 1e-4 + 1e-3 * np.abs(ref)
+        assert ok.mean() >= 0.999 and np.median(ad) <= 1e-5, (ok.mean(), np.median(ad))
+    else:
+        assert (rel <= 1e-6).mean() >= 0.999, (rel <= 1e-6).mean()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("half", [True, False])
+@pytest.mark.parametrize("size", [(135, 240), (37, 53)])
+def test_fast_post_chain_matches_oracle(engine_mod, oracle, half, size):
+    """The FAST contract of the post kernels (kernels_fast.hip) against the same oracle."""
+    import torch
+    h, w = size
+    cur, hist = _image(h, w), _image(h, w)
+    dc, dh = torch.from_numpy(cur).cuda(), torch.from_numpy(hist).cuda()
+    out = torch.zeros_like(dc)
+    with engine_mod.PhysicsEngine(1.0, 0.9) as e:
+        e.post_taa_resolve(w, h, dc, dh, out, half_storage=half, arith=engine_mod.ARITH_FAST)
+        torch.cuda.synchronize()
+        _close(out.cpu().numpy(), oracle.taa_resolve(cur, hist, 0.75, False, half), fast=True)
+        cam = _cam(oracle, engine_mod, (59.55, -7.31, 0.0), (59.0, -7.31, 4.0), w / h)
+        ap = engine_mod.AtaaParams()
+        ap.width, ap.height, ap.half_storage, ap.arith = w, h, 1 if half else 0, engine_mod.ARITH_FAST
+        for name in ("inv_view", "inv_proj", "prev_view_proj"):
+            for k in range(16):
+                getattr(ap, name)[k] = getattr(cam, name)[k]
+        for k in range(3):
+            ap.position[k] = cam.position[k]
+        e.post_ataa_resolve(ap, dc, dh, out)
+        torch.cuda.synchronize()
+        _close(out.cpu().numpy(), oracle.ataa_resolve(cam, cur, hist, half), fast=True)
+        scene = _image(h, w, hdr=6.0)
+        ds = torch.from_numpy(scene).cuda()
+        e.post_bloom(w, h, ds, out, half_storage=1 if half else 0, arith=engine_mod.ARITH_FAST)
+        torch.cuda.synchronize()
+        _close(out.cpu().numpy(), oracle.bloom(scene, 0.8, 0.5, 2, half), fast=True)
 
 
 @pytest.mark.gpu

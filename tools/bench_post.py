@@ -46,10 +46,15 @@ if __name__ == "__main__":
         for k in range(3):
             ap.position[k] = cam.position[k]
         s = torch.cuda.current_stream().cuda_stream
+        apf = bh.AtaaParams.from_buffer_copy(ap)
+        apf.arith = bh.ARITH_FAST
         cases = [
             ("taa_resolve", 48, lambda: e.post_taa_resolve(W, H, cur, hist, out, stream=s)),
             ("ataa_resolve", 48, lambda: e.post_ataa_resolve(ap, cur, hist, out, stream=s)),
             ("bloom (bright + 2x(H,V) + combine)", 56, lambda: e.post_bloom(W, H, cur, out, stream=s)),
+            ("taa_resolve FAST", 48, lambda: e.post_taa_resolve(W, H, cur, hist, out, stream=s, arith=bh.ARITH_FAST)),
+            ("ataa_resolve FAST", 48, lambda: e.post_ataa_resolve(apf, cur, hist, out, stream=s)),
+            ("bloom FAST", 56, lambda: e.post_bloom(W, H, cur, out, stream=s, arith=bh.ARITH_FAST)),
         ]
         for name, bpp, fn in cases:
             ms = timed(fn)
