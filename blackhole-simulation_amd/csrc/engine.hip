@@ -181,6 +181,15 @@ hipError_t launch_segment(int arith, int kind, int method, const RayWorkspace &w
                : launch_segment_strict(kind, method, ws, P, live_in, n_live, live_out, cnt, s);
 }
 
+hipError_t launch_refill(int arith, int kind, int method, const RayWorkspace &ws,
+                         const SegmentParams &P, uint32_t *cursor, int n_cu, hipStream_t s) {
+    return arith == GRV_ARITH_FAST ? launch_refill_fast(kind, method, ws, P, cursor, n_cu, s)
+                                   : launch_refill_strict(kind, method, ws, P, cursor, n_cu, s);
+}
+
+// tries between two refill checks of a wave in the refill kernel
+constexpr uint32_t kRefillPeriod = 8;
+
 // Runs segments until no ray is live.  The workspace must have been initialised;
 // the first launch walks every slot (identity live list), later launches walk the
 // compacted list the previous one appended.
@@ -374,9 +383,18 @@ int grv_integrate_batch_device(grv_engine *e, size_t n, const double *d_states,
     GRV_HIP(e, hipMemsetAsync(e->d_stats, 0, sizeof(FrameStatsDev), s));
     GRV_HIP(e, launch_init_states(opt->metric_kind, e->ws, P, d_states, opt->initial_step,
                                   opt->method == GRV_METHOD_RKF45, s));
-    // independent rays diverge freely in a batch: compact every 64 tries unless told otherwise
-    rc = run_segments(e, *opt, P, opt->segment_tries > 0 ? (uint32_t)opt->segment_tries : 64u, s, false);
-    if (rc != GRV_OK) return rc;
+    // independent rays diverge freely in a batch.  Default: one resident launch whose waves
+    // refill finished lanes from a device-side cursor (no host round trip); segment_tries > 0
+    // asks for the relaunch + live-list compaction schedule instead.
+    if (opt->segment_tries > 0) {
+        rc = run_segments(e, *opt, P, (uint32_t)opt->segment_tries, s, false);
+        if (rc != GRV_OK) return rc;
+    } else {
+        P.max_tries = opt->segment_tries < 0 ? (uint32_t)(-(int64_t)opt->segment_tries) : kRefillPeriod;
+        GRV_HIP(e, launch_refill(opt->arith, opt->metric_kind, opt->method, e->ws, P,
+                                 e->d_counters + 2, e->n_cu, s));
+        e->last_launches = 1;
+    }
     GRV_HIP(e, launch_finalize_batch(e->ws, d_out_states, d_steps, d_termination, d_drift,
                                      e->d_stats, s));
     return GRV_OK;

@@ -105,6 +105,8 @@ struct FrameStatsDev {
 hipError_t launch_segment_strict(int kind, int method, const RayWorkspace &ws,
                                  const SegmentParams &P, const uint32_t *live_in, uint32_t n_live,
                                  uint32_t *live_out, uint32_t *live_out_count, hipStream_t s);
+hipError_t launch_refill_strict(int kind, int method, const RayWorkspace &ws, const SegmentParams &P,
+                                uint32_t *cursor, int n_cu, hipStream_t s);
 hipError_t launch_init_states(int kind, const RayWorkspace &ws, const SegmentParams &P,
                               const double *states, double h0, int adaptive, hipStream_t s);
 hipError_t launch_init_pixels(int kind, const RayWorkspace &ws, const SegmentParams &P,
@@ -165,5 +167,7 @@ hipError_t launch_wgsl_symplectic_fast(const FrameGeom &G, const WgslParams &P, 
 hipError_t launch_segment_fast(int kind, int method, const RayWorkspace &ws,
                                const SegmentParams &P, const uint32_t *live_in, uint32_t n_live,
                                uint32_t *live_out, uint32_t *live_out_count, hipStream_t s);
+hipError_t launch_refill_fast(int kind, int method, const RayWorkspace &ws, const SegmentParams &P,
+                              uint32_t *cursor, int n_cu, hipStream_t s);
 
 } // namespace grvhip

@@ -337,6 +337,87 @@ __device__ __forceinline__ void store_ray(const RayWorkspace &ws, uint32_t s, co
 }
 
 // ---------------------------------------------------------------------------
+// One integrator try of a live ray (integrator.rs:83-123 for RKF45) and, when it
+// completes a step, the loop-body epilogue.  Returns the ray's liveness.
+// ---------------------------------------------------------------------------
+template <int KIND, int ARITH, int METHOD>
+__device__ __forceinline__ bool advance_one(const Hole<double> &bh, RayRegs &y,
+                                            const SegmentParams &P, const RayWorkspace &ws,
+                                            uint32_t slot, const KsRayConsts &rc) {
+    const double r_prev = y.r, th_prev = y.th;
+    bool stepped;
+    if constexpr (METHOD == GRV_METHOD_RKF45) {
+        Deriv<double> inc;
+        const double h = y.h;
+        const double err = rkf45_try<KIND, ARITH>(bh, y, h, inc, rc);
+        y.tries += 1;
+        const bool forced = (y.flags & kFlagForced) != 0u;
+        double ratio;
+        if constexpr (ARITH == GRV_ARITH_FAST)
+            ratio = err * P.inv_tolerance; // err == 0 -> 0 without the special case
+        else
+            ratio = (err == 0.0) ? 0.0 : err / P.tolerance;
+        // integrator.rs:99-104: the forced minimum step is taken unconditionally and
+        // its own size is handed back as the next h.
+        stepped = forced || ratio <= 1.0;
+        if (stepped) {
+            y.t = y.t + h * inc.dt;
+            y.r = y.r + h * inc.dr;
+            y.th = y.th + h * inc.dth;
+            y.ph = y.ph + h * inc.dph;
+            y.pr = y.pr + h * inc.dpr;
+            y.pth = y.pth + h * inc.dpth;
+            if (!forced) {
+                double growth;
+                if constexpr (ARITH == GRV_ARITH_FAST)
+                    growth = (ratio < 1e-4) ? 5.0 : 0.9 * fast_pow_m1_5(ratio);
+                else
+                    growth = (ratio < 1e-4) ? 5.0 : 0.9 * pow(ratio, -0.2);
+                y.h = clamp_rs(h * fmin(growth, 5.0), -10.0, 10.0);
+            }
+            y.flags &= ~kFlagForced;
+        } else {
+            double shrink;
+            if constexpr (ARITH == GRV_ARITH_FAST)
+                shrink = 0.9 * fast_pow_m1_4(ratio);
+            else
+                shrink = 0.9 * pow(ratio, -0.25);
+            double hn = h * fmax(shrink, 0.1);
+            if (fabs(hn) < 1e-5) {
+                hn = 1e-5 * signum_rs(hn);
+                y.flags |= kFlagForced;
+            }
+            y.h = hn;
+        }
+    } else if constexpr (METHOD == GRV_METHOD_RK4) {
+        rk4_step<KIND, ARITH>(bh, y, P.step_size);
+        y.tries += 1;
+        stepped = true;
+    } else {
+        symplectic_step<KIND, ARITH>(bh, y, P.step_size);
+        y.tries += 1;
+        stepped = true;
+    }
+    if (stepped) {
+        after_step<KIND, ARITH>(bh, y, r_prev, th_prev, P, ws, slot, rc);
+        return ray_live(y);
+    }
+    return true;
+}
+
+// Per-ray values derived from a state that just came from HBM.
+template <int KIND, int ARITH>
+__device__ __forceinline__ void ray_resume(const Hole<double> &bh, RayRegs &y,
+                                           const SegmentParams &P, bool live, KsRayConsts &rc) {
+    y.phase = P.renorm_interval ? y.steps % P.renorm_interval : 1u;
+    rc = ks_ray_consts(bh, y.pt, y.pph); // p_t, p_phi never change
+    if constexpr (kStage1Cache<KIND, ARITH>) {
+        // rebuild the stage-1 cache
+        if (live) y.k1 = rhs_ks_geom(bh, ks_geom(bh, y.r, y.th), y.r, rc, y.pr, y.pth);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // The segment kernel.
 // ---------------------------------------------------------------------------
 template <int KIND, int ARITH, int METHOD>
@@ -354,74 +435,11 @@ __global__ __launch_bounds__(kBlock) void integrate_segment_kernel(
     const Hole<double> bh{P.M, P.a, P.a2, 2.0 * P.M};
 
     bool live = have && ray_live(y);
-    y.phase = P.renorm_interval ? y.steps % P.renorm_interval : 1u;
-    const KsRayConsts rc = ks_ray_consts(bh, y.pt, y.pph); // p_t, p_phi never change
-    if constexpr (kStage1Cache<KIND, ARITH>) {
-        // state came from HBM: rebuild the stage-1 cache
-        if (live) y.k1 = rhs_ks_geom(bh, ks_geom(bh, y.r, y.th), y.r, rc, y.pr, y.pth);
-    }
+    KsRayConsts rc;
+    ray_resume<KIND, ARITH>(bh, y, P, live, rc);
     for (uint32_t it = 0; it < P.max_tries; ++it) {
         if (__ballot(live) == 0ull) break; // whole wave finished: early out
-        if (live) {
-            const double r_prev = y.r, th_prev = y.th;
-            bool stepped;
-            if constexpr (METHOD == GRV_METHOD_RKF45) {
-                Deriv<double> inc;
-                const double h = y.h;
-                const double err = rkf45_try<KIND, ARITH>(bh, y, h, inc, rc);
-                y.tries += 1;
-                const bool forced = (y.flags & kFlagForced) != 0u;
-                double ratio;
-                if constexpr (ARITH == GRV_ARITH_FAST)
-                    ratio = err * P.inv_tolerance; // err == 0 -> 0 without the special case
-                else
-                    ratio = (err == 0.0) ? 0.0 : err / P.tolerance;
-                // integrator.rs:99-104: the forced minimum step is taken unconditionally and
-                // its own size is handed back as the next h.
-                stepped = forced || ratio <= 1.0;
-                if (stepped) {
-                    y.t = y.t + h * inc.dt;
-                    y.r = y.r + h * inc.dr;
-                    y.th = y.th + h * inc.dth;
-                    y.ph = y.ph + h * inc.dph;
-                    y.pr = y.pr + h * inc.dpr;
-                    y.pth = y.pth + h * inc.dpth;
-                    if (!forced) {
-                        double growth;
-                        if constexpr (ARITH == GRV_ARITH_FAST)
-                            growth = (ratio < 1e-4) ? 5.0 : 0.9 * fast_pow_m1_5(ratio);
-                        else
-                            growth = (ratio < 1e-4) ? 5.0 : 0.9 * pow(ratio, -0.2);
-                        y.h = clamp_rs(h * fmin(growth, 5.0), -10.0, 10.0);
-                    }
-                    y.flags &= ~kFlagForced;
-                } else {
-                    double shrink;
-                    if constexpr (ARITH == GRV_ARITH_FAST)
-                        shrink = 0.9 * fast_pow_m1_4(ratio);
-                    else
-                        shrink = 0.9 * pow(ratio, -0.25);
-                    double hn = h * fmax(shrink, 0.1);
-                    if (fabs(hn) < 1e-5) {
-                        hn = 1e-5 * signum_rs(hn);
-                        y.flags |= kFlagForced;
-                    }
-                    y.h = hn;
-                }
-            } else if constexpr (METHOD == GRV_METHOD_RK4) {
-                rk4_step<KIND, ARITH>(bh, y, P.step_size);
-                y.tries += 1;
-                stepped = true;
-            } else {
-                symplectic_step<KIND, ARITH>(bh, y, P.step_size);
-                y.tries += 1;
-                stepped = true;
-            }
-            if (stepped) {
-                after_step<KIND, ARITH>(bh, y, r_prev, th_prev, P, ws, slot, rc);
-                live = ray_live(y);
-            }
-        }
+        if (live) live = advance_one<KIND, ARITH, METHOD>(bh, y, P, ws, slot, rc);
     }
 
     if (have) store_ray(ws, slot, y);
@@ -448,6 +466,60 @@ __global__ __launch_bounds__(kBlock) void integrate_segment_kernel(
             live_out[off + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = slot;
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// The refill kernel: a resident grid (one launch) whose waves pull rays from a
+// global cursor.  Every `P.max_tries` tries a wave hands its finished lanes' rays
+// back to HBM and gives those lanes the next unclaimed slots (one wave-aggregated
+// atomic), so an incoherent batch keeps its lanes busy without relaunching.  A ray's
+// arithmetic does not depend on the lane that runs it: results are bitwise those of
+// the segment kernel.
+// ---------------------------------------------------------------------------
+template <int KIND, int ARITH, int METHOD>
+__global__ __launch_bounds__(kBlock) void integrate_refill_kernel(RayWorkspace ws, SegmentParams P,
+                                                                  uint32_t *__restrict__ cursor) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const Hole<double> bh{P.M, P.a, P.a2, 2.0 * P.M};
+    RayRegs y;
+    y.flags = 0;
+    y.pt = y.pph = 0.0;
+    KsRayConsts rc = ks_ray_consts(bh, 0.0, 0.0);
+    uint32_t slot = 0;
+    bool have = false, live = false, more = true; // `more` is wave-uniform
+    for (;;) {
+        if (more) {
+            const unsigned long long need = __ballot(!live);
+            if (need) {
+                if (!live && have) store_ray(ws, slot, y);
+                const uint32_t cnt = (uint32_t)__popcll(need);
+                uint32_t base = 0;
+                if (lane == (uint32_t)__ffsll((long long)need) - 1u) base = atomicAdd(cursor, cnt);
+                base = __shfl(base, __ffsll((long long)need) - 1);
+                more = base + cnt < ws.n;
+                if (!live) {
+                    const uint32_t mine = base + (uint32_t)__popcll(need & below);
+                    have = mine < ws.n;
+                    if (have) {
+                        slot = mine;
+                        load_ray(ws, slot, y);
+                        live = ray_live(y);
+                        ray_resume<KIND, ARITH>(bh, y, P, live, rc);
+                    }
+                }
+            }
+        }
+        if (__ballot(live) == 0ull) {
+            if (!more) break;
+            continue; // every claimed ray was already finished: claim again
+        }
+        for (uint32_t it = 0; it < P.max_tries; ++it) {
+            if (live) live = advance_one<KIND, ARITH, METHOD>(bh, y, P, ws, slot, rc);
+            if (__ballot(live) == 0ull) break;
+        }
+    }
+    if (have) store_ray(ws, slot, y);
 }
 
 // ---------------------------------------------------------------------------

@@ -45,6 +45,12 @@ hipError_t launch_segment_fast(int kind, int method, const RayWorkspace &ws,
     }
 }
 
+#define GRV_REFILL_ARITH GRV_ARITH_FAST
+#define GRV_REFILL_FN launch_refill_fast
+#include "refill_launch.inc"
+#undef GRV_REFILL_ARITH
+#undef GRV_REFILL_FN
+
 hipError_t launch_wgsl_symplectic_fast(const FrameGeom &G, const WgslParams &P, float *out_rgba,
                                        uint32_t *out_steps, unsigned long long *total_steps,
                                        uint32_t n_slots, hipStream_t s) {

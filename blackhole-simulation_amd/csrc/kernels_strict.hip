@@ -42,6 +42,12 @@ hipError_t launch_segment_strict(int kind, int method, const RayWorkspace &ws,
     }
 }
 
+#define GRV_REFILL_ARITH GRV_ARITH_STRICT
+#define GRV_REFILL_FN launch_refill_strict
+#include "refill_launch.inc"
+#undef GRV_REFILL_ARITH
+#undef GRV_REFILL_FN
+
 hipError_t launch_init_states(int kind, const RayWorkspace &ws, const SegmentParams &P,
                               const double *states, double h0, int adaptive, hipStream_t s) {
     const uint32_t grid = (ws.n + kBlock - 1) / kBlock;

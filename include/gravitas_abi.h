@@ -70,8 +70,13 @@ typedef struct {
     uint64_t renormalize_interval; /* 0 = never (Rust would panic) */
     double step_size;
     int32_t arith;                 /* GRV_ARITH_* */
-    int32_t segment_tries;         /* batch calls: integrator tries per launch before live-ray
-                                      compaction; 0 = engine default (64) */
+    int32_t segment_tries;         /* batch calls, how finished rays give up their lanes:
+                                      0  = engine default: one resident launch, waves refill
+                                           finished lanes from a device-side cursor every 8 tries;
+                                      <0 = the same with a refill check every -segment_tries tries;
+                                      >0 = relaunch with live-ray compaction every segment_tries
+                                           tries (one host read-back per launch).
+                                      Results do not depend on this field. */
 } GrvOptions;
 
 /* f64 mirror of the CameraUniforms fields the compute kernel reads

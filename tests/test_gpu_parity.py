@@ -175,6 +175,40 @@ def test_edge_cases(bh, oracle):
             e.integrate_batch(st, bh.engine.default_options(tolerance=0.0))
 
 
+@pytest.mark.parametrize("method,arith", [(0, 0), (0, 1), (1, 1), (2, 0)])
+def test_batch_schedules_agree_bitwise(bh, oracle, method, arith):
+    """The refill kernel (default), its refill period, and relaunch + compaction at any K run the
+    same per-ray arithmetic: outputs must not depend on GrvOptions.segment_tries, also when the
+    batch mixes already-finished rays, 3-step rays and max_steps rays in one wave."""
+    rng = np.random.default_rng(21)
+    n = 40 * 1000 + 37  # ragged tail
+    st = np.zeros((n, 8))
+    st[:, 1] = rng.uniform(2.2, 60, n)
+    st[:, 2] = rng.uniform(0.05, 3.09, n)
+    st[:, 4] = -1
+    st[:, 5] = rng.uniform(-1, 1, n)
+    st[:, 6] = rng.uniform(-6, 6, n)
+    st[:, 7] = rng.uniform(-6, 6, n)
+    st[::17, 1] = 1.3      # inside 1.001 r+: finished before the first try
+    st[5::29, 1] = 5000.0  # beyond the escape radius
+    kw = dict(max_steps=300, method=method, arith=arith, step_size=0.05)
+    with bh.PhysicsEngine(1.0, 0.9) as e:
+        base = e.integrate_batch(st, bh.engine.default_options(segment_tries=0, **kw))
+        assert set(np.unique(base["term"])) >= {bh.TERM_HORIZON, bh.TERM_ESCAPE}
+        assert base["steps"].min() == 0 and base["steps"].max() == 300
+        for K in (-1, -3, -64, 5, 64, 1 << 20):
+            got = e.integrate_batch(st, bh.engine.default_options(segment_tries=K, **kw))
+            for key in ("states", "steps", "term", "drift"):
+                assert np.array_equal(got[key], base[key], equal_nan=True), (K, key)
+    # and the default schedule is the oracle's answer on a sample
+    idx = rng.choice(n, 400, replace=False)
+    m = oracle.metric(oracle.KERR_KS, 1.0, 0.9)
+    ref = oracle.integrate_batch(m, oracle.options(max_steps=300, method=method, step_size=0.05), st[idx])
+    assert np.array_equal(base["term"][idx], ref["term"])
+    if arith == 0:
+        assert np.array_equal(base["steps"][idx], ref["steps"])
+
+
 @pytest.mark.parametrize("mass,spin", [(2.5, 0.7), (0.3, -0.95), (1.0, 1.0), (1.0, -1.0), (4.0, 0.0), (1.0, 1.6)])
 @pytest.mark.parametrize("kind", ["ks", "bl"])
 def test_mass_and_spin_sweep(bh, oracle, mass, spin, kind):

@@ -1,7 +1,8 @@
 """Secondary measurement: what ray compaction buys on an incoherent batch.
 The 1080p frame's rays are integrated as a batch (grv_integrate_batch_device) in image order
 (neighbouring lanes take near-identical step counts) and in a random permutation (every wave
-mixes 35..435-step rays), with segment lengths K = 16, 64, 256 and one launch (no compaction).
+mixes 35..435-step rays), under the refill kernel (the default), relaunch + compaction with
+segment lengths K = 16, 64, 256, and one launch without either.
 Run on the GPU box: python tools/bench_batch.py"""
 import json
 import os
@@ -32,7 +33,7 @@ if __name__ == "__main__":
         steps = torch.zeros(n, dtype=torch.int32, device="cuda:0")
         ref = None
         for order, states in (("image order", fs), ("random permutation", fs[perm].contiguous())):
-            for K in (16, 64, 256, 1 << 20):
+            for K in (0, -4, -32, 16, 64, 256, 1 << 20):
                 o = bh.engine.default_options(max_steps=2048, arith=bh.ARITH_FAST, segment_tries=K)
                 e.integrate_batch_device(n, states, o, out, steps)
                 torch.cuda.synchronize()
@@ -46,7 +47,8 @@ if __name__ == "__main__":
                 if ref is None:
                     ref = res.clone()
                 same = bool(torch.equal(res, ref))  # results must not depend on K or on the order
-                print(json.dumps({"order": order, "segment_tries": K if K < (1 << 20) else "one launch",
+                print(json.dumps({"order": order, "schedule": ("refill every %d tries" % (-K or 8)) if K <= 0 else
+                                  ("compaction every %d tries" % K if K < (1 << 20) else "one launch"),
                                   "rays": n, "accepted_steps": tot, "ms": round(ms, 3),
                                   "Mray_steps_per_s": round(tot / ms / 1e3, 1),
                                   "bitwise_equal_to_first": same}), flush=True)
