@@ -4,6 +4,7 @@
 #include "geodesic_kernels.hpp"
 #include "wgsl_fast_kernel.hpp"
 #include "wgsl_pk_kernel.hpp"
+#include <atomic>
 #include <cstring>
 
 #include "glsl_fragment.hpp"

@@ -1,6 +1,7 @@
 // kernels_strict.hip -- STRICT arithmetic contract: compiled with
 // -ffp-contract=off (reference operation order, IEEE divide/sqrt, no FMA).
 // Also holds the kernels that exist once: init, live-list, finalize/shade, LUT.
+#include <atomic>
 #include <cstring>
 
 #include "shader_kernels.hpp"
@@ -105,12 +106,17 @@ hipError_t launch_finalize_frame(const RayWorkspace &ws, const FrameGeom &G, con
                                  hipStream_t s) {
     if (ws.n == 0) return hipSuccess;
     const size_t lds = (shading && lut) ? (size_t)S.lds_rows * S.lut_w * sizeof(float4) : 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(finalize_frame_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+    // the attribute belongs to the (function, device) pair: one bit per device, set once
+    static std::atomic<uint64_t> attr_set{0};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(attr_set.load(std::memory_order_acquire) & bit)) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(finalize_frame_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set.fetch_or(bit, std::memory_order_release);
     }
     const uint32_t need = (ws.n + 1023u) / 1024u;
     uint32_t grid = (uint32_t)n_blocks;

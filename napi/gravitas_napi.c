@@ -99,6 +99,10 @@ static napi_value engine_new(napi_env env, napi_callback_info info) {
     double mass = argc > 0 ? arg_f64(env, argv[0]) : 1.0;
     double spin = argc > 1 ? arg_f64(env, argv[1]) : 0.0;
     engine_box *box = (engine_box *)calloc(1, sizeof *box);
+    if (!box) {
+        napi_throw_error(env, NULL, "PhysicsEngine: out of memory");
+        return NULL;
+    }
     int rc = grv_engine_create(mass, spin, 0, &box->h);
     if (rc != GRV_OK) {
         free(box);
@@ -245,10 +249,17 @@ static napi_value m_compute_shadow_curve(napi_env env, napi_callback_info info) 
     napi_get_value_uint32(env, argv[1], &n);
     if (n > 4096) n = 4096;
     float *tmp = (float *)malloc(((size_t)4 * n + 8) * sizeof(float)); /* n or 2n (alpha, beta) pairs */
+    if (!tmp) {
+        napi_throw_error(env, NULL, "compute_shadow_curve: out of memory");
+        return NULL;
+    }
     size_t m = grv_compute_shadow_curve(b->h, arg_f64(env, argv[0]), n, tmp);
     napi_value ab, ta;
     void *dst;
-    NAPI_OK(napi_create_arraybuffer(env, 2 * m * sizeof(float), &dst, &ab));
+    if (napi_create_arraybuffer(env, 2 * m * sizeof(float), &dst, &ab) != napi_ok) {
+        free(tmp);
+        return NULL;
+    }
     memcpy(dst, tmp, 2 * m * sizeof(float));
     free(tmp);
     NAPI_OK(napi_create_typedarray(env, napi_float32_array, 2 * m, ab, 0, &ta));
@@ -383,6 +394,10 @@ static napi_value field_common(napi_env env, napi_callback_info info, int field)
     const uint32_t nr = arg_u32(env, argv[2]), np = arg_u32(env, argv[3]);
     const size_t n = (size_t)3 * nr * np;
     float *tmp = (float *)malloc((n ? n : 1) * sizeof(float));
+    if (!tmp) {
+        napi_throw_error(env, NULL, "out of memory");
+        return NULL;
+    }
     if (grv_generate_field(b->h, field, arg_f64(env, argv[0]), arg_f64(env, argv[1]), nr, np, tmp) !=
         GRV_OK) {
         free(tmp);
@@ -412,6 +427,10 @@ static napi_value m_generate_embedding_mesh(napi_env env, napi_callback_info inf
     const uint32_t nr = arg_u32(env, argv[2]), na = arg_u32(env, argv[3]);
     const size_t n = (size_t)3 * nr * na;
     float *tmp = (float *)malloc((n ? n : 1) * sizeof(float));
+    if (!tmp) {
+        napi_throw_error(env, NULL, "out of memory");
+        return NULL;
+    }
     if (grv_generate_embedding_mesh(b->h, arg_f64(env, argv[0]), arg_f64(env, argv[1]), nr, na, tmp) !=
         GRV_OK) {
         free(tmp);
@@ -432,6 +451,10 @@ static napi_value m_generate_ergosphere_mesh(napi_env env, napi_callback_info in
     const uint32_t np = arg_u32(env, argv[0]), na = arg_u32(env, argv[1]);
     const size_t n = (size_t)3 * np * na;
     float *tmp = (float *)malloc((n ? n : 1) * sizeof(float));
+    if (!tmp) {
+        napi_throw_error(env, NULL, "out of memory");
+        return NULL;
+    }
     if (grv_generate_ergosphere_mesh(b->h, np, na, tmp) != GRV_OK) {
         free(tmp);
         napi_throw_error(env, NULL, grv_last_error(b->h));
