@@ -1,6 +1,7 @@
 // engine.hip -- lifecycle, closed forms, batch / single-ray / frame entry points of the C ABI
 // (include/gravitas_abi.h) on top of the segment kernels.  See engine_internal.hpp.
 #include "engine_internal.hpp"
+#include "strict_libm.hpp"
 
 namespace grvhost {
 
@@ -46,7 +47,7 @@ double dilation(double m, double a_star, double r) {
 // physics/redshift.rs:65-95
 double g_factor(double r, double mass, double spin, double lambda) {
     const double a = spin * mass, r2 = r * r, a2 = a * a, m = mass;
-    const double omega = std::sqrt(m) / (std::pow(r, 1.5) + a * std::sqrt(m));
+    const double omega = std::sqrt(m) / (strictm::sl_pow(r, 1.5) + a * std::sqrt(m)); // as on the device
     const double sigma = r2;
     const double g_tt = -(1.0 - 2.0 * m * r / sigma);
     const double g_tphi = -(2.0 * m * r * a) / sigma;
@@ -541,6 +542,19 @@ int grv_render_frame_device(grv_engine *e, const GrvCamera *cam, const GrvRender
     std::memcpy(cd.inv_view, cam->inv_view, sizeof cd.inv_view);
     std::memcpy(cd.inv_proj, cam->inv_proj, sizeof cd.inv_proj);
     std::memcpy(cd.off, cam->pixel_offset, sizeof cd.off);
+    {
+        // compute.wgsl.ts:172-176: r0, theta0 = acos(y / r0), phi0 = atan2(z, x)
+        const double *c = cam->position;
+        cd.r0 = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+        double cy = c[1] / cd.r0;
+        cy = cy < -1.0 ? -1.0 : (cy > 1.0 ? 1.0 : cy);
+        cd.theta0 = std::acos(cy);
+        cd.phi0 = std::atan2(c[2], c[0]);
+        cd.st = std::sin(cd.theta0);
+        cd.ct = std::cos(cd.theta0);
+        cd.sp = std::sin(cd.phi0);
+        cd.cp = std::cos(cd.phi0);
+    }
 
     if (profile) GRV_HIP(e, hipEventRecord(e->ev[0], s));
     GRV_HIP(e, launch_init_pixels(p->opt.metric_kind, e->ws, P, G, cd, p->opt.initial_step,

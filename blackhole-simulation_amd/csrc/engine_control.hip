@@ -56,6 +56,27 @@ int grv_generate_spectrum_lut(grv_engine *e, size_t width, size_t height, double
     return GRV_OK;
 }
 
+int grv_strict_math(grv_engine *e, int op, size_t n, const double *x, const double *y, double *out) {
+    if (!e) return GRV_ERR_INVALID;
+    if (op < GRV_MATH_SINCOS_SIN || op > GRV_MATH_POW) return fail(e, GRV_ERR_INVALID, "bad op %d", op);
+    if (n == 0) return GRV_OK;
+    if (!x || !out || (op == GRV_MATH_POW && !y) || n > (1ull << 26))
+        return fail(e, GRV_ERR_INVALID, "bad strict_math request");
+    GRV_HIP(e, hipSetDevice(e->device));
+    const size_t b = align_up(n * sizeof(double), 256);
+    int rc = ensure_stage(e, 3 * b);
+    if (rc != GRV_OK) return rc;
+    char *base = static_cast<char *>(e->stage_mem);
+    double *dx = reinterpret_cast<double *>(base), *dy = reinterpret_cast<double *>(base + b),
+           *dout = reinterpret_cast<double *>(base + 2 * b);
+    GRV_HIP(e, hipMemcpy(dx, x, n * sizeof(double), hipMemcpyHostToDevice));
+    if (y) GRV_HIP(e, hipMemcpy(dy, y, n * sizeof(double), hipMemcpyHostToDevice));
+    GRV_HIP(e, launch_strict_math(op, (uint32_t)n, dx, y ? dy : dx, dout, nullptr));
+    GRV_HIP(e, hipDeviceSynchronize());
+    GRV_HIP(e, hipMemcpy(out, dout, n * sizeof(double), hipMemcpyDeviceToHost));
+    return GRV_OK;
+}
+
 const float *grv_get_sab_ptr(const grv_engine *e) { return e ? e->sab.data() : nullptr; }
 
 int grv_attach_sab(grv_engine *e, float *ptr) {

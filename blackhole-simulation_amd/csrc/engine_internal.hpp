@@ -97,6 +97,7 @@ double g_factor(double r, double mass, double spin, double lambda);
 int ensure_workspace(grv_engine *e, size_t slots);
 int ensure_stage(grv_engine *e, size_t bytes);
 int ensure_lut(grv_engine *e, uint32_t w, uint32_t h, double tmax, hipStream_t s);
+size_t align_up(size_t x, size_t a);
 SegmentParams make_segment_params(const grv_engine *e, const GrvOptions &o);
 bool options_valid(const GrvOptions &o);
 int run_segments(grv_engine *e, const GrvOptions &o, SegmentParams P, uint32_t seg_tries, hipStream_t s,

@@ -59,6 +59,8 @@ struct CameraDev {
     double inv_view[16];
     double inv_proj[16];
     double off[2];
+    // compute.wgsl.ts:172-176, per-frame constants of the pixel -> state map (host-evaluated)
+    double r0, theta0, phi0, st, ct, sp, cp;
 };
 
 struct ShadeParams {
@@ -128,6 +130,8 @@ hipError_t launch_wgsl_symplectic(const FrameGeom &G, const WgslParams &P, float
 hipError_t launch_glsl_fragment(const FrameGeom &G, const GlslParams &P, float *out_rgba,
                               uint32_t *out_steps, unsigned long long *total_steps,
                               uint32_t n_slots, hipStream_t s);
+hipError_t launch_strict_math(int op, uint32_t n, const double *x, const double *y, double *out,
+                              hipStream_t s);
 hipError_t launch_spectrum_lut(float *out, uint32_t width, uint32_t height, double max_temp,
                                hipStream_t s);
 // ---- post chain (post_kernels.hpp, in kernels_strict.hip) ----

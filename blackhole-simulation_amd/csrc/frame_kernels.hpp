@@ -118,7 +118,7 @@ __device__ __forceinline__ double kerr_g_factor_dev(double r, double mass, doubl
     const double r2 = r * r;
     const double a2 = a * a;
     const double m = mass;
-    const double omega = sqrt(m) / (pow(r, 1.5) + a * sqrt(m));
+    const double omega = sqrt(m) / (pow_rs(r, 1.5) + a * sqrt(m));
     const double sigma = r2;
     const double g_tt = -(1.0 - 2.0 * m * r / sigma);
     const double g_tphi = -(2.0 * m * r * a) / sigma;
@@ -135,7 +135,7 @@ __device__ __forceinline__ double disk_temp_profile_dev(double r, double disk_in
     double isco_r = disk_inner / r;
     isco_r = isco_r < 0.0 ? 0.0 : (isco_r > 1.0 ? 1.0 : isco_r);
     const double nt = fmax(0.0, 1.0 - sqrt(isco_r));
-    return pow(isco_r, 0.75) * pow(nt, 0.25);
+    return pow_rs(isco_r, 0.75) * pow_rs(nt, 0.25);
 }
 
 // texel fetch: LDS for the staged rows [row0, row0+rows), HBM/L2 otherwise
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(1024) void finalize_frame_kernel(
                         const double g = kerr_g_factor_dev(r_c, S.M, S.spin, lambda);
                         const double temp = S.disk_temp * disk_temp_profile_dev(r_c, S.disk_inner);
                         // inverse LUT axes (spectrum.rs:82,85)
-                        const double u = pow(fmax(temp, 0.0) / S.lut_max_temp, 1.0 / 2.5);
+                        const double u = pow_rs(fmax(temp, 0.0) / S.lut_max_temp, 1.0 / 2.5);
                         double fx = u * (double)(S.lut_w > 1 ? S.lut_w - 1 : 1);
                         double fy = (g - 0.05) / (5.0 - 0.05) * (double)(S.lut_h > 1 ? S.lut_h - 1 : 1);
                         if (!(fx > 0.0)) fx = 0.0;
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(kBlock) void spectrum_lut_kernel(float4 *__restrict
     const uint32_t hden = (height > 1) ? height - 1 : 1;
     const uint32_t wden = (width > 1) ? width - 1 : 1;
     const double g = 0.05 + (5.0 - 0.05) * ((double)y / (double)hden);
-    const double t = pow((double)x / (double)wden, 2.5) * max_temp;
+    const double t = pow_rs((double)x / (double)wden, 2.5) * max_temp;
     const double t_eff = t * g;
 
     constexpr double SI_C = 299792458.0, SI_KB = 1.380649e-23, HP = 6.62607015e-34;

@@ -372,7 +372,7 @@ __device__ __forceinline__ bool advance_one(const Hole<double> &bh, RayRegs &y,
                 if constexpr (ARITH == GRV_ARITH_FAST)
                     growth = (ratio < 1e-4) ? 5.0 : 0.9 * fast_pow_m1_5(ratio);
                 else
-                    growth = (ratio < 1e-4) ? 5.0 : 0.9 * pow(ratio, -0.2);
+                    growth = (ratio < 1e-4) ? 5.0 : 0.9 * pow_rs(ratio, -0.2);
                 y.h = clamp_rs(h * fmin(growth, 5.0), -10.0, 10.0);
             }
             y.flags &= ~kFlagForced;
@@ -381,7 +381,7 @@ __device__ __forceinline__ bool advance_one(const Hole<double> &bh, RayRegs &y,
             if constexpr (ARITH == GRV_ARITH_FAST)
                 shrink = 0.9 * fast_pow_m1_4(ratio);
             else
-                shrink = 0.9 * pow(ratio, -0.25);
+                shrink = 0.9 * pow_rs(ratio, -0.25);
             double hn = h * fmax(shrink, 0.1);
             if (fabs(hn) < 1e-5) {
                 hn = 1e-5 * signum_rs(hn);
@@ -616,14 +616,10 @@ __global__ __launch_bounds__(kBlock) void init_from_pixels_kernel(RayWorkspace w
     len = sqrt(wd[0] * wd[0] + wd[1] * wd[1] + wd[2] * wd[2]);
     const double wx = wd[0] / len, wy = wd[1] / len, wz = wd[2] / len;
 
-    const double r0 = sqrt(cam.pos[0] * cam.pos[0] + cam.pos[1] * cam.pos[1] + cam.pos[2] * cam.pos[2]);
-    double cy = cam.pos[1] / r0;
-    cy = cy < -1.0 ? -1.0 : (cy > 1.0 ? 1.0 : cy);
-    const double theta0 = acos(cy);
-    const double phi0 = atan2(cam.pos[2], cam.pos[0]);
-    double st, ct, sp, cp;
-    sincos(theta0, &st, &ct);
-    sincos(phi0, &sp, &cp);
+    // the camera's own (r, theta, phi) and their sines/cosines are per-frame constants: formed
+    // once on the host (engine.hip: camera_constants) instead of 8.3 M times here
+    const double r0 = cam.r0, theta0 = cam.theta0, phi0 = cam.phi0;
+    const double st = cam.st, ct = cam.ct, sp = cam.sp, cp = cam.cp;
     const double pr_far = wx * (st * cp) + wy * ct + wz * (st * sp);
     const double pth_far = (wx * (ct * cp) + wy * (-st) + wz * (ct * sp)) / r0;
     const double safe_st = fmax(st, 1e-4);

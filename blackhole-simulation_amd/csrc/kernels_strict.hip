@@ -1,6 +1,7 @@
 // kernels_strict.hip -- STRICT arithmetic contract: compiled with
 // -ffp-contract=off (reference operation order, IEEE divide/sqrt, no FMA).
 // Also holds the kernels that exist once: init, live-list, finalize/shade, LUT.
+#define GRV_SPECIFIED_LIBM 1 // sin / cos / pow of this unit: strict_libm.hpp
 #include <atomic>
 #include <cstring>
 
@@ -155,6 +156,34 @@ hipError_t launch_glsl_fragment(const FrameGeom &G, const GlslParams &P, float *
     if (n_slots == 0) return hipSuccess;
     hipLaunchKernelGGL((glsl_fragment_kernel<GRV_ARITH_STRICT>), dim3((n_slots + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
                        G, P, reinterpret_cast<float4 *>(out_rgba), out_steps, total_steps, n_slots);
+    return hipGetLastError();
+}
+
+namespace {
+// evaluates the STRICT unit's sin / cos / pow on the device (grv_strict_math: parity tests
+// compare them bit for bit with oracle/ref_libm.c)
+__global__ __launch_bounds__(kBlock) void strict_math_kernel(int op, uint32_t n,
+                                                            const double *__restrict__ x,
+                                                            const double *__restrict__ y,
+                                                            double *__restrict__ out) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    double s, c;
+    switch (op) {
+    case 0: sincos_t<double>(x[i], &s, &c); out[i] = s; break;
+    case 1: sincos_t<double>(x[i], &s, &c); out[i] = c; break;
+    case 2: out[i] = strictm::sl_sin(x[i]); break;
+    case 3: out[i] = strictm::sl_cos(x[i]); break;
+    default: out[i] = pow_rs(x[i], y[i]); break;
+    }
+}
+} // namespace
+
+hipError_t launch_strict_math(int op, uint32_t n, const double *x, const double *y, double *out,
+                              hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(strict_math_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, op, n,
+                       x, y, out);
     return hipGetLastError();
 }
 

@@ -21,6 +21,9 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/gravitas_abi.h"
+#if defined(GRV_SPECIFIED_LIBM)
+#include "strict_libm.hpp"
+#endif
 
 namespace {
 
@@ -50,7 +53,17 @@ template <typename T> __device__ __forceinline__ T sqrt_t(T a);
 template <> __device__ __forceinline__ double sqrt_t<double>(double a) { return sqrt(a); }
 template <> __device__ __forceinline__ float sqrt_t<float>(float a) { return sqrtf(a); }
 template <typename T> __device__ __forceinline__ void sincos_t(T x, T *s, T *c);
+// f64 transcendental functions of the ray path.  The STRICT unit (kernels_strict.hip) defines
+// GRV_SPECIFIED_LIBM and gets the written-out routines of strict_libm.hpp, whose results are a
+// pure function of the argument (the checker in oracle/ evaluates the same published algorithms);
+// the FAST unit's reference-order metrics (BL, Schwarzschild) use the device library.
+#if defined(GRV_SPECIFIED_LIBM)
+template <> __device__ __forceinline__ void sincos_t<double>(double x, double *s, double *c) { strictm::sl_sincos(x, s, c); }
+__device__ __forceinline__ double pow_rs(double x, double y) { return strictm::sl_pow(x, y); }
+#else
 template <> __device__ __forceinline__ void sincos_t<double>(double x, double *s, double *c) { sincos(x, s, c); }
+__device__ __forceinline__ double pow_rs(double x, double y) { return pow(x, y); }
+#endif
 template <> __device__ __forceinline__ void sincos_t<float>(float x, float *s, float *c) { sincosf(x, s, c); }
 
 // ---------------------------------------------------------------------------

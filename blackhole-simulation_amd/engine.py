@@ -18,6 +18,7 @@ _LIB = os.path.join(_HERE, "libgravitas_hip.so")
 KERR_BL, KERR_KS, SCHWARZSCHILD = 0, 1, 2
 METHOD_RKF45, METHOD_RK4, METHOD_SYMPLECTIC = 0, 1, 2
 ARITH_STRICT, ARITH_FAST = 0, 1
+MATH_SINCOS_SIN, MATH_SINCOS_COS, MATH_SIN, MATH_COS, MATH_POW = 0, 1, 2, 3, 4
 TERM_NONE, TERM_HORIZON, TERM_ESCAPE, TERM_MAXSTEPS, TERM_DISK_CROSSING = 0, 1, 2, 3, 4
 _STATUS = {0: "GRV_OK", 1: "GRV_ERR_INVALID", 2: "GRV_ERR_NO_DEVICE", 3: "GRV_ERR_HIP",
            4: "GRV_ERR_OOM"}
@@ -186,6 +187,8 @@ def load_library():
     L.grv_options_default.argtypes = [C.POINTER(Options)]
     L.grv_generate_spectrum_lut.restype = i
     L.grv_generate_spectrum_lut.argtypes = [p, sz, sz, d, p]
+    L.grv_strict_math.restype = i
+    L.grv_strict_math.argtypes = [p, i, sz, p, p, p]
     L.grv_generate_spectrum_lut_device.restype = i
     L.grv_generate_spectrum_lut_device.argtypes = [p, sz, sz, d, p, p]
     L.grv_wgsl_params_default.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(Camera), d, d,
@@ -532,6 +535,15 @@ class PhysicsEngine:
         out = np.zeros(width * height * 4, np.float32)
         self._check(self._lib.grv_generate_spectrum_lut(self._h, width, height, float(max_temp),
                                                         _np_ptr(out)), "generate_spectrum_lut")
+        return out
+
+    def strict_math(self, op, x, y=None):
+        """The STRICT contract's sin / cos / pow evaluated on the device (op: MATH_*)."""
+        x = np.ascontiguousarray(x, np.float64)
+        y = None if y is None else np.ascontiguousarray(y, np.float64)
+        out = np.zeros_like(x)
+        self._check(self._lib.grv_strict_math(self._h, int(op), x.size, _np_ptr(x), _np_ptr(y),
+                                              _np_ptr(out)), "strict_math")
         return out
 
     # ---- lib.rs:107-110, 161-205 ----

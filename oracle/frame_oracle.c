@@ -3,6 +3,7 @@
  * ONLY; see frame_oracle.h for what is restated vs defined ("parity unpinned").
  */
 #include "frame_oracle.h"
+#include "ref_libm.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -113,14 +114,14 @@ double orc_disk_temp_profile(double r, double disk_inner) {
     if (isco_r < 0.0) isco_r = 0.0;
     if (isco_r > 1.0) isco_r = 1.0;
     double nt_factor = fmax(0.0, 1.0 - sqrt(isco_r));
-    return pow(isco_r, 0.75) * pow(nt_factor, 0.25);
+    return orc_pow(isco_r, 0.75) * orc_pow(nt_factor, 0.25);
 }
 
 /* inverse of the LUT axes of physics/spectrum.rs:82,85:
  *   g = 0.05 + 4.95 * y/(H-1) ; T = (x/(W-1))^2.5 * Tmax */
 void orc_lut_sample(const float *lut, uint32_t w, uint32_t h, double max_temp, double temp,
                     double g, double rgb[3]) {
-    double u = pow(fmax(temp, 0.0) / max_temp, 1.0 / 2.5);
+    double u = orc_pow(fmax(temp, 0.0) / max_temp, 1.0 / 2.5);
     double fx = u * (double)(w > 1 ? w - 1 : 1);
     double fy = (g - 0.05) / (5.0 - 0.05) * (double)(h > 1 ? h - 1 : 1);
     if (!(fx > 0.0)) fx = 0.0;

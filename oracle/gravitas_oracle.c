@@ -13,10 +13,16 @@
  *   f64::max/min  -> fmax/fmin (NaN-ignoring)
  *   f64::clamp    -> rs_clamp  (x<lo?lo : x>hi?hi : x ; NaN passes through)
  *   f64::powi(n)  -> compiler-rt __powidf2 square-and-multiply (rs_powi)
- *   f64::powf     -> libm pow
+ *   f64::powf, f64::sin, f64::cos on the per-ray path (metric, Hamilton derivatives, step
+ *                    controller, g-factor, LUT axes) -> orc_pow / orc_sin / orc_cos of ref_libm.c:
+ *                    written-out fdlibm-lineage routines with a specified result (the reference
+ *                    takes these from whichever libm its target links; see ref_libm.h).  Closed
+ *                    forms evaluated once per engine (ISCO, photon sphere ...) use the host libm,
+ *                    as the engine's host code does.
  *   f64::signum   -> +1 for +0.0/positive, -1 for -0.0/negative, NaN for NaN
  */
 #include "gravitas_oracle.h"
+#include "ref_libm.h"
 
 #include <math.h>
 #include <string.h>
@@ -146,8 +152,8 @@ static void covariant_bl(const orc_metric *mt, double r, double theta, double g[
     double a = kerr_a(mt);
     double r2 = r * r;
     double a2 = a * a;
-    double sin_theta = sin(theta);
-    double cos_theta = cos(theta);
+    double sin_theta = orc_sin(theta);
+    double cos_theta = orc_cos(theta);
     double sin2 = sin_theta * sin_theta;
     double cos2 = cos_theta * cos_theta;
     double sigma = r2 + a2 * cos2;
@@ -172,8 +178,8 @@ static void contravariant_bl(const orc_metric *mt, double r, double theta, doubl
     double a = kerr_a(mt);
     double r2 = r * r;
     double a2 = a * a;
-    double sin_theta = sin(theta);
-    double cos_theta = cos(theta);
+    double sin_theta = orc_sin(theta);
+    double cos_theta = orc_cos(theta);
     double sin2 = sin_theta * sin_theta;
     double cos2 = cos_theta * cos_theta;
     double sigma = r2 + a2 * cos2;
@@ -199,8 +205,8 @@ static void hamiltonian_derivs_bl(const orc_metric *mt, double r, double theta, 
     double a = kerr_a(mt);
     double r2 = r * r;
     double a2 = a * a;
-    double cos_theta = cos(theta);
-    double sin_theta = sin(theta);
+    double cos_theta = orc_cos(theta);
+    double sin_theta = orc_sin(theta);
     double sin2 = sin_theta * sin_theta;
     double cos2 = cos_theta * cos_theta;
 
@@ -261,7 +267,7 @@ static void covariant_ks(const orc_metric *mt, double r, double theta, double g[
     double a = kerr_a(mt);
     double r2 = r * r;
     double a2 = a * a;
-    double cos2 = rs_powi(cos(theta), 2);
+    double cos2 = rs_powi(orc_cos(theta), 2);
     double sin2 = 1.0 - cos2;
     double sigma = r2 + a2 * cos2;
     double h = (m * r) / sigma;
@@ -290,7 +296,7 @@ static void contravariant_ks(const orc_metric *mt, double r, double theta, doubl
     double a = kerr_a(mt);
     double r2 = r * r;
     double a2 = a * a;
-    double sin2 = fmax(rs_powi(sin(theta), 2), 1e-12);
+    double sin2 = fmax(rs_powi(orc_sin(theta), 2), 1e-12);
     double cos2 = 1.0 - sin2;
     double sigma = r2 + a2 * cos2;
     double delta = r2 - 2.0 * m * r + a2;
@@ -318,8 +324,8 @@ static void hamiltonian_derivs_ks(const orc_metric *mt, double r, double theta, 
     double a = kerr_a(mt);
     double r2 = r * r;
     double a2 = a * a;
-    double sin_theta = sin(theta);
-    double cos_theta = cos(theta);
+    double sin_theta = orc_sin(theta);
+    double cos_theta = orc_cos(theta);
     double sin2 = fmax(sin_theta * sin_theta, 1e-12);
     double cos2 = 1.0 - sin2;
     double sigma = r2 + a2 * cos2;
@@ -367,7 +373,7 @@ static void hamiltonian_derivs_ks(const orc_metric *mt, double r, double theta, 
 static void covariant_schw(const orc_metric *mt, double r, double theta, double g[16]) {
     double m = mt->mass;
     double rs = 2.0 * m;
-    double sin2 = rs_powi(sin(theta), 2);
+    double sin2 = rs_powi(orc_sin(theta), 2);
     memset(g, 0, 16 * sizeof(double));
     g[0] = -(1.0 - rs / r);
     g[5] = 1.0 / (1.0 - rs / r);
@@ -379,7 +385,7 @@ static void covariant_schw(const orc_metric *mt, double r, double theta, double 
 static void contravariant_schw(const orc_metric *mt, double r, double theta, double g[16]) {
     double m = mt->mass;
     double rs = 2.0 * m;
-    double sin2 = fmax(rs_powi(sin(theta), 2), 1e-12);
+    double sin2 = fmax(rs_powi(orc_sin(theta), 2), 1e-12);
     memset(g, 0, 16 * sizeof(double));
     g[0] = -1.0 / (1.0 - rs / r);
     g[5] = 1.0 - rs / r;
@@ -393,8 +399,8 @@ static void hamiltonian_derivs_schw(const orc_metric *mt, double r, double theta
     double m = mt->mass;
     double r2 = r * r;
     double r3 = r2 * r;
-    double sin_theta = sin(theta);
-    double cos_theta = cos(theta);
+    double sin_theta = orc_sin(theta);
+    double cos_theta = orc_cos(theta);
     double sin2 = sin_theta * sin_theta;
 
     double f = 1.0 - 2.0 * m / r;
@@ -536,8 +542,8 @@ double orc_carter_constant(const orc_state *s, const orc_metric *m) {
     double p_ph = s->p[3];
     double theta = s->x[2];
     double a = m->spin * m->mass;
-    double cos_theta = cos(theta);
-    double sin_theta = sin(theta);
+    double cos_theta = orc_cos(theta);
+    double sin_theta = orc_sin(theta);
     double sin2 = sin_theta * sin_theta;
     double energy = -p_t;
     double e2 = energy * energy;
@@ -649,11 +655,11 @@ double orc_adaptive_step(orc_state *state, const orc_metric *m, double h_try, do
 
         if (error_ratio <= 1.0) {
             *state = new_state;
-            double growth = (error_ratio < 1e-4) ? 5.0 : safety_factor * pow(error_ratio, -0.2);
+            double growth = (error_ratio < 1e-4) ? 5.0 : safety_factor * orc_pow(error_ratio, -0.2);
             double next_h = h * fmin(growth, 5.0);
             return rs_clamp(next_h, -max_step, max_step);
         } else {
-            double shrink = safety_factor * pow(error_ratio, -0.25);
+            double shrink = safety_factor * orc_pow(error_ratio, -0.25);
             h *= fmax(shrink, 0.1);
             if (fabs(h) < min_step) {
                 orc_state forced;
@@ -844,7 +850,7 @@ double orc_kerr_g_factor(double r, double mass, double spin, double lambda) {
     double a2 = a * a;
     double m = mass;
 
-    double omega = sqrt(m) / (pow(r, 1.5) + a * sqrt(m));
+    double omega = sqrt(m) / (orc_pow(r, 1.5) + a * sqrt(m));
 
     double sigma = r2;
     double g_tt = -(1.0 - 2.0 * m * r / sigma);
@@ -944,7 +950,7 @@ void orc_generate_blackbody_lut(size_t width, size_t height, double max_temp, fl
     for (size_t y = 0; y < height; y++) {
         double g = min_g + (max_g - min_g) * ((double)y / (double)hden);
         for (size_t x = 0; x < width; x++) {
-            double t = pow((double)x / (double)wden, 2.5) * max_temp;
+            double t = orc_pow((double)x / (double)wden, 2.5) * max_temp;
             double t_eff = t * g;
             double xyz[3];
             orc_integrate_planck_xyz(t_eff, xyz);

@@ -105,6 +105,11 @@ def lib():
         L = C.CDLL(_LIB_PATH)
         d, i, u64, p = C.c_double, C.c_int, C.c_uint64, C.c_void_p
         MP, SP, OP = C.POINTER(Metric), C.POINTER(State), C.POINTER(Options)
+        for name in ("orc_sin", "orc_cos"):  # ref_libm.c
+            getattr(L, name).restype = d
+            getattr(L, name).argtypes = [d]
+        L.orc_pow.restype = d
+        L.orc_pow.argtypes = [d, d]
         L.orc_metric_make.restype = Metric
         L.orc_metric_make.argtypes = [i, d, d]
         L.orc_options_default.restype = Options
@@ -208,6 +213,22 @@ def lib():
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def ref_sin(x):
+    f = lib().orc_sin
+    return np.array([f(float(v)) for v in np.ravel(x)]).reshape(np.shape(x))
+
+
+def ref_cos(x):
+    f = lib().orc_cos
+    return np.array([f(float(v)) for v in np.ravel(x)]).reshape(np.shape(x))
+
+
+def ref_pow(x, y):
+    f = lib().orc_pow
+    x, y = np.broadcast_arrays(np.asarray(x, np.float64), np.asarray(y, np.float64))
+    return np.array([f(float(a), float(b)) for a, b in zip(x.ravel(), y.ravel())]).reshape(x.shape)
 
 
 def metric(kind, mass, spin):

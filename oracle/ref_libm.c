@@ -1,0 +1,324 @@
+/* ref_libm.c -- see ref_libm.h.  TEST INFRASTRUCTURE ONLY.
+ * Restates the published fdlibm / FreeBSD msun algorithms (k_sin.c, k_cos.c, e_rem_pio2.c medium
+ * range, e_pow.c).  Plain IEEE double arithmetic, round-to-nearest, no FMA (the Makefile passes
+ * -ffp-contract=off). */
+#include "ref_libm.h"
+
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+static inline uint64_t bits_of(double x) {
+    uint64_t u;
+    memcpy(&u, &x, sizeof u);
+    return u;
+}
+static inline double from_bits(uint64_t u) {
+    double x;
+    memcpy(&x, &u, sizeof x);
+    return x;
+}
+static inline int32_t hi_word(double x) { return (int32_t)(bits_of(x) >> 32); }
+static inline uint32_t lo_word(double x) { return (uint32_t)bits_of(x); }
+static inline double with_hi(double x, int32_t hi) {
+    return from_bits(((uint64_t)(uint32_t)hi << 32) | (bits_of(x) & 0xffffffffull));
+}
+static inline double clear_lo(double x) { return from_bits(bits_of(x) & 0xffffffff00000000ull); }
+
+/* ---- k_sin / k_cos on [-pi/4, pi/4], argument x + y (y = tail) ---- */
+static const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                    S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                    S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+static const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                    C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                    C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+
+static double k_sin(double x, double y, int iy) {
+    const double z = x * x;
+    const double w = z * z;
+    const double r = S2 + z * (S3 + z * S4) + z * w * (S5 + z * S6);
+    const double v = z * x;
+    if (iy == 0) return x + v * (S1 + z * r);
+    return x - ((z * (0.5 * y - v * r) - y) - v * S1);
+}
+
+static double k_cos(double x, double y) {
+    const double z = x * x;
+    double w = z * z;
+    const double r = z * (C1 + z * (C2 + z * C3)) + (w * w) * (C4 + z * (C5 + z * C6));
+    const double hz = 0.5 * z;
+    w = 1.0 - hz;
+    return w + (((1.0 - w) - hz) + (z * r - x * y));
+}
+
+/* ---- x = n pi/2 + (y0 + y1), |y0 + y1| <= pi/4: Cody-Waite with 33+33+33+53 bits of pi/2 ---- */
+static int rem_pio2_medium(double x, double *y0, double *y1) {
+    static const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00,
+                        pio2_1t = 6.07710050650619224932e-11, pio2_2 = 6.07710050630396597660e-11,
+                        pio2_2t = 2.02226624879595063154e-21, pio2_3 = 2.02226624871116645580e-21,
+                        pio2_3t = 8.47842766036889956997e-32;
+    const double fn = rint(x * invpio2);
+    double r = x - fn * pio2_1;
+    double w = fn * pio2_1t; /* 1st round, good to 85 bits */
+    double y = r - w;
+    const int ex = (hi_word(x) >> 20) & 0x7ff;
+    int ey = (hi_word(y) >> 20) & 0x7ff;
+    if (ex - ey > 16) { /* 2nd round, good to 118 bits */
+        double t = r;
+        w = fn * pio2_2;
+        r = t - w;
+        w = fn * pio2_2t - ((t - r) - w);
+        y = r - w;
+        ey = (hi_word(y) >> 20) & 0x7ff;
+        if (ex - ey > 49) { /* 3rd round, good to 151 bits */
+            t = r;
+            w = fn * pio2_3;
+            r = t - w;
+            w = fn * pio2_3t - ((t - r) - w);
+            y = r - w;
+        }
+    }
+    *y0 = y;
+    *y1 = (r - y) - w;
+    /* quadrant = fn mod 4, exact for any integer-valued fn */
+    return (int)(fn - 4.0 * floor(fn * 0.25));
+}
+
+double orc_sin(double x) {
+    const int32_t ix = hi_word(x) & 0x7fffffff;
+    if (ix <= 0x3fe921fb) { /* |x| <= pi/4 */
+        if (ix < 0x3e500000) return x; /* |x| < 2^-26 */
+        return k_sin(x, 0.0, 0);
+    }
+    if (ix >= 0x7ff00000) return x - x; /* inf, NaN */
+    double y0, y1;
+    const int n = rem_pio2_medium(x, &y0, &y1);
+    switch (n & 3) {
+    case 0: return k_sin(y0, y1, 1);
+    case 1: return k_cos(y0, y1);
+    case 2: return -k_sin(y0, y1, 1);
+    default: return -k_cos(y0, y1);
+    }
+}
+
+double orc_cos(double x) {
+    const int32_t ix = hi_word(x) & 0x7fffffff;
+    if (ix <= 0x3fe921fb) {
+        if (ix < 0x3e46a09e) return 1.0; /* |x| < 2^-27 sqrt(2) */
+        return k_cos(x, 0.0);
+    }
+    if (ix >= 0x7ff00000) return x - x;
+    double y0, y1;
+    const int n = rem_pio2_medium(x, &y0, &y1);
+    switch (n & 3) {
+    case 0: return k_cos(y0, y1);
+    case 1: return -k_sin(y0, y1, 1);
+    case 2: return -k_cos(y0, y1);
+    default: return k_sin(y0, y1, 1);
+    }
+}
+
+/* ---- x * 2^n without double rounding on the way into the subnormals ---- */
+static double scale2(double x, int n) {
+    double y = x;
+    if (n > 1023) {
+        y *= 0x1p1023;
+        n -= 1023;
+        if (n > 1023) {
+            y *= 0x1p1023;
+            n -= 1023;
+            if (n > 1023) n = 1023;
+        }
+    } else if (n < -1022) {
+        y *= 0x1p-1022 * 0x1p53;
+        n += 1022 - 53;
+        if (n < -1022) {
+            y *= 0x1p-1022 * 0x1p53;
+            n += 1022 - 53;
+            if (n < -1022) n = -1022;
+        }
+    }
+    return y * from_bits((uint64_t)(0x3ff + n) << 52);
+}
+
+/* ---- pow: log2(x) in two pieces to ~ 2^-77, times y in two pieces, then 2^z ---- */
+double orc_pow(double x, double y) {
+    static const double bp[2] = {1.0, 1.5}, dp_h[2] = {0.0, 5.84962487220764160156e-01},
+                        dp_l[2] = {0.0, 1.35003920212974897128e-08};
+    static const double two53 = 9007199254740992.0, huge = 1.0e300, tiny = 1.0e-300;
+    static const double L1 = 5.99999999999994648725e-01, L2 = 4.28571428578550184252e-01,
+                        L3 = 3.33333329818377432918e-01, L4 = 2.72728123808534006489e-01,
+                        L5 = 2.30660745775561754067e-01, L6 = 2.06975017800338417784e-01;
+    static const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
+                        P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06,
+                        P5 = 4.13813679705723846039e-08;
+    static const double lg2 = 6.93147180559945286227e-01, lg2_h = 6.93147182464599609375e-01,
+                        lg2_l = -1.90465429995776804525e-09, ovt = 8.0085662595372944372e-17,
+                        cp = 9.61796693925975554329e-01, cp_h = 9.61796700954437255859e-01,
+                        cp_l = -7.02846165095275826516e-09, ivln2 = 1.44269504088896338700e+00,
+                        ivln2_h = 1.44269502162933349609e+00, ivln2_l = 1.92596299112661746887e-08;
+
+    const int32_t hx = hi_word(x), hy = hi_word(y);
+    const uint32_t lx = lo_word(x), ly = lo_word(y);
+    int32_t ix = hx & 0x7fffffff;
+    const int32_t iy = hy & 0x7fffffff;
+
+    if (((uint32_t)iy | ly) == 0) return 1.0;          /* x^0 = 1 */
+    if (hx == 0x3ff00000 && lx == 0) return 1.0;       /* 1^y = 1, even for NaN */
+    if (ix > 0x7ff00000 || (ix == 0x7ff00000 && lx != 0) || iy > 0x7ff00000 ||
+        (iy == 0x7ff00000 && ly != 0))
+        return (x + 0.0) + (y + 0.0);                  /* NaN in, NaN out */
+
+    /* for x < 0: 0 = y not an integer, 1 = odd integer, 2 = even integer */
+    int yisint = 0;
+    if (hx < 0) {
+        if (iy >= 0x43400000)
+            yisint = 2;
+        else if (iy >= 0x3ff00000) {
+            const int k = (iy >> 20) - 0x3ff;
+            if (k > 20) {
+                const uint32_t j = ly >> (52 - k);
+                if ((j << (52 - k)) == ly) yisint = 2 - (int)(j & 1u);
+            } else if (ly == 0) {
+                const int32_t j = iy >> (20 - k);
+                if ((j << (20 - k)) == iy) yisint = 2 - (j & 1);
+            }
+        }
+    }
+
+    if (ly == 0) { /* special exponents */
+        if (iy == 0x7ff00000) {
+            if ((((uint32_t)(ix - 0x3ff00000)) | lx) == 0) return 1.0; /* (-1)^+-inf */
+            if (ix >= 0x3ff00000) return hy >= 0 ? y : 0.0;
+            return hy < 0 ? -y : 0.0;
+        }
+        if (iy == 0x3ff00000) return hy < 0 ? 1.0 / x : x;
+        if (hy == 0x40000000) return x * x;
+        if (hy == 0x3fe00000 && hx >= 0) return sqrt(x);
+    }
+
+    double ax = fabs(x);
+    if (lx == 0 && (ix == 0x7ff00000 || ix == 0 || ix == 0x3ff00000)) { /* x = +-0, +-inf, +-1 */
+        double z = ax;
+        if (hy < 0) z = 1.0 / z;
+        if (hx < 0) {
+            if (((ix - 0x3ff00000) | yisint) == 0)
+                z = (z - z) / (z - z); /* (-1)^non-integer */
+            else if (yisint == 1)
+                z = -z;
+        }
+        return z;
+    }
+
+    const int neg = hx < 0;
+    if (neg && yisint == 0) return (x - x) / (x - x); /* negative ^ non-integer */
+    const double sgn = (neg && yisint == 1) ? -1.0 : 1.0;
+
+    double t1, t2;
+    if (iy > 0x41e00000) { /* |y| > 2^31 */
+        if (iy > 0x43f00000) { /* |y| > 2^64: must over/underflow */
+            if (ix <= 0x3fefffff) return hy < 0 ? huge * huge : tiny * tiny;
+            if (ix >= 0x3ff00000) return hy > 0 ? huge * huge : tiny * tiny;
+        }
+        if (ix < 0x3fefffff) return hy < 0 ? sgn * huge * huge : sgn * tiny * tiny;
+        if (ix > 0x3ff00000) return hy > 0 ? sgn * huge * huge : sgn * tiny * tiny;
+        /* |1 - x| <= 2^-20: log(x) by x - x^2/2 + x^3/3 - x^4/4 */
+        const double t = ax - 1.0;
+        const double w = (t * t) * (0.5 - t * (0.3333333333333333333333 - t * 0.25));
+        const double u = ivln2_h * t;
+        const double v = t * ivln2_l - w * ivln2;
+        t1 = clear_lo(u + v);
+        t2 = v - (t1 - u);
+    } else {
+        int n = 0;
+        if (ix < 0x00100000) { /* subnormal x */
+            ax *= two53;
+            n -= 53;
+            ix = hi_word(ax);
+        }
+        n += (ix >> 20) - 0x3ff;
+        const int32_t j = ix & 0x000fffff;
+        int k;
+        ix = j | 0x3ff00000;
+        if (j <= 0x3988E)
+            k = 0; /* |x| < sqrt(3/2) */
+        else if (j < 0xBB67A)
+            k = 1; /* |x| < sqrt(3) */
+        else {
+            k = 0;
+            n += 1;
+            ix -= 0x00100000;
+        }
+        ax = with_hi(ax, ix);
+
+        /* ss = s_h + s_l = (x - bp) / (x + bp) */
+        double u = ax - bp[k];
+        double v = 1.0 / (ax + bp[k]);
+        const double ss = u * v;
+        const double s_h = clear_lo(ss);
+        double t_h = with_hi(0.0, ((ix >> 1) | 0x20000000) + 0x00080000 + (k << 18));
+        double t_l = ax - (t_h - bp[k]);
+        const double s_l = v * ((u - s_h * t_h) - s_h * t_l);
+        /* log(ax) */
+        double s2 = ss * ss;
+        double r = s2 * s2 * (L1 + s2 * (L2 + s2 * (L3 + s2 * (L4 + s2 * (L5 + s2 * L6)))));
+        r += s_l * (s_h + ss);
+        s2 = s_h * s_h;
+        t_h = clear_lo(3.0 + s2 + r);
+        t_l = r - ((t_h - 3.0) - s2);
+        u = s_h * t_h;
+        v = s_l * t_h + t_l * ss;
+        /* 2/(3 log 2) * (ss + ...) */
+        const double p_h = clear_lo(u + v);
+        const double p_l = v - (p_h - u);
+        const double z_h = cp_h * p_h;
+        const double z_l = cp_l * p_h + p_l * cp + dp_l[k];
+        /* log2(ax) = n + dp_h + z_h + z_l */
+        const double t = (double)n;
+        t1 = clear_lo(((z_h + z_l) + dp_h[k]) + t);
+        t2 = z_l - (((t1 - t) - dp_h[k]) - z_h);
+    }
+
+    /* (y1 + y2) * (t1 + t2) */
+    const double y1 = clear_lo(y);
+    double p_l = (y - y1) * t1 + y * t2;
+    double p_h = y1 * t1;
+    double z = p_l + p_h;
+    int32_t j = hi_word(z);
+    const uint32_t i0 = lo_word(z);
+    if (j >= 0x40900000) { /* z >= 1024 */
+        if ((((uint32_t)(j - 0x40900000)) | i0) != 0) return sgn * huge * huge;
+        if (p_l + ovt > z - p_h) return sgn * huge * huge;
+    } else if ((j & 0x7fffffff) >= 0x4090cc00) { /* z <= -1075 */
+        if ((((uint32_t)j - 0xc090cc00u) | i0) != 0) return sgn * tiny * tiny;
+        if (p_l <= z - p_h) return sgn * tiny * tiny;
+    }
+    /* 2^(p_h + p_l) */
+    const int32_t i = j & 0x7fffffff;
+    int k = (i >> 20) - 0x3ff;
+    int32_t n = 0;
+    if (i > 0x3fe00000) { /* |z| > 0.5: n = [z + 0.5] */
+        n = j + (0x00100000 >> (k + 1));
+        k = ((n & 0x7fffffff) >> 20) - 0x3ff;
+        const double t = with_hi(0.0, n & ~(0x000fffff >> k));
+        n = ((n & 0x000fffff) | 0x00100000) >> (20 - k);
+        if (j < 0) n = -n;
+        p_h -= t;
+    }
+    double t = clear_lo(p_l + p_h);
+    const double u = t * lg2_h;
+    const double v = (p_l - (t - p_h)) * lg2 + t * lg2_l;
+    z = u + v;
+    const double w = v - (z - u);
+    t = z * z;
+    const double tt = z - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    const double r = (z * tt) / (tt - 2.0) - (w + z * w);
+    z = 1.0 - (r - z);
+    j = hi_word(z);
+    j += (int32_t)((uint32_t)n << 20);
+    if ((j >> 20) <= 0)
+        z = scale2(z, n); /* subnormal result */
+    else
+        z = with_hi(z, j);
+    return sgn * z;
+}

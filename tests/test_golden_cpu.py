@@ -1,5 +1,7 @@
-"""The oracle must reproduce the committed golden vectors bit-for-bit on this
-machine class (same libm): guards the checker itself against silent change."""
+"""The oracle must reproduce the committed golden vectors bit-for-bit: guards the checker
+itself against silent change.  The ray path's sin/cos/pow are the written-out routines of
+oracle/ref_libm.c, so the ray vectors do not depend on the host's libm; the frame vectors also
+contain the camera's acos/atan2/sin/cos from the host libm (tolerance kept there)."""
 import os
 
 import numpy as np
@@ -31,8 +33,8 @@ def test_oracle_reproduces_ray_golden(oracle):
         res = oracle.integrate_batch(m, opt, z[key + "_in"], nthreads=2)
         assert np.array_equal(res["term"], z[key + "_term"]), key
         assert np.array_equal(res["steps"], z[key + "_steps"]), key
-        # libm last-ulp differences across hosts are allowed for; same host -> identical
-        np.testing.assert_allclose(res["states"], z[key + "_out"], rtol=1e-9, atol=1e-9, err_msg=key)
+        assert np.array_equal(res["states"], z[key + "_out"], equal_nan=True), key
+        assert np.array_equal(res["drift"], z[key + "_drift"], equal_nan=True), key
 
 
 def test_oracle_reproduces_frame_golden(oracle):

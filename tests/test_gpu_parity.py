@@ -61,6 +61,11 @@ def test_golden_rays(bh, arith):
             got = e.integrate_batch(z[key + "_in"], o)
         assert np.array_equal(got["term"], z[key + "_term"]), key
         assert np.array_equal(got["steps"], z[key + "_steps"]), key
+        if arith == 0:
+            # STRICT: reference operation order + the specified sin/cos/pow (strict_libm.hpp <->
+            # oracle/ref_libm.c) -> the same bits as the checker, every metric and method
+            assert np.array_equal(got["states"], z[key + "_out"], equal_nan=True), key
+            assert np.array_equal(got["drift"], z[key + "_drift"], equal_nan=True), key
         err = rel_err(got["states"], z[key + "_out"])
         if int(kind) == bh.SCHWARZSCHILD or key.startswith("bl_"):
             # BL / Schwarzschild coordinates are singular at the horizon: captured rays end
@@ -104,6 +109,11 @@ def test_golden_frame(bh, torch_mod, arith):
     assert np.array_equal(steps.cpu().numpy().astype(np.uint32), z["steps"])
     err = rel_err(fs.cpu().numpy(), z["states"])
     assert err.max() <= TOL_MAX[arith] and np.median(err) <= TOL_MED[arith]
+    if arith == 0:  # bit-identical end states, drift and pixels (the camera's seven constants are
+        # evaluated by the host libm on both sides; same image on the GPU box)
+        assert np.array_equal(fs.cpu().numpy(), z["states"], equal_nan=True)
+        assert np.array_equal(drift.cpu().numpy(), z["drift"], equal_nan=True)
+        assert np.array_equal(rgba.cpu().numpy(), z["rgba"].reshape(n, 4))
     ref = z["rgba"].reshape(n, 4)
     scale = ref[:, :3].max()
     assert np.abs(rgba.cpu().numpy() - ref).max() <= 1e-5 * scale  # f32 colour, 1e-5 of peak

@@ -1,0 +1,123 @@
+"""oracle/ref_libm.c: the specified sin / cos / pow of the f64 ray path (fdlibm-lineage routines,
+IEEE + - * / sqrt only).  CPU: accuracy against mpmath, IEEE special cases, and pinned bit
+patterns (the routines are pure functions of their argument: the same bits on any host).
+GPU: the STRICT kernels' copies (csrc/strict_libm.hpp) return the same bits."""
+import numpy as np
+import pytest
+
+
+def _ulps(got, exact, mp):
+    if exact == 0:
+        return abs(got)
+    u = mp.mpf(2) ** (mp.floor(mp.log(abs(exact), 2)) - 52)
+    return float(abs(mp.mpf(got) - exact) / u)
+
+
+def _sincos_args(rng, n):
+    return np.concatenate([
+        rng.uniform(-8, 8, n), rng.uniform(-200, 200, n), rng.uniform(-1e5, 1e5, n // 2),
+        rng.uniform(-1e-3, 1e-3, n // 4), 10.0 ** rng.uniform(-30, -3, n // 4),
+        np.array([0.0, -0.0, np.pi / 4, np.pi / 2, np.pi, 3 * np.pi / 2, 2 * np.pi, 0.7853981633974483,
+                  0.7853981633974484, 1.5707963267948966, 3.141592653589793, 6.283185307179586,
+                  1e-300, 5e-324, 710.0, 1e6, 1.6e6])])
+
+
+def _pow_args(rng, n):
+    ys = np.array([-0.2, -0.25, 1.5, 0.75, 0.25, 2.5, 0.4, 1.0 / 3.0, -3.7, 7.1, 0.5, 2.0, -1.0, 3.0])
+    x = np.concatenate([10.0 ** rng.uniform(-12, 8, n), rng.uniform(0.5, 2.0, n // 2),
+                        10.0 ** rng.uniform(-300, 300, n // 4)])
+    y = rng.choice(ys, x.size)
+    return x, y
+
+
+def test_accuracy_against_mpmath(oracle):
+    mp = pytest.importorskip("mpmath")
+    mp.mp.prec = 200
+    rng = np.random.default_rng(2024)
+    worst = 0.0
+    for x in _sincos_args(rng, 600):
+        worst = max(worst, _ulps(float(oracle.ref_sin(x)), mp.sin(mp.mpf(float(x))), mp),
+                    _ulps(float(oracle.ref_cos(x)), mp.cos(mp.mpf(float(x))), mp))
+    assert worst < 1.0, worst
+    x, y = _pow_args(rng, 1500)
+    worst_p = 0.0
+    for a, b in zip(x, y):
+        ex = mp.power(mp.mpf(float(a)), mp.mpf(float(b)))
+        if ex > mp.mpf(2) ** 1023 or ex < mp.mpf(2) ** -1021:
+            continue  # overflow / subnormal results: covered by the special-case test
+        worst_p = max(worst_p, _ulps(float(oracle.ref_pow(a, b)), ex, mp))
+    assert worst_p < 1.0, worst_p
+
+
+def test_ieee_special_cases(oracle):
+    inf, nan = np.inf, np.nan
+    with np.errstate(all="ignore"):
+        for x, y in ((1e300, 2.5), (1e-300, 2.5), (2.0, -1074.0), (2.0, -1080.0), (0.0, -0.2), (-0.0, -3.0),
+                     (inf, -0.2), (inf, 0.2), (-inf, 3.0), (-inf, 2.0), (-8.0, 1.0 / 3.0), (-8.0, 3.0), (-2.0, 2.0),
+                     (nan, 0.0), (1.0, nan), (nan, 1.0), (2.0, nan), (2.0, 1023.5), (2.0, 1024.0),
+                     (5e-324, 0.5), (0.5, inf), (0.5, -inf), (2.0, inf), (2.0, -inf), (-1.0, inf),
+                     (0.0, 0.0), (0.0, 2.0), (-0.0, 3.0), (1.0000001, 1e9), (7.0, 0.5), (3.0, 2.0)):
+            got, want = float(oracle.ref_pow(x, y)), float(np.float64(x) ** np.float64(y))
+            if np.isnan(want):
+                assert np.isnan(got), (x, y, got)
+            elif np.isinf(want) or want == 0.0 or y in (0.5, 2.0, 1.0, -1.0):
+                assert got == want and np.signbit(got) == np.signbit(want), (x, y, got, want)
+            else:
+                assert abs(got - want) <= 2e-16 * abs(want) + 5e-324, (x, y, got, want)
+    for f in (oracle.ref_sin, oracle.ref_cos):
+        assert np.isnan(float(f(inf))) and np.isnan(float(f(-inf))) and np.isnan(float(f(nan)))
+    assert float(oracle.ref_sin(0.0)) == 0.0 and np.signbit(float(oracle.ref_sin(-0.0)))
+    assert float(oracle.ref_cos(0.0)) == 1.0 and float(oracle.ref_sin(1e-300)) == 1e-300
+    # odd / even symmetry is exact
+    xs = np.random.default_rng(1).uniform(-50, 50, 200)
+    assert np.array_equal(oracle.ref_sin(-xs), -oracle.ref_sin(xs))
+    assert np.array_equal(oracle.ref_cos(-xs), oracle.ref_cos(xs))
+
+
+# bit patterns recorded from oracle/ref_libm.c; any IEEE-754 host must reproduce them
+PINS = (("sin", 1.0, None), ("cos", 1.0, None), ("sin", 100.0, None), ("cos", 1.5707963267948966, None),
+        ("sin", 3.141592653589793, None), ("cos", 12345.678, None), ("pow", 0.37, -0.2),
+        ("pow", 123.456, -0.25), ("pow", 9.5, 1.5), ("pow", 0.015625, 0.75), ("pow", 0.3, 0.4))
+PIN_HEX = (
+    '0x1.aed548f090ceep-1',
+    '0x1.14a280fb5068cp-1',
+    '-0x1.03425b78c4db8p-1',
+    '0x1.1a62633145c07p-54',
+    '0x1.1a62633145c07p-53',
+    '0x1.6b94c3bbe24b8p-1',
+    '0x1.3851e33fd110fp+0',
+    '0x1.3333536991f84p-2',
+    '0x1.d47ed6be5578ap+4',
+    '0x1.6a09e667f3bccp-5',
+    '0x1.3c5064a1418b7p-1')
+
+
+def _eval(oracle, name, x, y):
+    return float({"sin": oracle.ref_sin, "cos": oracle.ref_cos}[name](x)) if y is None else float(oracle.ref_pow(x, y))
+
+
+def test_pinned_bit_patterns(oracle):
+    for (name, x, y), want in zip(PINS, PIN_HEX):
+        assert _eval(oracle, name, x, y).hex() == want, (name, x, y)
+
+
+@pytest.mark.gpu
+def test_device_routines_return_the_same_bits(engine_mod, oracle):
+    bh = engine_mod
+    rng = np.random.default_rng(77)
+    xs = _sincos_args(rng, 40000)
+    xs = np.concatenate([xs, [np.inf, -np.inf, np.nan]])
+    px, py = _pow_args(rng, 60000)
+    sx = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, -1.0, -8.0, 5e-324, 1e300, 2.0, 2.0, 0.5, 1.0000001])
+    sy = np.array([-0.2, -3.0, -0.2, 3.0, 0.0, np.nan, np.inf, 3.0, 0.3, 2.5, -1074.0, 1023.5, np.inf, 1e9])
+    px, py = np.concatenate([px, sx]), np.concatenate([py, sy])
+    with bh.PhysicsEngine(1.0, 0.5) as e:
+        for op, ref in ((bh.engine.MATH_SIN, oracle.ref_sin), (bh.engine.MATH_COS, oracle.ref_cos),
+                        (bh.engine.MATH_SINCOS_SIN, oracle.ref_sin), (bh.engine.MATH_SINCOS_COS, oracle.ref_cos)):
+            got, want = e.strict_math(op, xs), ref(xs)
+            assert np.array_equal(got.view(np.uint64)[~np.isnan(want)], want.view(np.uint64)[~np.isnan(want)]), op
+            assert np.array_equal(np.isnan(got), np.isnan(want))
+        got, want = e.strict_math(bh.engine.MATH_POW, px, py), oracle.ref_pow(px, py)
+        ok = ~np.isnan(want)
+        assert np.array_equal(got.view(np.uint64)[ok], want.view(np.uint64)[ok])
+        assert np.array_equal(np.isnan(got), np.isnan(want))
