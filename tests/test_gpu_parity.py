@@ -129,7 +129,7 @@ def test_single_ray_ffi(bh, oracle):
             got = e.integrate_ray_relativistic(v, 10000, 1e-8, ks)
             ref = oracle.integrate_ray_relativistic(1.0, 0.9, v, 10000, 1e-8, ks)
             assert got.shape == (8,)
-            assert rel_err(got[None], ref[None])[0] <= 1e-6
+            assert np.array_equal(got, ref)   # the FFI entry runs the STRICT contract
         assert e.integrate_ray_relativistic([1.0, 2.0, 3.0], 10, 1e-8, True).tolist() == [1.0, 2.0, 3.0]
         assert e.integratePhotonGeodesic(v, 5, 1e-8, True).shape == (8,)
         # update_params rebuilds both metrics (lib.rs:78-83)
@@ -162,7 +162,7 @@ def test_edge_cases(bh, oracle):
             got = e.integrate_batch(st, o)
             ref = oracle.integrate_batch(m, oracle.options(max_steps=50), st)
             assert np.array_equal(got["term"], ref["term"]) and np.array_equal(got["steps"], ref["steps"])
-            assert rel_err(got["states"], ref["states"]).max() <= 1e-6
+            assert np.array_equal(got["states"], ref["states"]) and np.array_equal(got["drift"], ref["drift"])
         # max_steps = 0 -> MaxSteps immediately, state only renormalised (mod.rs:200-202,246)
         st = np.array([[0, 10.0, 1.0, 0, -1, -0.5, 1.0, 2.0]])
         got = e.integrate_batch(st, bh.engine.default_options(max_steps=0))
@@ -243,6 +243,9 @@ def test_mass_and_spin_sweep(bh, oracle, mass, spin, kind):
         for arith, tol in ((bh.ARITH_STRICT, 1e-6), (bh.ARITH_FAST, 1e-5)):
             o = bh.engine.default_options(max_steps=600, escape_radius=1000.0 * mass, metric_kind=bkind, arith=arith)
             got = e.integrate_batch(st, o)
+            if arith == bh.ARITH_STRICT:   # the checker's bits, also at |a| = M and next to Delta = 0
+                for key in ("states", "steps", "term", "drift"):
+                    assert np.array_equal(got[key], ref[key], equal_nan=True), key
             same = got["steps"] == ref["steps"]
             assert np.array_equal(got["term"][same], ref["term"][same]) and same.mean() >= 0.97
             err = rel_err(got["states"][same], ref["states"][same])
@@ -279,6 +282,11 @@ def test_frames_from_other_cameras(bh, oracle, torch_mod, eye, spin):
             e.render_frame_device(cam, p, rgba, fs, steps, term)
             st = e.frame_stats()
             torch.cuda.synchronize()
+            if arith == bh.ARITH_STRICT:   # bit-identical, the ill-conditioned on-axis camera included
+                assert np.array_equal(steps.cpu().numpy().astype(np.uint32), ref["steps"])
+                assert np.array_equal(term.cpu().numpy(), ref["term"])
+                assert np.array_equal(fs.cpu().numpy(), ref["states"], equal_nan=True)
+                assert np.array_equal(rgba.cpu().numpy(), ref["rgba"].reshape(-1, 4))
             same = steps.cpu().numpy().astype(np.uint32) == ref["steps"]
             err = rel_err(fs.cpu().numpy()[same], ref["states"][same])
             peak = max(float(ref["rgba"][..., :3].max()), 1e-30)
@@ -312,6 +320,8 @@ def test_forced_min_step_and_nan_rays(bh, oracle, arith):
         ref = oracle.integrate_batch(m, oracle.options(max_steps=60, tolerance=1e-30), st)
         assert np.array_equal(got["term"], ref["term"]) and np.array_equal(got["steps"], ref["steps"])
         assert rel_err(got["states"], ref["states"]).max() <= 1e-9
+        if arith == 0:
+            assert np.array_equal(got["states"], ref["states"]) and np.array_equal(got["drift"], ref["drift"])
         # every step was the forced one: 60 steps of 1e-5 move the ray by < 1e-2
         assert np.all(got["steps"] == 60) and np.abs(got["states"][:, 1] - st[:, 1]).max() < 1e-2
         bad = st.copy()
@@ -321,6 +331,8 @@ def test_forced_min_step_and_nan_rays(bh, oracle, arith):
         ref = oracle.integrate_batch(m, oracle.options(max_steps=40), bad)
         assert np.array_equal(got["term"], ref["term"]) and np.array_equal(got["steps"], ref["steps"])
         assert got["term"][0] == bh.TERM_MAXSTEPS and np.isnan(got["states"][0, 1])
+        if arith == 0:   # NaN placement included
+            assert np.array_equal(got["states"], ref["states"], equal_nan=True)
         # the healthy ray in the same wave is untouched by its neighbours
         assert rel_err(got["states"][2:3], ref["states"][2:3]).max() <= 1e-6
 
@@ -480,6 +492,10 @@ def test_4k_strided_subset_vs_oracle(bh, oracle, torch_mod, arith, tol):
     ref = oracle.render_frame(ocam, fp, None, stride=(8, 8), nthreads=max(1, os.cpu_count() or 1))
     mism = g_term != ref["term"]
     dsteps = np.abs(g_steps.astype(np.int64) - ref["steps"].astype(np.int64))
+    if arith == 0:   # STRICT at tol 1e-9: the checker's bits on all 129 600 rays
+        assert not mism.any() and dsteps.max() == 0
+        assert np.array_equal(g_fs, ref["states"], equal_nan=True)
+        assert np.array_equal(g_rgba, ref["rgba"].reshape(-1, 4))
     ok = (~mism) & (dsteps == 0)
     err = rel_err(g_fs[ok], ref["states"][ok])
     print(f"arith={arith} tol={tol}: class mismatches {int(mism.sum())}/{mism.size}, step mismatches "
