@@ -263,7 +263,7 @@ __global__ __launch_bounds__(kBlock) void unpack_tiles_kernel(FrameGeom G,
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ double cie_lobe_dev(double l_nm, double mean, double sd) {
     const double x = (l_nm - mean) / sd;
-    return exp(-0.5 * x * x);
+    return exp_rs(-0.5 * x * x);
 }
 
 __global__ __launch_bounds__(kBlock) void spectrum_lut_kernel(float4 *__restrict__ out,
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(kBlock) void spectrum_lut_kernel(float4 *__restrict
             if (!(exponent > 100.0)) {
                 const double l2 = lambda * lambda;
                 const double l5 = lambda * (l2 * l2); // powi(5) = a * (a^2)^2
-                intensity = (C1 / l5) / (exp(exponent) - 1.0);
+                intensity = (C1 / l5) / (exp_rs(exponent) - 1.0);
             }
             const double l_nm = lambda * 1e9;
             const double cx = fmax(1.056 * cie_lobe_dev(l_nm, 599.0, 37.9) +

@@ -60,9 +60,11 @@ template <typename T> __device__ __forceinline__ void sincos_t(T x, T *s, T *c);
 #if defined(GRV_SPECIFIED_LIBM)
 template <> __device__ __forceinline__ void sincos_t<double>(double x, double *s, double *c) { strictm::sl_sincos(x, s, c); }
 __device__ __forceinline__ double pow_rs(double x, double y) { return strictm::sl_pow(x, y); }
+__device__ __forceinline__ double exp_rs(double x) { return strictm::sl_exp(x); }
 #else
 template <> __device__ __forceinline__ void sincos_t<double>(double x, double *s, double *c) { sincos(x, s, c); }
 __device__ __forceinline__ double pow_rs(double x, double y) { return pow(x, y); }
+__device__ __forceinline__ double exp_rs(double x) { return exp(x); }
 #endif
 template <> __device__ __forceinline__ void sincos_t<float>(float x, float *s, float *c) { sincosf(x, s, c); }
 

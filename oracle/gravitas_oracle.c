@@ -885,12 +885,12 @@ static const double ORC_C2 = ORC_H * ORC_SI_C / ORC_SI_KB;
 double orc_planck_law(double lambda, double temperature) {
     double exponent = ORC_C2 / (lambda * temperature);
     if (exponent > 100.0) return 0.0;
-    return (ORC_C1 / rs_powi(lambda, 5)) / (exp(exponent) - 1.0);
+    return (ORC_C1 / rs_powi(lambda, 5)) / (orc_exp(exponent) - 1.0);
 }
 
 static double cie_lobe(double l_nm, double mean, double std) {
     double x = (l_nm - mean) / std;
-    return exp(-0.5 * x * x);
+    return orc_exp(-0.5 * x * x);
 }
 
 /* physics/spectrum.rs:50-62 */

@@ -322,3 +322,47 @@ double orc_pow(double x, double y) {
         z = with_hi(z, j);
     return sgn * z;
 }
+
+/* ---- exp: x = k ln2 + r, |r| <= 0.5 ln2; exp(r) by the (r c)/(2 - c) rational form ---- */
+double orc_exp(double x) {
+    static const double o_threshold = 7.09782712893383973096e+02, u_threshold = -7.45133219101941108420e+02,
+                        ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
+                        invln2 = 1.44269504088896338700e+00, P1 = 1.66666666666666019037e-01,
+                        P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                        P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08,
+                        huge = 1.0e+300, twom1000 = 9.33263618503218878990e-302; /* 2^-1000 */
+    uint32_t hx = (uint32_t)hi_word(x);
+    const int xsb = (int)(hx >> 31);
+    hx &= 0x7fffffffu;
+    double hi = 0.0, lo = 0.0;
+    int k = 0;
+    if (hx >= 0x40862E42u) { /* |x| >= 709.78 */
+        if (hx >= 0x7ff00000u) {
+            if (((hx & 0xfffffu) | lo_word(x)) != 0) return x + x; /* NaN */
+            return xsb == 0 ? x : 0.0;                            /* exp(+-inf) = inf, 0 */
+        }
+        if (x > o_threshold) return huge * huge;
+        if (x < u_threshold) return twom1000 * twom1000;
+    }
+    if (hx > 0x3fd62e42u) {     /* |x| > 0.5 ln2 */
+        if (hx < 0x3FF0A2B2u) { /* and |x| < 1.5 ln2 */
+            hi = xsb ? x + ln2HI : x - ln2HI;
+            lo = xsb ? -ln2LO : ln2LO;
+            k = 1 - xsb - xsb;
+        } else {
+            k = (int)(invln2 * x + (xsb ? -0.5 : 0.5));
+            const double t = (double)k;
+            hi = x - t * ln2HI;
+            lo = t * ln2LO;
+        }
+        x = hi - lo;
+    } else if (hx < 0x3e300000u) { /* |x| < 2^-28 */
+        return 1.0 + x;
+    }
+    const double t = x * x;
+    const double c = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    if (k == 0) return 1.0 - ((x * c) / (c - 2.0) - x);
+    const double y = 1.0 - ((lo - (x * c) / (2.0 - c)) - hi);
+    if (k >= -1021) return with_hi(y, hi_word(y) + (int32_t)((uint32_t)k << 20));
+    return with_hi(y, hi_word(y) + (int32_t)((uint32_t)(k + 1000) << 20)) * twom1000;
+}

@@ -47,6 +47,10 @@ def test_accuracy_against_mpmath(oracle):
             continue  # overflow / subnormal results: covered by the special-case test
         worst_p = max(worst_p, _ulps(float(oracle.ref_pow(a, b)), ex, mp))
     assert worst_p < 1.0, worst_p
+    worst_e = 0.0
+    for x in np.concatenate([rng.uniform(-708, 709.7, 800), rng.uniform(-2, 2, 400), [0.0, 1.0, -1.0, 0.34657359027997264]]):
+        worst_e = max(worst_e, _ulps(float(oracle.ref_exp(x)), mp.exp(mp.mpf(float(x))), mp))
+    assert worst_e < 1.0, worst_e
 
 
 def test_ieee_special_cases(oracle):
@@ -66,6 +70,10 @@ def test_ieee_special_cases(oracle):
                 assert abs(got - want) <= 2e-16 * abs(want) + 5e-324, (x, y, got, want)
     for f in (oracle.ref_sin, oracle.ref_cos):
         assert np.isnan(float(f(inf))) and np.isnan(float(f(-inf))) and np.isnan(float(f(nan)))
+    with np.errstate(all="ignore"):
+        for x in (inf, -inf, 710.0, -746.0, -745.0, 0.0, -0.0, 1e-300, 709.782712893384, -745.1332191019411):
+            assert float(oracle.ref_exp(x)) == float(np.exp(x)), x
+    assert np.isnan(float(oracle.ref_exp(nan)))
     assert float(oracle.ref_sin(0.0)) == 0.0 and np.signbit(float(oracle.ref_sin(-0.0)))
     assert float(oracle.ref_cos(0.0)) == 1.0 and float(oracle.ref_sin(1e-300)) == 1e-300
     # odd / even symmetry is exact
@@ -77,7 +85,8 @@ def test_ieee_special_cases(oracle):
 # bit patterns recorded from oracle/ref_libm.c; any IEEE-754 host must reproduce them
 PINS = (("sin", 1.0, None), ("cos", 1.0, None), ("sin", 100.0, None), ("cos", 1.5707963267948966, None),
         ("sin", 3.141592653589793, None), ("cos", 12345.678, None), ("pow", 0.37, -0.2),
-        ("pow", 123.456, -0.25), ("pow", 9.5, 1.5), ("pow", 0.015625, 0.75), ("pow", 0.3, 0.4))
+        ("pow", 123.456, -0.25), ("pow", 9.5, 1.5), ("pow", 0.015625, 0.75), ("pow", 0.3, 0.4),
+        ("exp", 1.0, None), ("exp", -37.25, None), ("exp", 700.5, None), ("exp", -730.0, None))
 PIN_HEX = (
     '0x1.aed548f090ceep-1',
     '0x1.14a280fb5068cp-1',
@@ -89,11 +98,17 @@ PIN_HEX = (
     '0x1.3333536991f84p-2',
     '0x1.d47ed6be5578ap+4',
     '0x1.6a09e667f3bccp-5',
-    '0x1.3c5064a1418b7p-1')
+    '0x1.3c5064a1418b7p-1',
+    '0x1.5bf0a8b14576ap+1',
+    '0x1.3278bcd70e981p-54',
+    '0x1.8625c7d4f56c2p+1010',
+    '0x0.00000001c7ea3p-1022')
 
 
 def _eval(oracle, name, x, y):
-    return float({"sin": oracle.ref_sin, "cos": oracle.ref_cos}[name](x)) if y is None else float(oracle.ref_pow(x, y))
+    if y is None:
+        return float({"sin": oracle.ref_sin, "cos": oracle.ref_cos, "exp": oracle.ref_exp}[name](x))
+    return float(oracle.ref_pow(x, y))
 
 
 def test_pinned_bit_patterns(oracle):
@@ -117,6 +132,11 @@ def test_device_routines_return_the_same_bits(engine_mod, oracle):
             got, want = e.strict_math(op, xs), ref(xs)
             assert np.array_equal(got.view(np.uint64)[~np.isnan(want)], want.view(np.uint64)[~np.isnan(want)]), op
             assert np.array_equal(np.isnan(got), np.isnan(want))
+        ex = np.concatenate([rng.uniform(-750, 712, 40000), rng.uniform(-2, 2, 20000),
+                             [0.0, -0.0, np.inf, -np.inf, np.nan, 1e-300, 709.782712893384, -745.1332191019411]])
+        got, want = e.strict_math(bh.engine.MATH_EXP, ex), oracle.ref_exp(ex)
+        assert np.array_equal(got.view(np.uint64)[~np.isnan(want)], want.view(np.uint64)[~np.isnan(want)])
+        assert np.array_equal(np.isnan(got), np.isnan(want))
         got, want = e.strict_math(bh.engine.MATH_POW, px, py), oracle.ref_pow(px, py)
         ok = ~np.isnan(want)
         assert np.array_equal(got.view(np.uint64)[ok], want.view(np.uint64)[ok])
