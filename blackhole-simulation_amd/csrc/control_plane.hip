@@ -1,6 +1,7 @@
 // control_plane.hip -- see control_plane.hpp.  Compiled with -ffp-contract=off so the
 // scalar formulas keep the reference's operation order.
 #include "control_plane.hpp"
+#include "strict_libm.hpp"
 
 #include <cmath>
 
@@ -23,7 +24,7 @@ __host__ __device__ inline double orbit_lz(double r, double m, double a) {
     return den <= 0.0 ? 0.0 : num / sqrt(den);
 }
 __host__ __device__ inline double orbit_omega(double r, double m, double a) {
-    return sqrt(m) / (pow(r, 1.5) + a * sqrt(m));
+    return sqrt(m) / (strictm::sl_pow(r, 1.5) + a * sqrt(m));
 }
 __host__ __device__ inline double torque_integrand(double rp, double m, double a) {
     const double drp = rp * 1e-5;
@@ -34,7 +35,8 @@ __host__ __device__ inline double torque_integrand(double rp, double m, double a
 __host__ __device__ inline double isco_pro(double m, double a_star) {
     if (fabs(a_star) < 1e-6) return m * 6.0;
     const double a2 = a_star * a_star;
-    const double z1 = 1.0 + pow(1.0 - a2, 1.0 / 3.0) * (pow(1.0 + a_star, 1.0 / 3.0) + pow(1.0 - a_star, 1.0 / 3.0));
+    const double z1 = 1.0 + strictm::sl_pow(1.0 - a2, 1.0 / 3.0) *
+                               (strictm::sl_pow(1.0 + a_star, 1.0 / 3.0) + strictm::sl_pow(1.0 - a_star, 1.0 / 3.0));
     const double z2 = sqrt(3.0 * a2 + z1 * z1);
     const double disc = (3.0 - z1) * (3.0 + z1 + 2.0 * z2);
     return m * (3.0 + z2 - (disc < 0.0 ? 0.0 : sqrt(disc)));
@@ -63,7 +65,7 @@ __host__ __device__ inline double pt_flux(double r, double m, double a_star, dou
 __host__ __device__ inline double pt_temperature(double r, double m, double a_star, double m_dot) {
     const double flux = pt_flux(r, m, a_star, m_dot);
     if (flux <= 0.0) return 0.0;
-    return 1e7 * pow(m_dot, 0.25) * pow(flux, 0.25);
+    return 1e7 * strictm::sl_pow(m_dot, 0.25) * strictm::sl_pow(flux, 0.25);
 }
 
 // one block: thread i evaluates entry i (strided), block max, normalise (disk.rs:175-201)

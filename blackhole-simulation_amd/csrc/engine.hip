@@ -21,8 +21,8 @@ double event_horizon(double m, double spin) {
 double isco_prograde(double m, double a_star) {
     if (std::fabs(a_star) < 1e-6) return m * 6.0;
     const double a2 = a_star * a_star;
-    const double z1 = 1.0 + std::pow(1.0 - a2, 1.0 / 3.0) *
-                                (std::pow(1.0 + a_star, 1.0 / 3.0) + std::pow(1.0 - a_star, 1.0 / 3.0));
+    const double z1 = 1.0 + strictm::sl_pow(1.0 - a2, 1.0 / 3.0) *
+                                (strictm::sl_pow(1.0 + a_star, 1.0 / 3.0) + strictm::sl_pow(1.0 - a_star, 1.0 / 3.0));
     const double z2 = std::sqrt(3.0 * a2 + z1 * z1);
     const double disc = (3.0 - z1) * (3.0 + z1 + 2.0 * z2);
     const double root = disc < 0.0 ? 0.0 : std::sqrt(disc);

@@ -175,7 +175,8 @@ __global__ __launch_bounds__(kBlock) void strict_math_kernel(int op, uint32_t n,
     case 2: out[i] = strictm::sl_sin(x[i]); break;
     case 3: out[i] = strictm::sl_cos(x[i]); break;
     case 4: out[i] = pow_rs(x[i], y[i]); break;
-    default: out[i] = exp_rs(x[i]); break;
+    case 5: out[i] = exp_rs(x[i]); break;
+    default: out[i] = strictm::sl_atan(x[i]); break;
     }
 }
 } // namespace

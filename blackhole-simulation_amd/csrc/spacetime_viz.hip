@@ -1,6 +1,7 @@
 // spacetime_viz.hip -- see spacetime_viz.hpp.  Compiled with -ffp-contract=off so the
 // closed forms keep the reference's operation order on host and device alike.
 #include "spacetime_viz.hpp"
+#include "strict_libm.hpp"
 
 #include <cmath>
 
@@ -18,7 +19,7 @@ struct CovBL {
 __host__ __device__ inline CovBL covariant_bl(const VizHole &bh, double r, double theta) {
     const double m = bh.mass, a = bh.a_bl;
     const double rr = r * r, aa = a * a;
-    const double st = sin(theta), ct = cos(theta);
+    const double st = strictm::sl_sin(theta), ct = strictm::sl_cos(theta);
     const double s2 = st * st, c2 = ct * ct;
     const double sigma = rr + aa * c2;
     const double delta = rr - 2.0 * m * r + aa;
@@ -35,7 +36,7 @@ __host__ __device__ inline double kretschner_at(const VizHole &bh, double r, dou
     // raw spin: the reference hands (mass, spin) to a free function, no Kerr::new clamp
     const double a = bh.spin_raw * bh.mass;
     const double r2 = r * r, a2 = a * a;
-    const double c = cos(theta);
+    const double c = strictm::sl_cos(theta);
     const double c2 = c * c, c4 = c2 * c2, c6 = c4 * c2;
     const double r4 = r2 * r2, r6 = r4 * r2;
     const double a4 = a2 * a2, a6 = a4 * a2;
@@ -52,7 +53,7 @@ __host__ __device__ inline double tilt_at(const VizHole &bh, double r, double th
     // Boyer-Lindquist: g_tr == 0, so only the diagonal branch of lightcone.rs:26-33 is live
     if (g.tt >= 0.0) return kHalfPi;
     const double ratio = fmax(-g.tt / g.rr, 0.0);
-    return atan(sqrt(ratio));
+    return strictm::sl_atan(sqrt(ratio));
 }
 
 __host__ __device__ inline double omega_at(const VizHole &bh, double r, double theta) {
@@ -61,7 +62,7 @@ __host__ __device__ inline double omega_at(const VizHole &bh, double r, double t
 }
 
 __host__ __device__ inline double ergosphere_at(const VizHole &bh, double theta) {
-    const double c = cos(theta);
+    const double c = strictm::sl_cos(theta);
     const double disc = bh.mass * bh.mass - bh.a_bl * bh.a_bl * c * c;
     return disc < 0.0 ? bh.mass : bh.mass + sqrt(disc);
 }
@@ -114,9 +115,9 @@ __global__ __launch_bounds__(256) void embedding_mesh_kernel(VizHole bh, double 
     const double height = fabs(bh.spin_raw) < 1e-6 ? flamm_at(r, bh.mass)
                                                    : radial_midpoint_sum<true>(bh, r, r_max, 100);
     const double phi = 2.0 * kPi * (double)j / (double)n_angular;
-    out[3 * k + 0] = (float)(r * cos(phi));
+    out[3 * k + 0] = (float)(r * strictm::sl_cos(phi));
     out[3 * k + 1] = (float)(-height);
-    out[3 * k + 2] = (float)(r * sin(phi));
+    out[3 * k + 2] = (float)(r * strictm::sl_sin(phi));
 }
 
 __global__ __launch_bounds__(256) void ergosphere_mesh_kernel(VizHole bh, uint32_t n_polar,
@@ -128,9 +129,9 @@ __global__ __launch_bounds__(256) void ergosphere_mesh_kernel(VizHole bh, uint32
     const double theta = kPi * (double)i / (double)(n_polar - 1u);
     const double re = ergosphere_at(bh, theta);
     const double phi = 2.0 * kPi * (double)j / (double)n_azimuthal;
-    out[3 * k + 0] = (float)(re * sin(theta) * cos(phi));
-    out[3 * k + 1] = (float)(re * cos(theta));
-    out[3 * k + 2] = (float)(re * sin(theta) * sin(phi));
+    out[3 * k + 0] = (float)(re * strictm::sl_sin(theta) * strictm::sl_cos(phi));
+    out[3 * k + 1] = (float)(re * strictm::sl_cos(theta));
+    out[3 * k + 2] = (float)(re * strictm::sl_sin(theta) * strictm::sl_sin(phi));
 }
 
 inline dim3 grid_for(uint32_t n) { return dim3((n + 255u) / 256u); }

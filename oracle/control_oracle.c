@@ -3,6 +3,7 @@
  * Citations: file:line under /root/reference/physics-engine/.
  */
 #include "control_oracle.h"
+#include "ref_libm.h"
 
 #include <math.h>
 #include <string.h>
@@ -36,7 +37,7 @@ static double specific_angular_momentum(double r, double m, double a) {
 
 /* disk.rs:62-64 */
 static double angular_velocity(double r, double m, double a) {
-    return sqrt(m) / (pow(r, 1.5) + a * sqrt(m));
+    return sqrt(m) / (orc_pow(r, 1.5) + a * sqrt(m));
 }
 
 static double pt_integrand(double rp, double m, double a) { /* disk.rs:122-134 */
@@ -86,8 +87,8 @@ double orc_page_thorne_flux(double r, double mass, double spin, double m_dot) {
 double orc_disk_temperature(double r, double mass, double spin, double m_dot) {
     double flux = orc_page_thorne_flux(r, mass, spin, m_dot);
     if (flux <= 0.0) return 0.0;
-    double t_scale = 1e7 * pow(m_dot, 0.25);
-    return t_scale * pow(flux, 0.25);
+    double t_scale = 1e7 * orc_pow(m_dot, 0.25);
+    return t_scale * orc_pow(flux, 0.25);
 }
 
 /* disk.rs:175-201 */

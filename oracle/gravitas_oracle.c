@@ -118,8 +118,8 @@ double orc_isco(const orc_metric *mt, int retrograde) {
     double m = mt->mass;
     if (fabs(a_star) < 1e-6) return m * 6.0;
     double a2 = a_star * a_star;
-    double z1 = 1.0 + pow(1.0 - a2, 1.0 / 3.0) *
-                          (pow(1.0 + a_star, 1.0 / 3.0) + pow(1.0 - a_star, 1.0 / 3.0));
+    double z1 = 1.0 + orc_pow(1.0 - a2, 1.0 / 3.0) *
+                          (orc_pow(1.0 + a_star, 1.0 / 3.0) + orc_pow(1.0 - a_star, 1.0 / 3.0));
     double z2 = sqrt(3.0 * a2 + z1 * z1);
     double sign = retrograde ? 1.0 : -1.0;
     double disc = (3.0 - z1) * (3.0 + z1 + 2.0 * z2);
@@ -141,7 +141,7 @@ double orc_ergosphere(const orc_metric *mt, double theta) {
 double orc_keplerian_frequency(const orc_metric *mt, double r) {
     double m = mt->mass;
     double a = kerr_a(mt);
-    return sqrt(m) / (pow(r, 1.5) + a * sqrt(m));
+    return sqrt(m) / (orc_pow(r, 1.5) + a * sqrt(m));
 }
 
 /* ----------------------------------------------------------------- metric */

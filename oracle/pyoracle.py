@@ -105,7 +105,7 @@ def lib():
         L = C.CDLL(_LIB_PATH)
         d, i, u64, p = C.c_double, C.c_int, C.c_uint64, C.c_void_p
         MP, SP, OP = C.POINTER(Metric), C.POINTER(State), C.POINTER(Options)
-        for name in ("orc_sin", "orc_cos", "orc_exp"):  # ref_libm.c
+        for name in ("orc_sin", "orc_cos", "orc_exp", "orc_atan"):  # ref_libm.c
             getattr(L, name).restype = d
             getattr(L, name).argtypes = [d]
         L.orc_pow.restype = d
@@ -227,6 +227,11 @@ def ref_cos(x):
 
 def ref_exp(x):
     f = lib().orc_exp
+    return np.array([f(float(v)) for v in np.ravel(x)]).reshape(np.shape(x))
+
+
+def ref_atan(x):
+    f = lib().orc_atan
     return np.array([f(float(v)) for v in np.ravel(x)]).reshape(np.shape(x))
 
 

@@ -366,3 +366,52 @@ double orc_exp(double x) {
     if (k >= -1021) return with_hi(y, hi_word(y) + (int32_t)((uint32_t)k << 20));
     return with_hi(y, hi_word(y) + (int32_t)((uint32_t)(k + 1000) << 20)) * twom1000;
 }
+
+/* ---- atan: argument folded onto [0, 7/16] around 0, 1/2, 1, 3/2, inf; odd/even split series ---- */
+double orc_atan(double x) {
+    static const double atanhi[4] = {4.63647609000806093515e-01, 7.85398163397448278999e-01,
+                                     9.82793723247329054082e-01, 1.57079632679489655800e+00};
+    static const double atanlo[4] = {2.26987774529616870924e-17, 3.06161699786838301793e-17,
+                                     1.39033110312309984516e-17, 6.12323399573676603587e-17};
+    static const double aT[11] = {3.33333333333329318027e-01,  -1.99999999998764832476e-01,
+                                  1.42857142725034663711e-01,  -1.11111104054623557880e-01,
+                                  9.09088713343650656196e-02,  -7.69187620504482999495e-02,
+                                  6.66107313738753120669e-02,  -5.83357013379057348645e-02,
+                                  4.97687799461593236017e-02,  -3.65315727442169155270e-02,
+                                  1.62858201153657823623e-02};
+    const int32_t hx = hi_word(x);
+    const int32_t ix = hx & 0x7fffffff;
+    int id;
+    if (ix >= 0x44100000) { /* |x| >= 2^66 */
+        if (ix > 0x7ff00000 || (ix == 0x7ff00000 && lo_word(x) != 0)) return x + x; /* NaN */
+        return hx > 0 ? atanhi[3] + atanlo[3] : -atanhi[3] - atanlo[3];
+    }
+    if (ix < 0x3fdc0000) {            /* |x| < 0.4375 */
+        if (ix < 0x3e200000) return x; /* |x| < 2^-29 */
+        id = -1;
+    } else {
+        x = fabs(x);
+        if (ix < 0x3ff30000) {     /* |x| < 1.1875 */
+            if (ix < 0x3fe60000) { /* 7/16 <= |x| < 11/16 */
+                id = 0;
+                x = (2.0 * x - 1.0) / (2.0 + x);
+            } else { /* 11/16 <= |x| < 19/16 */
+                id = 1;
+                x = (x - 1.0) / (x + 1.0);
+            }
+        } else if (ix < 0x40038000) { /* |x| < 2.4375 */
+            id = 2;
+            x = (x - 1.5) / (1.0 + 1.5 * x);
+        } else { /* 2.4375 <= |x| < 2^66 */
+            id = 3;
+            x = -1.0 / x;
+        }
+    }
+    const double z = x * x;
+    const double w = z * z;
+    const double s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))));
+    const double s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))));
+    if (id < 0) return x - x * (s1 + s2);
+    const double r = atanhi[id] - ((x * (s1 + s2) - atanlo[id]) - x);
+    return hx < 0 ? -r : r;
+}

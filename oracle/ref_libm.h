@@ -8,7 +8,7 @@
  * libm's, not the reference's ("last-ulp differences are inherent").  For a parity
  * statement that does not depend on which libm happens to be linked, the oracle and the engine's
  * STRICT kernels both evaluate these functions by the routines restated here -- the published
- * fdlibm / msun algorithms (k_sin, k_cos, medium-range rem_pio2, e_pow, e_exp): IEEE add, multiply,
+ * fdlibm / msun algorithms (k_sin, k_cos, medium-range rem_pio2, e_pow, e_exp, s_atan): IEEE add, multiply,
  * divide and sqrt only, no FMA, so the result is a pure function of the argument on any IEEE-754
  * machine.  Accuracy is checked against mpmath in tests/test_ref_libm.py (< 1 ulp).
  *
@@ -27,6 +27,7 @@ double orc_sin(double x);
 double orc_cos(double x);
 double orc_pow(double x, double y);
 double orc_exp(double x);
+double orc_atan(double x);
 
 #ifdef __cplusplus
 }

@@ -1,5 +1,6 @@
 /* viz_oracle.c -- see viz_oracle.h.  TEST INFRASTRUCTURE ONLY.  Plain C, reference operation order. */
 #include "viz_oracle.h"
+#include "ref_libm.h"
 
 #include <math.h>
 
@@ -13,7 +14,7 @@ typedef struct {
 /* Kerr::covariant_bl, metric/kerr.rs:241-264 */
 static cov_bl covariant_bl(double r, double theta, double m, double a) {
     const double r2 = r * r, a2 = a * a;
-    const double sin_theta = sin(theta), cos_theta = cos(theta);
+    const double sin_theta = orc_sin(theta), cos_theta = orc_cos(theta);
     const double sin2 = sin_theta * sin_theta, cos2 = cos_theta * cos_theta;
     const double sigma = r2 + a2 * cos2;
     const double delta = r2 - 2.0 * m * r + a2;
@@ -32,7 +33,7 @@ static double clamp_spin(double s) { return s < -1.0 ? -1.0 : (s > 1.0 ? 1.0 : s
 double orc_kretschner_kerr(double r, double theta, double mass, double spin) {
     const double a = spin * mass;
     const double r2 = r * r, a2 = a * a;
-    const double cos_theta = cos(theta);
+    const double cos_theta = orc_cos(theta);
     const double cos2 = cos_theta * cos_theta, cos4 = cos2 * cos2, cos6 = cos4 * cos2;
     const double r4 = r2 * r2, r6 = r4 * r2;
     const double a4 = a2 * a2, a6 = a4 * a2;
@@ -51,13 +52,13 @@ double orc_light_cone_tilt_bl(double r, double theta, double mass, double spin) 
     if (fabs(g_tr) < 1e-12) {
         if (g.tt >= 0.0) return ORC_PI_2;
         const double ratio = fmax(-g.tt / g.rr, 0.0);
-        return atan(sqrt(ratio));
+        return orc_atan(sqrt(ratio));
     } else {
         const double disc = g_tr * g_tr - g.tt * g.rr;
         if (disc < 0.0) return ORC_PI_2;
         const double sq = sqrt(disc);
         const double slope_out = (-g_tr + sq) / g.rr, slope_in = (-g_tr - sq) / g.rr;
-        return atan(fabs(slope_out - slope_in) / 2.0);
+        return orc_atan(fabs(slope_out - slope_in) / 2.0);
     }
 }
 
@@ -71,7 +72,7 @@ double orc_frame_dragging_omega(double r, double theta, double mass, double spin
 /* Kerr::ergosphere, metric/kerr.rs:157-167 */
 double orc_ergosphere_radius(double theta, double mass, double spin) {
     const double a = clamp_spin(spin) * mass;
-    const double c = cos(theta);
+    const double c = orc_cos(theta);
     const double disc = mass * mass - a * a * c * c;
     return disc < 0.0 ? mass : mass + sqrt(disc);
 }
@@ -141,9 +142,9 @@ void orc_embedding_mesh(double mass, double spin_raw, double r_min, double r_max
         for (size_t j = 0; j < n_angular; ++j) {
             const double phi = 2.0 * ORC_PI * (double)j / (double)n_angular;
             float *o = out + 3 * (i * n_angular + j);
-            o[0] = (float)(r * cos(phi));
+            o[0] = (float)(r * orc_cos(phi));
             o[1] = (float)(-height);
-            o[2] = (float)(r * sin(phi));
+            o[2] = (float)(r * orc_sin(phi));
         }
     }
 }
@@ -156,9 +157,9 @@ void orc_ergosphere_mesh(double mass, double spin, size_t n_polar, size_t n_azim
         for (size_t j = 0; j < n_azimuthal; ++j) {
             const double phi = 2.0 * ORC_PI * (double)j / (double)n_azimuthal;
             float *o = out + 3 * (i * n_azimuthal + j);
-            o[0] = (float)(r_ergo * sin(theta) * cos(phi));
-            o[1] = (float)(r_ergo * cos(theta));
-            o[2] = (float)(r_ergo * sin(theta) * sin(phi));
+            o[0] = (float)(r_ergo * orc_sin(theta) * orc_cos(phi));
+            o[1] = (float)(r_ergo * orc_cos(theta));
+            o[2] = (float)(r_ergo * orc_sin(theta) * orc_sin(phi));
         }
     }
 }

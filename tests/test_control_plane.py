@@ -107,15 +107,15 @@ def test_engine_disk_and_shadow_match_oracle(engine_mod, oracle, spin):
     with engine_mod.PhysicsEngine(1.0, spin) as e:
         lut = e.generate_disk_lut()          # GPU kernel
         ref = oracle.temperature_lut(1.0, spin)
-        assert np.abs(lut - ref).max() <= 2e-6
+        assert np.array_equal(lut, ref)   # Page-Thorne flux with the specified pow: same bits
         for r in (3.0, 7.0, 25.0):
             a, b = e.compute_disk_flux(r), oracle.lib().orc_page_thorne_flux(r, 1.0, spin, 1.0)
-            assert abs(a - b) <= 1e-12 * max(1.0, abs(b))
+            assert a == b
         for th in (PI_2, 1.0, 1e-12):
             got = e.compute_shadow_curve(th, 32).reshape(-1, 2)
             want = oracle.bardeen_shadow(1.0, spin, th, 32)
             assert got.shape == want.shape
-            assert np.abs(got - want.astype(np.float32)).max() <= 1e-5
+            assert np.array_equal(got, want.astype(np.float32))   # host code, host libm on both sides
         assert e.compute_shadow_radius() == 3.0 * math.sqrt(3.0)
 
 
@@ -133,7 +133,7 @@ def test_engine_tick_sab_matches_oracle(engine_mod, oracle):
             o.sab[1], o.sab[3] = 0.5 * k, -0.1
             e.tick_sab(0.016)
             want = oracle.tick_sab(o, 0.016)
-            assert np.allclose(view, want, rtol=1e-6, atol=1e-6)
+            assert np.array_equal(view, np.asarray(want, np.float32))
         # attach_sab redirects the tick to caller memory (lib.rs:74, 309-313)
         ext = np.zeros(2048, np.float32)
         e.attach_sab(ext)

@@ -51,6 +51,10 @@ def test_accuracy_against_mpmath(oracle):
     for x in np.concatenate([rng.uniform(-708, 709.7, 800), rng.uniform(-2, 2, 400), [0.0, 1.0, -1.0, 0.34657359027997264]]):
         worst_e = max(worst_e, _ulps(float(oracle.ref_exp(x)), mp.exp(mp.mpf(float(x))), mp))
     assert worst_e < 1.0, worst_e
+    worst_a = 0.0
+    for x in np.concatenate([rng.uniform(-5, 5, 800), 10.0 ** rng.uniform(-12, 20, 300), [0.4375, 0.6875, 1.1875, 2.4375, 1.0]]):
+        worst_a = max(worst_a, _ulps(float(oracle.ref_atan(x)), mp.atan(mp.mpf(float(x))), mp))
+    assert worst_a < 1.0, worst_a
 
 
 def test_ieee_special_cases(oracle):
@@ -73,7 +77,10 @@ def test_ieee_special_cases(oracle):
     with np.errstate(all="ignore"):
         for x in (inf, -inf, 710.0, -746.0, -745.0, 0.0, -0.0, 1e-300, 709.782712893384, -745.1332191019411):
             assert float(oracle.ref_exp(x)) == float(np.exp(x)), x
-    assert np.isnan(float(oracle.ref_exp(nan)))
+    assert np.isnan(float(oracle.ref_exp(nan))) and np.isnan(float(oracle.ref_atan(nan)))
+    for x in (inf, -inf, 1e70, -1e70, 0.0, 1e-300):
+        assert float(oracle.ref_atan(x)) == float(np.arctan(x)), x
+    assert np.signbit(float(oracle.ref_atan(-0.0)))
     assert float(oracle.ref_sin(0.0)) == 0.0 and np.signbit(float(oracle.ref_sin(-0.0)))
     assert float(oracle.ref_cos(0.0)) == 1.0 and float(oracle.ref_sin(1e-300)) == 1e-300
     # odd / even symmetry is exact
@@ -86,7 +93,8 @@ def test_ieee_special_cases(oracle):
 PINS = (("sin", 1.0, None), ("cos", 1.0, None), ("sin", 100.0, None), ("cos", 1.5707963267948966, None),
         ("sin", 3.141592653589793, None), ("cos", 12345.678, None), ("pow", 0.37, -0.2),
         ("pow", 123.456, -0.25), ("pow", 9.5, 1.5), ("pow", 0.015625, 0.75), ("pow", 0.3, 0.4),
-        ("exp", 1.0, None), ("exp", -37.25, None), ("exp", 700.5, None), ("exp", -730.0, None))
+        ("exp", 1.0, None), ("exp", -37.25, None), ("exp", 700.5, None), ("exp", -730.0, None),
+        ("atan", 0.3, None), ("atan", 0.6, None), ("atan", 1.0, None), ("atan", 2.0, None), ("atan", -77.7, None))
 PIN_HEX = (
     '0x1.aed548f090ceep-1',
     '0x1.14a280fb5068cp-1',
@@ -102,12 +110,17 @@ PIN_HEX = (
     '0x1.5bf0a8b14576ap+1',
     '0x1.3278bcd70e981p-54',
     '0x1.8625c7d4f56c2p+1010',
-    '0x0.00000001c7ea3p-1022')
+    '0x0.00000001c7ea3p-1022',
+    '0x1.2a73a661eaf06p-2',
+    '0x1.14b1dd5f90ce1p-1',
+    '0x1.921fb54442d18p-1',
+    '0x1.1b6e192ebbe44p+0',
+    '-0x1.8ed44e3384d23p+0')
 
 
 def _eval(oracle, name, x, y):
     if y is None:
-        return float({"sin": oracle.ref_sin, "cos": oracle.ref_cos, "exp": oracle.ref_exp}[name](x))
+        return float({"sin": oracle.ref_sin, "cos": oracle.ref_cos, "exp": oracle.ref_exp, "atan": oracle.ref_atan}[name](x))
     return float(oracle.ref_pow(x, y))
 
 
@@ -135,6 +148,11 @@ def test_device_routines_return_the_same_bits(engine_mod, oracle):
         ex = np.concatenate([rng.uniform(-750, 712, 40000), rng.uniform(-2, 2, 20000),
                              [0.0, -0.0, np.inf, -np.inf, np.nan, 1e-300, 709.782712893384, -745.1332191019411]])
         got, want = e.strict_math(bh.engine.MATH_EXP, ex), oracle.ref_exp(ex)
+        assert np.array_equal(got.view(np.uint64)[~np.isnan(want)], want.view(np.uint64)[~np.isnan(want)])
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        ax = np.concatenate([rng.uniform(-5, 5, 40000), 10.0 ** rng.uniform(-20, 30, 10000) * rng.choice([-1.0, 1.0], 10000),
+                             [0.0, -0.0, np.inf, -np.inf, np.nan, 0.4375, 0.6875, 1.1875, 2.4375]])
+        got, want = e.strict_math(bh.engine.MATH_ATAN, ax), oracle.ref_atan(ax)
         assert np.array_equal(got.view(np.uint64)[~np.isnan(want)], want.view(np.uint64)[~np.isnan(want)])
         assert np.array_equal(np.isnan(got), np.isnan(want))
         got, want = e.strict_math(bh.engine.MATH_POW, px, py), oracle.ref_pow(px, py)

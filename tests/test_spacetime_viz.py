@@ -90,23 +90,23 @@ def test_engine_spacetime_readouts_match_oracle(engine_mod, oracle, spin):
             for got, want in ((e.compute_kretschner(r, th), L.orc_kretschner_kerr(r, th, 1.0, spin)),
                               (e.compute_light_cone_tilt(r, th), L.orc_light_cone_tilt_bl(r, th, 1.0, spin)),
                               (e.compute_frame_drag_omega(r, th), L.orc_frame_dragging_omega(r, th, 1.0, spin))):
-                assert abs(got - want) <= 1e-13 * max(1.0, abs(want))
+                assert got == want or (math.isinf(got) and math.isinf(want))   # specified sin/cos/atan: same bits
         assert e.compute_flamm_height(2.0) == 0.0
         assert e.compute_flamm_height(100.0) == L.orc_flamm_height(100.0, 1.0)
         a, b = e.compute_proper_distance(20.0, 4.0, 500), L.orc_proper_distance(20.0, 4.0, 500, 1.0, spin)
-        assert abs(a - b) <= 1e-12 * b
+        assert a == b
         for kind, fn in ((0, e.generate_curvature_field), (1, e.generate_tilt_field),
                          (2, e.generate_frame_drag_field)):
             got = fn(2.2, 40.0, 33, 17)                      # one thread per grid point
             want = oracle.scalar_field(kind, 1.0, spin, 2.2, 40.0, 33, 17)
             assert got.shape == want.shape
-            assert np.allclose(got, want, rtol=2e-6, atol=1e-9)
+            assert np.array_equal(got, want)
         got = e.generate_embedding_mesh(2.5, 30.0, 24, 16)
         want = oracle.embedding_mesh(1.0, spin, 2.5, 30.0, 24, 16)
-        assert np.allclose(got, want, rtol=2e-6, atol=2e-6)
+        assert np.array_equal(got, want)
         got = e.generate_ergosphere_mesh(17, 12)
         want = oracle.ergosphere_mesh(1.0, spin, 17, 12)
-        assert np.allclose(got, want, rtol=2e-6, atol=2e-6)
+        assert np.array_equal(got, want)
         # empty grids are empty loops upstream
         assert e.generate_curvature_field(2.0, 10.0, 0, 5).size == 0
 
