@@ -58,9 +58,10 @@ int grv_generate_spectrum_lut(grv_engine *e, size_t width, size_t height, double
 
 int grv_strict_math(grv_engine *e, int op, size_t n, const double *x, const double *y, double *out) {
     if (!e) return GRV_ERR_INVALID;
-    if (op < GRV_MATH_SINCOS_SIN || op > GRV_MATH_ATAN) return fail(e, GRV_ERR_INVALID, "bad op %d", op);
+    if ((op & ~GRV_MATH_F32) < GRV_MATH_SINCOS_SIN || (op & ~GRV_MATH_F32) > GRV_MATH_ATAN2)
+        return fail(e, GRV_ERR_INVALID, "bad op %d", op);
     if (n == 0) return GRV_OK;
-    if (!x || !out || (op == GRV_MATH_POW && !y) || n > (1ull << 26))
+    if (!x || !out || (((op & ~GRV_MATH_F32) == GRV_MATH_POW || (op & ~GRV_MATH_F32) == GRV_MATH_ATAN2) && !y) || n > (1ull << 26))
         return fail(e, GRV_ERR_INVALID, "bad strict_math request");
     GRV_HIP(e, hipSetDevice(e->device));
     const size_t b = align_up(n * sizeof(double), 256);

@@ -126,15 +126,15 @@ __device__ __forceinline__ void glsl_fast_sincos(float ang, float &s, float &c) 
 // in the FAST contract.  pow(0, y > 0) = exp2(-inf) = 0 in both.
 template <int ARITH> __device__ __forceinline__ float pow_d(float x, float y) {
     if constexpr (ARITH == GRV_ARITH_FAST) return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
-    else return powf(x, y);
+    else return sh_powf(x, y);
 }
 template <int ARITH> __device__ __forceinline__ float exp_d(float x) {
     if constexpr (ARITH == GRV_ARITH_FAST) return __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
-    else return expf(x);
+    else return sh_expf(x);
 }
 template <int ARITH> __device__ __forceinline__ float log_d(float x) {
     if constexpr (ARITH == GRV_ARITH_FAST) return __builtin_amdgcn_logf(x) * 0.693147180559945309f;
-    else return logf(x);
+    else return sh_logf(x);
 }
 
 // chunks/common.ts:44-47 : `v.ab *= rot(ang)`
@@ -144,8 +144,8 @@ __device__ __forceinline__ void glsl_rot(float ang, float &x, float &y) {
     if constexpr (ARITH == GRV_ARITH_FAST) {
         glsl_fast_sincos(ang, s, c);
     } else {
-        s = sinf(ang);
-        c = cosf(ang);
+        s = sh_sinf(ang);
+        c = sh_cosf(ang);
     }
     const float nx = x * c + y * (-s);
     const float ny = x * s + y * c;
@@ -240,7 +240,7 @@ __device__ void glsl_starfield(const GlslParams &U, F3 dir, float stars[3]) {
         const float brightness = pow_d<ARITH>(starNoise, 10.0f) * 2.0f;
         const float bv = glsl_hash(T, F3{cell.x + 127.1f, cell.y + 127.1f, cell.z + 127.1f}) * 2.4f - 0.4f;
         const float twinkle =
-            0.85f + 0.15f * sinf(U.time * (3.0f + glsl_hash(T, F3{cell.x + 73.7f, cell.y + 73.7f, cell.z + 73.7f}) * 2.0f));
+            0.85f + 0.15f * sh_sinf(U.time * (3.0f + glsl_hash(T, F3{cell.x + 73.7f, cell.y + 73.7f, cell.z + 73.7f}) * 2.0f));
         float sc[3];
         glsl_star_color(bv, sc);
         for (int c = 0; c < 3; ++c) stars[c] = sc[c] * brightness * twinkle;
@@ -288,7 +288,7 @@ __device__ __forceinline__ void glsl_sample_disk(const GlslParams &U, F3 p, F3 p
         const float signSpinPhase = sign_d(U.spin + 1e-8f);
         const float OmegaPhase = (signSpinPhase * sqrt_Mp) / (sampleR * sqrtf(sampleR) + a * sqrt_Mp);
         const float rotAngle = OmegaPhase * U.time * 0.12f * 10.0f;
-        const float cs = cosf(rotAngle), sn = sinf(rotAngle);
+        const float cs = sh_cosf(rotAngle), sn = sh_sinf(rotAngle);
         F3 np{sp.x * cs + sp.z * (-sn), sp.y, sp.x * sn + sp.z * cs};
         np = scale_f3(np, 0.75f);
         turbulence = glsl_noise(U.noise_r, np) * 0.5f + glsl_noise(U.noise_r, scale_f3(np, 2.5f)) * 0.25f;
@@ -406,7 +406,7 @@ __device__ uint32_t glsl_fragment(const GlslParams &U, uint32_t width, uint32_t 
     const float rh = M + sqrtf(fmaxf(0.0f, M * M - a * a)); // metric.ts:13-15
     // metric.ts:32-37
     const float a_star = clampf_d(a / M, -0.9999f, 0.9999f);
-    const float rph = 2.0f * M * (1.0f + cosf((2.0f / 3.0f) * acosf(clampf_d(-a_star, -1.0f, 1.0f))));
+    const float rph = 2.0f * M * (1.0f + sh_cosf((2.0f / 3.0f) * sh_acosf(clampf_d(-a_star, -1.0f, 1.0f))));
     // metric.ts:18-29
     const float absS = fabsf(clampf_d(a / M, -0.9999f, 0.9999f));
     const float z1 = 1.0f + pow_d<ARITH>(1.0f - absS * absS, 1.0f / 3.0f) *

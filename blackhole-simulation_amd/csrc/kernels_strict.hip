@@ -169,6 +169,22 @@ __global__ __launch_bounds__(kBlock) void strict_math_kernel(int op, uint32_t n,
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     double s, c;
+    if (op & 16) { // f32 forms of the shader-order kernels
+        const float xf = (float)x[i], yf = (float)y[i];
+        float r;
+        switch (op & 15) {
+        case 0: case 2: r = sh_sinf(xf); break;
+        case 1: case 3: r = sh_cosf(xf); break;
+        case 4: r = sh_powf(xf, yf); break;
+        case 5: r = sh_expf(xf); break;
+        case 7: r = sh_logf(xf); break;
+        case 8: r = sh_acosf(xf); break;
+        case 9: r = sh_atan2f(xf, yf); break;
+        default: r = (float)strictm::sl_atan((double)xf); break;
+        }
+        out[i] = (double)r;
+        return;
+    }
     switch (op) {
     case 0: sincos_t<double>(x[i], &s, &c); out[i] = s; break;
     case 1: sincos_t<double>(x[i], &s, &c); out[i] = c; break;
@@ -176,7 +192,10 @@ __global__ __launch_bounds__(kBlock) void strict_math_kernel(int op, uint32_t n,
     case 3: out[i] = strictm::sl_cos(x[i]); break;
     case 4: out[i] = pow_rs(x[i], y[i]); break;
     case 5: out[i] = exp_rs(x[i]); break;
-    default: out[i] = strictm::sl_atan(x[i]); break;
+    case 6: out[i] = strictm::sl_atan(x[i]); break;
+    case 7: out[i] = strictm::sl_log(x[i]); break;
+    case 8: out[i] = strictm::sl_acos(x[i]); break;
+    default: out[i] = strictm::sl_atan2(x[i], y[i]); break;
     }
 }
 } // namespace

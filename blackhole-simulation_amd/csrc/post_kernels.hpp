@@ -19,6 +19,7 @@
 #include <hip/hip_fp16.h>
 
 #include "engine_types.hpp"
+#include "shader_common.hpp"
 
 namespace {
 
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(256) void bloom_blur_kernel(uint32_t sw, uint32_t s
 // gamma: OCML powf in shader order; v_log_f32 / v_exp_f32 in the FAST contract
 template <int ARITH> __device__ __forceinline__ float post_pow(float x, float y) {
     if constexpr (ARITH == GRV_ARITH_FAST) return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
-    else return powf(x, y);
+    else return sh_powf(x, y);
 }
 __device__ __forceinline__ float post_aces(float c) {
     return post_clamp((c * (2.51f * c + 0.03f)) / (c * (2.43f * c + 0.59f) + 0.14f), 0.0f, 1.0f);
@@ -309,7 +310,9 @@ __global__ __launch_bounds__(256) void blit_reinhard_kernel(uint32_t w, uint32_t
                                                             float4 *__restrict__ dst) {
     uint32_t px, py;
     if (!post_pixel(w, h, px, py)) return;
-    const float4 c = post_sample(src, w, h, ((float)px + 0.5f) / (float)w, ((float)py + 0.5f) / (float)h);
+    // the blit samples the resolve target 1:1 at pixel centres, where a linear sampler returns
+    // the texel itself (8-bit fixed-point weights): a plain fetch
+    const float4 c = src[(size_t)py * w + px];
     dst[(size_t)py * w + px] = make_float4(c.x / (c.x + 1.0f), c.y / (c.y + 1.0f), c.z / (c.z + 1.0f), c.w);
 }
 

@@ -6,6 +6,29 @@
 
 namespace {
 
+// f32 transcendental functions of the shader-order (STRICT) kernels.  GLSL / WGSL leave their
+// precision to the implementation; the STRICT unit (GRV_SPECIFIED_LIBM) evaluates them as the
+// written-out f64 routines of strict_libm.hpp rounded once to f32, which the checker in oracle/
+// does too, so shader-order images are a pure function of their inputs.  The FAST unit only
+// reaches these from code it never instantiates for FAST arithmetic.
+#if defined(GRV_SPECIFIED_LIBM)
+__device__ __forceinline__ float sh_sinf(float x) { return strictm::sl_sinf(x); }
+__device__ __forceinline__ float sh_cosf(float x) { return strictm::sl_cosf(x); }
+__device__ __forceinline__ float sh_powf(float x, float y) { return strictm::sl_powf(x, y); }
+__device__ __forceinline__ float sh_expf(float x) { return strictm::sl_expf(x); }
+__device__ __forceinline__ float sh_logf(float x) { return strictm::sl_logf(x); }
+__device__ __forceinline__ float sh_acosf(float x) { return strictm::sl_acosf(x); }
+__device__ __forceinline__ float sh_atan2f(float y, float x) { return strictm::sl_atan2f(y, x); }
+#else
+__device__ __forceinline__ float sh_sinf(float x) { return sinf(x); }
+__device__ __forceinline__ float sh_cosf(float x) { return cosf(x); }
+__device__ __forceinline__ float sh_powf(float x, float y) { return powf(x, y); }
+__device__ __forceinline__ float sh_expf(float x) { return expf(x); }
+__device__ __forceinline__ float sh_logf(float x) { return logf(x); }
+__device__ __forceinline__ float sh_acosf(float x) { return acosf(x); }
+__device__ __forceinline__ float sh_atan2f(float y, float x) { return atan2f(y, x); }
+#endif
+
 struct F3 {
     float x, y, z;
 };

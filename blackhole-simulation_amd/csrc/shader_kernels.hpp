@@ -40,7 +40,7 @@ __device__ __forceinline__ D32 wgsl_derivs(const Ray32 &s, float M, float spin) 
     const float a = spin * M;
     const float r = s.r, theta = s.th;
     const float r2 = r * r, a2 = a * a;
-    const float sint = sinf(theta), cost = cosf(theta);
+    const float sint = sh_sinf(theta), cost = sh_cosf(theta);
     const float sin2 = fmaxf(sint * sint, 1e-12f);
     const float cos2 = 1.0f - sin2;
     const float sigma = r2 + a2 * cos2;
@@ -72,7 +72,7 @@ __device__ __forceinline__ D32 wgsl_derivs(const Ray32 &s, float M, float spin) 
     const float dg_thth_dth = -dsigma_dth / sigma2;
     const float dg_phph_dr = -dsigma_dr / (sigma2 * sin2);
     const float dg_phph_dth =
-        -(dsigma_dth * sin2 + sigma * sinf(2.0f * theta)) / (sigma2 * sin2 * sin2);
+        -(dsigma_dth * sin2 + sigma * sh_sinf(2.0f * theta)) / (sigma2 * sin2 * sin2);
     const float dg_rph_dr = -(a * dsigma_dr) / sigma2;
     const float dg_rph_dth = -(a * dsigma_dth) / sigma2;
 
@@ -146,9 +146,9 @@ __global__ __launch_bounds__(kBlock) void wgsl_symplectic_kernel(FrameGeom G, Wg
 
         const F3 cam{P.position[0], P.position[1], P.position[2]};
         const float r0 = length_f3(cam);
-        const float theta0 = acosf(clampf_d(cam.y / r0, -1.0f, 1.0f));
-        const float phi0 = atan2f(cam.z, cam.x);
-        const float st = sinf(theta0), ct = cosf(theta0), sp = sinf(phi0), cp = cosf(phi0);
+        const float theta0 = sh_acosf(clampf_d(cam.y / r0, -1.0f, 1.0f));
+        const float phi0 = sh_atan2f(cam.z, cam.x);
+        const float st = sh_sinf(theta0), ct = sh_cosf(theta0), sp = sh_sinf(phi0), cp = sh_cosf(phi0);
         const float pr_far = dot_f3(wd, F3{st * cp, ct, st * sp});
         const float pth_far = dot_f3(wd, F3{ct * cp, -st, ct * sp}) / r0;
         const float safe_st = fmaxf(st, 1e-4f);
@@ -170,8 +170,8 @@ __global__ __launch_bounds__(kBlock) void wgsl_symplectic_kernel(FrameGeom G, Wg
         const float disc = M * M - a * a;
         const float rh = disc < 0.0f ? M : M + sqrtf(disc);
         const float absS = fabsf(clampf_d(a / M, -0.999f, 0.999f));
-        const float z1 = 1.0f + powf(1.0f - absS * absS, 1.0f / 3.0f) *
-                                    (powf(1.0f + absS, 1.0f / 3.0f) + powf(1.0f - absS, 1.0f / 3.0f));
+        const float z1 = 1.0f + sh_powf(1.0f - absS * absS, 1.0f / 3.0f) *
+                                    (sh_powf(1.0f + absS, 1.0f / 3.0f) + sh_powf(1.0f - absS, 1.0f / 3.0f));
         const float z2 = sqrtf(3.0f * absS * absS + z1 * z1);
         const float isco = M * (3.0f + z2 - sqrtf((3.0f - z1) * (3.0f + z1 + 2.0f * z2)));
 
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(kBlock) void wgsl_symplectic_kernel(FrameGeom G, Wg
             if (r > 100.0f) { // compute.wgsl.ts:199-206
                 if (P.stars) {
                     const F3 vdir = normalize_f3(F3{s.pr, s.pth / r, s.pph / (r * safe_st)});
-                    const float sn = sinf(vdir.x * 12.9898f + vdir.y * 78.233f + vdir.z * 45.164f) * 43758.5453f;
+                    const float sn = sh_sinf(vdir.x * 12.9898f + vdir.y * 78.233f + vdir.z * 45.164f) * 43758.5453f;
                     if (sn - floorf(sn) > 0.999f)
                         for (int c = 0; c < 3; ++c) col[c] += 1.0f * (1.0f - alpha);
                 }
@@ -195,19 +195,19 @@ __global__ __launch_bounds__(kBlock) void wgsl_symplectic_kernel(FrameGeom G, Wg
             ++steps;
             const float curr_theta = s.th;
             if ((prev_theta - PI * 0.5f) * (curr_theta - PI * 0.5f) <= 0.0f && r > isco && r < 30.0f) {
-                const float Omega = 1.0f / (powf(r, 1.5f) + a);
+                const float Omega = 1.0f / (sh_powf(r, 1.5f) + a);
                 const float u_t =
                     1.0f / sqrtf(fmaxf(1.0f - 2.0f * M / r - Omega * Omega * (r * r + a * a), 1e-4f));
                 const float u_phi = Omega * u_t;
                 const float g_factor = -s.pt / fmaxf(-(u_t * s.pt + u_phi * s.pph), 1e-4f);
-                const float artistic_T = (1.0f / powf(fmaxf(r / isco, 1.0f), 0.75f)) * g_factor;
+                const float artistic_T = (1.0f / sh_powf(fmaxf(r / isco, 1.0f), 0.75f)) * g_factor;
                 const float base[3] = {1.0f, 0.5f, 0.1f}, blue[3] = {0.5f, 0.7f, 1.0f},
                             red[3] = {1.0f, 0.2f, 0.0f};
                 const float bs = fmaxf(g_factor - 1.0f, 0.0f), rs = fmaxf(1.0f - g_factor, 0.0f) * 0.5f;
                 const float target_opacity = 0.6f * artistic_T;
-                const float g4 = powf(g_factor, 4.0f);
-                const float mri_shear = powf(r, -1.5f);
-                const float mri_sat = 1.0f + 0.0001f * sinf(r * 100.0f * mri_shear);
+                const float g4 = sh_powf(g_factor, 4.0f);
+                const float mri_shear = sh_powf(r, -1.5f);
+                const float mri_sat = 1.0f + 0.0001f * sh_sinf(r * 100.0f * mri_shear);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const float target = (base[c] + blue[c] * bs - red[c] * rs) * artistic_T * 4.0f;

@@ -1,10 +1,11 @@
-// strict_libm.hpp -- sin, cos, pow, exp and atan with a specified result, for the STRICT contract.
+// strict_libm.hpp -- sin, cos, pow, exp, log, atan, atan2 and acos with a specified result
+// (f64, and f32 forms = the f64 routine rounded once), for the STRICT contract.
 //
 // The reference calls Rust's f64::sin / cos / powf; their last bit belongs to whichever libm the
 // build links (the wasm target's bundled msun port, or the platform's).  So that a STRICT result
 // is a pure function of its inputs -- the same bits from this engine on any device and from the
 // checker in oracle/ -- the STRICT kernels evaluate them by the published fdlibm / FreeBSD msun
-// algorithms written out here (k_sin, k_cos, the medium-range Cody-Waite rem_pio2, e_pow, e_exp, s_atan): IEEE
+// algorithms written out here (k_sin, k_cos, the medium-range Cody-Waite rem_pio2, e_pow, e_exp, s_atan, e_log, e_acos, e_atan2): IEEE
 // add / multiply / divide / sqrt only, round-to-nearest, no FMA (this header is only used from
 // translation units built with -ffp-contract=off).  < 1 ulp, see tests/test_ref_libm.py.
 // Not restated: rem_pio2's Payne-Hanek branch; |x| >= 2^20 pi/2 goes through the same
@@ -428,6 +429,163 @@ GRV_HD inline double sl_atan(double x) {
     const double r = hi_c - ((x * (s1 + s2) - lo_c) - x);
     return hx < 0 ? -r : r;
 }
+
+/* ---- log: x = 2^k (1 + f), log(1 + f) = f - hfsq + s (hfsq + R(s^2)), s = f / (2 + f) ---- */
+GRV_HD inline double sl_log(double x) {
+    constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                        two54 = 1.80143985094819840000e+16, Lg1 = 6.666666666666735130e-01,
+                        Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                        Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01,
+                        Lg6 = 1.531383769920937332e-01, Lg7 = 1.479819860511658591e-01;
+    int32_t hx = hi_word(x);
+    const uint32_t lx = lo_word(x);
+    int k = 0;
+    if (hx < 0x00100000) { /* x < 2^-1022 */
+        if ((((uint32_t)hx & 0x7fffffffu) | lx) == 0) return from_bits(0xfff0000000000000ull); /* log(+-0) = -inf */
+        if (hx < 0) return (x - x) / (x - x);                               /* log(-#) = NaN */
+        k -= 54;
+        x *= two54; /* subnormal: scale up */
+        hx = hi_word(x);
+    }
+    if (hx >= 0x7ff00000) return x + x;
+    k += (hx >> 20) - 1023;
+    hx &= 0x000fffff;
+    const int32_t i = (hx + 0x95f64) & 0x100000;
+    x = with_hi(x, hx | (i ^ 0x3ff00000)); /* normalize x or x/2 */
+    k += (i >> 20);
+    const double f = x - 1.0;
+    const double dk = (double)k;
+    if ((0x000fffff & (2 + hx)) < 3) { /* -2^-20 <= f < 2^-20 */
+        if (f == 0.0) {
+            if (k == 0) return 0.0;
+            return dk * ln2_hi + dk * ln2_lo;
+        }
+        const double R = f * f * (0.5 - 0.33333333333333333 * f);
+        if (k == 0) return f - R;
+        return dk * ln2_hi - ((R - dk * ln2_lo) - f);
+    }
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    const int32_t ii = hx - 0x6147a;
+    const double w = z * z;
+    const int32_t jj = 0x6b851 - hx;
+    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    const double R = t2 + t1;
+    if ((ii | jj) > 0) {
+        const double hfsq = 0.5 * f * f;
+        if (k == 0) return f - (hfsq - s * (hfsq + R));
+        return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+    }
+    if (k == 0) return f - s * (f - R);
+    return dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
+}
+
+/* ---- acos: rational R(x^2) on |x| < 1/2, sqrt-based identities beyond ---- */
+GRV_HD inline double sl_acos(double x) {
+    constexpr double pio2_hi = 1.57079632679489655800e+00, pio2_lo = 6.12323399573676603587e-17,
+                        pi = 3.14159265358979311600e+00, pS0 = 1.66666666666666657415e-01,
+                        pS1 = -3.25565818622400915405e-01, pS2 = 2.01212532134862925881e-01,
+                        pS3 = -4.00555345006794114027e-02, pS4 = 7.91534994289814532176e-04,
+                        pS5 = 3.47933107596021167570e-05, qS1 = -2.40339491173441421878e+00,
+                        qS2 = 2.02094576023350569471e+00, qS3 = -6.88283971605453293030e-01,
+                        qS4 = 7.70381505559019352791e-02;
+    const int32_t hx = hi_word(x);
+    const int32_t ix = hx & 0x7fffffff;
+    if (ix >= 0x3ff00000) { /* |x| >= 1 */
+        if ((((uint32_t)(ix - 0x3ff00000)) | lo_word(x)) == 0) return hx > 0 ? 0.0 : pi + 2.0 * pio2_lo;
+        return (x - x) / (x - x); /* |x| > 1: NaN */
+    }
+    if (ix < 0x3fe00000) { /* |x| < 0.5 */
+        if (ix <= 0x3c600000) return pio2_hi + pio2_lo; /* |x| < 2^-57 */
+        const double z = x * x;
+        const double p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        const double q = 1.0 + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        const double r = p / q;
+        return pio2_hi - (x - (pio2_lo - x * r));
+    }
+    if (hx < 0) { /* x < -0.5 */
+        const double z = (1.0 + x) * 0.5;
+        const double p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        const double q = 1.0 + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        const double s = ::sqrt(z);
+        const double r = p / q;
+        const double w = r * s - pio2_lo;
+        return pi - 2.0 * (s + w);
+    }
+    /* x > 0.5 */
+    const double z = (1.0 - x) * 0.5;
+    const double s = ::sqrt(z);
+    const double df = clear_lo(s);
+    const double c = (z - df * df) / (s + df);
+    const double p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    const double q = 1.0 + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    const double r = p / q;
+    const double w = r * s + c;
+    return 2.0 * (df + w);
+}
+
+/* ---- atan2: quadrant logic around atan(|y / x|) ---- */
+GRV_HD inline double sl_atan2(double y, double x) {
+    constexpr double pi = 3.1415926535897931160E+00, pi_lo = 1.2246467991473531772E-16;
+    const int32_t hx = hi_word(x), hy = hi_word(y);
+    const uint32_t lx = lo_word(x), ly = lo_word(y);
+    const int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    if (ix > 0x7ff00000 || (ix == 0x7ff00000 && lx != 0) || iy > 0x7ff00000 || (iy == 0x7ff00000 && ly != 0))
+        return x + y; /* NaN */
+    if ((((uint32_t)(hx - 0x3ff00000)) | lx) == 0) return sl_atan(y); /* x = 1 */
+    const int m = (int)(((uint32_t)hy >> 31) & 1u) | (int)(((uint32_t)hx >> 30) & 2u); /* 2 sign(x) + sign(y) */
+    if (((uint32_t)iy | ly) == 0) { /* y = 0 */
+        switch (m) {
+        case 0:
+        case 1: return y;  /* atan(+-0, +anything) = +-0 */
+        case 2: return pi; /* atan(+0, -anything) = pi */
+        default: return -pi;
+        }
+    }
+    if (((uint32_t)ix | lx) == 0) return hy < 0 ? -pi / 2.0 : pi / 2.0; /* x = 0 */
+    if (ix == 0x7ff00000) { /* x = inf */
+        if (iy == 0x7ff00000) {
+            switch (m) {
+            case 0: return pi / 4.0;
+            case 1: return -pi / 4.0;
+            case 2: return 3.0 * pi / 4.0;
+            default: return -3.0 * pi / 4.0;
+            }
+        }
+        switch (m) {
+        case 0: return 0.0;
+        case 1: return -0.0;
+        case 2: return pi;
+        default: return -pi;
+        }
+    }
+    if (iy == 0x7ff00000) return hy < 0 ? -pi / 2.0 : pi / 2.0; /* y = inf */
+    double z;
+    const int k = (iy - ix) >> 20;
+    if (k > 60) { /* |y / x| > 2^60 */
+        z = pi / 2.0 + 0.5 * pi_lo;
+    } else if (hx < 0 && k < -60) {
+        z = 0.0; /* 0 > |y| / x > -2^-60 */
+    } else {
+        z = sl_atan(::fabs(y / x));
+    }
+    switch (m) {
+    case 0: return z;   /* atan(+, +) */
+    case 1: return -z;  /* atan(-, +) */
+    case 2: return pi - (z - pi_lo); /* atan(+, -) */
+    default: return (z - pi_lo) - pi; /* atan(-, -) */
+    }
+}
+
+/* ---- f32 forms: the f64 routine rounded once to f32 (what the shader-order f32 kernels use) ---- */
+GRV_HD inline float sl_sinf(float x) { return (float)sl_sin((double)x); }
+GRV_HD inline float sl_cosf(float x) { return (float)sl_cos((double)x); }
+GRV_HD inline float sl_powf(float x, float y) { return (float)sl_pow((double)x, (double)y); }
+GRV_HD inline float sl_expf(float x) { return (float)sl_exp((double)x); }
+GRV_HD inline float sl_logf(float x) { return (float)sl_log((double)x); }
+GRV_HD inline float sl_acosf(float x) { return (float)sl_acos((double)x); }
+GRV_HD inline float sl_atan2f(float y, float x) { return (float)sl_atan2((double)y, (double)x); }
 
 // both at once (one argument reduction)
 GRV_HD inline void sl_sincos(double x, double *sn, double *cs) {

@@ -334,13 +334,15 @@ int grv_generate_spectrum_lut(grv_engine *e, size_t width, size_t height, double
 int grv_generate_spectrum_lut_device(grv_engine *e, size_t width, size_t height,
                                      double max_temp, float *d_out, void *stream);
 
-/* ---- the STRICT contract's sin / cos / pow / exp / atan, evaluated on the device ----
+/* ---- the STRICT contract's transcendental functions, evaluated on the device ----
  * Rust's f64::sin/cos/powf (kerr.rs:415, integrator.rs:93,97 ...) take their last bit from the
  * linked libm; the STRICT kernels use written-out fdlibm-lineage routines instead (csrc/
  * strict_libm.hpp) so that a STRICT result is a pure function of its inputs.  This entry point
  * exposes them for verification: out[i] = op(x[i] [, y[i]]), host buffers. */
 enum { GRV_MATH_SINCOS_SIN = 0, GRV_MATH_SINCOS_COS = 1, GRV_MATH_SIN = 2, GRV_MATH_COS = 3,
-       GRV_MATH_POW = 4, GRV_MATH_EXP = 5, GRV_MATH_ATAN = 6 };
+       GRV_MATH_POW = 4, GRV_MATH_EXP = 5, GRV_MATH_ATAN = 6, GRV_MATH_LOG = 7, GRV_MATH_ACOS = 8,
+       GRV_MATH_ATAN2 = 9 /* atan2(x[i], y[i]) */,
+       GRV_MATH_F32 = 16 /* or-ed in: the f32 form (float)op((double)(float)x) of the shader-order kernels */ };
 int grv_strict_math(grv_engine *e, int op, size_t n, const double *x, const double *y, double *out);
 
 /* ---- disk / shadow helpers next to the path ---- */

@@ -1,5 +1,6 @@
 /* post_oracle.c -- see post_oracle.h.  TEST INFRASTRUCTURE ONLY.  Shader evaluation order, f32. */
 #include "post_oracle.h"
+#include "ref_libm.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -218,7 +219,7 @@ void orc_bloom(uint32_t w, uint32_t h, const float *scene, float threshold, floa
         sample_linear(scene, w, h, u, v, sc);
         sample_linear(src, sw, sh, u, v, bl);
         float *o = out + 4 * k;
-        for (int c = 0; c < 3; c++) o[c] = powf(aces(sc[c] + bl[c] * intensity), 0.4545f);
+        for (int c = 0; c < 3; c++) o[c] = orc_powf(aces(sc[c] + bl[c] * intensity), 0.4545f);
         o[3] = 1.0f;
     }
     free(bright);

@@ -105,11 +105,18 @@ def lib():
         L = C.CDLL(_LIB_PATH)
         d, i, u64, p = C.c_double, C.c_int, C.c_uint64, C.c_void_p
         MP, SP, OP = C.POINTER(Metric), C.POINTER(State), C.POINTER(Options)
-        for name in ("orc_sin", "orc_cos", "orc_exp", "orc_atan"):  # ref_libm.c
+        for name in ("orc_sin", "orc_cos", "orc_exp", "orc_atan", "orc_log", "orc_acos"):  # ref_libm.c
             getattr(L, name).restype = d
             getattr(L, name).argtypes = [d]
-        L.orc_pow.restype = d
-        L.orc_pow.argtypes = [d, d]
+        for name in ("orc_pow", "orc_atan2"):
+            getattr(L, name).restype = d
+            getattr(L, name).argtypes = [d, d]
+        for name in ("orc_sinf", "orc_cosf", "orc_expf", "orc_logf", "orc_acosf"):
+            getattr(L, name).restype = C.c_float
+            getattr(L, name).argtypes = [C.c_float]
+        for name in ("orc_powf", "orc_atan2f"):
+            getattr(L, name).restype = C.c_float
+            getattr(L, name).argtypes = [C.c_float, C.c_float]
         L.orc_metric_make.restype = Metric
         L.orc_metric_make.argtypes = [i, d, d]
         L.orc_options_default.restype = Options
@@ -223,6 +230,18 @@ def ref_sin(x):
 def ref_cos(x):
     f = lib().orc_cos
     return np.array([f(float(v)) for v in np.ravel(x)]).reshape(np.shape(x))
+
+
+def ref_fn(name, x, y=None):
+    """orc_<name> of ref_libm.c over arrays (name: sin, cos, exp, log, atan, acos, pow, atan2, and
+    the f32 forms sinf ... atan2f)."""
+    f = getattr(lib(), "orc_" + name)
+    dt = np.float32 if name.endswith("f") else np.float64
+    x = np.asarray(x, dt)
+    if y is None:
+        return np.array([f(v.item()) for v in x.ravel()], dt).reshape(x.shape)
+    x, y = np.broadcast_arrays(x, np.asarray(y, dt))
+    return np.array([f(a.item(), b.item()) for a, b in zip(x.ravel(), y.ravel())], dt).reshape(x.shape)
 
 
 def ref_exp(x):

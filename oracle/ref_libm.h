@@ -8,7 +8,7 @@
  * libm's, not the reference's ("last-ulp differences are inherent").  For a parity
  * statement that does not depend on which libm happens to be linked, the oracle and the engine's
  * STRICT kernels both evaluate these functions by the routines restated here -- the published
- * fdlibm / msun algorithms (k_sin, k_cos, medium-range rem_pio2, e_pow, e_exp, s_atan): IEEE add, multiply,
+ * fdlibm / msun algorithms (k_sin, k_cos, medium-range rem_pio2, e_pow, e_exp, s_atan, e_log, e_acos, e_atan2): IEEE add, multiply,
  * divide and sqrt only, no FMA, so the result is a pure function of the argument on any IEEE-754
  * machine.  Accuracy is checked against mpmath in tests/test_ref_libm.py (< 1 ulp).
  *
@@ -28,6 +28,18 @@ double orc_cos(double x);
 double orc_pow(double x, double y);
 double orc_exp(double x);
 double orc_atan(double x);
+double orc_log(double x);
+double orc_acos(double x);
+double orc_atan2(double y, double x);
+
+/* f32 forms used by the shader-order f32 kernels and their oracle: the f64 routine, rounded once */
+float orc_sinf(float x);
+float orc_cosf(float x);
+float orc_powf(float x, float y);
+float orc_expf(float x);
+float orc_logf(float x);
+float orc_acosf(float x);
+float orc_atan2f(float y, float x);
 
 #ifdef __cplusplus
 }

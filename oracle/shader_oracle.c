@@ -5,9 +5,12 @@
  * Restated as written: every formula of the cited shader lines, in f32, in the
  * shader's evaluation order.  Deliberately fixed (the reference is not
  * reproducible there):
+ *   - the shaders' sin / cos / pow / exp / log / acos / atan2 (precision left to the GPU by the
+ *     GLSL ES and WGSL specifications): the f32 forms of ref_libm.c (the written-out f64 routine,
+ *     rounded once), which the engine's shader-order kernels use too -- so those kernels return
+ *     this file's bits, and FAST kernels are compared statistically;
  *   - WGSL star hash (compute.wgsl.ts:201-204): fract(sin(.) * 43758.5453) amplifies the last
- *     ulp of sin by 4e4 -- restated with sinf, a handful of star pixels may flip between libms
- *     (inside the statistical tolerance); `stars = 0` skips it;
+ *     ulp of sin by 4e4: a different sin moves stars; `stars = 0` skips it for the FAST kernels;
  *   - GLSL noise textures (webgl-utils.ts:259-305 fills them with Math.random()): the caller
  *     supplies the two 256x256 R channels (orc_seeded_noise_rgba8 makes seeded ones);
  *     hash() = texture(u_noiseTex, (uv+0.5)/256).r with LINEAR/REPEAT is evaluated with f32
@@ -18,6 +21,7 @@
  * the GLSL ES 3.00 specification.
  */
 #include "shader_oracle.h"
+#include "ref_libm.h"
 
 #include <math.h>
 #include <string.h>
@@ -60,8 +64,8 @@ static float wgsl_horizon(float M, float a) {
 static float wgsl_isco(float M, float a) {
     float rs = a / M;
     float absS = fabsf(clampf(rs, -0.999f, 0.999f));
-    float z1 = 1.0f + powf(1.0f - absS * absS, 1.0f / 3.0f) *
-                          (powf(1.0f + absS, 1.0f / 3.0f) + powf(1.0f - absS, 1.0f / 3.0f));
+    float z1 = 1.0f + orc_powf(1.0f - absS * absS, 1.0f / 3.0f) *
+                          (orc_powf(1.0f + absS, 1.0f / 3.0f) + orc_powf(1.0f - absS, 1.0f / 3.0f));
     float z2 = sqrtf(3.0f * absS * absS + z1 * z1);
     return M * (3.0f + z2 - sqrtf((3.0f - z1) * (3.0f + z1 + 2.0f * z2)));
 }
@@ -71,7 +75,7 @@ static void wgsl_derivs(const ray32 *s, float M, float spin, float dx[4], float 
     float a = spin * M;
     float r = s->x[1], theta = s->x[2];
     float r2 = r * r, a2 = a * a;
-    float sint = sinf(theta), cost = cosf(theta);
+    float sint = orc_sinf(theta), cost = orc_cosf(theta);
     float sin2 = fmaxf(sint * sint, 1e-12f);
     float cos2 = 1.0f - sin2;
     float sigma = r2 + a2 * cos2;
@@ -104,7 +108,7 @@ static void wgsl_derivs(const ray32 *s, float M, float spin, float dx[4], float 
     float dg_thth_dr = -dsigma_dr / sigma2;
     float dg_thth_dth = -dsigma_dth / sigma2;
     float dg_phph_dr = -dsigma_dr / (sigma2 * sin2);
-    float dg_phph_dth = -(dsigma_dth * sin2 + sigma * sinf(2.0f * theta)) / (sigma2 * sin2 * sin2);
+    float dg_phph_dth = -(dsigma_dth * sin2 + sigma * orc_sinf(2.0f * theta)) / (sigma2 * sin2 * sin2);
     float dg_rph_dr = -(a * dsigma_dr) / sigma2;
     float dg_rph_dth = -(a * dsigma_dth) / sigma2;
 
@@ -166,9 +170,9 @@ uint32_t orc_wgsl_pixel(const orc_wgsl_params *P, uint32_t ix, uint32_t iy, floa
 
     v3 cam = {P->position[0], P->position[1], P->position[2]};
     float r0 = length3(cam);
-    float theta0 = acosf(clampf(cam.y / r0, -1.0f, 1.0f));
-    float phi0 = atan2f(cam.z, cam.x);
-    float st = sinf(theta0), ct = cosf(theta0), sp = sinf(phi0), cp = cosf(phi0);
+    float theta0 = orc_acosf(clampf(cam.y / r0, -1.0f, 1.0f));
+    float phi0 = orc_atan2f(cam.z, cam.x);
+    float st = orc_sinf(theta0), ct = orc_cosf(theta0), sp = orc_sinf(phi0), cp = orc_cosf(phi0);
 
     v3 e_r = {st * cp, ct, st * sp}, e_th = {ct * cp, -st, ct * sp}, e_ph = {-sp, 0.0f, cp};
     float pr_far = dot3(wd, e_r);
@@ -196,7 +200,7 @@ uint32_t orc_wgsl_pixel(const orc_wgsl_params *P, uint32_t ix, uint32_t iy, floa
             if (P->stars) {
                 v3 vdir = {s.p[1], s.p[2] / r, s.p[3] / (r * safe_st)};
                 vdir = normalize3(vdir);
-                float sn = sinf(vdir.x * 12.9898f + vdir.y * 78.233f + vdir.z * 45.164f) * 43758.5453f;
+                float sn = orc_sinf(vdir.x * 12.9898f + vdir.y * 78.233f + vdir.z * 45.164f) * 43758.5453f;
                 float star = sn - floorf(sn); /* fract */
                 if (star > 0.999f)
                     for (int c = 0; c < 3; c++) color[c] += 1.0f * (1.0f - alpha);
@@ -209,17 +213,17 @@ uint32_t orc_wgsl_pixel(const orc_wgsl_params *P, uint32_t ix, uint32_t iy, floa
         steps++;
         float curr_theta = s.x[2];
         if ((prev_theta - PI * 0.5f) * (curr_theta - PI * 0.5f) <= 0.0f && r > isco && r < 30.0f) {
-            float Omega = 1.0f / (powf(r, 1.5f) + a);
+            float Omega = 1.0f / (orc_powf(r, 1.5f) + a);
             float u_t = 1.0f / sqrtf(fmaxf(1.0f - 2.0f * M / r - Omega * Omega * (r * r + a * a), 1e-4f));
             float u_phi = Omega * u_t;
             float g_factor = -s.p[0] / fmaxf(-(u_t * s.p[0] + u_phi * s.p[3]), 1e-4f);
-            float artistic_T = (1.0f / powf(fmaxf(r / isco, 1.0f), 0.75f)) * g_factor;
+            float artistic_T = (1.0f / orc_powf(fmaxf(r / isco, 1.0f), 0.75f)) * g_factor;
             float base[3] = {1.0f, 0.5f, 0.1f}, blue[3] = {0.5f, 0.7f, 1.0f}, red[3] = {1.0f, 0.2f, 0.0f};
             float bs = fmaxf(g_factor - 1.0f, 0.0f), rs = fmaxf(1.0f - g_factor, 0.0f) * 0.5f;
             float target_opacity = 0.6f * artistic_T;
-            float g4 = powf(g_factor, 4.0f);
-            float mri_shear = powf(r, -1.5f);
-            float mri_sat = 1.0f + 0.0001f * sinf(r * 100.0f * mri_shear);
+            float g4 = orc_powf(g_factor, 4.0f);
+            float mri_shear = orc_powf(r, -1.5f);
+            float mri_sat = 1.0f + 0.0001f * orc_sinf(r * 100.0f * mri_shear);
             for (int c = 0; c < 3; c++) {
                 float target = (base[c] + blue[c] * bs - red[c] * rs) * artistic_T * 4.0f;
                 float I_em = target * target_opacity / fmaxf(g4, 1e-5f);
@@ -265,8 +269,8 @@ static float gl_horizon(float M, float a) { return M + sqrtf(fmaxf(0.0f, M * M -
 static float gl_isco(float M, float a) {
     float rs = a / M;
     float absS = fabsf(clampf(rs, -0.9999f, 0.9999f));
-    float z1 = 1.0f + powf(1.0f - absS * absS, 1.0f / 3.0f) *
-                          (powf(1.0f + absS, 1.0f / 3.0f) + powf(1.0f - absS, 1.0f / 3.0f));
+    float z1 = 1.0f + orc_powf(1.0f - absS * absS, 1.0f / 3.0f) *
+                          (orc_powf(1.0f + absS, 1.0f / 3.0f) + orc_powf(1.0f - absS, 1.0f / 3.0f));
     float z2 = sqrtf(3.0f * absS * absS + z1 * z1);
     float signOfA = signf(a);
     if (signOfA == 0.0f) signOfA = 1.0f;
@@ -275,8 +279,8 @@ static float gl_isco(float M, float a) {
 static float gl_photon_sphere(float M, float a) {
     float a_star = clampf(a / M, -0.9999f, 0.9999f);
     float arg = clampf(-a_star, -1.0f, 1.0f);
-    float theta = (2.0f / 3.0f) * acosf(arg);
-    return 2.0f * M * (1.0f + cosf(theta));
+    float theta = (2.0f / 3.0f) * orc_acosf(arg);
+    return 2.0f * M * (1.0f + orc_cosf(theta));
 }
 
 /* chunks/metric.ts:96-149 */
@@ -316,22 +320,22 @@ static void gl_blackbody(float temp, float rgb[3]) {
     float r, g, b;
     if (t <= 66.0f) {
         r = 255.0f;
-        g = 99.4708025861f * logf(t) - 161.1195681661f;
+        g = 99.4708025861f * orc_logf(t) - 161.1195681661f;
         if (t <= 19.0f) b = 0.0f;
-        else b = 138.5177312231f * logf(t - 10.0f) - 305.0447927307f;
+        else b = 138.5177312231f * orc_logf(t - 10.0f) - 305.0447927307f;
     } else {
-        r = 329.698727446f * powf(t - 60.0f, -0.1332047592f);
-        g = 288.1221695283f * powf(t - 60.0f, -0.0755148492f);
+        r = 329.698727446f * orc_powf(t - 60.0f, -0.1332047592f);
+        g = 288.1221695283f * orc_powf(t - 60.0f, -0.0755148492f);
         b = 255.0f;
     }
-    rgb[0] = powf(fmaxf(r / 255.0f, 0.0f), 2.2f);
-    rgb[1] = powf(fmaxf(g / 255.0f, 0.0f), 2.2f);
-    rgb[2] = powf(fmaxf(b / 255.0f, 0.0f), 2.2f);
+    rgb[0] = orc_powf(fmaxf(r / 255.0f, 0.0f), 2.2f);
+    rgb[1] = orc_powf(fmaxf(g / 255.0f, 0.0f), 2.2f);
+    rgb[2] = orc_powf(fmaxf(b / 255.0f, 0.0f), 2.2f);
 }
 
 /* chunks/common.ts:44-47 : mat2(c,-s,s,c), and `v.xy *= m` is row-vector * matrix */
 static void gl_rot_apply(float ang, float *x, float *y) {
-    float s = sinf(ang), c = cosf(ang);
+    float s = orc_sinf(ang), c = orc_cosf(ang);
     float nx = *x * c + *y * (-s);
     float ny = *x * s + *y * c;
     *x = nx;
@@ -399,9 +403,9 @@ static void gl_starfield(const orc_glsl_params *U, v3 dir, float stars[3]) {
     v3 cell = {floorf(dir.x * 200.0f), floorf(dir.y * 200.0f), floorf(dir.z * 200.0f)};
     float starNoise = gl_hash(U, cell);
     if (starNoise > 0.998f) {
-        float brightness = powf(starNoise, 10.0f) * 2.0f;
+        float brightness = orc_powf(starNoise, 10.0f) * 2.0f;
         float bv = gl_hash(U, (v3){cell.x + 127.1f, cell.y + 127.1f, cell.z + 127.1f}) * 2.4f - 0.4f;
-        float twinkle = 0.85f + 0.15f * sinf(U->time * (3.0f + gl_hash(U, (v3){cell.x + 73.7f, cell.y + 73.7f, cell.z + 73.7f}) * 2.0f));
+        float twinkle = 0.85f + 0.15f * orc_sinf(U->time * (3.0f + gl_hash(U, (v3){cell.x + 73.7f, cell.y + 73.7f, cell.z + 73.7f}) * 2.0f));
         float sc[3];
         gl_star_color(bv, sc);
         for (int c = 0; c < 3; c++) stars[c] = sc[c] * brightness * twinkle;
@@ -409,7 +413,7 @@ static void gl_starfield(const orc_glsl_params *U, v3 dir, float stars[3]) {
     cell = (v3){floorf(dir.x * 500.0f), floorf(dir.y * 500.0f), floorf(dir.z * 500.0f)};
     starNoise = gl_hash(U, cell);
     if (starNoise > 0.996f) {
-        float brightness = powf(starNoise, 20.0f) * 1.5f;
+        float brightness = orc_powf(starNoise, 20.0f) * 1.5f;
         float bv = gl_hash(U, (v3){cell.x + 217.3f, cell.y + 217.3f, cell.z + 217.3f}) * 2.4f - 0.4f;
         float sc[3];
         gl_star_color(bv, sc);
@@ -450,7 +454,7 @@ static void gl_sample_disk(const orc_glsl_params *U, v3 p, v3 p_prev, v3 v, floa
         float rotAngle = OmegaPhase * U->time * 0.12f * 10.0f;
         v3 np = sp;
         /* mat2(cos, -sin, sin, cos); noiseP.xz *= rotPhase (row vector * matrix) */
-        float cs = cosf(rotAngle), sn = sinf(rotAngle);
+        float cs = orc_cosf(rotAngle), sn = orc_sinf(rotAngle);
         float nx = np.x * cs + np.z * (-sn), nz = np.x * sn + np.z * cs;
         np.x = nx;
         np.z = nz;
@@ -458,7 +462,7 @@ static void gl_sample_disk(const orc_glsl_params *U, v3 p, v3 p_prev, v3 v, floa
         turbulence = gl_noise(U, np) * 0.5f + gl_noise(U, scale3(np, 2.5f)) * 0.25f;
     }
     float samplesDiskHeight = sampleR * effH;
-    float heightFalloff = expf(-fabsf(sp.y) / fmaxf(0.001f, samplesDiskHeight * 0.25f));
+    float heightFalloff = orc_expf(-fabsf(sp.y) / fmaxf(0.001f, samplesDiskHeight * 0.25f));
     float radialFalloff = smoothstepf(diskOuter, diskInner, sampleR);
     float baseDensity = turbulence * heightFalloff * radialFalloff;
     if (!(baseDensity > 0.001f)) return;
@@ -474,10 +478,10 @@ static void gl_sample_disk(const orc_glsl_params *U, v3 p, v3 p_prev, v3 v, floa
     float u_t = 1.0f / sqrtf(fmaxf(1e-6f, u_t_sq));
     float L_photon = p.z * v.x - p.x * v.z;
     float delta = 1.0f / fmaxf(0.01f, u_t * (1.0f - Omega * L_photon));
-    float beaming = (U->features & ORC_GLSL_DOPPLER) ? fmaxf(0.01f, powf(delta, 3.5f)) : 1.0f;
+    float beaming = (U->features & ORC_GLSL_DOPPLER) ? fmaxf(0.01f, orc_powf(delta, 3.5f)) : 1.0f;
     float isco_r = clampf(isco / sampleR, 0.0f, 1.0f);
     float nt_factor = fmaxf(0.0f, 1.0f - sqrtf(isco_r));
-    float radialTempGradient = powf(isco_r, 0.75f) * powf(nt_factor, 0.25f);
+    float radialTempGradient = orc_powf(isco_r, 0.75f) * orc_powf(nt_factor, 0.25f);
     float temperature = U->disk_temp * radialTempGradient * delta;
     float bb[3];
     gl_blackbody(temperature, bb);
@@ -494,8 +498,8 @@ static void gl_sample_jets(const orc_glsl_params *U, v3 p, v3 v, float rh, float
     float jetRadialDist = sqrtf(p.x * p.x + p.z * p.z);
     float jetWidth = 1.0f + jetVerticalPos * 0.15f;
     if (!(jetRadialDist < jetWidth * 2.0f)) return;
-    float radialFalloff = expf(-(jetRadialDist * jetRadialDist) / (jetWidth * 0.5f));
-    float lengthFalloff = expf(-jetVerticalPos * 0.05f);
+    float radialFalloff = orc_expf(-(jetRadialDist * jetRadialDist) / (jetWidth * 0.5f));
+    float lengthFalloff = orc_expf(-jetVerticalPos * 0.05f);
     float flowCombined = p.y * 2.0f - U->time * 8.0f;
     v3 uvJet = {p.x, flowCombined, p.z};
     float noiseVal = gl_noise(U, scale3(uvJet, 0.5f)) * 0.6f + gl_noise(U, scale3(uvJet, 1.5f)) * 0.4f;
@@ -508,7 +512,7 @@ static void gl_sample_jets(const orc_glsl_params *U, v3 p, v3 v, float rh, float
     float betaJet = fabsf(jetVel);
     float gammaJet = 1.0f / sqrtf(1.0f - betaJet * betaJet);
     float deltaJet = 1.0f / (gammaJet * (1.0f - betaJet * cosThetaJet));
-    float beamingJet = powf(deltaJet, 3.5f);
+    float beamingJet = orc_powf(deltaJet, 3.5f);
     const float base[3] = {0.4f, 0.7f, 1.0f};
     for (int c = 0; c < 3; c++) color[c] += base[c] * jetDensity * 0.05f * beamingJet * dt * (1.0f - *alpha);
     *alpha += jetDensity * 0.05f * dt;
@@ -569,12 +573,12 @@ uint32_t orc_glsl_pixel(const orc_glsl_params *U, uint32_t ix, uint32_t iy, floa
         gl_starfield(U, rd, bg);
         float d = length3(cross3(ro, rd));
         float shadow = smoothstepf(rh * 1.2f, rh * 0.9f, d);
-        float glow = expf(-fabsf(d - rph) * 12.0f) * 0.8f;
+        float glow = orc_expf(-fabsf(d - rph) * 12.0f) * 0.8f;
         const float glowCol[3] = {0.3f * glow, 0.6f * glow, 1.0f * glow};
         float diskMask = smoothstepf(isco * 2.0f, isco * 1.0f, d) * (1.0f - smoothstepf(isco * 1.0f, isco * 0.8f, d));
         const float diskCol[3] = {1.0f * diskMask * 0.6f, 0.7f * diskMask * 0.6f, 0.3f * diskMask * 0.6f};
         for (int c = 0; c < 3; c++)
-            rgba[c] = powf(bg[c] * (1.0f - shadow) + glowCol[c] + diskCol[c], 0.4545f);
+            rgba[c] = orc_powf(bg[c] * (1.0f - shadow) + glowCol[c] + diskCol[c], 0.4545f);
         return 0;
     }
 
@@ -679,12 +683,12 @@ uint32_t orc_glsl_pixel(const orc_glsl_params *U, uint32_t ix, uint32_t iy, floa
     float photonColor = 0.0f;
     if ((F & ORC_GLSL_PHOTON_GLOW) && !hitHorizon) { /* fragment.glsl.ts:246-258 */
         float distToPhotonRing = fabsf(length3(p) - rph);
-        float directRing = expf(-distToPhotonRing * 40.0f) * 1.8f * U->lensing_strength;
+        float directRing = orc_expf(-distToPhotonRing * 40.0f) * 1.8f * U->lensing_strength;
         float higherOrderRing = 0.0f;
         if (photonCrossings > 0) {
             float ringSharpness = 60.0f + (float)photonCrossings * 30.0f;
-            float ringBrightness = expf(-(float)photonCrossings * 1.0f) * 1.2f;
-            higherOrderRing = expf(-distToPhotonRing * ringSharpness) * ringBrightness * U->lensing_strength;
+            float ringBrightness = orc_expf(-(float)photonCrossings * 1.0f) * 1.2f;
+            higherOrderRing = orc_expf(-distToPhotonRing * ringSharpness) * ringBrightness * U->lensing_strength;
         }
         photonColor = 1.0f * (directRing + higherOrderRing);
     }
@@ -694,7 +698,7 @@ uint32_t orc_glsl_pixel(const orc_glsl_params *U, uint32_t ix, uint32_t iy, floa
         float rFinal = length3(p);
         float cosTheta = p.y / fmaxf(rFinal, 0.001f);
         float r_ergo = M + sqrtf(fmaxf(0.0f, M * M - a * a * cosTheta * cosTheta));
-        float ergoGlow = expf(-fabsf(rFinal - r_ergo) * 20.0f) * 0.35f * absA;
+        float ergoGlow = orc_expf(-fabsf(rFinal - r_ergo) * 20.0f) * 0.35f * absA;
         ergo[0] = 0.3f * ergoGlow;
         ergo[1] = 0.35f * ergoGlow;
         ergo[2] = 0.9f * ergoGlow;
@@ -742,7 +746,7 @@ uint32_t orc_glsl_pixel(const orc_glsl_params *U, uint32_t ix, uint32_t iy, floa
 
     for (int c = 0; c < 3; c++) {
         float f = fin[c];
-        if (U->tone_map) f = powf(fmaxf(aces(f), 0.0f), 0.4545f);
+        if (U->tone_map) f = orc_powf(fmaxf(aces(f), 0.0f), 0.4545f);
         rgba[c] = f;
     }
     return steps;

@@ -18,10 +18,10 @@ def gold():
 
 
 def _same_frame(rgba, steps, g_rgba, g_steps, exact):
-    if exact:   # same host class, same libm: the restatement must not drift
+    if exact:   # specified f32 functions: the restatement, and the shader-order kernels, reproduce the bits
         assert np.array_equal(steps, g_steps)
-        np.testing.assert_allclose(rgba, g_rgba, rtol=1e-5, atol=1e-7)
-    else:       # device libm vs glibc over hundreds of f32 steps: the statistical tolerance
+        assert np.array_equal(rgba, g_rgba, equal_nan=True)
+    else:       # FAST kernels: rounding differences over hundreds of f32 steps, the statistical tolerance
         ds = np.abs(steps.astype(np.int64) - g_steps.astype(np.int64))
         peak = max(float(np.abs(g_rgba[..., :3]).max()), 1e-12)
         dc = np.abs(rgba - g_rgba)[..., :3].max(-1) / peak
@@ -43,14 +43,14 @@ def test_oracle_reproduces_shader_golden(oracle, engine_mod, gold):
 
 def test_oracle_reproduces_post_and_readout_golden(oracle, gold):
     cur, hist = G.post_image(7), G.post_image(8)
-    np.testing.assert_allclose(oracle.taa_resolve(cur, hist, 0.75, False, True), gold["post_taa"], rtol=1e-6)
-    np.testing.assert_allclose(oracle.taa_resolve(cur, hist, 0.75, True, True), gold["post_taa_moving"], rtol=1e-6)
-    np.testing.assert_allclose(oracle.bloom(G.post_image(9, hdr=6.0), 0.8, 0.5, 2, True), gold["post_bloom"],
-                               rtol=1e-6, atol=1e-7)
+    # every function on these paths is IEEE arithmetic or a specified routine of ref_libm.c: exact
+    assert np.array_equal(oracle.taa_resolve(cur, hist, 0.75, False, True), gold["post_taa"])
+    assert np.array_equal(oracle.taa_resolve(cur, hist, 0.75, True, True), gold["post_taa_moving"])
+    assert np.array_equal(oracle.bloom(G.post_image(9, hdr=6.0), 0.8, 0.5, 2, True), gold["post_bloom"])
     for kind, key in ((0, "viz_curvature"), (1, "viz_tilt"), (2, "viz_frame_drag")):
-        np.testing.assert_allclose(oracle.scalar_field(kind, 1.0, 0.9, 2.2, 40.0, 9, 7), gold[key], rtol=1e-6)
-    np.testing.assert_allclose(oracle.embedding_mesh(1.0, 0.9, 2.5, 30.0, 8, 6), gold["viz_embedding"], rtol=1e-6, atol=1e-6)
-    np.testing.assert_allclose(oracle.ergosphere_mesh(1.0, 0.9, 9, 6), gold["viz_ergosphere"], rtol=1e-6, atol=1e-6)
+        assert np.array_equal(oracle.scalar_field(kind, 1.0, 0.9, 2.2, 40.0, 9, 7), gold[key])
+    assert np.array_equal(oracle.embedding_mesh(1.0, 0.9, 2.5, 30.0, 8, 6), gold["viz_embedding"])
+    assert np.array_equal(oracle.ergosphere_mesh(1.0, 0.9, 9, 6), gold["viz_ergosphere"])
 
 
 @pytest.mark.gpu
@@ -70,12 +70,12 @@ def test_shader_kernels_against_golden(engine_mod, gold, arith):
             gp = engine_mod.wgsl_params(G.W, G.H, cam, 1.0, 0.999, max_steps=300, arith=wa, stars=0)
             gp.jitter[0], gp.jitter[1] = 0.0, -1.0 / 6.0
             e.render_frame_wgsl(gp, rgba, steps)
-            _same_frame(*grab(), gold["wgsl_rgba"], gold["wgsl_steps"], False)
+            _same_frame(*grab(), gold["wgsl_rgba"], gold["wgsl_steps"], wa == 0)
         for name in G.GLSL_CASES:
             p = G.glsl_case(name)
             p.arith = arith
             e.render_frame_glsl(p, rgba, steps)
-            _same_frame(*grab(), gold["glsl_%s_rgba" % name], gold["glsl_%s_steps" % name], False)
+            _same_frame(*grab(), gold["glsl_%s_rgba" % name], gold["glsl_%s_steps" % name], arith == 0)
 
 
 @pytest.mark.gpu
@@ -85,9 +85,8 @@ def test_post_and_readouts_against_golden(engine_mod, gold):
     out = torch.zeros_like(cur)
     h, w = cur.shape[:2]
 
-    def close(got, ref):
-        d = np.abs(got - ref) / np.maximum(1.0, np.abs(ref))
-        assert d.max() <= 1e-3 and (d <= 1e-6).mean() >= 0.995
+    def close(got, ref):   # shader-order kernels against the committed vectors: the same bits
+        assert np.array_equal(got, ref, equal_nan=True)
     with engine_mod.PhysicsEngine(1.0, 0.9) as e:
         e.post_taa_resolve(w, h, cur, hist, out)
         torch.cuda.synchronize()
@@ -101,6 +100,6 @@ def test_post_and_readouts_against_golden(engine_mod, gold):
         close(out.cpu().numpy(), gold["post_bloom"])
         for fn, key in ((e.generate_curvature_field, "viz_curvature"), (e.generate_tilt_field, "viz_tilt"),
                         (e.generate_frame_drag_field, "viz_frame_drag")):
-            assert np.allclose(fn(2.2, 40.0, 9, 7), gold[key], rtol=2e-6, atol=1e-9)
-        assert np.allclose(e.generate_embedding_mesh(2.5, 30.0, 8, 6), gold["viz_embedding"], rtol=2e-6, atol=2e-6)
-        assert np.allclose(e.generate_ergosphere_mesh(9, 6), gold["viz_ergosphere"], rtol=2e-6, atol=2e-6)
+            assert np.array_equal(fn(2.2, 40.0, 9, 7), gold[key])
+        assert np.array_equal(e.generate_embedding_mesh(2.5, 30.0, 8, 6), gold["viz_embedding"])
+        assert np.array_equal(e.generate_ergosphere_mesh(9, 6), gold["viz_ergosphere"])

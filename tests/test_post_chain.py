@@ -131,8 +131,8 @@ def _close(got, ref, fast=False):
         ad = np.abs(got - ref)
         ok = ad <= 1e-4 + 1e-3 * np.abs(ref)
         assert ok.mean() >= 0.999 and np.median(ad) <= 1e-5, (ok.mean(), np.median(ad))
-    else:
-        assert (rel <= 1e-6).mean() >= 0.999, (rel <= 1e-6).mean()
+    else:   # shader order, IEEE divide / sqrt, specified powf: the checker's bits
+        assert np.array_equal(got, ref, equal_nan=True), (rel <= 1e-6).mean()
 
 
 @pytest.mark.gpu

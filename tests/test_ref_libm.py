@@ -55,6 +55,21 @@ def test_accuracy_against_mpmath(oracle):
     for x in np.concatenate([rng.uniform(-5, 5, 800), 10.0 ** rng.uniform(-12, 20, 300), [0.4375, 0.6875, 1.1875, 2.4375, 1.0]]):
         worst_a = max(worst_a, _ulps(float(oracle.ref_atan(x)), mp.atan(mp.mpf(float(x))), mp))
     assert worst_a < 1.0, worst_a
+    worst_l = worst_c = worst_2 = 0.0
+    for x in np.concatenate([10.0 ** rng.uniform(-300, 300, 500), rng.uniform(0.5, 2.0, 500), [5e-324, 2.0, 0.5]]):
+        worst_l = max(worst_l, _ulps(float(oracle.ref_fn("log", x)), mp.log(mp.mpf(float(x))), mp))
+    for x in np.concatenate([rng.uniform(-1, 1, 800), 1 - 10.0 ** rng.uniform(-16, -1, 100), [0.5, -0.5, 0.0]]):
+        worst_c = max(worst_c, _ulps(float(oracle.ref_fn("acos", x)), mp.acos(mp.mpf(float(x))), mp))
+    for y, x in zip(rng.uniform(-5, 5, 800) * 10.0 ** rng.uniform(-3, 3, 800), rng.uniform(-5, 5, 800)):
+        worst_2 = max(worst_2, _ulps(float(oracle.ref_fn("atan2", y, x)), mp.atan2(mp.mpf(float(y)), mp.mpf(float(x))), mp))
+    assert worst_l < 1.0 and worst_c < 1.0 and worst_2 < 1.5, (worst_l, worst_c, worst_2)
+    # f32 forms = the f64 routine rounded once: within half an f32 ulp (+ the f64 error) of the truth
+    for name, fn, xs in (("sinf", mp.sin, rng.uniform(-50, 50, 300)), ("expf", mp.exp, rng.uniform(-80, 80, 300)),
+                         ("logf", mp.log, 10.0 ** rng.uniform(-30, 30, 300)), ("acosf", mp.acos, rng.uniform(-1, 1, 300))):
+        for x in xs.astype(np.float32):
+            got, ex = float(oracle.ref_fn(name, x)), fn(mp.mpf(float(x)))
+            if ex != 0 and mp.mpf(2) ** -120 < abs(ex) < mp.mpf(2) ** 120:
+                assert abs(mp.mpf(got) - ex) <= mp.mpf(2) ** (mp.floor(mp.log(abs(ex), 2)) - 23) * mp.mpf("0.5000001"), (name, x)
 
 
 def test_ieee_special_cases(oracle):
@@ -81,6 +96,16 @@ def test_ieee_special_cases(oracle):
     for x in (inf, -inf, 1e70, -1e70, 0.0, 1e-300):
         assert float(oracle.ref_atan(x)) == float(np.arctan(x)), x
     assert np.signbit(float(oracle.ref_atan(-0.0)))
+    with np.errstate(all="ignore"):
+        for y, x in ((0.0, 1.0), (-0.0, 1.0), (0.0, -1.0), (-0.0, -1.0), (1.0, 0.0), (-1.0, 0.0), (inf, inf), (-inf, inf),
+                     (inf, -inf), (-inf, -inf), (1.0, inf), (-1.0, inf), (1.0, -inf), (-1.0, -inf), (inf, 1.0),
+                     (1e300, 1e-300), (1e-300, -1e300), (0.0, 0.0), (-0.0, -0.0), (0.0, -0.0)):
+            got, want = float(oracle.ref_fn("atan2", y, x)), float(np.arctan2(y, x))
+            assert got == want and np.signbit(got) == np.signbit(want), (y, x)
+        for x in (0.0, -0.0, inf, 1.0, 5e-324):
+            assert float(oracle.ref_fn("log", x)) == float(np.log(x)), x
+        assert np.isnan(float(oracle.ref_fn("log", -1.0))) and np.isnan(float(oracle.ref_fn("acos", 1.5)))
+        assert float(oracle.ref_fn("acos", 1.0)) == 0.0 and float(oracle.ref_fn("acos", -1.0)) == np.pi
     assert float(oracle.ref_sin(0.0)) == 0.0 and np.signbit(float(oracle.ref_sin(-0.0)))
     assert float(oracle.ref_cos(0.0)) == 1.0 and float(oracle.ref_sin(1e-300)) == 1e-300
     # odd / even symmetry is exact
@@ -94,7 +119,9 @@ PINS = (("sin", 1.0, None), ("cos", 1.0, None), ("sin", 100.0, None), ("cos", 1.
         ("sin", 3.141592653589793, None), ("cos", 12345.678, None), ("pow", 0.37, -0.2),
         ("pow", 123.456, -0.25), ("pow", 9.5, 1.5), ("pow", 0.015625, 0.75), ("pow", 0.3, 0.4),
         ("exp", 1.0, None), ("exp", -37.25, None), ("exp", 700.5, None), ("exp", -730.0, None),
-        ("atan", 0.3, None), ("atan", 0.6, None), ("atan", 1.0, None), ("atan", 2.0, None), ("atan", -77.7, None))
+        ("atan", 0.3, None), ("atan", 0.6, None), ("atan", 1.0, None), ("atan", 2.0, None), ("atan", -77.7, None),
+        ("log", 10.0, None), ("log", 1.0000001, None), ("log", 3e-310, None), ("acos", 0.3, None), ("acos", -0.7, None),
+        ("acos", 0.99, None), ("atan2", 1.0, -2.0), ("atan2", -3.0, 0.5))
 PIN_HEX = (
     '0x1.aed548f090ceep-1',
     '0x1.14a280fb5068cp-1',
@@ -115,13 +142,19 @@ PIN_HEX = (
     '0x1.14b1dd5f90ce1p-1',
     '0x1.921fb54442d18p-1',
     '0x1.1b6e192ebbe44p+0',
-    '-0x1.8ed44e3384d23p+0')
+    '-0x1.8ed44e3384d23p+0',
+    '0x1.26bb1bbb55516p+1',
+    '0x1.ad7f2847b6492p-24',
+    '-0x1.6459f44103e87p+9',
+    '0x1.441f5ecbeef59p+0',
+    '0x1.2c501446cd5f2p+1',
+    '0x1.21df72882bfd8p-3',
+    '0x1.56c6e7397f5aep+1',
+    '-0x1.67d8863bc99bdp+0')
 
 
 def _eval(oracle, name, x, y):
-    if y is None:
-        return float({"sin": oracle.ref_sin, "cos": oracle.ref_cos, "exp": oracle.ref_exp, "atan": oracle.ref_atan}[name](x))
-    return float(oracle.ref_pow(x, y))
+    return float(oracle.ref_fn(name, x, y))
 
 
 def test_pinned_bit_patterns(oracle):
@@ -155,6 +188,32 @@ def test_device_routines_return_the_same_bits(engine_mod, oracle):
         got, want = e.strict_math(bh.engine.MATH_ATAN, ax), oracle.ref_atan(ax)
         assert np.array_equal(got.view(np.uint64)[~np.isnan(want)], want.view(np.uint64)[~np.isnan(want)])
         assert np.array_equal(np.isnan(got), np.isnan(want))
+        E = bh.engine
+
+        def same(got, want):
+            ok = ~np.isnan(want)
+            return np.array_equal(got[ok], want[ok]) and np.array_equal(np.signbit(got[ok]), np.signbit(want[ok])) \
+                and np.array_equal(np.isnan(got), np.isnan(want))
+        lx = np.concatenate([10.0 ** rng.uniform(-320, 300, 30000), rng.uniform(0.5, 2, 20000), [0.0, -0.0, -1.0, np.inf, np.nan, 5e-324]])
+        assert same(e.strict_math(E.MATH_LOG, lx), oracle.ref_fn("log", lx))
+        cx = np.concatenate([rng.uniform(-1, 1, 40000), 1 - 10.0 ** rng.uniform(-16, -1, 5000), [1.0, -1.0, 0.0, 1.5, np.nan]])
+        assert same(e.strict_math(E.MATH_ACOS, cx), oracle.ref_fn("acos", cx))
+        ay = np.concatenate([rng.uniform(-5, 5, 40000) * 10.0 ** rng.uniform(-3, 3, 40000), [0.0, -0.0, 0.0, 1.0, np.inf, -np.inf, 1e300]])
+        axx = np.concatenate([rng.uniform(-5, 5, 40000), [1.0, -1.0, -0.0, 0.0, np.inf, -np.inf, 1e-300]])
+        assert same(e.strict_math(E.MATH_ATAN2, ay, axx), oracle.ref_fn("atan2", ay, axx))
+        # f32 forms of the shader-order kernels
+        f = np.float32
+        for op, name, a, b in ((E.MATH_SIN, "sinf", rng.uniform(-100, 100, 30000), None),
+                               (E.MATH_COS, "cosf", rng.uniform(-100, 100, 30000), None),
+                               (E.MATH_EXP, "expf", rng.uniform(-110, 95, 30000), None),
+                               (E.MATH_LOG, "logf", 10.0 ** rng.uniform(-44, 38, 30000), None),
+                               (E.MATH_ACOS, "acosf", rng.uniform(-1, 1, 30000), None),
+                               (E.MATH_POW, "powf", 10.0 ** rng.uniform(-6, 6, 30000), rng.uniform(-8, 8, 30000)),
+                               (E.MATH_ATAN2, "atan2f", rng.uniform(-9, 9, 30000), rng.uniform(-9, 9, 30000))):
+            a32 = a.astype(f)
+            b32 = None if b is None else b.astype(f)
+            got = e.strict_math(op | E.MATH_F32, a32.astype(np.float64), None if b is None else b32.astype(np.float64))
+            assert same(got.astype(f), oracle.ref_fn(name, a32, b32)), name
         got, want = e.strict_math(bh.engine.MATH_POW, px, py), oracle.ref_pow(px, py)
         ok = ~np.isnan(want)
         assert np.array_equal(got.view(np.uint64)[ok], want.view(np.uint64)[ok])
