@@ -183,10 +183,13 @@ __device__ __forceinline__ float glsl_hash_uv(const uint8_t *__restrict__ T, flo
     const float fu = floorf(u), fv = floorf(v);
     const float a = u - fu, b = v - fv;
     // REPEAT wrap of the texel index: (int)fu & 255 equals (int)fmod(fu, 256) & 255 whenever fu fits
-    // an int32 (two's complement), which every lattice coordinate of the shader does; the fmod form
-    // is kept for out-of-range coordinates only
+    // an int32 (two's complement), which every lattice coordinate of the shader does.
+    // beyond it: fu - 256 floor(fu / 256) is exact in f32 (power-of-two scalings, exact floor and
+    // difference) and congruent to fmod(fu, 256) mod 256, so the masked index is the same -- without
+    // fmodf's division loop inlined at every noise() corner
     const bool small = fabsf(fu) < 1.0e9f && fabsf(fv) < 1.0e9f;
-    const int i0 = small ? (int)fu : (int)fmodf(fu, 256.0f), j0 = small ? (int)fv : (int)fmodf(fv, 256.0f);
+    const int i0 = small ? (int)fu : (int)(fu - 256.0f * floorf(fu * 0.00390625f));
+    const int j0 = small ? (int)fv : (int)(fv - 256.0f * floorf(fv * 0.00390625f));
     // integer lattice points (every noise() corner) land on a texel centre: weights (1, 0, 0, 0),
     // and 0 * texel is exactly 0 for UNORM8 data -- one fetch gives the bitwise same value
     if (a == 0.0f && b == 0.0f) return glsl_texel(T, i0, j0);
@@ -239,8 +242,14 @@ __device__ void glsl_starfield(const GlslParams &U, F3 dir, float stars[3]) {
     if (starNoise > 0.998f) {
         const float brightness = pow_d<ARITH>(starNoise, 10.0f) * 2.0f;
         const float bv = glsl_hash(T, F3{cell.x + 127.1f, cell.y + 127.1f, cell.z + 127.1f}) * 2.4f - 0.4f;
-        const float twinkle =
-            0.85f + 0.15f * sh_sinf(U.time * (3.0f + glsl_hash(T, F3{cell.x + 73.7f, cell.y + 73.7f, cell.z + 73.7f}) * 2.0f));
+        const float tw_arg = U.time * (3.0f + glsl_hash(T, F3{cell.x + 73.7f, cell.y + 73.7f, cell.z + 73.7f}) * 2.0f);
+        float tw_s, tw_c;
+        if constexpr (ARITH == GRV_ARITH_FAST) {
+            glsl_fast_sincos(tw_arg, tw_s, tw_c);
+        } else {
+            tw_s = sh_sinf(tw_arg);
+        }
+        const float twinkle = 0.85f + 0.15f * tw_s;
         float sc[3];
         glsl_star_color(bv, sc);
         for (int c = 0; c < 3; ++c) stars[c] = sc[c] * brightness * twinkle;
@@ -288,7 +297,13 @@ __device__ __forceinline__ void glsl_sample_disk(const GlslParams &U, F3 p, F3 p
         const float signSpinPhase = sign_d(U.spin + 1e-8f);
         const float OmegaPhase = (signSpinPhase * sqrt_Mp) / (sampleR * sqrtf(sampleR) + a * sqrt_Mp);
         const float rotAngle = OmegaPhase * U.time * 0.12f * 10.0f;
-        const float cs = sh_cosf(rotAngle), sn = sh_sinf(rotAngle);
+        float cs, sn;
+        if constexpr (ARITH == GRV_ARITH_FAST) {
+            glsl_fast_sincos(rotAngle, sn, cs);
+        } else {
+            cs = sh_cosf(rotAngle);
+            sn = sh_sinf(rotAngle);
+        }
         F3 np{sp.x * cs + sp.z * (-sn), sp.y, sp.x * sn + sp.z * cs};
         np = scale_f3(np, 0.75f);
         turbulence = glsl_noise(U.noise_r, np) * 0.5f + glsl_noise(U.noise_r, scale_f3(np, 2.5f)) * 0.25f;
