@@ -5,7 +5,7 @@
 //
 // Two arithmetic contracts, one per translation unit:
 //   STRICT (kernels_strict.hip, -ffp-contract=off): the shader's operation order, IEEE divide /
-//          sqrt, OCML sinf / cosf;
+//          sqrt, the specified f32 sin / cos / pow / exp / log / acos (shader_common.hpp: sh_*f);
 //   FAST   (kernels_fast.hip, -ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt):
 //          the same expressions with FMA contraction, v_rcp_f32 / v_sqrt_f32 based divide and
 //          sqrt, and a polynomial sin / cos for the ZAMO twist.  f32 rounding differences only.
@@ -122,7 +122,7 @@ __device__ __forceinline__ void glsl_fast_sincos(float ang, float &s, float &c) 
     c = ((q + 1) & 2) ? -c0 : c0;
 }
 
-// pow / exp / log: OCML in the STRICT contract; v_log_f32 / v_exp_f32 (base 2, ~1 ulp each)
+// pow / exp / log: the specified f32 forms (sh_*f) in the STRICT contract; v_log_f32 / v_exp_f32 (base 2, ~1 ulp each)
 // in the FAST contract.  pow(0, y > 0) = exp2(-inf) = 0 in both.
 template <int ARITH> __device__ __forceinline__ float pow_d(float x, float y) {
     if constexpr (ARITH == GRV_ARITH_FAST) return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));

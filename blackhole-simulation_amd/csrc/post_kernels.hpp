@@ -1,6 +1,6 @@
 // post_kernels.hpp -- the reference's post chain as HIP kernels.  Two arithmetic
 // contracts, one per translation unit, as for the shader marches: STRICT (kernels_strict.hip,
-// -ffp-contract=off: the shaders' operation order, IEEE divide / sqrt, OCML powf) and FAST
+// -ffp-contract=off: the shaders' operation order, IEEE divide / sqrt, specified powf) and FAST
 // (kernels_fast.hip: FMA contraction, reciprocal-based divide / sqrt, v_log / v_exp gamma):
 //   taa_resolve_kernel   src/shaders/postprocess/reprojection.glsl.ts:44-116
 //                        (driven by src/rendering/reprojection.ts:196-262, renderScale = 1)
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void bloom_blur_kernel(uint32_t sw, uint32_t s
         make_float4(post_store(r, half_storage), post_store(g, half_storage), post_store(b, half_storage), 1.0f);
 }
 
-// gamma: OCML powf in shader order; v_log_f32 / v_exp_f32 in the FAST contract
+// gamma: the specified powf (sh_powf) in shader order; v_log_f32 / v_exp_f32 in the FAST contract
 template <int ARITH> __device__ __forceinline__ float post_pow(float x, float y) {
     if constexpr (ARITH == GRV_ARITH_FAST) return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
     else return sh_powf(x, y);
