@@ -1,6 +1,7 @@
 // engine_control.hip -- LUTs, disk / shadow helpers, the SAB protocol and the spacetime
 // read-outs behind the C ABI.  See engine_internal.hpp.
 #include "engine_internal.hpp"
+#include "strict_libm.hpp"
 
 using namespace grvhost;
 
@@ -75,6 +76,33 @@ int grv_strict_math(grv_engine *e, int op, size_t n, const double *x, const doub
     GRV_HIP(e, launch_strict_math(op, (uint32_t)n, dx, y ? dy : dx, dout, nullptr));
     GRV_HIP(e, hipDeviceSynchronize());
     GRV_HIP(e, hipMemcpy(out, dout, n * sizeof(double), hipMemcpyDeviceToHost));
+    return GRV_OK;
+}
+
+int grv_strict_math_host(int op, size_t n, const double *x, const double *y, double *out) {
+    const int base = op & ~GRV_MATH_F32;
+    if (base < GRV_MATH_SINCOS_SIN || base > GRV_MATH_ATAN2) return GRV_ERR_INVALID;
+    if (n == 0) return GRV_OK;
+    if (!x || !out || ((base == GRV_MATH_POW || base == GRV_MATH_ATAN2) && !y)) return GRV_ERR_INVALID;
+    const bool f32 = (op & GRV_MATH_F32) != 0;
+    for (size_t i = 0; i < n; ++i) {
+        const double a = f32 ? (double)(float)x[i] : x[i];
+        const double b = y ? (f32 ? (double)(float)y[i] : y[i]) : 0.0;
+        double r;
+        switch (base) {
+        case GRV_MATH_SINCOS_SIN:
+        case GRV_MATH_SIN: r = strictm::sl_sin(a); break;
+        case GRV_MATH_SINCOS_COS:
+        case GRV_MATH_COS: r = strictm::sl_cos(a); break;
+        case GRV_MATH_POW: r = strictm::sl_pow(a, b); break;
+        case GRV_MATH_EXP: r = strictm::sl_exp(a); break;
+        case GRV_MATH_ATAN: r = strictm::sl_atan(a); break;
+        case GRV_MATH_LOG: r = strictm::sl_log(a); break;
+        case GRV_MATH_ACOS: r = strictm::sl_acos(a); break;
+        default: r = strictm::sl_atan2(a, b); break;
+        }
+        out[i] = f32 ? (double)(float)r : r;
+    }
     return GRV_OK;
 }
 

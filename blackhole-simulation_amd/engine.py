@@ -188,6 +188,8 @@ def load_library():
     L.grv_options_default.argtypes = [C.POINTER(Options)]
     L.grv_generate_spectrum_lut.restype = i
     L.grv_generate_spectrum_lut.argtypes = [p, sz, sz, d, p]
+    L.grv_strict_math_host.restype = i
+    L.grv_strict_math_host.argtypes = [i, sz, p, p, p]
     L.grv_strict_math.restype = i
     L.grv_strict_math.argtypes = [p, i, sz, p, p, p]
     L.grv_generate_spectrum_lut_device.restype = i
@@ -267,6 +269,17 @@ def _dev_ptr(t):
     if isinstance(t, int):
         return C.c_void_p(t)
     return C.c_void_p(t.data_ptr())
+
+
+def strict_math_host(op, x, y=None):
+    """The STRICT contract's transcendental routines, host build (no device needed)."""
+    x = np.ascontiguousarray(x, np.float64)
+    y = None if y is None else np.ascontiguousarray(y, np.float64)
+    out = np.zeros_like(x)
+    rc = load_library().grv_strict_math_host(int(op), x.size, _np_ptr(x), _np_ptr(y), _np_ptr(out))
+    if rc != 0:
+        raise GravitasError("strict_math_host failed (%d)" % rc)
+    return out
 
 
 def default_options(**kw):

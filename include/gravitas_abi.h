@@ -344,6 +344,9 @@ enum { GRV_MATH_SINCOS_SIN = 0, GRV_MATH_SINCOS_COS = 1, GRV_MATH_SIN = 2, GRV_M
        GRV_MATH_ATAN2 = 9 /* atan2(x[i], y[i]) */,
        GRV_MATH_F32 = 16 /* or-ed in: the f32 form (float)op((double)(float)x) of the shader-order kernels */ };
 int grv_strict_math(grv_engine *e, int op, size_t n, const double *x, const double *y, double *out);
+/* the same routines compiled for the host (they also serve the engine's host-side closed forms):
+ * no device needed.  op as above; GRV_MATH_SINCOS_* evaluate sin / cos. */
+int grv_strict_math_host(int op, size_t n, const double *x, const double *y, double *out);
 
 /* ---- disk / shadow helpers next to the path ---- */
 /* generate_disk_lut lib.rs:107-110 (physics/disk.rs:175-201): 512 normalised temperatures */

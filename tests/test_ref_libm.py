@@ -162,6 +162,45 @@ def test_pinned_bit_patterns(oracle):
         assert _eval(oracle, name, x, y).hex() == want, (name, x, y)
 
 
+def _same_bits(got, want):
+    ok = ~np.isnan(want)
+    return (np.array_equal(got[ok], want[ok]) and np.array_equal(np.signbit(got[ok]), np.signbit(want[ok]))
+            and np.array_equal(np.isnan(got), np.isnan(want)))
+
+
+def test_engine_host_routines_return_the_oracle_bits(engine_mod, oracle):
+    """csrc/strict_libm.hpp (product, host build: no device needed) against oracle/ref_libm.c."""
+    E = engine_mod.engine
+    rng = np.random.default_rng(9)
+    inf, nan = np.inf, np.nan
+    xs = np.concatenate([_sincos_args(rng, 4000), [inf, -inf, nan]])
+    assert _same_bits(E.strict_math_host(E.MATH_SIN, xs), oracle.ref_fn("sin", xs))
+    assert _same_bits(E.strict_math_host(E.MATH_COS, xs), oracle.ref_fn("cos", xs))
+    px, py = _pow_args(rng, 6000)
+    px = np.concatenate([px, [0.0, -0.0, inf, -inf, nan, 1.0, -1.0, -8.0, 5e-324, 1e300, 2.0, 2.0, 0.5, 1.0000001]])
+    py = np.concatenate([py, [-0.2, -3.0, -0.2, 3.0, 0.0, nan, inf, 3.0, 0.3, 2.5, -1074.0, 1023.5, inf, 1e9]])
+    assert _same_bits(E.strict_math_host(E.MATH_POW, px, py), oracle.ref_fn("pow", px, py))
+    ex = np.concatenate([rng.uniform(-750, 712, 5000), rng.uniform(-2, 2, 2000), [0.0, -0.0, inf, -inf, nan, 1e-300]])
+    assert _same_bits(E.strict_math_host(E.MATH_EXP, ex), oracle.ref_fn("exp", ex))
+    lx = np.concatenate([10.0 ** rng.uniform(-320, 300, 4000), rng.uniform(0.5, 2, 2000), [0.0, -0.0, -1.0, inf, nan, 5e-324]])
+    assert _same_bits(E.strict_math_host(E.MATH_LOG, lx), oracle.ref_fn("log", lx))
+    ax = np.concatenate([rng.uniform(-5, 5, 4000), 10.0 ** rng.uniform(-20, 30, 1000), [0.0, -0.0, inf, -inf, nan, 0.4375, 0.6875, 1.1875, 2.4375]])
+    assert _same_bits(E.strict_math_host(E.MATH_ATAN, ax), oracle.ref_fn("atan", ax))
+    cx = np.concatenate([rng.uniform(-1, 1, 5000), 1 - 10.0 ** rng.uniform(-16, -1, 500), [1.0, -1.0, 0.0, 1.5, nan]])
+    assert _same_bits(E.strict_math_host(E.MATH_ACOS, cx), oracle.ref_fn("acos", cx))
+    ay = np.concatenate([rng.uniform(-5, 5, 5000) * 10.0 ** rng.uniform(-3, 3, 5000), [0.0, -0.0, 0.0, 1.0, inf, -inf, 1e300]])
+    axx = np.concatenate([rng.uniform(-5, 5, 5000), [1.0, -1.0, -0.0, 0.0, inf, -inf, 1e-300]])
+    assert _same_bits(E.strict_math_host(E.MATH_ATAN2, ay, axx), oracle.ref_fn("atan2", ay, axx))
+    f = np.float32
+    for op, name, a, b in ((E.MATH_SIN, "sinf", rng.uniform(-100, 100, 3000), None), (E.MATH_EXP, "expf", rng.uniform(-110, 95, 3000), None),
+                           (E.MATH_LOG, "logf", 10.0 ** rng.uniform(-44, 38, 3000), None), (E.MATH_ACOS, "acosf", rng.uniform(-1, 1, 3000), None),
+                           (E.MATH_POW, "powf", 10.0 ** rng.uniform(-6, 6, 3000), rng.uniform(-8, 8, 3000)),
+                           (E.MATH_ATAN2, "atan2f", rng.uniform(-9, 9, 3000), rng.uniform(-9, 9, 3000))):
+        a32, b32 = a.astype(f), None if b is None else b.astype(f)
+        got = E.strict_math_host(op | E.MATH_F32, a32.astype(np.float64), None if b is None else b32.astype(np.float64))
+        assert _same_bits(got.astype(f), oracle.ref_fn(name, a32, b32)), name
+
+
 @pytest.mark.gpu
 def test_device_routines_return_the_same_bits(engine_mod, oracle):
     bh = engine_mod
