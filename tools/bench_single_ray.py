@@ -1,0 +1,39 @@
+"""Latency of the reference's path entry, integrate_ray_relativistic (lib.rs:422-464), one ray per
+call: a serial chain on one GPU lane.  Reports the per-call wall time for the doc-test ray
+(~220 accepted steps), for a 1-step call (fixed overhead: copies, three launches, syncs) and the
+per-ray time of the same rays in batches.  Run on the GPU box: python tools/bench_single_ray.py"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import blackhole_simulation_amd as bh  # noqa: E402
+
+if __name__ == "__main__":
+    v = np.array([0, 20.0, np.pi / 2, 0, -1.0, -1.0, 0.0, 3.5])
+    with bh.PhysicsEngine(1.0, 0.9) as e:
+        for steps, label in ((10000, "doc-test ray to termination"), (1, "one step (call overhead)")):
+            e.integrate_ray_relativistic(v, steps, 1e-8, True)
+            t = time.perf_counter()
+            n = 200
+            for _ in range(n):
+                e.integrate_ray_relativistic(v, steps, 1e-8, True)
+            dt = (time.perf_counter() - t) / n
+            print(json.dumps({"call": "integrate_ray_relativistic", "case": label, "us_per_call": round(dt * 1e6, 1)}), flush=True)
+        for nb in (1, 64, 4096, 262144):
+            st = np.tile(v, (nb, 1))
+            st[:, 7] = np.linspace(3.0, 4.0, nb) if nb > 1 else 3.5
+            for arith, an in ((bh.ARITH_STRICT, "strict"), (bh.ARITH_FAST, "fast")):
+                o = bh.engine.default_options(max_steps=10000, arith=arith)
+                e.integrate_batch(st, o)
+                t = time.perf_counter()
+                reps = 20 if nb < 100000 else 3
+                for _ in range(reps):
+                    r = e.integrate_batch(st, o)
+                dt = (time.perf_counter() - t) / reps
+                print(json.dumps({"call": "integrate_batch (host buffers)", "rays": nb, "arith": an,
+                                  "ms_per_call": round(dt * 1e3, 3), "us_per_ray": round(dt / nb * 1e6, 3),
+                                  "mean_steps": float(r["steps"].mean())}), flush=True)
