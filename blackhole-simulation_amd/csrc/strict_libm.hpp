@@ -533,7 +533,7 @@ GRV_HD inline double sl_atan2(double y, double x) {
     const int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
     if (ix > 0x7ff00000 || (ix == 0x7ff00000 && lx != 0) || iy > 0x7ff00000 || (iy == 0x7ff00000 && ly != 0))
         return x + y; /* NaN */
-    if ((((uint32_t)(hx - 0x3ff00000)) | lx) == 0) return sl_atan(y); /* x = 1 */
+    if ((((uint32_t)hx - 0x3ff00000u) | lx) == 0) return sl_atan(y); /* x = 1 */
     const int m = (int)(((uint32_t)hy >> 31) & 1u) | (int)(((uint32_t)hx >> 30) & 2u); /* 2 sign(x) + sign(y) */
     if (((uint32_t)iy | ly) == 0) { /* y = 0 */
         switch (m) {
