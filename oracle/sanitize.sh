@@ -1,7 +1,7 @@
 #!/bin/bash
 # CPU-side sanitizer pass (GPU ASan is not available on this pool): builds the oracle -- the
 # specified libm included, whose text the STRICT kernels share -- with UBSan and with ASan and runs
-# the oracle-backed CPU tests against each build.  Usage: bash tools/sanitize_oracle.sh
+# the oracle-backed CPU tests against each build.  Usage: bash oracle/sanitize.sh
 set -eu
 R=$(cd "$(dirname "$0")/.." && pwd)
 SRC="gravitas_oracle.c frame_oracle.c control_oracle.c shader_oracle.c viz_oracle.c post_oracle.c ref_libm.c"
