@@ -44,8 +44,9 @@ def test_config1_256x256_schwarzschild_symplectic(engine_mod, oracle):
 
 
 def test_config2_1080p_fixed_step_f32(engine_mod, oracle):
-    """C2: 1920x1080, a = 0.999, 512 max steps, both f32 fixed-step loops.  Full size by
-    properties + a 1/36 strided subset against the f32 restatement."""
+    """C2: 1920x1080, a = 0.999, 512 max steps, both f32 fixed-step loops in shader order.  Full
+    size by properties + a 1/9 strided subset (230 400 rays) against the f32 restatement: the
+    checker's step counts and pixels, bit for bit (stars on)."""
     import torch
     bh = engine_mod
     W, H = 1920, 1080
@@ -56,13 +57,13 @@ def test_config2_1080p_fixed_step_f32(engine_mod, oracle):
         steps = torch.zeros(n, dtype=torch.int32, device="cuda:0")
         for name in ("wgsl", "glsl"):
             if name == "wgsl":
-                gp = bh.wgsl_params(W, H, cam, 1.0, 0.999, max_steps=512, stars=0)
+                gp = bh.wgsl_params(W, H, cam, 1.0, 0.999, max_steps=512, stars=1)
                 tot = e.render_frame_wgsl(gp, rgba, steps)
-                ref_rgba, ref_steps = oracle.wgsl_frame(oracle.wgsl_params_from(gp), stride=(6, 6), nthreads=8)
+                ref_rgba, ref_steps = oracle.wgsl_frame(oracle.wgsl_params_from(gp), stride=(3, 3), nthreads=16)
             else:
                 gp = bh.glsl_params(W, H, 1.0, 0.999, max_ray_steps=512)
                 tot = e.render_frame_glsl(gp, rgba, steps)
-                ref_rgba, ref_steps = oracle.glsl_frame(oracle.glsl_params_from(gp), stride=(6, 6), nthreads=8)
+                ref_rgba, ref_steps = oracle.glsl_frame(oracle.glsl_params_from(gp), stride=(3, 3), nthreads=16)
             s = steps.cpu().numpy().reshape(H, W)
             c = rgba.cpu().numpy().reshape(H, W, 4)
             assert tot == int(s.sum()) and s.max() <= (512 if name == "wgsl" else 500) and s.min() >= 0
@@ -70,10 +71,8 @@ def test_config2_1080p_fixed_step_f32(engine_mod, oracle):
             # linear GLSL output may dip below 0 behind an over-dense disk: the shader lets the
             # accumulated alpha pass 1 and composites background * (1 - alpha) (fragment.glsl.ts:276)
             assert name == "glsl" or c[..., :3].min() >= 0.0
-            ds = np.abs(s[::6, ::6].astype(np.int64) - ref_steps.astype(np.int64))
-            peak = ref_rgba[..., :3].max()
-            dc = np.abs(c[::6, ::6] - ref_rgba)[..., :3].max(-1) / peak
-            assert (ds == 0).mean() >= 0.99 and (dc <= 2e-3).mean() >= 0.99 and (dc <= 5e-2).mean() >= 0.999
+            assert np.array_equal(s[::3, ::3], ref_steps)
+            assert np.array_equal(c[::3, ::3], ref_rgba)
 
 
 def test_config4_8k_tiled_over_8_ranks_fixed_1024(engine_mod):
