@@ -108,7 +108,7 @@ void critical_orbit(double r, double m, double a, double &xi, double &eta) {
 
 // glam 0.24.2 DQuat::from_rotation_y(angle).mul_vec3(v)
 void rotate_about_y(double angle, double v[3]) {
-    const double s = std::sin(angle * 0.5), w = std::cos(angle * 0.5);
+    const double s = strictm::sl_sin(angle * 0.5), w = strictm::sl_cos(angle * 0.5);
     const double b[3] = {0.0, s, 0.0};
     const double b2 = b[0] * b[0] + b[1] * b[1] + b[2] * b[2];
     const double dot = v[0] * b[0] + v[1] * b[1] + v[2] * b[2];
@@ -136,26 +136,26 @@ double schwarzschild_shadow_radius_host(double mass) { return 3.0 * std::sqrt(3.
 std::vector<double> bardeen_shadow_host(double m, double a_star, double theta_obs, size_t n) {
     constexpr double kPi = 3.14159265358979323846;
     const double a = a_star * m;
-    const double so = std::sin(theta_obs), co = std::cos(theta_obs);
+    const double so = strictm::sl_sin(theta_obs), co = strictm::sl_cos(theta_obs);
     std::vector<double> pts;
     if (std::fabs(a) < 1e-10) { // shadow.rs:90-98
         const double radius = schwarzschild_shadow_radius_host(m);
         for (size_t i = 0; i < n; ++i) {
             const double phi = 2.0 * kPi * (double)i / (double)n;
-            pts.push_back(radius * std::cos(phi));
-            pts.push_back(radius * std::sin(phi));
+            pts.push_back(radius * strictm::sl_cos(phi));
+            pts.push_back(radius * strictm::sl_sin(phi));
         }
         return pts;
     }
     if (std::fabs(so) < 1e-10) { // shadow.rs:100-112
-        const double r_ph = 2.0 * m * (1.0 + std::cos((2.0 / 3.0) * std::acos(-a_star)));
+        const double r_ph = 2.0 * m * (1.0 + strictm::sl_cos((2.0 / 3.0) * strictm::sl_acos(-a_star)));
         double xi, eta;
         critical_orbit(r_ph, m, a, xi, eta);
         const double radius = std::sqrt(std::fmax(eta + a * a, 0.0));
         for (size_t i = 0; i < 2 * n; ++i) {
             const double phi = 2.0 * kPi * (double)i / (2.0 * (double)n);
-            pts.push_back(radius * std::cos(phi));
-            pts.push_back(radius * std::sin(phi));
+            pts.push_back(radius * strictm::sl_cos(phi));
+            pts.push_back(radius * strictm::sl_sin(phi));
         }
         return pts;
     }
@@ -165,8 +165,8 @@ std::vector<double> bardeen_shadow_host(double m, double a_star, double theta_ob
         return eta + a * a * co * co - xi * xi * co * co / (so * so);
     };
     const double as = a / m;
-    const double r_pro = 2.0 * m * (1.0 + std::cos((2.0 / 3.0) * std::acos(-std::fabs(as))));
-    const double r_ret = 2.0 * m * (1.0 + std::cos((2.0 / 3.0) * std::acos(std::fabs(as))));
+    const double r_pro = 2.0 * m * (1.0 + strictm::sl_cos((2.0 / 3.0) * strictm::sl_acos(-std::fabs(as))));
+    const double r_ret = 2.0 * m * (1.0 + strictm::sl_cos((2.0 / 3.0) * strictm::sl_acos(std::fabs(as))));
     double r_min = r_pro, r_max = r_ret;
     const int steps = 1000;
     for (int i = 0; i <= steps; ++i) {
@@ -186,7 +186,7 @@ std::vector<double> bardeen_shadow_host(double m, double a_star, double theta_ob
     const size_t den = n > 1 ? n - 1 : 1;
     auto emit = [&](size_t i, double sign) {
         const double phase = kPi * (double)i / (double)den;
-        const double t = 0.5 - 0.5 * std::cos(phase);
+        const double t = 0.5 - 0.5 * strictm::sl_cos(phase);
         const double r = r_min + t * (r_max - r_min);
         double xi, eta;
         critical_orbit(r, m, a, xi, eta);
@@ -210,7 +210,7 @@ bool CameraFilter::finite() const {
 void CameraFilter::update(double mouse_dx, double mouse_dy, double zoom_delta, double dt) {
     (void)mouse_dy; // camera.rs reads only dx
     if (dt <= 0.0) return;
-    const double friction = std::exp(-5.0 * dt);
+    const double friction = strictm::sl_exp(-5.0 * dt);
     for (int i = 0; i < 3; ++i) velocity[i] *= friction;
     for (int i = 0; i < 3; ++i) position[i] += velocity[i] * dt;
     rotate_about_y(-mouse_dx * 2.0 * dt, position);
@@ -246,7 +246,7 @@ void tick_sab_host(float *sab, double mass, double spin, double spin_clamped, do
     const double *p = cam.position;
     const double r_cam = std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
     if (r_cam > 0.0) {
-        const double theta_obs = std::acos(p[1] / r_cam);
+        const double theta_obs = strictm::sl_acos(p[1] / r_cam);
         const std::vector<double> curve = bardeen_shadow_host(mass, spin_clamped, theta_obs, 32);
         const size_t n = curve.size() / 2;
         // the reference clears 128 floats from PHYSICS+16, i.e. through TELEMETRY+15

@@ -30,15 +30,15 @@ double isco_prograde(double m, double a_star) {
 }
 // metric/kerr.rs:91-94
 double photon_sphere(double m, double a_star) {
-    const double term = (2.0 / 3.0) * std::acos(-a_star);
-    return 2.0 * m * (1.0 + std::cos(term));
+    const double term = (2.0 / 3.0) * strictm::sl_acos(-a_star);
+    return 2.0 * m * (1.0 + strictm::sl_cos(term));
 }
 // metric/kerr.rs:181-189 on covariant_bl g_tt (kerr.rs:241-254), theta = pi/2;
 // gravitas-wasm/src/lib.rs:97-105
 double dilation(double m, double a_star, double r) {
     const double a = a_star * m;
     const double theta = 1.57079632679489661923;
-    const double cos_theta = std::cos(theta);
+    const double cos_theta = strictm::sl_cos(theta);
     const double sigma = r * r + a * a * (cos_theta * cos_theta);
     const double g_tt = -(1.0 - (2.0 * m * r) / sigma);
     const double td = g_tt >= 0.0 ? 0.0 : std::sqrt(-g_tt);
@@ -548,12 +548,12 @@ int grv_render_frame_device(grv_engine *e, const GrvCamera *cam, const GrvRender
         cd.r0 = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
         double cy = c[1] / cd.r0;
         cy = cy < -1.0 ? -1.0 : (cy > 1.0 ? 1.0 : cy);
-        cd.theta0 = std::acos(cy);
-        cd.phi0 = std::atan2(c[2], c[0]);
-        cd.st = std::sin(cd.theta0);
-        cd.ct = std::cos(cd.theta0);
-        cd.sp = std::sin(cd.phi0);
-        cd.cp = std::cos(cd.phi0);
+        cd.theta0 = strictm::sl_acos(cy);
+        cd.phi0 = strictm::sl_atan2(c[2], c[0]);
+        cd.st = strictm::sl_sin(cd.theta0);
+        cd.ct = strictm::sl_cos(cd.theta0);
+        cd.sp = strictm::sl_sin(cd.phi0);
+        cd.cp = strictm::sl_cos(cd.phi0);
     }
 
     if (profile) GRV_HIP(e, hipEventRecord(e->ev[0], s));
@@ -689,7 +689,7 @@ void grv_camera_look_at(const double eye[3], const double target[3], const doubl
     }
     cam->inv_view[15] = 1.0;
     const double near = 0.1, far = 1000.0; // WebGPUCanvas.tsx:151
-    const double f = 1.0 / std::tan(fovy_rad / 2.0);
+    const double f = strictm::sl_cos(fovy_rad / 2.0) / strictm::sl_sin(fovy_rad / 2.0); // 1 / tan, specified
     const double a = f / aspect, b = f;
     const double c = (far + near) / (near - far);
     const double d = 2.0 * far * near / (near - far);

@@ -1,6 +1,7 @@
 // engine_shaders.hip -- f32 shader frames (WGSL compute march, GLSL fragment shader), the post
 // chain and the two renderers' render() sequences behind the C ABI.  See engine_internal.hpp.
 #include "engine_internal.hpp"
+#include "strict_libm.hpp"
 
 using namespace grvhost;
 
@@ -40,7 +41,7 @@ void grv_glsl_params_default(uint32_t width, uint32_t height, double mass, doubl
     p->disk_size = 50.0f;                         // simulation.config.ts:138-139
     p->disk_scale_height = 0.2f;                  // :147-148
     p->disk_density = 4.0f;                       // :167-168
-    p->disk_temp = (float)(9500.0 * std::pow(mass, -0.25)); // renderer.ts:352-356
+    p->disk_temp = (float)(9500.0 * strictm::sl_pow(mass, -0.25)); // renderer.ts:352-356
     p->lensing_strength = 1.0f;                   // renderer.ts:340
     p->time = 0.0f;
     p->turbulence = -1.0f;                        // sample the noise texture (disk.ts:55)

@@ -198,10 +198,13 @@ __device__ __forceinline__ Deriv<T> rhs_ref(const Hole<T> &bh, T r, T theta, T p
     const T a2 = bh.a2;
 
     if constexpr (KIND == GRV_METRIC_KERR_KS) {
-        d.dt = g.tt * p_t + g.tr * p_r;
+        // the contraction of get_state_derivative keeps the structurally zero entries of the
+        // metric (hamiltonian.rs:19-28): 0 * p is not 0 for a non-finite momentum, and x + 0 loses
+        // the sign of x = -0
+        d.dt = g.tt * p_t + g.tr * p_r + g.tph * p_ph;
         d.dr = g.tr * p_t + g.rr * p_r + g.rph * p_ph;
         d.dth = g.thth * p_th;
-        d.dph = g.rph * p_r + g.phph * p_ph;
+        d.dph = g.tph * p_t + g.rph * p_r + g.phph * p_ph;
 
         const T r2 = r * r;
         const T sin2 = fmax_t(sin_theta * sin_theta, T(1e-12));
@@ -238,10 +241,13 @@ __device__ __forceinline__ Deriv<T> rhs_ref(const Hole<T> &bh, T r, T theta, T p
         d.dpr = -dh_dr;
         d.dpth = -dh_dtheta;
     } else if constexpr (KIND == GRV_METRIC_KERR_BL) {
-        d.dt = g.tt * p_t + g.tph * p_ph;
-        d.dr = g.rr * p_r;
+        // the contraction of get_state_derivative keeps the structurally zero entries of the
+        // metric (hamiltonian.rs:19-28): 0 * p is not 0 for a non-finite momentum, and x + 0 loses
+        // the sign of x = -0
+        d.dt = g.tt * p_t + g.tr * p_r + g.tph * p_ph;
+        d.dr = g.tr * p_t + g.rr * p_r + g.rph * p_ph;
         d.dth = g.thth * p_th;
-        d.dph = g.tph * p_t + g.phph * p_ph;
+        d.dph = g.tph * p_t + g.rph * p_r + g.phph * p_ph;
 
         const T r2 = r * r;
         const T sin2 = sin_theta * sin_theta;
@@ -296,10 +302,13 @@ __device__ __forceinline__ Deriv<T> rhs_ref(const Hole<T> &bh, T r, T theta, T p
         d.dpr = -dh_dr;
         d.dpth = -dh_dtheta;
     } else {
-        d.dt = g.tt * p_t;
-        d.dr = g.rr * p_r;
+        // the contraction of get_state_derivative keeps the structurally zero entries of the
+        // metric (hamiltonian.rs:19-28): 0 * p is not 0 for a non-finite momentum, and x + 0 loses
+        // the sign of x = -0
+        d.dt = g.tt * p_t + g.tr * p_r + g.tph * p_ph;
+        d.dr = g.tr * p_t + g.rr * p_r + g.rph * p_ph;
         d.dth = g.thth * p_th;
-        d.dph = g.phph * p_ph;
+        d.dph = g.tph * p_t + g.rph * p_r + g.phph * p_ph;
 
         const T r2 = r * r;
         const T r3 = r2 * r;
@@ -469,22 +478,17 @@ __device__ __forceinline__ Deriv<T> rhs(const Hole<T> &bh, T r, T theta, T p_t, 
 // ---------------------------------------------------------------------------
 template <int KIND, typename T>
 __device__ __forceinline__ T hamiltonian_of(const GInv<T> &g, T p_t, T p_r, T p_th, T p_ph) {
-    T h = g.tt * p_t * p_t + g.rr * p_r * p_r + g.thth * p_th * p_th + g.phph * p_ph * p_ph;
-    if constexpr (KIND == GRV_METRIC_KERR_BL) h = h + T(2) * g.tph * p_t * p_ph;
-    if constexpr (KIND == GRV_METRIC_KERR_KS) {
-        h = h + T(2) * g.tr * p_t * p_r;
-        h = h + T(2) * g.rph * p_r * p_ph;
-    }
-    return T(0.5) * h;
+    // invariants/mod.rs:25-37, zero entries of the metric included (see rhs_ref)
+    return T(0.5) * (g.tt * p_t * p_t + g.rr * p_r * p_r + g.thth * p_th * p_th + g.phph * p_ph * p_ph +
+                     T(2) * g.tph * p_t * p_ph + T(2) * g.tr * p_t * p_r + T(2) * g.rph * p_r * p_ph);
 }
 
 template <int KIND, int ARITH, typename T>
 __device__ __forceinline__ T renormalized_pr(const GInv<T> &g, T p_t, T p_r, T p_th, T p_ph) {
     const T a_quad = g.rr;
-    T b_quad = T(0);
-    if constexpr (KIND == GRV_METRIC_KERR_KS) b_quad = T(2) * (g.tr * p_t + g.rph * p_ph);
-    T c_quad = g.tt * p_t * p_t + g.thth * p_th * p_th + g.phph * p_ph * p_ph;
-    if constexpr (KIND == GRV_METRIC_KERR_BL) c_quad = c_quad + T(2) * g.tph * p_t * p_ph;
+    // renormalization.rs:21-27, zero entries of the metric included (see rhs_ref)
+    const T b_quad = T(2) * (g.tr * p_t + g.rph * p_ph);
+    const T c_quad = g.tt * p_t * p_t + g.thth * p_th * p_th + g.phph * p_ph * p_ph + T(2) * g.tph * p_t * p_ph;
     T out = p_r;
     if (fabs_t(a_quad) > T(1e-12)) {
         const T disc = b_quad * b_quad - T(4) * a_quad * c_quad;

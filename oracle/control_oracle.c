@@ -144,15 +144,15 @@ size_t orc_bardeen_shadow(double mass, double spin, double theta_obs, size_t n_p
     orc_metric bh = orc_metric_make(ORC_KERR_BL, mass, spin);
     double m = bh.mass;
     double a = bh.spin * bh.mass;
-    double sin_obs = sin(theta_obs), cos_obs = cos(theta_obs);
+    double sin_obs = orc_sin(theta_obs), cos_obs = orc_cos(theta_obs);
     size_t k = 0;
 
     if (fabs(a) < 1e-10) {
         double radius = orc_schwarzschild_shadow_radius(m);
         for (size_t i = 0; i < n_points; i++) {
             double phi = 2.0 * ORC_PI * (double)i / (double)n_points;
-            out[2 * k] = radius * cos(phi);
-            out[2 * k + 1] = radius * sin(phi);
+            out[2 * k] = radius * orc_cos(phi);
+            out[2 * k + 1] = radius * orc_sin(phi);
             k++;
         }
         return k;
@@ -164,16 +164,16 @@ size_t orc_bardeen_shadow(double mass, double spin, double theta_obs, size_t n_p
         double radius = sqrt(fmax(eta + a * a, 0.0));
         for (size_t i = 0; i < 2 * n_points; i++) {
             double phi = 2.0 * ORC_PI * (double)i / (2.0 * (double)n_points);
-            out[2 * k] = radius * cos(phi);
-            out[2 * k + 1] = radius * sin(phi);
+            out[2 * k] = radius * orc_cos(phi);
+            out[2 * k + 1] = radius * orc_sin(phi);
             k++;
         }
         return k;
     }
 
     double a_star = a / m;
-    double r_ph_pro = 2.0 * m * (1.0 + cos((2.0 / 3.0) * acos(-fabs(a_star))));
-    double r_ph_retro = 2.0 * m * (1.0 + cos((2.0 / 3.0) * acos(fabs(a_star))));
+    double r_ph_pro = 2.0 * m * (1.0 + orc_cos((2.0 / 3.0) * orc_acos(-fabs(a_star))));
+    double r_ph_retro = 2.0 * m * (1.0 + orc_cos((2.0 / 3.0) * orc_acos(fabs(a_star))));
     double r_min = r_ph_pro, r_max = r_ph_retro;
     int steps = 1000;
     for (int i = 0; i <= steps; i++) {
@@ -195,7 +195,7 @@ size_t orc_bardeen_shadow(double mass, double spin, double theta_obs, size_t n_p
     size_t den = (n_points > 1) ? n_points - 1 : 1;
     for (size_t i = 0; i < n_points; i++) {
         double phase = ORC_PI * (double)i / (double)den;
-        double t = 0.5 - 0.5 * cos(phase);
+        double t = 0.5 - 0.5 * orc_cos(phase);
         double r = r_min + t * (r_max - r_min);
         double xi, eta;
         critical_params(r, m, a, &xi, &eta);
@@ -207,7 +207,7 @@ size_t orc_bardeen_shadow(double mass, double spin, double theta_obs, size_t n_p
     }
     for (size_t ii = n_points; ii-- > 0;) {
         double phase = ORC_PI * (double)ii / (double)den;
-        double t = 0.5 - 0.5 * cos(phase);
+        double t = 0.5 - 0.5 * orc_cos(phase);
         double r = r_min + t * (r_max - r_min);
         double xi, eta;
         critical_params(r, m, a, &xi, &eta);
@@ -232,7 +232,7 @@ void orc_sab_engine_init(orc_sab_engine *e, double mass, double spin) {
 
 /* glam 0.24.2 DQuat::from_rotation_y + DQuat::mul_vec3 (scalar path) */
 static void rotate_y(double angle, double v[3]) {
-    double s = sin(angle * 0.5), c = cos(angle * 0.5);
+    double s = orc_sin(angle * 0.5), c = orc_cos(angle * 0.5);
     double b[3] = {0.0, s, 0.0};
     double w = c;
     double b2 = b[0] * b[0] + b[1] * b[1] + b[2] * b[2];
@@ -247,7 +247,7 @@ void orc_camera_update(orc_camera_state *s, double mouse_dx, double mouse_dy, do
                        double dt) {
     (void)mouse_dy;
     if (dt <= 0.0) return;
-    double friction = exp(-5.0 * dt);
+    double friction = orc_exp(-5.0 * dt);
     for (int i = 0; i < 3; i++) s->velocity[i] *= friction;
     for (int i = 0; i < 3; i++) s->position[i] += s->velocity[i] * dt;
     double sensitivity = 2.0;
@@ -303,7 +303,7 @@ void orc_tick_sab(orc_sab_engine *e, double dt_override) {
     double r_cam = sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
     if (r_cam > 0.0) {
         double cos_theta = p[1] / r_cam;
-        double theta_obs = acos(cos_theta);
+        double theta_obs = orc_acos(cos_theta);
         double curve[2 * 2 * 32];
         size_t n = orc_bardeen_shadow(e->mass, e->spin, theta_obs, 32, curve);
         for (int i = 0; i < 128; i++) sab[PHYSICS + 16 + i] = 0.0f; /* overruns TELEMETRY: F10 */

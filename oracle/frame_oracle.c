@@ -43,7 +43,7 @@ void orc_camera_look_at(const double eye[3], const double target[3], const doubl
     cam->inv_view[15] = 1.0;
 
     const double near = 0.1, far = 1000.0;
-    double f = 1.0 / tan(fovy_rad / 2.0);
+    double f = orc_cos(fovy_rad / 2.0) / orc_sin(fovy_rad / 2.0); /* 1 / tan, specified */
     double a = f / aspect, b = f;
     double c = (far + near) / (near - far);
     double d = 2.0 * far * near / (near - far);
@@ -85,11 +85,11 @@ void orc_pixel_state(const orc_camera *cam, uint32_t width, uint32_t height, uin
     double cy = cp3[1] / r0;
     if (cy < -1.0) cy = -1.0;
     if (cy > 1.0) cy = 1.0;
-    double theta0 = acos(cy);
-    double phi0 = atan2(cp3[2], cp3[0]);
+    double theta0 = orc_acos(cy);
+    double phi0 = orc_atan2(cp3[2], cp3[0]);
 
-    double st = sin(theta0), ct = cos(theta0);
-    double sp = sin(phi0), cp = cos(phi0);
+    double st = orc_sin(theta0), ct = orc_cos(theta0);
+    double sp = orc_sin(phi0), cp = orc_cos(phi0);
 
     double pr_far = wd[0] * (st * cp) + wd[1] * ct + wd[2] * (st * sp);
     double pth_far = (wd[0] * (ct * cp) + wd[1] * (-st) + wd[2] * (ct * sp)) / r0;

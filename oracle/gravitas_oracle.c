@@ -107,8 +107,8 @@ double orc_cauchy_horizon(const orc_metric *mt) {
 /* metric/kerr.rs:91-94 ; Schwarzschild: metric/schwarzschild.rs:41-43 */
 double orc_photon_sphere(const orc_metric *mt) {
     if (mt->kind == ORC_SCHWARZSCHILD) return 3.0 * mt->mass;
-    double term = (2.0 / 3.0) * acos(-mt->spin);
-    return 2.0 * mt->mass * (1.0 + cos(term));
+    double term = (2.0 / 3.0) * orc_acos(-mt->spin);
+    return 2.0 * mt->mass * (1.0 + orc_cos(term));
 }
 
 /* metric/kerr.rs:100-123 ; Schwarzschild: metric/schwarzschild.rs:36-38 */
@@ -131,7 +131,7 @@ double orc_isco(const orc_metric *mt, int retrograde) {
 double orc_ergosphere(const orc_metric *mt, double theta) {
     double m = mt->mass;
     double a = kerr_a(mt);
-    double cos_theta = cos(theta);
+    double cos_theta = orc_cos(theta);
     double disc = m * m - a * a * cos_theta * cos_theta;
     if (disc < 0.0) return m;
     return m + sqrt(disc);

@@ -1,0 +1,160 @@
+"""Randomised differential test of the f64 path: many small batches with random engine
+parameters (metric, spin incl. |a| > M, mass, method, tolerance, step sizes of either sign, escape
+radius, renormalisation interval, step budget) and hostile rays (polar, near-horizon, outside the
+escape radius, NaN / inf components).  The STRICT contract must return the checker's bits for every
+one of them; the FAST contract its termination classes on all but a bounded fraction."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+SEEDS = int(os.environ.get("GRV_FUZZ_SEEDS", "6"))   # a longer campaign: GRV_FUZZ_SEEDS=300
+
+
+def _rays(rng, n, mass):
+    st = np.zeros((n, 8))
+    st[:, 0] = rng.uniform(-5, 5, n)
+    st[:, 1] = rng.uniform(1.5, 70.0, n) * mass
+    st[:, 2] = rng.uniform(0.0, np.pi, n)
+    st[:, 3] = rng.uniform(-7, 7, n)
+    st[:, 4] = rng.choice([-1.0, -0.5, -2.0], n, p=[0.8, 0.1, 0.1])
+    st[:, 5] = rng.uniform(-1.2, 1.2, n)
+    st[:, 6] = rng.uniform(-8, 8, n) * mass
+    st[:, 7] = rng.uniform(-8, 8, n) * mass
+    k = max(1, n // 40)
+    st[rng.choice(n, k, False), 2] = rng.choice([0.0, 1e-13, 1e-7, np.pi, np.pi - 1e-9], k)   # the poles
+    st[rng.choice(n, k, False), 1] = rng.uniform(0.05, 2.1, k) * mass                          # inside / at the horizon
+    st[rng.choice(n, k, False), 1] = rng.uniform(900.0, 5000.0, k)                             # around the escape radius
+    st[rng.choice(n, k, False), 7] = 0.0
+    st[rng.choice(n, k, False), rng.integers(0, 8, k)] = rng.choice([np.nan, np.inf, -np.inf, 1e300, 1e-300], k)
+    return st
+
+
+@pytest.mark.parametrize("seed", range(SEEDS))
+def test_random_configurations_strict_is_bit_exact(engine_mod, oracle, seed):
+    bh = engine_mod
+    rng = np.random.default_rng(1000 + seed)
+    kinds = ((oracle.KERR_KS, bh.KERR_KS), (oracle.KERR_BL, bh.KERR_BL), (oracle.SCHWARZSCHILD, bh.SCHWARZSCHILD))
+    checked = 0
+    for _ in range(10):
+        okind, bkind = kinds[rng.integers(0, 3)]
+        mass = float(rng.choice([1.0, 0.37, 2.5]))
+        spin = 0.0 if okind == oracle.SCHWARZSCHILD else float(rng.choice([0.0, 0.3, 0.9, 0.999, -0.7, 1.0, 1.3]))
+        method = int(rng.integers(0, 3))
+        kw = dict(method=method, tolerance=float(10.0 ** rng.uniform(-10, -5)),
+                  initial_step=float(rng.choice([0.01, 0.5, -0.01, -0.3, 20.0])),
+                  max_steps=int(rng.choice([0, 1, 7, 60, 250])), escape_radius=float(rng.choice([1000.0, 80.0, 3.0])),
+                  renormalize_interval=int(rng.choice([1, 3, 10, 1000])), step_size=float(rng.choice([0.05, -0.05, 0.3])))
+        st = _rays(rng, 400, mass)
+        ref = oracle.integrate_batch(oracle.metric(okind, mass, spin), oracle.options(**kw), st, nthreads=4)
+        with bh.PhysicsEngine(mass, spin) as e:
+            got = e.integrate_batch(st, bh.engine.default_options(metric_kind=bkind, arith=bh.ARITH_STRICT, **kw))
+            fast = e.integrate_batch(st, bh.engine.default_options(metric_kind=bkind, arith=bh.ARITH_FAST, **kw))
+        for key in ("steps", "term", "states", "drift"):
+            assert np.array_equal(got[key], ref[key], equal_nan=True), (seed, kw, okind, spin, mass, key)
+        # FAST: same classes except where a rounding flips a decision (near-critical / singular rays)
+        finite = np.isfinite(st).all(axis=1)
+        assert (fast["term"][finite] == ref["term"][finite]).mean() >= 0.97, (seed, kw, okind, spin)
+        checked += st.shape[0]
+    assert checked == 4000
+
+
+@pytest.mark.parametrize("seed", range(SEEDS))
+def test_random_frames_strict_is_bit_exact(engine_mod, oracle, seed):
+    """Random cameras (on the axis, in the disk plane, close in, far out), frame shapes that are not
+    multiples of the 8x8 wave block or the 64x64 tile, random disk / LUT / exposure parameters and
+    both shading modes: pixels, end states, step counts and classes are the checker's."""
+    import torch
+    bh = engine_mod
+    rng = np.random.default_rng(5000 + seed)
+    for _ in range(4):
+        W, H = int(rng.integers(1, 90)), int(rng.integers(1, 70))
+        r0 = float(rng.choice([4.0, 12.0, 60.0, 300.0]))
+        th, ph = float(rng.choice([0.0, 1e-6, 0.3, np.pi / 2, 1.7, np.pi])), float(rng.uniform(0, 2 * np.pi))
+        eye = (r0 * np.sin(th) * np.cos(ph), r0 * np.cos(th), r0 * np.sin(th) * np.sin(ph))
+        spin = float(rng.choice([0.0, 0.5, 0.999, -0.9, 1.2]))
+        kind = [(oracle.KERR_KS, bh.KERR_KS), (oracle.KERR_BL, bh.KERR_BL)][int(rng.integers(0, 2))]
+        kw = dict(shading=int(rng.integers(0, 2)), disk_inner=float(rng.choice([0.0, 3.0, 8.0])),
+                  disk_outer=float(rng.choice([30.0, 12.0])), disk_temp=float(rng.choice([9500.0, 3e4, 800.0])),
+                  disk_opacity=float(rng.choice([0.6, 0.95, 0.35])), exposure=float(rng.choice([1.0, 0.2, 4.0])),
+                  lut_width=int(rng.choice([512, 64, 7])), lut_height=int(rng.choice([64, 1, 5])),
+                  lut_max_temp=float(rng.choice([1e5, 2e4])))
+        okw = dict(max_steps=int(rng.choice([0, 5, 120, 600])), tolerance=float(10.0 ** rng.uniform(-9, -6)),
+                   escape_radius=float(rng.choice([1000.0, 100.0])), renormalize_interval=int(rng.choice([1, 10])))
+        fovy = float(rng.choice([60.0, 20.0, 110.0]))
+        up = (0.0, 1.0, 0.0) if th not in (0.0, np.pi) else (1.0, 0.0, 0.0)
+        ocam = oracle.camera_look_at(eye, up=up, fovy_deg=fovy, aspect=W / H)
+        ref = oracle.render_frame(ocam, oracle.frame_params(W, H, spin=spin, metric_kind=kind[0], opt=oracle.options(**okw), **kw),
+                                  None, nthreads=4)
+        n = W * H
+        with bh.PhysicsEngine(1.0, spin) as e:
+            cam = bh.camera_look_at(eye, up=up, fovy_deg=fovy, aspect=W / H)
+            p = bh.render_params(W, H, arith=bh.ARITH_STRICT, metric_kind=kind[1], **okw, **kw)
+            rgba = torch.zeros(n, 4, dtype=torch.float32, device="cuda:0")
+            fs = torch.zeros(n, 8, dtype=torch.float64, device="cuda:0")
+            steps = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+            term = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
+            drift = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+            e.render_frame_device(cam, p, rgba, fs, steps, term, drift)
+            st = e.frame_stats()
+            torch.cuda.synchronize()
+        tag = (seed, W, H, eye, spin, kind[0], kw, okw, fovy)
+        assert np.array_equal(steps.cpu().numpy().astype(np.uint32), ref["steps"]), tag
+        assert np.array_equal(term.cpu().numpy(), ref["term"]), tag
+        assert np.array_equal(fs.cpu().numpy(), ref["states"], equal_nan=True), tag
+        assert np.array_equal(drift.cpu().numpy(), ref["drift"], equal_nan=True), tag
+        assert np.array_equal(rgba.cpu().numpy(), ref["rgba"].reshape(-1, 4), equal_nan=True), tag
+        assert st.accepted_steps == int(ref["steps"].sum()) and st.rays == n
+
+
+@pytest.mark.parametrize("seed", range(SEEDS))
+def test_random_shader_frames_strict_are_bit_exact(engine_mod, oracle, seed):
+    """The two f32 shaders in shader order with random uniforms: every ShaderManager feature
+    combination, spins of either sign, mouse / SAB cameras, animated time, overlays, quality
+    levels, ragged frame shapes, stars on."""
+    import torch
+    bh = engine_mod
+    rng = np.random.default_rng(9000 + seed)
+    for _ in range(3):
+        W, H = int(rng.integers(1, 100)), int(rng.integers(1, 64))
+        n = W * H
+        spin = float(rng.choice([0.0, 0.3, 0.9, 0.999, -0.8]))
+        mass = float(rng.choice([1.0, 0.5, 2.0]))
+        rgba = torch.zeros(n, 4, dtype=torch.float32, device="cuda:0")
+        steps = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+        with bh.PhysicsEngine(mass, spin) as e:
+            # GLSL fragment shader
+            kw = dict(max_ray_steps=int(rng.choice([1, 40, 300, 700])), tone_map=int(rng.integers(0, 2)),
+                      features=int(rng.integers(0, 256)), quality=int(rng.choice([0, 1, 2])),
+                      time=float(rng.choice([0.0, 2.5, 137.0])), turbulence=float(rng.choice([-1.0, 0.75, 0.0])),
+                      zoom=float(rng.choice([30.0, 8.0, 120.0])), mouse=(float(rng.uniform(0, 1)), float(rng.uniform(0, 1))),
+                      disk_size=float(rng.choice([15.0, 6.0, 40.0])), disk_density=float(rng.choice([1.0, 5.0, 0.1])),
+                      disk_temp=float(rng.choice([9500.0, 2e4, 1500.0])), lensing_strength=float(rng.choice([1.0, 0.5, 2.0])),
+                      show_redshift=float(rng.choice([0.0, 1.0])), debug=float(rng.choice([0.0, 0.0, 1.0])))
+            if rng.random() < 0.4:
+                kw["cam_pos"] = tuple(float(x) for x in rng.uniform(-40, 40, 3))
+                q = rng.normal(size=4)
+                kw["cam_quat"] = tuple(float(x) for x in q / np.linalg.norm(q))
+            if rng.random() < 0.3:
+                kw["show_kerr_shadow"] = 1.0
+                kw["shadow_curve"] = oracle.bardeen_shadow(mass, min(abs(spin), 1.0), 1.3, 24)[:64]
+            gp = bh.glsl_params(W, H, mass, spin, arith=bh.ARITH_STRICT, **kw)
+            tot = e.render_frame_glsl(gp, rgba, steps)
+            ref_rgba, ref_steps = oracle.glsl_frame(oracle.glsl_params_from(gp), nthreads=4)
+            assert np.array_equal(steps.cpu().numpy().reshape(H, W), ref_steps), (seed, W, H, spin, kw)
+            assert np.array_equal(rgba.cpu().numpy().reshape(H, W, 4), ref_rgba, equal_nan=True), (seed, W, H, spin, kw)
+            assert tot == int(ref_steps.sum())
+            # WGSL compute march
+            r0 = float(rng.choice([8.0, 30.0, 60.0]))
+            th, ph = float(rng.choice([0.2, np.pi / 2, 1.7, 2.9])), float(rng.uniform(0, 2 * np.pi))
+            eye = (r0 * np.sin(th) * np.cos(ph), r0 * np.cos(th), r0 * np.sin(th) * np.sin(ph))
+            cam = bh.camera_look_at(eye, fovy_deg=float(rng.choice([60.0, 25.0])), aspect=W / H)
+            wp = bh.wgsl_params(W, H, cam, mass, spin, max_steps=int(rng.choice([1, 60, 150, 400])), arith=bh.ARITH_STRICT,
+                                stars=int(rng.integers(0, 2)))
+            wp.jitter[0], wp.jitter[1] = float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.5, 0.5))
+            tot = e.render_frame_wgsl(wp, rgba, steps)
+            ref_rgba, ref_steps = oracle.wgsl_frame(oracle.wgsl_params_from(wp), nthreads=4)
+            assert np.array_equal(steps.cpu().numpy().reshape(H, W), ref_steps), (seed, W, H, spin, eye)
+            assert np.array_equal(rgba.cpu().numpy().reshape(H, W, 4), ref_rgba, equal_nan=True), (seed, W, H, spin, eye)
+            assert tot == int(ref_steps.sum())
