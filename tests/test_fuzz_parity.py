@@ -158,3 +158,112 @@ def test_random_shader_frames_strict_are_bit_exact(engine_mod, oracle, seed):
             assert np.array_equal(steps.cpu().numpy().reshape(H, W), ref_steps), (seed, W, H, spin, eye)
             assert np.array_equal(rgba.cpu().numpy().reshape(H, W, 4), ref_rgba, equal_nan=True), (seed, W, H, spin, eye)
             assert tot == int(ref_steps.sum())
+
+
+def _hostile_image(rng, h, w):
+    img = (rng.uniform(0, 1, (h, w, 4)) ** 3 * rng.choice([1.0, 8.0, 300.0])).astype(np.float32)
+    img[..., 3] = rng.choice([1.0, 0.5], (h, w))
+    k = max(1, h * w // 30)
+    for val in (0.0, -0.25, 65504.0, 7e4, 1e-7, 6e-8, 1e-41, np.inf, np.nan, 3.0e38):
+        img[rng.integers(0, h, k), rng.integers(0, w, k), rng.integers(0, 3, k)] = val
+    return img
+
+
+@pytest.mark.parametrize("seed", range(SEEDS))
+def test_random_post_chain_strict_is_bit_exact(engine_mod, oracle, seed):
+    """TAA, ATAA and bloom in shader order on hostile images (negatives, beyond the binary16
+    range, denormals, inf, NaN), ragged sizes down to 1x1, random parameters."""
+    import torch
+    bh = engine_mod
+    rng = np.random.default_rng(13000 + seed)
+    with bh.PhysicsEngine(1.0, 0.9) as e:
+        for _ in range(3):
+            h, w = int(rng.integers(1, 70)), int(rng.integers(1, 90))
+            cur, hist = _hostile_image(rng, h, w), _hostile_image(rng, h, w)
+            dc, dh = torch.from_numpy(cur).cuda(), torch.from_numpy(hist).cuda()
+            out = torch.zeros_like(dc)
+            half = bool(rng.integers(0, 2))
+            blend, moving = float(rng.choice([0.75, 0.0, 1.0, 0.9])), bool(rng.integers(0, 2))
+            e.post_taa_resolve(w, h, dc, dh, out, blend_factor=blend, camera_moving=moving, half_storage=half)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), oracle.taa_resolve(cur, hist, blend, moving, half), equal_nan=True), \
+                (seed, h, w, "taa", blend, moving, half)
+            eye = tuple(float(x) for x in rng.uniform(-60, 60, 3))
+            prev = tuple(float(x + d) for x, d in zip(eye, rng.uniform(-3, 3, 3)))
+            cam = oracle.AtaaCamera()
+            c0, c1 = bh.camera_look_at(eye, aspect=w / h), bh.camera_look_at(prev, aspect=w / h)
+            iv, ip = np.array(c0.inv_view).reshape(4, 4).T, np.array(c0.inv_proj).reshape(4, 4).T
+            pvp = np.linalg.inv(np.array(c1.inv_proj).reshape(4, 4).T) @ np.linalg.inv(np.array(c1.inv_view).reshape(4, 4).T)
+            ap = bh.AtaaParams()
+            ap.width, ap.height, ap.half_storage = w, h, 1 if half else 0
+            for k in range(16):
+                for obj in (cam, ap):
+                    obj.inv_view[k], obj.inv_proj[k] = np.float32(iv.T.ravel()[k]), np.float32(ip.T.ravel()[k])
+                    obj.prev_view_proj[k] = np.float32(pvp.T.ravel()[k])
+            for k in range(3):
+                cam.position[k] = ap.position[k] = np.float32(eye[k])
+            e.post_ataa_resolve(ap, dc, dh, out)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), oracle.ataa_resolve(cam, cur, hist, half), equal_nan=True), (seed, h, w, "ataa")
+            thr, inten, passes = float(rng.choice([0.8, 0.0, 5.0])), float(rng.choice([0.5, 0.0, 2.0])), int(rng.integers(0, 4))
+            e.post_bloom(w, h, dc, out, threshold=thr, intensity=inten, blur_passes=passes, half_storage=1 if half else 0)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), oracle.bloom(cur, thr, inten, passes, half), equal_nan=True), \
+                (seed, h, w, "bloom", thr, inten, passes, half)
+
+
+@pytest.mark.parametrize("seed", range(SEEDS))
+def test_random_control_plane_is_bit_exact(engine_mod, oracle, seed):
+    """Disk LUT (GPU), Page-Thorne flux, Bardeen curve, closed forms, spectrum LUT (GPU), spacetime
+    fields and meshes (GPU) for random masses / spins / grids."""
+    bh = engine_mod
+    rng = np.random.default_rng(17000 + seed)
+    L = oracle.lib()
+    for _ in range(3):
+        mass = float(rng.choice([1.0, 0.4, 3.0]))
+        spin = float(rng.choice([0.0, 1e-7, 0.3, 0.9, 0.998, 1.0, -0.6, 1.4]))
+        m = oracle.metric(oracle.KERR_KS, mass, spin)
+        with bh.PhysicsEngine(mass, spin) as e:
+            assert e.compute_horizon() == L.orc_event_horizon(m) and e.compute_photon_sphere() == L.orc_photon_sphere(m)
+            assert e.compute_isco() == L.orc_isco(m, 0)
+            for r in rng.uniform(1.0, 50.0, 4) * mass:
+                assert e.compute_dilation(float(r)) == L.orc_compute_dilation(m, float(r))
+                lam = float(rng.uniform(-6, 6))
+                assert e.compute_g_factor(float(r), lam) == L.orc_kerr_g_factor(float(r), mass, spin, lam)
+                a, b = e.compute_disk_flux(float(r)), L.orc_page_thorne_flux(float(r), mass, min(max(spin, -1.0), 1.0), 1.0)
+                assert a == b or (np.isnan(a) and np.isnan(b)), (mass, spin, r, a, b)
+            assert np.array_equal(e.generate_disk_lut(), oracle.temperature_lut(mass, min(max(spin, -1.0), 1.0)), equal_nan=True), (mass, spin)
+            th = float(rng.choice([np.pi / 2, 1.0, 0.2, 1e-12, 2.5]))
+            npts = int(rng.choice([1, 7, 32, 200]))
+            assert np.array_equal(e.compute_shadow_curve(th, npts).reshape(-1, 2),
+                                  oracle.bardeen_shadow(mass, min(max(spin, -1.0), 1.0), th, npts).astype(np.float32), equal_nan=True), \
+                (mass, spin, th, npts)
+            w, h, tmax = int(rng.choice([1, 5, 64, 300])), int(rng.choice([1, 2, 9])), float(rng.choice([1e5, 3e3, 1e7]))
+            assert np.array_equal(e.generate_spectrum_lut(w, h, tmax), oracle.blackbody_lut(w, h, tmax)), (w, h, tmax)
+            r_min, r_max = float(rng.uniform(1.0, 3.0) * mass), float(rng.uniform(5.0, 60.0) * mass)
+            nr, npol = int(rng.integers(2, 20)), int(rng.integers(2, 15))
+            for kind, fn in ((0, e.generate_curvature_field), (1, e.generate_tilt_field), (2, e.generate_frame_drag_field)):
+                assert np.array_equal(fn(r_min, r_max, nr, npol), oracle.scalar_field(kind, mass, spin, r_min, r_max, nr, npol),
+                                      equal_nan=True), (mass, spin, kind, r_min, r_max, nr, npol)
+            assert np.array_equal(e.generate_embedding_mesh(r_min, r_max, nr, npol),
+                                  oracle.embedding_mesh(mass, spin, r_min, r_max, nr, npol), equal_nan=True), (mass, spin, r_min, r_max)
+            assert np.array_equal(e.generate_ergosphere_mesh(nr, npol), oracle.ergosphere_mesh(mass, spin, nr, npol), equal_nan=True)
+
+
+@pytest.mark.parametrize("seed", range(SEEDS))
+def test_random_batches_do_not_depend_on_the_schedule(engine_mod, seed):
+    """Hostile batches under the refill kernel at random periods and relaunch + compaction at
+    random segment lengths, both contracts: the same bits from every schedule."""
+    bh = engine_mod
+    rng = np.random.default_rng(21000 + seed)
+    mass, spin = 1.0, float(rng.choice([0.0, 0.9, 0.999, -0.5]))
+    st = _rays(rng, int(rng.integers(1, 3000)), mass)
+    kw = dict(max_steps=int(rng.choice([1, 30, 300])), method=int(rng.integers(0, 3)), step_size=0.05,
+              metric_kind=int(rng.choice([bh.KERR_KS, bh.KERR_BL])), arith=int(rng.integers(0, 2)),
+              renormalize_interval=int(rng.choice([1, 10])))
+    with bh.PhysicsEngine(mass, spin) as e:
+        base = e.integrate_batch(st, bh.engine.default_options(segment_tries=0, **kw))
+        for K in (int(-rng.integers(1, 100)), int(rng.integers(1, 100)), 1 << 20):
+            got = e.integrate_batch(st, bh.engine.default_options(segment_tries=K, **kw))
+            for key in ("states", "steps", "term", "drift"):
+                assert np.array_equal(got[key], base[key], equal_nan=True), (seed, K, key, kw)
