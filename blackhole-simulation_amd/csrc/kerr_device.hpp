@@ -486,9 +486,11 @@ __device__ __forceinline__ T hamiltonian_of(const GInv<T> &g, T p_t, T p_r, T p_
 template <int KIND, int ARITH, typename T>
 __device__ __forceinline__ T renormalized_pr(const GInv<T> &g, T p_t, T p_r, T p_th, T p_ph) {
     const T a_quad = g.rr;
-    // renormalization.rs:21-27, zero entries of the metric included (see rhs_ref)
+    // renormalization.rs:21-27.  STRICT keeps the zero entries of the metric (see rhs_ref); the
+    // FAST contract, defined on finite states only, drops the Kerr-Schild g^{t phi} = 0 term
     const T b_quad = T(2) * (g.tr * p_t + g.rph * p_ph);
-    const T c_quad = g.tt * p_t * p_t + g.thth * p_th * p_th + g.phph * p_ph * p_ph + T(2) * g.tph * p_t * p_ph;
+    T c_quad = g.tt * p_t * p_t + g.thth * p_th * p_th + g.phph * p_ph * p_ph;
+    if constexpr (!(ARITH == GRV_ARITH_FAST && KIND == GRV_METRIC_KERR_KS)) c_quad = c_quad + T(2) * g.tph * p_t * p_ph;
     T out = p_r;
     if (fabs_t(a_quad) > T(1e-12)) {
         const T disc = b_quad * b_quad - T(4) * a_quad * c_quad;

@@ -88,7 +88,7 @@ __device__ __forceinline__ void wf32_m4v4(const float *m, float x, float y, floa
     for (int r = 0; r < 4; ++r) o[r] = m[0 + r] * x + m[4 + r] * y + m[8 + r] * z + m[12 + r] * w;
 }
 
-__global__ __launch_bounds__(kBlock) void wgsl_symplectic_fast_kernel(FrameGeom G, WgslParams P,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void wgsl_symplectic_fast_kernel(FrameGeom G, WgslParams P,
                                                                       float4 *__restrict__ out_rgba,
                                                                       uint32_t *__restrict__ out_steps,
                                                                       unsigned long long *total_steps,

@@ -131,7 +131,7 @@ __device__ __forceinline__ void pk_shade(float rb, float M, float a, float isco,
     alpha += target_opacity * mri_sat;
 }
 
-__global__ __launch_bounds__(kBlock) void wgsl_symplectic_pk_kernel(FrameGeom G, WgslParams P,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void wgsl_symplectic_pk_kernel(FrameGeom G, WgslParams P,
                                                                     float4 *__restrict__ out_rgba,
                                                                     uint32_t *__restrict__ out_steps,
                                                                     unsigned long long *total_steps,

@@ -1,0 +1,101 @@
+"""Static checks on the gfx950 code objects inside libgravitas_hip.so (no GPU needed): the AMDGPU
+metadata note of every kernel is decoded (clang offload bundle -> ELF -> NT_AMDGPU_METADATA msgpack)
+and the properties the performance numbers rest on are asserted, so that a change which silently
+costs the headline kernel a wave of occupancy or spills a hot kernel to scratch fails here."""
+import os
+import struct
+
+import pytest
+
+msgpack = pytest.importorskip("msgpack")
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+def _kernels(path):
+    data = open(path, "rb").read()
+    out, pos = {}, 0
+    while True:
+        base = data.find(MAGIC, pos)
+        if base < 0:
+            break
+        pos = base + 1
+        (n,) = struct.unpack_from("<Q", data, base + 24)
+        off = base + 32
+        for _ in range(n):
+            o, s, t = struct.unpack_from("<QQQ", data, off)
+            off += 24
+            triple = data[off:off + t].decode()
+            off += t
+            if "amdgcn" not in triple or s == 0:
+                continue
+            assert "gfx950" in triple, triple          # this library is built for one target
+            elf = data[base + o:base + o + s]
+            assert elf[:4] == b"\x7fELF"
+            (shoff,) = struct.unpack_from("<Q", elf, 0x28)
+            shentsize, shnum, _ = struct.unpack_from("<HHH", elf, 0x3A)
+            for k in range(shnum):
+                sh = struct.unpack_from("<IIQQQQIIQQ", elf, shoff + k * shentsize)
+                if sh[1] != 7:      # SHT_NOTE
+                    continue
+                p, end = sh[4], sh[4] + sh[5]
+                while p < end:
+                    namesz, descsz, ntype = struct.unpack_from("<III", elf, p)
+                    p += 12
+                    name = elf[p:p + namesz]
+                    p += (namesz + 3) & ~3
+                    desc = elf[p:p + descsz]
+                    p += (descsz + 3) & ~3
+                    if name.startswith(b"AMDGPU") and ntype == 32:
+                        md = msgpack.unpackb(desc, raw=False, strict_map_key=False)
+                        for kd in md["amdhsa.kernels"]:
+                            out[kd[".name"]] = kd
+    return out
+
+
+@pytest.fixture(scope="module")
+def kernels(engine_mod):
+    path = engine_mod.library_path()
+    assert os.path.exists(path)
+    ks = _kernels(path)
+    assert len(ks) >= 40
+    return ks
+
+
+def _find(kernels, *parts):
+    hits = [kd for n, kd in kernels.items() if all(p in n for p in parts)]
+    assert hits, parts
+    return hits
+
+
+def test_headline_kernel_keeps_three_waves_per_simd(kernels):
+    # integrate_segment_kernel<KerrSchild, FAST, RKF45>: 512 VGPRs per SIMD lane / 3 waves -> <= 168,
+    # no AGPRs, no scratch (2 waves/SIMD costs ~2.5 %)
+    (kd,) = _find(kernels, "integrate_segment_kernelILi1ELi1ELi0E")
+    assert kd[".vgpr_count"] + kd.get(".agpr_count", 0) <= 168, kd[".vgpr_count"]
+    assert kd[".private_segment_fixed_size"] == 0 and kd.get(".vgpr_spill_count", 0) == 0
+    assert kd[".wavefront_size"] == 64 and kd[".max_flat_workgroup_size"] == 256
+
+
+def test_no_hot_kernel_uses_scratch(kernels):
+    for part in ("integrate_segment_kernel", "integrate_refill_kernel", "wgsl_symplectic_pk_kernel", "init_from_pixels_kernel",
+                 "init_from_states_kernel", "finalize_frame_kernel", "finalize_batch_kernel", "taa_resolve_kernel",
+                 "ataa_resolve_kernel", "bloom_", "blit_reinhard_kernel"):
+        for kd in _find(kernels, part):
+            assert kd.get(".vgpr_spill_count", 0) == 0, (part, kd[".name"])
+            assert kd[".private_segment_fixed_size"] == 0, (part, kd[".name"], kd[".private_segment_fixed_size"])
+
+
+def test_f32_fast_marches_keep_their_occupancy(kernels):
+    # measured on MI355X (profiles/r01_shader_kernels.jsonl): the packed WGSL march gains 4-7 % from
+    # 4 waves/SIMD (<= 128 VGPRs) over 3, the one-ray-per-lane march 3-4 % from 6 (<= 80) over 5 at
+    # the price of one spilled register outside the step loop; the GLSL march holds 4
+    for part, limit, scratch in (("wgsl_symplectic_pk_kernel", 128, 0), ("wgsl_symplectic_fast_kernel", 80, 16),
+                                 ("glsl_fragment_kernelILi1E", 128, 0)):
+        (kd,) = _find(kernels, part)
+        assert kd[".vgpr_count"] + kd.get(".agpr_count", 0) <= limit, (part, kd[".vgpr_count"])
+        assert kd[".private_segment_fixed_size"] <= scratch, (part, kd[".private_segment_fixed_size"])
+
+
+def test_every_kernel_is_wave64_gfx950(kernels):
+    for n, kd in kernels.items():
+        assert kd[".wavefront_size"] == 64, n
