@@ -476,8 +476,11 @@ __global__ __launch_bounds__(kBlock) void integrate_segment_kernel(
 // arithmetic does not depend on the lane that runs it: results are bitwise those of
 // the segment kernel.
 // ---------------------------------------------------------------------------
+// (at least two waves per SIMD: the Boyer-Lindquist RKF45 form would otherwise take 257 registers
+// and run one)
 template <int KIND, int ARITH, int METHOD>
-__global__ __launch_bounds__(kBlock) void integrate_refill_kernel(RayWorkspace ws, SegmentParams P,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2)))
+void integrate_refill_kernel(RayWorkspace ws, SegmentParams P,
                                                                   uint32_t *__restrict__ cursor) {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long below = (1ull << lane) - 1ull;
