@@ -146,15 +146,32 @@ __global__ __launch_bounds__(256) void taa_resolve_kernel(uint32_t w, uint32_t h
     if (px >= w || py >= h) return;
     const float tx = 1.0f / (float)w, ty = 1.0f / (float)h;
     const float u = ((float)px + 0.5f) / (float)w, v = ((float)py + 0.5f) / (float)h;
-    const float4 cur = post_sample_tile(tile, current, w, h, u, v);
+    // the ten taps on the current frame sit on texel centres (pixel centre +- one texel), where a
+    // LINEAR sampler returns the texel itself.  Shader order evaluates them as the f32 bilinear
+    // arithmetic the oracle defines (a weight of ~1e-7 leaks from the neighbour when (px + 0.5 +- 1)
+    // / w * w - 0.5 does not round back to an integer); the FAST contract reads the texels.
+    float4 cur;
     Moments M{{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+    if constexpr (ARITH == GRV_ARITH_FAST) {
+        const int lx = (int)threadIdx.x + 2, ly = (int)threadIdx.y + 2; // tile origin is 2 texels out
+        cur = tile.t[ly][lx];
 #pragma unroll
-    for (int y = -1; y <= 1; ++y)
+        for (int y = -1; y <= 1; ++y)
 #pragma unroll
-        for (int x = -1; x <= 1; ++x) {
-            const float4 s = post_sample_tile(tile, current, w, h, u + (float)x * tx, v + (float)y * ty);
-            M.add(to_ycocg(s.x, s.y, s.z));
-        }
+            for (int x = -1; x <= 1; ++x) {
+                const float4 s = tile.t[ly + y][lx + x]; // halo texels are edge-clamped already
+                M.add(to_ycocg(s.x, s.y, s.z));
+            }
+    } else {
+        cur = post_sample_tile(tile, current, w, h, u, v);
+#pragma unroll
+        for (int y = -1; y <= 1; ++y)
+#pragma unroll
+            for (int x = -1; x <= 1; ++x) {
+                const float4 s = post_sample_tile(tile, current, w, h, u + (float)x * tx, v + (float)y * ty);
+                M.add(to_ycocg(s.x, s.y, s.z));
+            }
+    }
     float mean[3], sd[3];
     M.mean_std(mean, sd);
     const float4 h4 = post_sample(history, w, h, u, v);
