@@ -231,8 +231,14 @@ int grv_post_bloom(grv_engine *e, const GrvBloomParams *p, const float *d_scene,
 namespace {
 int ensure_targets(grv_engine *e, uint32_t w, uint32_t h, hipStream_t s) {
     if (e->rt.mem && e->rt.w == w && e->rt.h == h) return GRV_OK;
+    // resize: the reference recreates (zeroed) textures but keeps its frame counter and history
+    // index (webgpu/renderer.ts:269-278 initTextures, reprojection.ts:102-117), so the Halton
+    // jitter sequence runs on across a resolution change
+    const uint32_t frames = e->rt.frames, hist = e->rt.hist;
     if (e->rt.mem) (void)hipFree(e->rt.mem);
     e->rt = grv_engine::Targets{};
+    e->rt.frames = frames;
+    e->rt.hist = hist;
     const size_t bytes = (size_t)3 * w * h * 4 * sizeof(float);
     GRV_HIP(e, hipMalloc(reinterpret_cast<void **>(&e->rt.mem), bytes));
     GRV_HIP(e, hipMemsetAsync(e->rt.mem, 0, bytes, s)); // textures start zeroed

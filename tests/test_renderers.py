@@ -125,3 +125,80 @@ def test_webgl_renderer_sequence(engine_mod, oracle, bloom):
             assert np.array_equal(got, want), (f, d.max())   # shader order end to end: identical frames
             assert got[..., :3].min() >= 0.0 and got[..., :3].max() <= 1.0   # ACES + gamma
         assert e.renderer_frame_count() == 4
+
+
+def _camera_block_sized(engine_mod, eye, prev_eye, w, h):
+    def mats(e):
+        c = engine_mod.camera_look_at(e, aspect=w / h)
+        return (np.array(c.inv_view, np.float64).reshape(4, 4).T, np.array(c.inv_proj, np.float64).reshape(4, 4).T)
+    iv, ip = mats(eye)
+    piv, pip_ = mats(prev_eye)
+    cu = np.zeros(88, np.float32)
+    for k, m in enumerate((np.linalg.inv(iv), np.linalg.inv(ip), iv, ip, np.linalg.inv(pip_) @ np.linalg.inv(piv))):
+        cu[16 * k:16 * k + 16] = m.T.reshape(-1)
+    cu[80:83] = eye
+    return cu
+
+
+@pytest.mark.gpu
+def test_renderers_across_a_resize(engine_mod, oracle):
+    """A resolution change recreates the (zeroed) history textures but keeps the renderer's frame
+    counter and history index (webgpu/renderer.ts:269-278, reprojection.ts:102-117): the frame after
+    the resize blends against black and carries on the Halton jitter sequence.  Shader order: the
+    composed oracle frames bit for bit."""
+    import torch
+    sizes = [(96, 54), (96, 54), (70, 40), (70, 40), (128, 30)]
+    eyes = [(59.55, -7.31, 0.0), (59.4, -7.31, 3.0), (59.0, -7.0, 6.0), (58.5, -6.5, 9.0), (58.0, -6.0, 12.0)]
+    with engine_mod.PhysicsEngine(1.0, 0.9) as e:
+        hist, hi, prev_size = None, 0, None
+        for f, ((w, h), eye) in enumerate(zip(sizes, eyes)):
+            if (w, h) != prev_size:
+                hist = [np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)]   # recreated textures
+                prev_size = (w, h)
+            cu = _camera_block_sized(engine_mod, eye, eyes[f - 1] if f else eye, w, h)
+            pp = physics_block(1.0, 0.9)
+            pp[2], pp[3] = w, h
+            screen = torch.zeros(h, w, 4, dtype=torch.float32, device="cuda:0")
+            e.webgpu_render(cu, pp, screen, max_steps=120, arith=0)
+            torch.cuda.synchronize()
+            assert e.renderer_frame_count() == f + 1                   # never reset by a resize
+            gp = engine_mod.WgslParams()
+            gp.width, gp.height, gp.mass, gp.spin, gp.max_steps, gp.stars = w, h, 1.0, 0.9, 120, 1
+            for k in range(16):
+                gp.inv_view[k], gp.inv_proj[k] = cu[32 + k], cu[48 + k]
+            for k in range(3):
+                gp.position[k] = cu[80 + k]
+            gp.jitter[0] = halton((f % 8) + 1, 2) - np.float32(0.5)
+            gp.jitter[1] = halton((f % 8) + 1, 3) - np.float32(0.5)
+            rgba, _ = oracle.wgsl_frame(oracle.wgsl_params_from(gp), nthreads=4)
+            cam = oracle.AtaaCamera()
+            for k in range(16):
+                cam.inv_view[k], cam.inv_proj[k], cam.prev_view_proj[k] = cu[32 + k], cu[48 + k], cu[64 + k]
+            for k in range(3):
+                cam.position[k] = cu[80 + k]
+            resolved = oracle.ataa_resolve(cam, half(rgba), hist[hi], True)
+            hist[1 - hi] = resolved
+            hi = 1 - hi
+            want = resolved.copy()
+            want[..., :3] = resolved[..., :3] / (resolved[..., :3] + 1.0)
+            assert np.array_equal(screen.cpu().numpy(), want), (f, w, h)
+    # WebGL chain: same rule for the reprojection ping-pong
+    with engine_mod.PhysicsEngine(1.0, 0.9) as e:
+        hist, write, prev_size = None, 0, None
+        for f, (w, h) in enumerate(sizes):
+            if (w, h) != prev_size:
+                hist = [np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)]
+                prev_size = (w, h)
+            gp = engine_mod.glsl_params(w, h, 1.0, 0.9, max_ray_steps=120, time=0.5 * f, tone_map=1)
+            screen = torch.zeros(h, w, 4, dtype=torch.float32, device="cuda:0")
+            e.webgl_render(gp, screen, bloom=True, camera_moving=False)
+            torch.cuda.synchronize()
+            gp.tone_map = 0
+            scene, _ = oracle.glsl_frame(oracle.glsl_params_from(gp), nthreads=4)
+            read = hist[0] if write == 0 else hist[1]
+            resolved = oracle.taa_resolve(half(scene), read, 0.75, False, True)
+            hist[1 if write == 0 else 0] = resolved
+            write = 1 - write
+            want = oracle.bloom(resolved, 0.8, 0.5, 2, True)
+            assert np.array_equal(screen.cpu().numpy(), want), (f, w, h)
+        assert e.renderer_frame_count() == len(sizes)
