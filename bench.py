@@ -119,6 +119,12 @@ def main():
                     help="N > 1: wait for each frame's gather before integrating the next frame")
     args = ap.parse_args()
 
+    # stdout carries exactly one line, the JSON result: libraries that print banners on load
+    # (RCCL prints its version / host / library path) get stderr until that line is written
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -253,7 +259,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.width, args.height, eye)
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
         print(json.dumps(line), flush=True)
+        os.dup2(2, 1)  # teardown chatter, if any, goes to stderr too
 
     eng.close()
     if use_dist:
