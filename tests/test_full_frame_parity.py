@@ -9,7 +9,7 @@ import time
 import numpy as np
 import pytest
 
-W, H = 3840, 2160
+W, H = (int(v) for v in os.environ.get("GRV_PARITY_SIZE", "3840x2160").split("x"))   # 7680x4320: the maximum size BASELINE names
 EYE = (60.0 * np.sin(np.deg2rad(97.0)), 60.0 * np.cos(np.deg2rad(97.0)), 0.0)
 
 
