@@ -81,7 +81,9 @@ def test_random_frames_strict_is_bit_exact(engine_mod, oracle, seed):
                   lut_width=int(rng.choice([512, 64, 7])), lut_height=int(rng.choice([64, 1, 5])),
                   lut_max_temp=float(rng.choice([1e5, 2e4])))
         okw = dict(max_steps=int(rng.choice([0, 5, 120, 600])), tolerance=float(10.0 ** rng.uniform(-9, -6)),
-                   escape_radius=float(rng.choice([1000.0, 100.0])), renormalize_interval=int(rng.choice([1, 10])))
+                   escape_radius=float(rng.choice([1000.0, 100.0])), renormalize_interval=int(rng.choice([1, 10])),
+                   method=int(rng.choice([0, 0, 1, 2])), step_size=float(rng.choice([0.05, 0.4])),
+                   initial_step=float(rng.choice([0.01, 1.0])))
         fovy = float(rng.choice([60.0, 20.0, 110.0]))
         up = (0.0, 1.0, 0.0) if th not in (0.0, np.pi) else (1.0, 0.0, 0.0)
         ocam = oracle.camera_look_at(eye, up=up, fovy_deg=fovy, aspect=W / H)
