@@ -170,7 +170,13 @@ bool options_valid(const GrvOptions &o) {
     if (o.method < GRV_METHOD_RKF45 || o.method > GRV_METHOD_SYMPLECTIC) return false;
     if (o.metric_kind < GRV_METRIC_KERR_BL || o.metric_kind > GRV_METRIC_SCHWARZSCHILD) return false;
     if (o.arith != GRV_ARITH_STRICT && o.arith != GRV_ARITH_FAST) return false;
-    if (o.method == GRV_METHOD_RKF45 && !(o.tolerance > 0.0)) return false;
+    // STRICT takes any tolerance, as the reference does: 0 or NaN rejects every try and walks the
+    // forced 1e-5 steps, a negative one accepts every try (integrator.rs:76-104).  The FAST
+    // contract multiplies by 1 / tolerance and is defined for positive tolerances only.
+    if (o.method == GRV_METHOD_RKF45 && o.arith == GRV_ARITH_FAST && !(o.tolerance > 0.0)) return false;
+    // a NaN first step never completes a try (the reference's stepper loops forever on it,
+    // integrator.rs:75-105): refused here rather than handed to a kernel that could not end
+    if (o.method == GRV_METHOD_RKF45 && o.initial_step != o.initial_step) return false;
     return true;
 }
 

@@ -42,7 +42,8 @@ def test_random_configurations_strict_is_bit_exact(engine_mod, oracle, seed):
         mass = float(rng.choice([1.0, 0.37, 2.5]))
         spin = 0.0 if okind == oracle.SCHWARZSCHILD else float(rng.choice([0.0, 0.3, 0.9, 0.999, -0.7, 1.0, 1.3]))
         method = int(rng.integers(0, 3))
-        kw = dict(method=method, tolerance=float(10.0 ** rng.uniform(-10, -5)),
+        tol = float(10.0 ** rng.uniform(-10, -5)) if rng.random() < 0.9 else float(rng.choice([0.0, -1e-7, np.nan, np.inf, 1e-300, 1e300]))
+        kw = dict(method=method, tolerance=tol,
                   initial_step=float(rng.choice([0.01, 0.5, -0.01, -0.3, 20.0])),
                   max_steps=int(rng.choice([0, 1, 7, 60, 250])), escape_radius=float(rng.choice([1000.0, 80.0, 3.0])),
                   renormalize_interval=int(rng.choice([1, 3, 10, 1000])), step_size=float(rng.choice([0.05, -0.05, 0.3])))
@@ -50,12 +51,13 @@ def test_random_configurations_strict_is_bit_exact(engine_mod, oracle, seed):
         ref = oracle.integrate_batch(oracle.metric(okind, mass, spin), oracle.options(**kw), st, nthreads=4)
         with bh.PhysicsEngine(mass, spin) as e:
             got = e.integrate_batch(st, bh.engine.default_options(metric_kind=bkind, arith=bh.ARITH_STRICT, **kw))
-            fast = e.integrate_batch(st, bh.engine.default_options(metric_kind=bkind, arith=bh.ARITH_FAST, **kw))
+            fast = e.integrate_batch(st, bh.engine.default_options(metric_kind=bkind, arith=bh.ARITH_FAST, **kw)) \
+                if (tol > 0 and np.isfinite(tol)) or method != 0 else None
         for key in ("steps", "term", "states", "drift"):
             assert np.array_equal(got[key], ref[key], equal_nan=True), (seed, kw, okind, spin, mass, key)
         # FAST: same classes except where a rounding flips a decision (near-critical / singular rays)
         finite = np.isfinite(st).all(axis=1)
-        assert (fast["term"][finite] == ref["term"][finite]).mean() >= 0.97, (seed, kw, okind, spin)
+        assert fast is None or (fast["term"][finite] == ref["term"][finite]).mean() >= 0.97, (seed, kw, okind, spin)
         checked += st.shape[0]
     assert checked == 4000
 

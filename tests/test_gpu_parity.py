@@ -181,8 +181,21 @@ def test_edge_cases(bh, oracle):
         # invalid options are rejected, not guessed
         with pytest.raises(bh.GravitasError):
             e.integrate_batch(st, bh.engine.default_options(method=7))
-        with pytest.raises(bh.GravitasError):
-            e.integrate_batch(st, bh.engine.default_options(tolerance=0.0))
+        with pytest.raises(bh.GravitasError):   # a NaN first step would never complete a try
+            e.integrate_batch(st, bh.engine.default_options(initial_step=float("nan")))
+        with pytest.raises(bh.GravitasError):   # FAST multiplies by 1 / tolerance: positive tolerances only
+            e.integrate_batch(st, bh.engine.default_options(tolerance=0.0, arith=bh.ARITH_FAST))
+        # STRICT follows the reference through degenerate tolerances (integrator.rs:76-104): 0 and NaN
+        # reject every try down to the forced 1e-5 step, a negative tolerance accepts everything
+        st3 = np.array([[0, 12.0, 1.1, 0.2, -1, -0.7, 1.0, 2.5], [0, 30.0, 2.0, 1.0, -1, 0.3, -2.0, 4.0]])
+        for tol in (0.0, -1e-8, float("nan"), float("inf")):
+            got = e.integrate_batch(st3, bh.engine.default_options(tolerance=tol, max_steps=40))
+            ref = oracle.integrate_batch(m, oracle.options(tolerance=tol, max_steps=40), st3)
+            for key in ("states", "steps", "term", "drift"):
+                assert np.array_equal(got[key], ref[key], equal_nan=True), (tol, key)
+        v = [0, 20.0, np.pi / 2, 0, -1.0, -1.0, 0.0, 3.5]
+        assert np.array_equal(e.integrate_ray_relativistic(v, 25, 0.0, True),
+                              oracle.integrate_ray_relativistic(1.0, 0.9, v, 25, 0.0, True))
 
 
 @pytest.mark.parametrize("method,arith", [(0, 0), (0, 1), (1, 1), (2, 0)])
