@@ -344,3 +344,76 @@ def test_random_tile_partitions_equal_the_whole_frame(engine_mod, seed):
             e.unpack_tiles_device(D.rank_params(p, R, r), r, buf, img, 16)
         torch.cuda.synchronize()
         assert torch.equal(img.reshape(-1, 4), whole), (seed, W, H, R, arith, "glsl")
+
+
+@pytest.mark.parametrize("seed", range(SEEDS))
+def test_random_renderer_sessions_are_bit_exact(engine_mod, oracle, seed):
+    """WebGPURenderer.render / WebGLRenderer.render driven for several frames with random camera
+    paths, masses / spins, step budgets and mid-session resizes, in shader order: every presented
+    frame equals the pass sequence composed from the oracle's pieces."""
+    import torch
+    import test_renderers as TR
+    bh = engine_mod
+    rng = np.random.default_rng(33000 + seed)
+    mass, spin = float(rng.choice([1.0, 0.6])), float(rng.choice([0.0, 0.9, -0.5]))
+    steps = int(rng.choice([40, 150]))
+    size = (int(rng.integers(8, 110)), int(rng.integers(8, 70)))
+    eye = np.array([60.0 * np.sin(1.7), 60.0 * np.cos(1.7), 0.0]) * rng.uniform(0.3, 1.5)
+    with bh.PhysicsEngine(mass, spin) as e:
+        hist, hi, prev, prev_eye = None, 0, None, eye
+        for f in range(5):
+            if rng.random() < 0.25:
+                size = (int(rng.integers(8, 110)), int(rng.integers(8, 70)))
+            w, h = size
+            if size != prev:
+                hist, prev = [np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)], size
+            eye = eye + rng.uniform(-2, 2, 3) * (rng.random() < 0.7)
+            cu = TR._camera_block_sized(bh, tuple(eye), tuple(prev_eye), w, h)
+            prev_eye = eye.copy()
+            pp = TR.physics_block(mass, spin)
+            pp[2], pp[3] = w, h
+            screen = torch.zeros(h, w, 4, dtype=torch.float32, device="cuda:0")
+            e.webgpu_render(cu, pp, screen, max_steps=steps, arith=0)
+            torch.cuda.synchronize()
+            gp = bh.WgslParams()
+            gp.width, gp.height, gp.mass, gp.spin, gp.max_steps, gp.stars = w, h, mass, spin, steps, 1
+            for k in range(16):
+                gp.inv_view[k], gp.inv_proj[k] = cu[32 + k], cu[48 + k]
+            for k in range(3):
+                gp.position[k] = cu[80 + k]
+            gp.jitter[0] = TR.halton((f % 8) + 1, 2) - np.float32(0.5)
+            gp.jitter[1] = TR.halton((f % 8) + 1, 3) - np.float32(0.5)
+            rgba, _ = oracle.wgsl_frame(oracle.wgsl_params_from(gp), nthreads=4)
+            cam = oracle.AtaaCamera()
+            for k in range(16):
+                cam.inv_view[k], cam.inv_proj[k], cam.prev_view_proj[k] = cu[32 + k], cu[48 + k], cu[64 + k]
+            for k in range(3):
+                cam.position[k] = cu[80 + k]
+            resolved = oracle.ataa_resolve(cam, TR.half(rgba), hist[hi], True)
+            hist[1 - hi], hi = resolved, 1 - hi
+            want = resolved.copy()
+            want[..., :3] = resolved[..., :3] / (resolved[..., :3] + 1.0)
+            assert np.array_equal(screen.cpu().numpy(), want, equal_nan=True), (seed, f, w, h)
+    with bh.PhysicsEngine(mass, spin) as e:
+        hist, write, prev = None, 0, None
+        bloom = bool(rng.integers(0, 2))
+        for f in range(5):
+            if rng.random() < 0.25:
+                size = (int(rng.integers(8, 110)), int(rng.integers(8, 70)))
+            w, h = size
+            if size != prev:
+                hist, prev = [np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)], size
+            moving = bool(rng.random() < 0.3)
+            gp = bh.glsl_params(w, h, mass, spin, max_ray_steps=steps, time=float(0.4 * f), tone_map=1,
+                                mouse=(float(rng.uniform(0, 1)), float(rng.uniform(0, 1))))
+            screen = torch.zeros(h, w, 4, dtype=torch.float32, device="cuda:0")
+            e.webgl_render(gp, screen, bloom=bloom, camera_moving=moving)
+            torch.cuda.synchronize()
+            gp.tone_map = 0
+            scene, _ = oracle.glsl_frame(oracle.glsl_params_from(gp), nthreads=4)
+            read = hist[0] if write == 0 else hist[1]
+            resolved = oracle.taa_resolve(TR.half(scene), read, 0.75, moving, True)
+            hist[1 if write == 0 else 0] = resolved
+            write = 1 - write
+            want = oracle.bloom(resolved, 0.8, 0.5, 2, True) if bloom else oracle.bloom(resolved, 3e38, 0.0, 0, True)
+            assert np.array_equal(screen.cpu().numpy(), want, equal_nan=True), (seed, f, w, h, bloom, moving)
