@@ -351,7 +351,9 @@ def test_random_renderer_sessions_are_bit_exact(engine_mod, oracle, seed):
     """WebGPURenderer.render / WebGLRenderer.render driven for several frames with random camera
     paths, masses / spins, step budgets and mid-session resizes, in shader order: every presented
     frame equals the pass sequence composed from the oracle's pieces."""
+    import sys
     import torch
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import test_renderers as TR
     bh = engine_mod
     rng = np.random.default_rng(33000 + seed)
