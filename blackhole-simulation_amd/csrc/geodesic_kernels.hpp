@@ -420,8 +420,14 @@ __device__ __forceinline__ void ray_resume(const Hole<double> &bh, RayRegs &y,
 // ---------------------------------------------------------------------------
 // The segment kernel.
 // ---------------------------------------------------------------------------
+// waves per SIMD the segment kernel is compiled for at least: the Kerr-Schild RKF45 forms sit at the
+// three-wave boundary (FAST 167 VGPRs; STRICT would take 171 and run two)
+template <int KIND, int METHOD>
+constexpr int kSegmentWavesMin = (KIND == GRV_METRIC_KERR_KS && METHOD == GRV_METHOD_RKF45) ? 3 : 1;
+
 template <int KIND, int ARITH, int METHOD>
-__global__ __launch_bounds__(kBlock) void integrate_segment_kernel(
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kSegmentWavesMin<KIND, METHOD>)))
+void integrate_segment_kernel(
     RayWorkspace ws, SegmentParams P, const uint32_t *__restrict__ live_in, uint32_t n_live,
     uint32_t *__restrict__ live_out, uint32_t *__restrict__ live_out_count) {
     const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
