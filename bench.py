@@ -1,15 +1,26 @@
 #!/usr/bin/env python
 """Headline benchmark: Mray-steps/s of the Kerr geodesic ray-marching path.
 
-Workload (BASELINE.json configs[2], the one the metric is quoted on):
-  3840x2160 per GPU, a = 0.999 Kerr-Schild, adaptive RKF45 tol 1e-8, <= 2048 steps,
+--config c3 (default; BASELINE.json configs[2], the one the metric is quoted on):
+  3840x2160, a = 0.999 Kerr-Schild, adaptive RKF45 tol 1e-8, <= 2048 steps, f64,
   + Planck (T x g) LUT redshift shading; camera r0 = 60 M, theta = 97 deg, fov 60 deg.
-A "step" is one frame: pixel->state init, integrate, shade (all on the GPU, outputs
-resident in HBM), and for N > 1 the single gather of finished tiles to rank 0.
+--config c4 (BASELINE.json configs[3]):
+  7680x4320, the f32 compute march (compute.wgsl.ts) at a fixed 1024-step budget: every
+  ray marches until it terminates or has done 1024 steps.
 
-N > 1 (weak scaling): the image plane grows to (3840*gx) x (2160*gy), gx*gy = N, cut in
-64x64 tiles dealt round-robin to the ranks, so every GPU integrates one 4K frame's
-worth of rays.  --scaling strong splits the one 3840x2160 frame instead.
+A "step" is one frame: pixel->state init, integrate, shade (all on the GPU, outputs resident
+in HBM), and for N > 1 the single gather of finished tiles to rank 0 (RCCL over xGMI).
+
+N > 1 (default --scaling strong, the split BASELINE's metric names: "at 3840x2160 ... 1/2/4/8
+GPU"): the ONE frame is cut in 64x64 tiles dealt round-robin to the N ranks, so total work is
+fixed and each rank integrates 1/N of the rays.  --scaling weak grows the image plane to
+(W*gx) x (H*gy), gx*gy = N, instead (every GPU integrates one full frame's worth of rays).
+
+The frame loop holds no host wait: frames are queued back to back, the per-frame counters
+accumulate on the device (grv_stats_accumulate) and are read once after the timed region.
+At N = 1 the integrate launches are bracketed by HIP events recorded on the launch stream
+(resolved after the loop); at N > 1 no events enter the timed loop and the roofline block
+comes from a few profiled frames run after it.
 
 Prints ONE JSON line on rank 0.
 """
@@ -25,8 +36,18 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 GRID = {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (4, 2)}
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
-B_STEP, B_RAY = 144, 96  # algorithmic bytes: SURVEY.md 8(d) / DESIGN.md
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_PEAK_TFLOPS = 78.6  # same guide: vector FP64
+FP32_PEAK_TFLOPS = 157.3  # same guide: vector FP32
+# algorithmic bytes and flops per unit: SURVEY.md 8(d) / DESIGN.md section 4
+B_STEP = {"c3": 144, "c4": 72}
+B_RAY = {"c3": 96, "c4": 56}
+FLOP_STEP = {"c3": 1300.0, "c4": 500.0}
+KERNEL_OF = {("c3", "fast"): "integrate_segment_kernel<1,1,0>",
+             ("c3", "strict"): "integrate_segment_kernel<1,0,0>",
+             ("c4", "fast"): "wgsl_symplectic_fast_kernel",
+             ("c4", "packed"): "wgsl_symplectic_pk_kernel",
+             ("c4", "strict"): "wgsl_symplectic_kernel"}
 
 
 def usable_cores():
@@ -56,7 +77,18 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(width, height, eye, target_seconds=15.0):
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_c3(width, height, eye, target_seconds=15.0):
     """The oracle (C restatement of gravitas-core) timed on the host cores on a bounded,
     pixel-strided sample of the same workload.  Checker/baseline only."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -86,22 +118,61 @@ def cpu_baseline(width, height, eye, target_seconds=15.0):
     one = po.render_frame(cam, fp, lut, stride=(32, 32), nthreads=1, want_states=False)
     one_rate = one["stats"].accepted_steps / max(time.time() - t1, 1e-3) / 1e6
     return {"value": round(st.accepted_steps / dt / 1e6, 4), "unit": "Mray-steps/s", "cores": cores,
-            "one_core_value": round(one_rate, 4), "kind": "port",
+            "cpu_model": cpu_model(), "one_core_value": round(one_rate, 4), "kind": "port",
             "sample": "C restatement of gravitas-core (Rust toolchain unavailable), OpenMP over "
                       "rays, 1/%d pixel-strided subset of the %dx%d frame: %d rays, %d accepted "
                       "steps in %.1f s" % (sx * sy, width, height, st.rays,
                                            st.accepted_steps, dt)}
 
 
-def load_committed_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC
-    passes (profiles/): measured off-line, never inside the timed region."""
+def cpu_baseline_c4(wp, width, height, target_seconds=12.0):
+    """The shader oracle's f32 compute march (C restatement of compute.wgsl.ts) on the host
+    cores, pixel-strided sample of the same 8K / 1024-step frame."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    cores = usable_cores()
+    op = po.wgsl_params_from(wp)
+    t = time.time()
+    probe = po.wgsl_frame(op, stride=(64, 64), nthreads=cores)
+    rate = float(np.sum(probe["steps"])) / max(time.time() - t, 1e-3)
+    total = 900.0 * width * height
+    sx = sy = 64
+    for cand in ((4, 4), (6, 6), (8, 8), (12, 12), (16, 16), (24, 24), (32, 32), (48, 48), (64, 64)):
+        if total / (cand[0] * cand[1]) / rate <= 1.6 * target_seconds:
+            sx, sy = cand
+            break
+    t = time.time()
+    out = po.wgsl_frame(op, stride=(sx, sy), nthreads=cores)
+    dt = time.time() - t
+    steps = int(np.sum(out["steps"]))
+    return {"value": round(steps / dt / 1e6, 4), "unit": "Mray-steps/s", "cores": cores,
+            "cpu_model": cpu_model(), "kind": "port",
+            "sample": "C restatement of the f32 compute march (compute.wgsl.ts; no TS/WGSL runtime "
+                      "here), OpenMP over rays, 1/%d pixel-strided subset of the %dx%d frame: %d "
+                      "rays, %d steps in %.1f s" % (sx * sy, width, height, out["steps"].size, steps, dt)}
+
+
+def committed_pmc(kernel_pretty, lib_path):
+    """HBM bytes and VALU issue fraction per launch of the dominant kernel from the committed
+    rocprofv3 PMC passes (profiles/traffic.json) -- valid only for the code object they were
+    measured on: the file carries the kernel's code hash, and a library whose kernel hashes
+    differently gets None (the figures would silently describe another kernel)."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
-            return json.load(f)
-    except Exception:
-        return None
+            t = json.load(f)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import kernel_resources as kr
+        now = kr.kernel_code_hash(lib_path, kernel_pretty)
+    except Exception as exc:  # no file / unreadable library: no committed figures
+        return None, "unavailable (%s)" % type(exc).__name__
+    ent = (t.get("kernels") or {}).get(kernel_pretty)
+    if not ent:
+        return None, "no committed PMC pass for %s" % kernel_pretty
+    if ent.get("code_hash") != now:
+        return None, ("stale: profiles/traffic.json was measured on code object %s, the library "
+                      "holds %s" % (ent.get("code_hash"), now))
+    return ent, "profiles/traffic.json (code object %s)" % now
 
 
 def main():
@@ -109,15 +180,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--arith", choices=["fast", "strict"], default="fast")
+    ap.add_argument("--config", choices=["c3", "c4"], default="c3")
+    ap.add_argument("--arith", choices=["fast", "strict", "packed"], default="fast")
     ap.add_argument("--segment-tries", type=int, default=0)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
-    ap.add_argument("--width", type=int, default=3840)
-    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: wait for each frame's gather before integrating the next frame")
+    ap.add_argument("--profile-frames", type=int, default=3,
+                    help="N > 1: profiled frames after the timed loop (roofline block)")
     args = ap.parse_args()
+    cfg = args.config
+    if cfg == "c3" and args.arith == "packed":
+        raise SystemExit("--arith packed is the two-rays-per-lane form of the f32 march (--config c4)")
+    base_w = args.width or (3840 if cfg == "c3" else 7680)
+    base_h = args.height or (2160 if cfg == "c3" else 4320)
 
     # stdout carries exactly one line, the JSON result: libraries that print banners on load
     # (RCCL prints its version / host / library path) get stderr until that line is written
@@ -154,16 +233,23 @@ def main():
                                 device_id=torch.device("cuda", local_rank))
 
     gx, gy = GRID.get(world, (world, 1)) if args.scaling == "weak" else (1, 1)
-    W, H = args.width * gx, args.height * gy
+    W, H = base_w * gx, base_h * gy
     th = np.deg2rad(97.0)
     eye = (60.0 * np.sin(th), 60.0 * np.cos(th), 0.0)
-    arith = bh.ARITH_FAST if args.arith == "fast" else bh.ARITH_STRICT
+    arith = {"fast": bh.ARITH_FAST, "strict": bh.ARITH_STRICT, "packed": bh.ARITH_FAST_PACKED}[args.arith]
 
     eng = bh.PhysicsEngine(1.0, 0.999, device=local_rank)
     cam = bh.camera_look_at(eye, aspect=W / H)
-    params = bh.render_params(W, H, arith=arith, segment_tries=args.segment_tries, profile=1)
+    params = bh.render_params(W, H, arith=arith if cfg == "c3" else bh.ARITH_FAST,
+                              segment_tries=args.segment_tries, profile=0)
     rp = D.rank_params(params, world, rank)
+    prof_rp = D.rank_params(params, world, rank)
+    prof_rp.profile = 1
     n_local = eng.frame_ray_count(rp)
+    wp = None
+    if cfg == "c4":
+        wp = bh.wgsl_params(W, H, cam, 1.0, 0.999, max_steps=1024, arith=arith,
+                            tile_world=world, tile_rank=rank)
     stream = torch.cuda.current_stream().cuda_stream
     # all buffers live outside the frame loop: the padded send buffer doubles as the render
     # target, rank 0 additionally holds the receive slots and the assembled image
@@ -173,19 +259,34 @@ def main():
     if overlap:
         tg.enable_pipeline()  # second send buffer: frame i's gather runs under frame i+1's kernels
     buf = tg.local_view(n_local) if tg else torch.empty((n_local, 4), dtype=torch.float32, device="cuda")
+    eng.stats_accumulate(True)  # counters stay in HBM across frames: no read-back in the loop
 
     def dev_unpack(rparams, r, packed, image):
         eng.unpack_tiles_device(rparams, r, packed, image, 16, stream)
 
-    def one_frame(i):
+    # c4 at N = 1: bracket each march launch with events on the launch stream (torch's current
+    # stream is the stream handed to the engine), resolved after the loop
+    ev_pairs = []
+
+    def render(target, profiled):
+        if cfg == "c3":
+            eng.render_frame_device(cam, prof_rp if profiled else rp, rgba=target, stream=stream)
+        else:
+            if profiled:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+            eng.render_frame_wgsl(wp, target, stream=stream, want_total=False)
+            if profiled:
+                b.record()
+                ev_pairs.append((a, b))
+
+    def one_frame(i, profiled):
         target = tg.pipelined_view(i, n_local) if overlap else buf
-        eng.render_frame_device(cam, rp, rgba=target, stream=stream)
-        st = eng.frame_stats(stream)
+        render(target, profiled)
         if overlap:
             tg.submit(i, dev_unpack, force_collective=True)  # finish frame i-1's exchange, start frame i's
         elif tg:
             tg.run(dev_unpack, force_collective=True)  # the one exchange: gather tiles -> rank 0
-        return st
 
     def fence():
         if overlap:
@@ -194,71 +295,119 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def read_stats():
+        st = eng.frame_stats(stream)
+        ms = st.integrate_ms
+        n = st.launches
+        if cfg == "c4":
+            ms = sum(a.elapsed_time(b) for a, b in ev_pairs)
+            n = len(ev_pairs)
+            del ev_pairs[:]
+        return st, ms, n
+
+    in_loop_profile = world == 1  # no events in a multi-rank timed loop
     for i in range(args.warmup):
-        one_frame(i)
+        one_frame(i, False)
     fence()
+    eng.frame_stats_reset(stream)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    steps_local = 0
-    integ_ms = 0.0
-    launches = 0
-    max_drift = 0.0
     for i in range(args.steps):
-        st = one_frame(args.warmup + i)
-        max_drift = max(max_drift, st.max_drift)
-        steps_local += st.accepted_steps
-        integ_ms += st.integrate_ms
-        launches += st.launches
+        one_frame(args.warmup + i, in_loop_profile)
     fence()
     elapsed = time.perf_counter() - t0
+    st, integ_ms, launches = read_stats()
+    steps_local = st.accepted_steps
+    rays_local = st.rays // max(args.steps, 1) if cfg == "c3" else min(n_local, W * H)
+    max_drift = st.max_drift
+    prof_note = "HIP events on the launch stream inside the timed region"
+    if not in_loop_profile:
+        # roofline of this rank's share from profiled frames outside the timed region
+        eng.frame_stats_reset(stream)
+        k = max(args.profile_frames, 1)
+        for i in range(k):
+            render(buf if not overlap else tg.pipelined_view(i, n_local), True)
+        torch.cuda.synchronize()
+        pst, integ_ms, launches = read_stats()
+        prof_steps_per_frame = pst.accepted_steps / k
+        prof_note = "%d profiled frames of rank 0's tile share after the timed loop" % k
+    else:
+        prof_steps_per_frame = steps_local / max(args.steps, 1)
 
-    agg = torch.tensor([elapsed, float(steps_local), float(n_local)], dtype=torch.float64, device="cuda")
+    agg = torch.tensor([elapsed, float(steps_local), float(rays_local)], dtype=torch.float64, device="cuda")
     if use_dist:
         tmax = agg[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(agg[1:], op=dist.ReduceOp.SUM)
         elapsed = float(tmax.item())
     total_steps = float(agg[1].item())
-    total_rays = float(agg[2].item())
+    total_rays = int(agg[2].item()) if cfg == "c3" else W * H
 
     if rank == 0:
         value = total_steps / elapsed / 1e6
-        # roofline of the dominant kernel (integrate_segment_kernel): algorithmic bytes of the
-        # rays this rank integrated per launch / mean HIP-event duration of a launch
-        per_frame_bytes = (steps_local / args.steps) * B_STEP + n_local * B_RAY
-        launches_per_frame = max(launches / args.steps, 1.0)
+        # roofline of the dominant kernel: algorithmic bytes of the rays this rank integrated per
+        # launch / mean HIP-event duration of a launch
+        per_frame_bytes = prof_steps_per_frame * B_STEP[cfg] + rays_local * B_RAY[cfg]
+        frames_prof = args.steps if in_loop_profile else max(args.profile_frames, 1)
+        launches_per_frame = max(launches / frames_prof, 1.0)
         avg_launch_ms = integ_ms / max(launches, 1)
         achieved = (per_frame_bytes / launches_per_frame) / (avg_launch_ms * 1e-3) / 1e9
-        traffic = load_committed_traffic()
+        kernel_pretty = KERNEL_OF[(cfg, args.arith)]
+        pmc, pmc_src = committed_pmc(kernel_pretty, bh.library_path())
+        usable_pmc = pmc if (pmc and world == 1 and not args.segment_tries and
+                             (W, H) == tuple(pmc.get("frame", (W, H)))) else None
+        flops = prof_steps_per_frame * FLOP_STEP[cfg] / launches_per_frame / (avg_launch_ms * 1e-3) / 1e12
+        peak_tf = FP64_PEAK_TFLOPS if cfg == "c3" else FP32_PEAK_TFLOPS
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": (traffic or {}).get("hbm_bytes_per_launch"),
-                    "kernel": "integrate_segment_kernel<KerrSchild,%s,RKF45>" % args.arith.upper(),
+                    "traffic": usable_pmc.get("hbm_bytes_per_launch") if usable_pmc else None,
+                    "traffic_source": pmc_src if usable_pmc or not pmc else
+                    "not applicable to this run (committed pass: 1 GPU, default schedule, %s)" % pmc_src,
+                    "kernel": kernel_pretty,
                     "avg_launch_ms": round(avg_launch_ms, 4),
                     "launches_per_frame": launches_per_frame,
-                    "algorithmic_bytes_per_launch": int(per_frame_bytes / launches_per_frame)}
-        if traffic and "valu" in traffic and args.arith == "fast" and not args.segment_tries:
-            # the honest secondary picture (committed PMC pass): the register-resident kernel is
-            # bound by FP64 VALU issue, not by HBM
-            roofline["valu_issue_frac"] = traffic["valu"]["issue_frac"]
+                    "algorithmic_bytes_per_launch": int(per_frame_bytes / launches_per_frame),
+                    "timing": prof_note,
+                    # what actually bounds the register-resident kernel: vector-ALU issue
+                    "bound_actual": "fp64_valu" if cfg == "c3" else "fp32_valu",
+                    "algorithmic_tflops": round(flops, 2), "peak_tflops": peak_tf,
+                    "flops_frac": round(flops / peak_tf, 4)}
+        if usable_pmc:
+            roofline["hbm_measured_GBps"] = round(usable_pmc["hbm_bytes_per_launch"] / (avg_launch_ms * 1e-3) / 1e9, 1)
+            if "valu" in usable_pmc:
+                roofline["valu_issue_frac"] = usable_pmc["valu"]["issue_frac"]
+        if cfg == "c3":
+            workload = ("%dx%d frame%s, a=0.999 Kerr-Schild, adaptive RKF45 tol=1e-8 h0=0.01 escape=1000 "
+                        "renorm=10 max_steps=2048, Planck LUT 512x64 Tmax=1e5 redshift shading, camera "
+                        "r0=60M theta=97deg fov=60deg"
+                        % (W, H, "" if world == 1 else (" split over %d GPUs" % world if args.scaling == "strong"
+                                                        else " (%dx%d per GPU x %d)" % (base_w, base_h, world))))
+        else:
+            workload = ("%dx%d frame%s, a=0.999, f32 compute march (Kerr-Schild implicit-midpoint, "
+                        "compute.wgsl.ts) at a fixed 1024-step budget, disk g-factor shading + star field, "
+                        "camera r0=60M theta=97deg fov=60deg"
+                        % (W, H, "" if world == 1 else (" split over %d GPUs" % world if args.scaling == "strong"
+                                                        else " (%dx%d per GPU x %d)" % (base_w, base_h, world))))
         line = {
             "metric": "Mray-steps/s", "value": round(value, 2), "unit": "Mray-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%dx%d frame (%dx%d per GPU x %d), a=0.999 Kerr-Schild, adaptive "
-                                   "RKF45 tol=1e-8 h0=0.01 escape=1000 renorm=10 max_steps=2048, "
-                                   "Planck LUT 512x64 Tmax=1e5 redshift shading, camera r0=60M "
-                                   "theta=97deg fov=60deg" % (W, H, args.width, args.height, world),
-                       "arith": args.arith, "segment_tries": args.segment_tries or "auto",
-                       "partition": ("64x64 tiles round-robin, one gather to rank 0 per frame%s"
+            "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "f64" if cfg == "c3" else "f32", "data": "synthetic",
+            "config": {"workload": workload, "baseline_config": "configs[2]" if cfg == "c3" else "configs[3]",
+                       "arith": args.arith, "segment_tries": args.segment_tries or "one launch",
+                       "partition": ("64x64 tiles round-robin, one RCCL gather to rank 0 per frame%s"
                                      % (", overlapped with the next frame" if overlap else ""))
                        if world > 1 else "single GPU",
-                       "rays": int(total_rays), "accepted_steps_per_frame": int(total_steps / args.steps),
-                       "max_hamiltonian_drift_rank0": max_drift},
+                       "rays": total_rays, "accepted_steps_per_frame": int(total_steps / args.steps),
+                       "host_waits_in_frame_loop": 0 if not args.segment_tries else "one per segment"},
             "roofline": roofline,
         }
+        if cfg == "c3":
+            line["config"]["max_hamiltonian_drift_rank0"] = max_drift
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.width, args.height, eye)
+            line["cpu_baseline"] = (cpu_baseline_c3(base_w, base_h, eye) if cfg == "c3"
+                                    else cpu_baseline_c4(wp, base_w, base_h))
         sys.stdout.flush()
         os.dup2(stdout_fd, 1)
         print(json.dumps(line), flush=True)

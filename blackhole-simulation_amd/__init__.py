@@ -6,7 +6,7 @@ of include/gravitas_abi.h.  All compute runs in libgravitas_hip.so on the GPU;
 there is no CPU fallback in this package.
 """
 from .engine import (  # noqa: F401
-    ARITH_FAST, ARITH_STRICT, KERR_BL, KERR_KS, METHOD_RK4, METHOD_RKF45, METHOD_SYMPLECTIC,
+    ARITH_FAST, ARITH_FAST_PACKED, ARITH_STRICT, DISK_PROFILE_PAGE_THORNE, DISK_PROFILE_SHORTCUT, KERR_BL, KERR_KS, METHOD_RK4, METHOD_RKF45, METHOD_SYMPLECTIC,
     SCHWARZSCHILD, TERM_DISK_CROSSING, TERM_ESCAPE, TERM_HORIZON, TERM_MAXSTEPS, TERM_NONE,
     Camera, FrameBuffers, FrameStats, GlslParams, GravitasError, Options, PhysicsEngine,
     RenderParams, WgslParams, build_library, camera_look_at, glsl_params, library_path,

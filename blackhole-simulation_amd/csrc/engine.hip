@@ -3,6 +3,8 @@
 #include "engine_internal.hpp"
 #include "strict_libm.hpp"
 
+#include <chrono>
+
 namespace grvhost {
 
 // ---------------------------------------------------------------------------
@@ -197,24 +199,31 @@ hipError_t launch_refill(int arith, int kind, int method, const RayWorkspace &ws
 // tries between two refill checks of a wave in the refill kernel
 constexpr uint32_t kRefillPeriod = 8;
 
-// Runs segments until no ray is live.  The workspace must have been initialised;
-// the first launch walks every slot (identity live list), later launches walk the
-// compacted list the previous one appended.
+// One integrate pass over the initialised workspace.
+//   seg_tries == 0 (default): ONE launch that runs every ray to its end.  A ray always ends: each
+//     completed step costs a bounded number of tries (a reject shrinks |h| by >= 10 % and the
+//     forced 1e-5 step of integrator.rs:99-104 is taken unconditionally) and steps <= max_steps,
+//     so the kernel needs no try budget, no live list, no counter read-back -- and the host does
+//     not wait for it: the call returns with the work queued on `s`.
+//   seg_tries  > 0: the compacting wavefront schedule.  Every launch appends its survivors to the
+//     next live list; the host reads the count back (one stream synchronise per launch) to size
+//     the next launch.  Results are bitwise those of the single launch.
 int run_segments(grv_engine *e, const GrvOptions &o, SegmentParams P, uint32_t seg_tries,
                  hipStream_t s, bool profile) {
-    if (seg_tries == 0) seg_tries = 4096;
+    if (seg_tries == 0) {
+        P.max_tries = 0xFFFFFFFFu;
+        GRV_HIP(e, launch_segment(o.arith, o.metric_kind, o.method, e->ws, P, nullptr, e->ws.n,
+                                  nullptr, nullptr, s));
+        e->last_launches += 1;
+        return GRV_OK;
+    }
     P.max_tries = seg_tries;
     uint32_t n_live = e->ws.n;
     const uint32_t *live_in = nullptr;
     int cur = 0;
-    e->last_launches = 0;
-    // every live ray completes a step within <= 9 tries (<= 7 shrinks by >= 10x from
-    // |h| <= 10 down to the forced 1e-5 step), so this bound is never reached.
-    const uint64_t hard_cap = ((uint64_t)P.max_steps * 9ull) / seg_tries + 4ull;
     float integ_ms = 0.f;
+    GRV_HIP(e, hipMemsetAsync(e->d_counters, 0, 4 * sizeof(uint32_t), s));
     while (n_live > 0) {
-        if (e->last_launches > hard_cap)
-            return fail(e, GRV_ERR_HIP, "segment loop exceeded its bound (%u live)", n_live);
         const int nxt = cur ^ 1;
         GRV_HIP(e, hipMemsetAsync(e->d_counters + nxt, 0, sizeof(uint32_t), s));
         if (profile) GRV_HIP(e, hipEventRecord(e->ev[2], s));
@@ -234,7 +243,56 @@ int run_segments(grv_engine *e, const GrvOptions &o, SegmentParams P, uint32_t s
         cur = nxt;
         e->last_launches++;
     }
-    e->last_ms[1] = integ_ms;
+    e->last_ms[1] += integ_ms;
+    return GRV_OK;
+}
+
+// Start of a frame / batch: clear the device counters unless the caller accumulates them.
+int begin_frame_stats(grv_engine *e, hipStream_t s) {
+    if (e->stats_accum) return GRV_OK;
+    GRV_HIP(e, hipMemsetAsync(e->d_stats, 0, sizeof(FrameStatsDev), s));
+    for (float &m : e->last_ms) m = 0.f;
+    e->last_launches = 0;
+    e->ev_frames = 0; // unresolved events of earlier frames describe counters that are gone
+    return GRV_OK;
+}
+
+// Four events of the next profiled frame from the ring (created on demand).  When the ring is
+// full the pending frames are resolved first (one synchronise every kEvRingFrames frames).
+constexpr size_t kEvRingFrames = 1024;
+static int ring_events(grv_engine *e, hipEvent_t **ev4) {
+    if (e->ev_frames >= kEvRingFrames) {
+        const int rc = resolve_frame_events(e);
+        if (rc != GRV_OK) return rc;
+    }
+    const size_t need = (e->ev_frames + 1) * 4;
+    while (e->ev_ring.size() < need) {
+        hipEvent_t ev;
+        GRV_HIP(e, hipEventCreate(&ev));
+        e->ev_ring.push_back(ev);
+    }
+    *ev4 = e->ev_ring.data() + e->ev_frames * 4;
+    return GRV_OK;
+}
+
+// Adds the elapsed times of the pending profiled frames to last_ms (blocks until the last of
+// their events has completed).  Called by grv_frame_stats, never by a frame call.
+int resolve_frame_events(grv_engine *e) {
+    if (e->ev_frames == 0) return GRV_OK;
+    GRV_HIP(e, hipEventSynchronize(e->ev_ring[e->ev_frames * 4 - 1]));
+    for (size_t f = 0; f < e->ev_frames; ++f) {
+        hipEvent_t *q = e->ev_ring.data() + f * 4;
+        float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
+        GRV_HIP(e, hipEventElapsedTime(&a, q[0], q[1]));
+        GRV_HIP(e, hipEventElapsedTime(&b, q[1], q[2]));
+        GRV_HIP(e, hipEventElapsedTime(&c, q[2], q[3]));
+        GRV_HIP(e, hipEventElapsedTime(&d, q[0], q[3]));
+        e->last_ms[0] += a;
+        if (!(f < e->ev_loop.size() && e->ev_loop[f])) e->last_ms[1] += b;
+        e->last_ms[3] += c;
+        e->last_ms[4] += d;
+    }
+    e->ev_frames = 0;
     return GRV_OK;
 }
 
@@ -316,6 +374,9 @@ int grv_engine_create(double mass, double spin, int device, grv_engine **out) {
     if (hipHostMalloc(reinterpret_cast<void **>(&e->h_counters), 4 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return bail(GRV_ERR_OOM);
     if (hipHostMalloc(reinterpret_cast<void **>(&e->h_stats), sizeof(FrameStatsDev), hipHostMallocDefault) != hipSuccess) return bail(GRV_ERR_OOM);
     std::memset(e->h_stats, 0, sizeof(FrameStatsDev));
+    if (hipHostMalloc(reinterpret_cast<void **>(&e->ray_out), sizeof(SingleRayOut), hipHostMallocDefault) != hipSuccess) return bail(GRV_ERR_OOM);
+    std::memset(e->ray_out, 0, sizeof(SingleRayOut));
+    if (hipStreamCreateWithFlags(&e->ray_stream, hipStreamNonBlocking) != hipSuccess) return bail(GRV_ERR_HIP);
     e->ev_ok = true;
     for (auto &ev : e->ev)
         if (hipEventCreate(&ev) != hipSuccess) e->ev_ok = false;
@@ -336,8 +397,14 @@ void grv_engine_destroy(grv_engine *e) {
     if (e->d_stats) (void)hipFree(e->d_stats);
     if (e->h_counters) (void)hipHostFree(e->h_counters);
     if (e->h_stats) (void)hipHostFree(e->h_stats);
+    if (e->ray_stream) {
+        (void)hipStreamSynchronize(e->ray_stream);
+        (void)hipStreamDestroy(e->ray_stream);
+    }
+    if (e->ray_out) (void)hipHostFree(e->ray_out);
     if (e->ev_ok)
         for (auto &ev : e->ev) (void)hipEventDestroy(ev);
+    for (auto &ev : e->ev_ring) (void)hipEventDestroy(ev);
     delete e;
 }
 
@@ -387,7 +454,8 @@ int grv_integrate_batch_device(grv_engine *e, size_t n, const double *d_states,
     if (rc != GRV_OK) return rc;
     SegmentParams P = make_segment_params(e, *opt);
     GRV_HIP(e, hipMemsetAsync(e->d_counters, 0, 4 * sizeof(uint32_t), s));
-    GRV_HIP(e, hipMemsetAsync(e->d_stats, 0, sizeof(FrameStatsDev), s));
+    rc = begin_frame_stats(e, s);
+    if (rc != GRV_OK) return rc;
     GRV_HIP(e, launch_init_states(opt->metric_kind, e->ws, P, d_states, opt->initial_step,
                                   opt->method == GRV_METHOD_RKF45, s));
     // independent rays diverge freely in a batch.  Default: one resident launch whose waves
@@ -400,7 +468,7 @@ int grv_integrate_batch_device(grv_engine *e, size_t n, const double *d_states,
         P.max_tries = opt->segment_tries < 0 ? (uint32_t)(-(int64_t)opt->segment_tries) : kRefillPeriod;
         GRV_HIP(e, launch_refill(opt->arith, opt->metric_kind, opt->method, e->ws, P,
                                  e->d_counters + 2, e->n_cu, s));
-        e->last_launches = 1;
+        e->last_launches += 1;
     }
     GRV_HIP(e, launch_finalize_batch(e->ws, d_out_states, d_steps, d_termination, d_drift,
                                      e->d_stats, s));
@@ -434,9 +502,14 @@ int grv_integrate_batch(grv_engine *e, size_t n, const double *states, const Grv
     return GRV_OK;
 }
 
-size_t grv_integrate_ray_relativistic(grv_engine *e, const double *initial_state, size_t n,
-                                      size_t steps, double tolerance, int use_kerr_schild,
-                                      double *out) {
+// One geodesic = one launch: the state travels in the kernel arguments, the kernel runs
+// init + integrate + write-back (single_ray_kernel) and stores the result in pinned host memory,
+// then the call's sequence number; the host polls that word instead of synchronising the stream
+// (a completion signal costs more than the PCIe write).  No workspace, no staging copies.
+size_t grv_integrate_ray_relativistic_ex(grv_engine *e, const double *initial_state, size_t n,
+                                         size_t steps, double tolerance, int use_kerr_schild,
+                                         double *out, uint32_t *steps_taken, uint8_t *termination,
+                                         double *max_drift) {
     if (!e || !initial_state || !out) return 0;
     if (n < 8) { // lib.rs:429-431
         for (size_t i = 0; i < n; ++i) out[i] = initial_state[i];
@@ -452,15 +525,48 @@ size_t grv_integrate_ray_relativistic(grv_engine *e, const double *initial_state
     o.escape_radius = 1000.0;
     o.renormalize_interval = 10;
     o.arith = GRV_ARITH_STRICT;
-    double res[8];
-    if (grv_integrate_batch(e, 1, initial_state, &o, res, nullptr, nullptr, nullptr) != GRV_OK) {
-        // no Result in the reference FFI: hand back NaNs so the caller's finite-guard
-        // (src/engine/physics-bridge.ts:174-180) trips; the error text stays on the handle
+    // no Result in the reference FFI: on any failure hand back NaNs so the caller's finite-guard
+    // (src/engine/physics-bridge.ts:174-180) trips; the error text stays on the handle
+    auto nan_out = [&](const char *why, hipError_t st) {
+        fail(e, GRV_ERR_HIP, "integrate_ray_relativistic: %s: %s", why, hipGetErrorString(st));
         for (int i = 0; i < 8; ++i) out[i] = std::nan("");
-        return 8;
+        return (size_t)8;
+    };
+    hipError_t st = hipSetDevice(e->device);
+    if (st != hipSuccess) return nan_out("hipSetDevice", st);
+    SegmentParams P = make_segment_params(e, o);
+    SingleRayIn in;
+    std::memcpy(in.v, initial_state, sizeof in.v);
+    const uint32_t seq = ++e->ray_seq ? e->ray_seq : ++e->ray_seq; // never 0 (the block starts zeroed)
+    st = launch_single_ray(o.metric_kind, P, in, o.initial_step, e->ray_out, seq, e->ray_stream);
+    if (st != hipSuccess) return nan_out("launch", st);
+    // poll the sequence word; a ray that runs for seconds falls back to a blocking wait
+    const uint32_t *flag = &e->ray_out->seq;
+    bool done = false;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spin = 1; !done; ++spin) {
+        done = __atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq;
+        if (!done && (spin & 0x3FFu) == 0u &&
+            std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200))
+            break;
     }
-    std::memcpy(out, res, sizeof res);
+    if (!done) {
+        st = hipStreamSynchronize(e->ray_stream);
+        if (st != hipSuccess) return nan_out("hipStreamSynchronize", st);
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) return nan_out("no result", hipErrorUnknown);
+    }
+    std::memcpy(out, e->ray_out->state, 8 * sizeof(double));
+    if (steps_taken) *steps_taken = e->ray_out->steps;
+    if (termination) *termination = (uint8_t)e->ray_out->term;
+    if (max_drift) *max_drift = e->ray_out->drift;
     return 8;
+}
+
+size_t grv_integrate_ray_relativistic(grv_engine *e, const double *initial_state, size_t n,
+                                      size_t steps, double tolerance, int use_kerr_schild,
+                                      double *out) {
+    return grv_integrate_ray_relativistic_ex(e, initial_state, n, steps, tolerance, use_kerr_schild,
+                                             out, nullptr, nullptr, nullptr);
 }
 
 size_t grv_frame_ray_count(const GrvRenderParams *p) {
@@ -492,6 +598,8 @@ void grv_render_params_default(uint32_t width, uint32_t height, GrvRenderParams 
     p->tile_rank = 0;
     p->segment_tries = 0;
     p->profile = 0;
+    p->disk_profile = GRV_DISK_PROFILE_SHORTCUT;
+    p->reserved1 = 0;
 }
 
 int grv_render_frame_device(grv_engine *e, const GrvCamera *cam, const GrvRenderParams *p,
@@ -500,8 +608,9 @@ int grv_render_frame_device(grv_engine *e, const GrvCamera *cam, const GrvRender
     if (!cam || !p || !out) return fail(e, GRV_ERR_INVALID, "null argument");
     if (!options_valid(p->opt)) return fail(e, GRV_ERR_INVALID, "invalid GrvOptions");
     if (p->width == 0 || p->height == 0) return fail(e, GRV_ERR_INVALID, "empty frame");
-    if (p->reserved0 != 0) return fail(e, GRV_ERR_INVALID, "reserved field must be 0");
-    if (p->tile_world > 1 && p->tile_rank >= p->tile_world) return fail(e, GRV_ERR_INVALID, "tile_rank >= tile_world");
+    if (p->reserved0 != 0 || p->reserved1 != 0) return fail(e, GRV_ERR_INVALID, "reserved field must be 0");
+    if (p->tile_world >= 1 && p->tile_rank >= p->tile_world) return fail(e, GRV_ERR_INVALID, "tile_rank >= tile_world"); // 0 = whole frame
+    if (p->disk_profile > GRV_DISK_PROFILE_PAGE_THORNE) return fail(e, GRV_ERR_INVALID, "unknown disk_profile");
     hipStream_t s = static_cast<hipStream_t>(stream);
     GRV_HIP(e, hipSetDevice(e->device));
     const bool profile = p->profile != 0 && e->ev_ok;
@@ -509,13 +618,11 @@ int grv_render_frame_device(grv_engine *e, const GrvCamera *cam, const GrvRender
     FrameGeom G;
     frame_geometry(*p, G);
     const size_t slots = (size_t)G.n_tiles_local * 4096u;
-    for (float &m : e->last_ms) m = 0.f;
-    e->last_launches = 0;
-    GRV_HIP(e, hipMemsetAsync(e->d_counters, 0, 4 * sizeof(uint32_t), s));
-    GRV_HIP(e, hipMemsetAsync(e->d_stats, 0, sizeof(FrameStatsDev), s));
+    int rc = begin_frame_stats(e, s);
+    if (rc != GRV_OK) return rc;
     if (slots == 0) return GRV_OK;
     if (slots > 0x7FFFFFFFull) return fail(e, GRV_ERR_INVALID, "frame too large for one rank");
-    int rc = ensure_workspace(e, slots);
+    rc = ensure_workspace(e, slots);
     if (rc != GRV_OK) return rc;
 
     SegmentParams P = make_segment_params(e, p->opt);
@@ -562,10 +669,17 @@ int grv_render_frame_device(grv_engine *e, const GrvCamera *cam, const GrvRender
         cd.cp = strictm::sl_cos(cd.phi0);
     }
 
-    if (profile) GRV_HIP(e, hipEventRecord(e->ev[0], s));
+    // profile: four events around the three kernels of the frame, recorded on `s` and resolved
+    // by grv_frame_stats -- nothing here waits for the device
+    hipEvent_t *ev4 = nullptr;
+    if (profile) {
+        rc = ring_events(e, &ev4);
+        if (rc != GRV_OK) return rc;
+        GRV_HIP(e, hipEventRecord(ev4[0], s));
+    }
     GRV_HIP(e, launch_init_pixels(p->opt.metric_kind, e->ws, P, G, cd, p->opt.initial_step,
                                   p->opt.method == GRV_METHOD_RKF45, s));
-    if (profile) GRV_HIP(e, hipEventRecord(e->ev[1], s));
+    if (profile) GRV_HIP(e, hipEventRecord(ev4[1], s));
     // neighbouring pixels take near-identical step counts (8x8-pixel waves run at >99 %
     // lane efficiency at 4K), so the frame default is one long segment; segment_tries
     // selects the compacting wavefront form
@@ -593,16 +707,17 @@ int grv_render_frame_device(grv_engine *e, const GrvCamera *cam, const GrvRender
         if ((uint32_t)r0 + S.lds_rows > S.lut_h) r0 = (int)(S.lut_h - S.lds_rows);
         S.lds_row0 = (uint32_t)r0;
     }
-    if (profile) GRV_HIP(e, hipEventRecord(e->ev[4], s));
+    if (profile) GRV_HIP(e, hipEventRecord(ev4[2], s));
     GRV_HIP(e, launch_finalize_frame(e->ws, G, S, p->shading, e->d_lut, out->rgba,
                                      out->final_state, out->steps, out->termination, out->drift,
                                      e->d_stats, e->n_cu, s));
     if (profile) {
-        GRV_HIP(e, hipEventRecord(e->ev[5], s));
-        GRV_HIP(e, hipEventSynchronize(e->ev[5]));
-        GRV_HIP(e, hipEventElapsedTime(&e->last_ms[0], e->ev[0], e->ev[1]));
-        GRV_HIP(e, hipEventElapsedTime(&e->last_ms[3], e->ev[4], e->ev[5]));
-        GRV_HIP(e, hipEventElapsedTime(&e->last_ms[4], e->ev[0], e->ev[5]));
+        GRV_HIP(e, hipEventRecord(ev4[3], s));
+        // the segment-loop schedule timed its launches one by one (it synchronises anyway): the
+        // ring's before-integrate..before-shade interval would count its host gaps as well
+        e->ev_loop.resize(e->ev_frames + 1);
+        e->ev_loop[e->ev_frames] = p->segment_tries != 0;
+        e->ev_frames += 1;
     }
     return GRV_OK;
 }
@@ -613,7 +728,26 @@ int grv_frame_stats(grv_engine *e, void *stream, GrvFrameStats *stats) {
     GRV_HIP(e, hipSetDevice(e->device));
     GRV_HIP(e, hipMemcpyAsync(e->h_stats, e->d_stats, sizeof(FrameStatsDev), hipMemcpyDeviceToHost, s));
     GRV_HIP(e, hipStreamSynchronize(s));
+    const int rc = resolve_frame_events(e);
+    if (rc != GRV_OK) return rc;
     stats_to_abi(e, *e->h_stats, stats);
+    return GRV_OK;
+}
+
+int grv_stats_accumulate(grv_engine *e, int enable) {
+    if (!e) return GRV_ERR_INVALID;
+    e->stats_accum = enable != 0;
+    return GRV_OK;
+}
+
+int grv_frame_stats_reset(grv_engine *e, void *stream) {
+    if (!e) return GRV_ERR_INVALID;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    GRV_HIP(e, hipSetDevice(e->device));
+    GRV_HIP(e, hipMemsetAsync(e->d_stats, 0, sizeof(FrameStatsDev), s));
+    for (float &m : e->last_ms) m = 0.f;
+    e->last_launches = 0;
+    e->ev_frames = 0;
     return GRV_OK;
 }
 

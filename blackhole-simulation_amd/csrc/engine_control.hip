@@ -138,10 +138,15 @@ double grv_compute_disk_flux(const grv_engine *e, double r) {
 
 double grv_compute_shadow_radius(const grv_engine *e) { return schwarzschild_shadow_radius_host(e->mass); }
 
-size_t grv_compute_shadow_curve(const grv_engine *e, double theta_obs, size_t n_points, float *out) {
-    if (!e || !out) return 0;
+size_t grv_compute_shadow_curve(const grv_engine *e, double theta_obs, size_t n_points, float *out,
+                                size_t out_capacity) {
+    if (!e) return 0;
     const std::vector<double> c = bardeen_shadow_host(e->mass, e->spin_c, theta_obs, n_points);
-    for (size_t i = 0; i < c.size(); ++i) out[i] = (float)c[i];
+    if (out) {
+        size_t n = c.size() < out_capacity ? c.size() : out_capacity;
+        n &= ~(size_t)1; // whole (alpha, beta) pairs
+        for (size_t i = 0; i < n; ++i) out[i] = (float)c[i];
+    }
     return c.size() / 2;
 }
 

@@ -41,6 +41,12 @@ struct grv_engine {
     uint32_t *h_counters = nullptr; // pinned
     grvhip::FrameStatsDev *h_stats = nullptr; // pinned
 
+    // single-ray entry (grv_integrate_ray_relativistic): its own non-blocking stream and a pinned
+    // result block the kernel writes and the host polls
+    hipStream_t ray_stream = nullptr;
+    grvhip::SingleRayOut *ray_out = nullptr; // pinned, host-coherent
+    uint32_t ray_seq = 0;
+
     // staging buffers for host-pointer entry points
     void *stage_mem = nullptr;
     size_t stage_bytes = 0;
@@ -50,11 +56,19 @@ struct grv_engine {
     uint32_t lut_w = 0, lut_h = 0;
     double lut_tmax = 0.0;
 
-    // last-frame bookkeeping
-    uint32_t last_launches = 0;
-    float last_ms[5] = {0, 0, 0, 0, 0};
-    hipEvent_t ev[8] = {};
+    // frame bookkeeping.  Counters live on the device (d_stats) and are read by grv_frame_stats
+    // only; with stats_accum they are not cleared between frames (grv_stats_accumulate), so a
+    // frame loop needs no host round trip at all.  profile=1 frames take four events from a ring
+    // (before init | before integrate | before shade | after shade); their elapsed times are
+    // resolved when the statistics are read, never inside the frame call.
+    bool stats_accum = false;
+    uint32_t last_launches = 0;      // integrate launches since the counters were last cleared
+    float last_ms[5] = {0, 0, 0, 0, 0}; // init, integrate, compact, shade, total (resolved events)
+    hipEvent_t ev[8] = {};           // blocking per-launch timing of the segment-loop schedule
     bool ev_ok = false;
+    std::vector<hipEvent_t> ev_ring; // 4 per profiled frame, created on demand
+    size_t ev_frames = 0;            // profiled frames whose events are still unresolved
+    std::vector<uint8_t> ev_loop;    // per pending frame: integrate was timed launch by launch
 
     // renderer layer (grv_webgpu_render / grv_webgl_render): full-size RGBA f32 targets
     struct Targets {
@@ -102,6 +116,8 @@ SegmentParams make_segment_params(const grv_engine *e, const GrvOptions &o);
 bool options_valid(const GrvOptions &o);
 int run_segments(grv_engine *e, const GrvOptions &o, SegmentParams P, uint32_t seg_tries, hipStream_t s,
                  bool profile);
+int begin_frame_stats(grv_engine *e, hipStream_t s);
+int resolve_frame_events(grv_engine *e);
 void frame_geometry(const GrvRenderParams &p, FrameGeom &G);
 void stats_to_abi(const grv_engine *e, const FrameStatsDev &d, GrvFrameStats *out);
 
@@ -112,7 +128,7 @@ template <typename Launch>
 int run_shader_frame(grv_engine *e, uint32_t width, uint32_t height, uint32_t tw, uint32_t tr,
                      uint64_t *total_steps, hipStream_t s, Launch &&launch) {
     if (width == 0 || height == 0) return fail(e, GRV_ERR_INVALID, "empty frame");
-    if (tw > 1 && tr >= tw) return fail(e, GRV_ERR_INVALID, "tile_rank >= tile_world");
+    if (tw >= 1 && tr >= tw) return fail(e, GRV_ERR_INVALID, "tile_rank >= tile_world"); // 0 = whole frame
     GRV_HIP(e, hipSetDevice(e->device));
     GrvRenderParams q{};
     q.width = width;
@@ -122,7 +138,10 @@ int run_shader_frame(grv_engine *e, uint32_t width, uint32_t height, uint32_t tw
     FrameGeom G;
     frame_geometry(q, G);
     const size_t slots = (size_t)G.n_tiles_local * 4096u;
-    GRV_HIP(e, hipMemsetAsync(e->d_stats, 0, sizeof(FrameStatsDev), s));
+    {
+        const int rc = begin_frame_stats(e, s);
+        if (rc != GRV_OK) return rc;
+    }
     if (slots > 0x7FFFFFFFull) return fail(e, GRV_ERR_INVALID, "frame too large for one rank");
     GRV_HIP(e, launch(G, (uint32_t)slots, &e->d_stats->accepted_steps));
     if (total_steps) {

@@ -97,6 +97,17 @@ struct GlslParams {
     const uint8_t *blue_r;  // 256x256 R channel of u_blueNoiseTex (device)
 };
 
+// single-ray entry (grv_integrate_ray_relativistic): arguments by value, result in pinned host memory
+struct SingleRayIn {
+    double v[8]; // GeodesicState: t, r, theta, phi, p_t, p_r, p_theta, p_phi (geodesic/mod.rs:23-30)
+};
+struct SingleRayOut {
+    double state[8];
+    double drift;
+    uint32_t steps, tries, term;
+    uint32_t seq; // written last (system scope): the call's sequence number
+};
+
 struct FrameStatsDev {
     unsigned long long accepted_steps, rkf_tries, term_count[5], crossings, rays;
     unsigned long long max_drift_bits;
@@ -109,6 +120,8 @@ hipError_t launch_segment_strict(int kind, int method, const RayWorkspace &ws,
                                  uint32_t *live_out, uint32_t *live_out_count, hipStream_t s);
 hipError_t launch_refill_strict(int kind, int method, const RayWorkspace &ws, const SegmentParams &P,
                                 uint32_t *cursor, int n_cu, hipStream_t s);
+hipError_t launch_single_ray(int kind, const SegmentParams &P, const SingleRayIn &in, double h0,
+                             SingleRayOut *out_pinned, uint32_t seq, hipStream_t s);
 hipError_t launch_init_states(int kind, const RayWorkspace &ws, const SegmentParams &P,
                               const double *states, double h0, int adaptive, hipStream_t s);
 hipError_t launch_init_pixels(int kind, const RayWorkspace &ws, const SegmentParams &P,

@@ -532,6 +532,55 @@ void integrate_refill_kernel(RayWorkspace ws, SegmentParams P,
 }
 
 // ---------------------------------------------------------------------------
+// The single-ray kernel: the whole of integrate_ray_relativistic (lib.rs:422-464) for ONE
+// geodesic in one launch.  The initial state arrives in the kernel arguments (no upload), lane 0
+// runs ray_begin + the try loop in registers, and the end state goes straight to a block of
+// pinned host memory, followed by the call's sequence number (system-scope release) that the host
+// is polling -- no workspace, no copies, no second launch.  Same advance_one as every other
+// schedule, so the result is bitwise that of a 1-ray batch.
+// ---------------------------------------------------------------------------
+template <int KIND, int ARITH>
+__global__ __launch_bounds__(64) void single_ray_kernel(SegmentParams P, SingleRayIn in, double h0,
+                                                        SingleRayOut *out, uint32_t seq) {
+    if (threadIdx.x != 0) return;
+    RayRegs y;
+    y.t = in.v[0];
+    y.r = in.v[1];
+    y.th = in.v[2];
+    y.ph = in.v[3];
+    y.pt = in.v[4];
+    y.pr = in.v[5];
+    y.pth = in.v[6];
+    y.pph = in.v[7];
+    y.h = h0;
+    y.drift = 0.0;
+    y.steps = 0;
+    y.tries = 0;
+    y.flags = kFlagValid;
+    const Hole<double> bh{P.M, P.a, P.a2, 2.0 * P.M};
+    ray_begin<KIND>(bh, y, P, true);
+    bool live = ray_live(y);
+    KsRayConsts rc;
+    ray_resume<KIND, ARITH>(bh, y, P, live, rc);
+    RayWorkspace ws{}; // only the crossing recorder writes to it, and P.shading == 0 here
+    while (live) live = advance_one<KIND, ARITH, GRV_METHOD_RKF45>(bh, y, P, ws, 0u, rc);
+    out->state[0] = y.t;
+    out->state[1] = y.r;
+    out->state[2] = y.th;
+    out->state[3] = y.ph;
+    out->state[4] = y.pt;
+    out->state[5] = y.pr;
+    out->state[6] = y.pth;
+    out->state[7] = y.pph;
+    out->drift = y.drift;
+    out->steps = y.steps;
+    out->tries = y.tries;
+    out->term = y.flags & kFlagTermMask;
+    __threadfence_system();
+    __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// ---------------------------------------------------------------------------
 // init kernels
 // ---------------------------------------------------------------------------
 // batch: AoS GeodesicState [n][8] -> SoA workspace (geodesic/mod.rs:23-30 layout)

@@ -50,6 +50,23 @@ hipError_t launch_segment_strict(int kind, int method, const RayWorkspace &ws,
 #undef GRV_REFILL_ARITH
 #undef GRV_REFILL_FN
 
+hipError_t launch_single_ray(int kind, const SegmentParams &P, const SingleRayIn &in, double h0,
+                             SingleRayOut *out_pinned, uint32_t seq, hipStream_t s) {
+    switch (kind) {
+    case GRV_METRIC_KERR_KS:
+        hipLaunchKernelGGL((single_ray_kernel<GRV_METRIC_KERR_KS, GRV_ARITH_STRICT>), dim3(1), dim3(64), 0, s, P, in, h0, out_pinned, seq);
+        break;
+    case GRV_METRIC_KERR_BL:
+        hipLaunchKernelGGL((single_ray_kernel<GRV_METRIC_KERR_BL, GRV_ARITH_STRICT>), dim3(1), dim3(64), 0, s, P, in, h0, out_pinned, seq);
+        break;
+    case GRV_METRIC_SCHWARZSCHILD:
+        hipLaunchKernelGGL((single_ray_kernel<GRV_METRIC_SCHWARZSCHILD, GRV_ARITH_STRICT>), dim3(1), dim3(64), 0, s, P, in, h0, out_pinned, seq);
+        break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_init_states(int kind, const RayWorkspace &ws, const SegmentParams &P,
                               const double *states, double h0, int adaptive, hipStream_t s) {
     const uint32_t grid = (ws.n + kBlock - 1) / kBlock;

@@ -110,6 +110,12 @@ class TileGather:
         if self.rank != 0:
             return None
         parts = self.parts if collective else [buf]
+        if self.world <= 1:
+            # a whole-frame render (tile_world <= 1) is already row-major (gravitas_abi.h,
+            # GrvFrameBuffers): nothing to de-interleave, the image is the first H*W pixels
+            n = self.params.height * self.params.width
+            self.image.view(n, -1).copy_(parts[0][:n])
+            return self.image
         for r in range(self.world):
             unpack(self.rparams[r], r, parts[r], self.image)
         return self.image

@@ -17,7 +17,8 @@ _LIB = os.path.join(_HERE, "libgravitas_hip.so")
 
 KERR_BL, KERR_KS, SCHWARZSCHILD = 0, 1, 2
 METHOD_RKF45, METHOD_RK4, METHOD_SYMPLECTIC = 0, 1, 2
-ARITH_STRICT, ARITH_FAST = 0, 1
+ARITH_STRICT, ARITH_FAST, ARITH_FAST_PACKED = 0, 1, 2
+DISK_PROFILE_SHORTCUT, DISK_PROFILE_PAGE_THORNE = 0, 1
 MATH_SINCOS_SIN, MATH_SINCOS_COS, MATH_SIN, MATH_COS, MATH_POW, MATH_EXP, MATH_ATAN = 0, 1, 2, 3, 4, 5, 6
 MATH_LOG, MATH_ACOS, MATH_ATAN2, MATH_F32 = 7, 8, 9, 16
 TERM_NONE, TERM_HORIZON, TERM_ESCAPE, TERM_MAXSTEPS, TERM_DISK_CROSSING = 0, 1, 2, 3, 4
@@ -49,7 +50,7 @@ class RenderParams(C.Structure):
                 ("lut_width", C.c_uint32), ("lut_height", C.c_uint32),
                 ("lut_max_temp", C.c_double), ("tile_world", C.c_uint32),
                 ("tile_rank", C.c_uint32), ("segment_tries", C.c_uint32),
-                ("profile", C.c_uint32)]
+                ("profile", C.c_uint32), ("disk_profile", C.c_uint32), ("reserved1", C.c_uint32)]
 
 
 class FrameStats(C.Structure):
@@ -178,6 +179,12 @@ def load_library():
                                           C.POINTER(FrameBuffers), p]
     L.grv_frame_stats.restype = i
     L.grv_frame_stats.argtypes = [p, p, C.POINTER(FrameStats)]
+    L.grv_stats_accumulate.restype = i
+    L.grv_stats_accumulate.argtypes = [p, i]
+    L.grv_frame_stats_reset.restype = i
+    L.grv_frame_stats_reset.argtypes = [p, p]
+    L.grv_integrate_ray_relativistic_ex.restype = sz
+    L.grv_integrate_ray_relativistic_ex.argtypes = [p, p, sz, sz, d, i, p, p, p, p]
     L.grv_unpack_tiles.restype = i
     L.grv_unpack_tiles.argtypes = [C.POINTER(RenderParams), C.c_uint32, p, p, sz]
     L.grv_unpack_tiles_device.restype = i
@@ -225,7 +232,7 @@ def load_library():
     L.grv_compute_disk_flux.restype = d
     L.grv_compute_disk_flux.argtypes = [p, d]
     L.grv_compute_shadow_curve.restype = sz
-    L.grv_compute_shadow_curve.argtypes = [p, d, sz, p]
+    L.grv_compute_shadow_curve.argtypes = [p, d, sz, p, sz]
     L.grv_compute_shadow_radius.restype = d
     L.grv_compute_shadow_radius.argtypes = [p]
     L.grv_compute_shadow_shift.restype = i
@@ -465,21 +472,25 @@ class PhysicsEngine:
             self._h, C.byref(camera), C.byref(params), C.byref(fb),
             C.c_void_p(stream) if stream else None), "render_frame_device")
 
-    def render_frame_wgsl(self, params, rgba, steps=None, stream=None):
-        """f32 WGSL-semantics frame (compute.wgsl.ts); returns total symplectic steps."""
+    def render_frame_wgsl(self, params, rgba, steps=None, stream=None, want_total=True):
+        """f32 WGSL-semantics frame (compute.wgsl.ts); returns total symplectic steps.
+        want_total=False queues the frame without waiting (the count stays in the device-side
+        counters, see stats_accumulate / frame_stats) and returns None."""
         tot = C.c_uint64(0)
         self._check(self._lib.grv_render_frame_wgsl(
-            self._h, C.byref(params), _dev_ptr(rgba), _dev_ptr(steps), C.byref(tot),
+            self._h, C.byref(params), _dev_ptr(rgba), _dev_ptr(steps),
+            C.byref(tot) if want_total else None,
             C.c_void_p(stream) if stream else None), "render_frame_wgsl")
-        return tot.value
+        return tot.value if want_total else None
 
-    def render_frame_glsl(self, params, rgba, steps=None, stream=None):
+    def render_frame_glsl(self, params, rgba, steps=None, stream=None, want_total=True):
         """f32 GLSL-semantics frame (fragment.glsl.ts march); returns total Verlet steps."""
         tot = C.c_uint64(0)
         self._check(self._lib.grv_render_frame_glsl(
-            self._h, C.byref(params), _dev_ptr(rgba), _dev_ptr(steps), C.byref(tot),
+            self._h, C.byref(params), _dev_ptr(rgba), _dev_ptr(steps),
+            C.byref(tot) if want_total else None,
             C.c_void_p(stream) if stream else None), "render_frame_glsl")
-        return tot.value
+        return tot.value if want_total else None
 
     def set_glsl_noise(self, noise_rgba8=None, blue_rgba8=None):
         """Override the shader's 256x256 RGBA8 noise / blue-noise textures (None keeps one)."""
@@ -539,6 +550,15 @@ class PhysicsEngine:
                                               C.byref(st)), "frame_stats")
         return st
 
+    def stats_accumulate(self, enable=True):
+        """Frames stop clearing the device-side counters: one frame_stats() after a loop of
+        frames reads their sums (no host wait inside the loop)."""
+        self._check(self._lib.grv_stats_accumulate(self._h, 1 if enable else 0), "stats_accumulate")
+
+    def frame_stats_reset(self, stream=None):
+        self._check(self._lib.grv_frame_stats_reset(self._h, C.c_void_p(stream) if stream else None),
+                    "frame_stats_reset")
+
     def unpack_tiles_device(self, params, rank, d_packed, d_image, bytes_per_pixel, stream=None):
         self._check(self._lib.grv_unpack_tiles_device(
             self._h, C.byref(params), int(rank), _dev_ptr(d_packed), _dev_ptr(d_image),
@@ -570,9 +590,11 @@ class PhysicsEngine:
         return self._lib.grv_compute_disk_flux(self._h, float(r))
 
     def compute_shadow_curve(self, theta_obs, n_points):
-        out = np.zeros(4 * n_points + 4, np.float32)
-        n = self._lib.grv_compute_shadow_curve(self._h, float(theta_obs), int(n_points), _np_ptr(out))
-        return out[:2 * n].copy()
+        n = self._lib.grv_compute_shadow_curve(self._h, float(theta_obs), int(n_points), None, 0)
+        out = np.zeros(2 * n, np.float32)  # size query first: 2n points on axis (shadow.rs:96-113)
+        self._lib.grv_compute_shadow_curve(self._h, float(theta_obs), int(n_points), _np_ptr(out),
+                                           out.size)
+        return out
 
     def compute_shadow_radius(self):
         return self._lib.grv_compute_shadow_radius(self._h)

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GRV_ABI_VERSION 1
+#define GRV_ABI_VERSION 2
 
 typedef struct grv_engine grv_engine;
 
@@ -106,9 +106,26 @@ typedef struct {
      * tiles k with k % tile_world == tile_rank, packed in tile order
      * (physics-engine/_legacy_src/tiling.rs:38-56 row-major grid). 1/0 = whole frame. */
     uint32_t tile_world, tile_rank;
-    uint32_t segment_tries; /* RKF45 tries per launch before live-ray compaction; 0 = engine default */
-    uint32_t profile;       /* 1: bracket each kernel with HIP events (GrvFrameStats.*_ms) */
+    uint32_t segment_tries; /* 0 = engine default: ONE integrate launch that runs every ray to its
+                               end, queued on the stream without any host wait;
+                               K > 0: the compacting wavefront schedule, K tries per launch, live
+                               rays re-listed between launches (one host read-back per launch).
+                               Results do not depend on this field. */
+    uint32_t profile;       /* 1: record HIP events around the frame's kernels on the stream; their
+                               elapsed times are resolved by grv_frame_stats (GrvFrameStats.*_ms),
+                               the frame call itself never waits */
+    uint32_t disk_profile;  /* GRV_DISK_PROFILE_*: radial temperature profile of the disk shading */
+    uint32_t reserved1;     /* must be 0 */
 } GrvRenderParams;
+
+/* radial temperature profile T(r)/T_max of the thin-disk shading:
+ *  SHORTCUT    : (isco/r)^3/4 (1 - sqrt(isco/r))^1/4, the shader's closed form
+ *                (src/shaders/blackhole/chunks/disk.ts:100-102);
+ *  PAGE_THORNE : the 512-entry Novikov-Thorne / Page-Thorne table of generate_disk_lut
+ *                (gravitas-core/src/physics/disk.rs:175-201: entry i at r = isco + (i/511)(50M - isco),
+ *                normalised to its maximum), sampled with linear interpolation as the uploaded
+ *                u_diskLUT texture is (src/rendering/webgl/renderer.ts LINEAR, CLAMP_TO_EDGE). */
+enum { GRV_DISK_PROFILE_SHORTCUT = 0, GRV_DISK_PROFILE_PAGE_THORNE = 1 };
 
 typedef struct {
     uint64_t rays;
@@ -119,7 +136,8 @@ typedef struct {
     double max_drift;
     uint32_t launches;      /* integrate-kernel launches (segments) */
     float init_ms, integrate_ms, compact_ms, shade_ms, total_ms; /* HIP-event times, profile=1 */
-} GrvFrameStats;
+} GrvFrameStats; /* with grv_stats_accumulate(e, 1): sums (max for max_drift) over every frame since
+                    the last grv_frame_stats_reset */
 
 /* Device-resident outputs of one frame (all optional except none: pass NULL to skip).
  * Pixel order: row-major over the rendered tile set (whole frame when tile_world<=1). */
@@ -151,6 +169,11 @@ double grv_compute_g_factor(const grv_engine *e, double r, double lambda);
 size_t grv_integrate_ray_relativistic(grv_engine *e, const double *initial_state, size_t n,
                                       size_t steps, double tolerance, int use_kerr_schild,
                                       double *out);
+/* the same call with the Trajectory scalars of geodesic/mod.rs:150-161 (any may be NULL) */
+size_t grv_integrate_ray_relativistic_ex(grv_engine *e, const double *initial_state, size_t n,
+                                         size_t steps, double tolerance, int use_kerr_schild,
+                                         double *out, uint32_t *steps_taken, uint8_t *termination,
+                                         double *max_drift);
 
 /* ---- batch extension: n independent integrate() calls (geodesic/mod.rs:180-253).
  * Host pointers; states AoS [n][8].  steps/termination/drift may be NULL. */
@@ -168,8 +191,13 @@ int grv_render_frame(grv_engine *e, const GrvCamera *cam, const GrvRenderParams 
                      float *rgba_host, GrvFrameStats *stats);
 int grv_render_frame_device(grv_engine *e, const GrvCamera *cam, const GrvRenderParams *p,
                             const GrvFrameBuffers *out, void *stream);
-/* synchronises `stream` and reads the counters of the last frame */
+/* synchronises `stream` and reads the counters of the last frame (the only host wait of the
+ * device-pointer frame path: grv_render_frame_device itself returns with its kernels queued) */
 int grv_frame_stats(grv_engine *e, void *stream, GrvFrameStats *stats);
+/* enable != 0: frame / batch / shader-frame calls stop clearing the device-side counters, so a
+ * loop of frames accumulates them in HBM and one grv_frame_stats after the loop reads the sums */
+int grv_stats_accumulate(grv_engine *e, int enable);
+int grv_frame_stats_reset(grv_engine *e, void *stream);
 /* host-only: scatter packed tile-order pixels of `rank` into a row-major W x H x C image */
 int grv_unpack_tiles(const GrvRenderParams *p, uint32_t rank, const void *packed, void *image,
                      size_t bytes_per_pixel);
@@ -353,9 +381,13 @@ int grv_strict_math_host(int op, size_t n, const double *x, const double *y, dou
 int grv_generate_disk_lut(grv_engine *e, float *out512);
 /* compute_disk_flux lib.rs:198-200 (physics/disk.rs:90-151, m_dot = 1) */
 double grv_compute_disk_flux(const grv_engine *e, double r);
-/* compute_shadow_curve lib.rs:161-169 (physics/shadow.rs:81-183): writes (alpha, beta) pairs as
- * f32; `out` must hold 4 * n_points floats; returns the number of points (n or 2n) */
-size_t grv_compute_shadow_curve(const grv_engine *e, double theta_obs, size_t n_points, float *out);
+/* compute_shadow_curve lib.rs:161-169 (physics/shadow.rs:81-183): (alpha, beta) pairs as f32.
+ * The curve has n_points points off axis and 2 * n_points for an on-axis observer
+ * (|sin theta_obs| < 1e-10, shadow.rs:96-113).  Returns the number of POINTS of the whole curve;
+ * at most out_capacity floats are written (whole pairs only), so out == NULL / out_capacity == 0
+ * is a size query and a too-small buffer is never overrun. */
+size_t grv_compute_shadow_curve(const grv_engine *e, double theta_obs, size_t n_points, float *out,
+                                size_t out_capacity);
 /* compute_shadow_radius lib.rs:172-174 ; compute_shadow_shift lib.rs:178-195 */
 double grv_compute_shadow_radius(const grv_engine *e);
 int grv_compute_shadow_shift(const grv_engine *e, double theta_obs, float out2[2]);

@@ -248,20 +248,13 @@ static napi_value m_compute_shadow_curve(napi_env env, napi_callback_info info) 
     uint32_t n = 0;
     napi_get_value_uint32(env, argv[1], &n);
     if (n > 4096) n = 4096;
-    float *tmp = (float *)malloc(((size_t)4 * n + 8) * sizeof(float)); /* n or 2n (alpha, beta) pairs */
-    if (!tmp) {
-        napi_throw_error(env, NULL, "compute_shadow_curve: out of memory");
-        return NULL;
-    }
-    size_t m = grv_compute_shadow_curve(b->h, arg_f64(env, argv[0]), n, tmp);
+    const double theta = arg_f64(env, argv[0]);
+    /* size query first: n points off axis, 2n for an on-axis observer (shadow.rs:96-113) */
+    const size_t m = grv_compute_shadow_curve(b->h, theta, n, NULL, 0);
     napi_value ab, ta;
     void *dst;
-    if (napi_create_arraybuffer(env, 2 * m * sizeof(float), &dst, &ab) != napi_ok) {
-        free(tmp);
-        return NULL;
-    }
-    memcpy(dst, tmp, 2 * m * sizeof(float));
-    free(tmp);
+    NAPI_OK(napi_create_arraybuffer(env, 2 * m * sizeof(float), &dst, &ab));
+    grv_compute_shadow_curve(b->h, theta, n, (float *)dst, 2 * m);
     NAPI_OK(napi_create_typedarray(env, napi_float32_array, 2 * m, ab, 0, &ta));
     return ta;
 }

@@ -81,3 +81,49 @@ def test_two_rank_tile_gather(tmp_path, w, h):
     tx = (w + 63) // 64
     owner = ((ys // 64) * tx + xs // 64) % 2
     assert np.array_equal(img[..., 2], owner)  # round-robin tile -> rank map
+
+
+def test_single_rank_gather_is_the_identity():
+    """world == 1: the renderer's output is already row-major (tile_world <= 1), so the
+    'gather' must hand it back unpermuted -- with and without the collective walked."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import blackhole_simulation_amd as bh
+    from blackhole_simulation_amd import distributed as D
+    w, h = 200, 130
+    p = bh.render_params(w, h)
+    truth = torch.arange(w * h * 4, dtype=torch.float32).reshape(h * w, 4)
+    img = D.gather_tiles(truth, p, 1, 0, None, D.host_unpack)
+    assert torch.equal(img.reshape(-1, 4), truth)
+    tg = D.TileGather(p, 1, 0, 4, torch.float32, torch.device("cpu")).enable_pipeline()
+    tg.pipelined_view(0, w * h).copy_(truth)
+    assert tg.submit(0, D.host_unpack) is None
+    assert torch.equal(tg.drain(D.host_unpack).reshape(-1, 4), truth)
+
+
+def _one_rank_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import blackhole_simulation_amd as bh
+    from blackhole_simulation_amd import distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        w, h = 130, 70
+        p = bh.render_params(w, h)
+        truth = torch.arange(w * h * 4, dtype=torch.float32).reshape(h * w, 4)
+        tg = D.TileGather(p, 1, 0, 4, torch.float32, torch.device("cpu"))
+        tg.local_view(w * h).copy_(truth)
+        img = tg.run(D.host_unpack, force_collective=True)  # bench.py under a 1-rank torchrun
+        np.save(out_path, (img.reshape(-1, 4) == truth).all().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_rank_collective_walk(tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "ok.npy")
+    mp.spawn(_one_rank_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    assert bool(np.load(out))

@@ -1,0 +1,183 @@
+"""GPU tests of the round-2 host path: the frame call that never waits, device-accumulated
+statistics, the event ring of profile=1, the fused single-ray entry and the one-GPU walk of the
+distributed frame.  Parity statements are bitwise (same kernels, different host schedule)."""
+import ctypes as C
+import os
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+EYE = (60.0 * np.sin(np.deg2rad(97.0)), 60.0 * np.cos(np.deg2rad(97.0)), 0.0)
+
+
+@pytest.fixture(scope="module")
+def bh(engine_mod):
+    return engine_mod
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _frame(bh, torch, e, W, H, **kw):
+    cam = bh.camera_look_at(EYE, aspect=W / H)
+    p = bh.render_params(W, H, **kw)
+    n = e.frame_ray_count(p)
+    out = dict(rgba=torch.zeros(n, 4, dtype=torch.float32, device="cuda:0"),
+               fs=torch.zeros(n, 8, dtype=torch.float64, device="cuda:0"),
+               steps=torch.zeros(n, dtype=torch.int32, device="cuda:0"),
+               term=torch.zeros(n, dtype=torch.uint8, device="cuda:0"),
+               drift=torch.zeros(n, dtype=torch.float64, device="cuda:0"))
+    e.render_frame_device(cam, p, out["rgba"], out["fs"], out["steps"], out["term"], out["drift"])
+    return out
+
+
+@pytest.mark.parametrize("arith", [0, 1])
+def test_single_launch_equals_segment_loop_bitwise(bh, torch_mod, arith):
+    """segment_tries = 0 is ONE launch with no try budget; K > 0 is the host-driven compaction
+    loop.  Same rays, same bits."""
+    torch = torch_mod
+    with bh.PhysicsEngine(1.0, 0.999) as e:
+        a = _frame(bh, torch, e, 320, 180, arith=arith)
+        sa = e.frame_stats()
+        b = _frame(bh, torch, e, 320, 180, arith=arith, segment_tries=8)
+        sb = e.frame_stats()
+    assert sa.launches == 1 and sb.launches > 1
+    assert sa.accepted_steps == sb.accepted_steps and sa.rkf_tries == sb.rkf_tries
+    for k in a:
+        assert torch.equal(a[k].view(torch.uint8), b[k].view(torch.uint8)), k
+
+
+def test_statistics_accumulate_on_the_device(bh, torch_mod):
+    torch = torch_mod
+    with bh.PhysicsEngine(1.0, 0.999) as e:
+        _frame(bh, torch, e, 256, 144, arith=1)
+        one = e.frame_stats()
+        e.stats_accumulate(True)
+        e.frame_stats_reset()
+        for _ in range(4):
+            _frame(bh, torch, e, 256, 144, arith=1, profile=1)
+        acc = e.frame_stats()
+        assert acc.rays == 4 * one.rays and acc.accepted_steps == 4 * one.accepted_steps
+        assert acc.rkf_tries == 4 * one.rkf_tries and acc.crossings == 4 * one.crossings
+        assert list(acc.term_count) == [4 * c for c in one.term_count]
+        assert acc.max_drift == one.max_drift and acc.launches == 4
+        # four profiled frames: the resolved event times are sums over the four
+        assert acc.integrate_ms > 0 and acc.total_ms >= acc.integrate_ms + acc.init_ms
+        again = e.frame_stats()  # reading does not clear; the events were consumed
+        assert again.accepted_steps == acc.accepted_steps and again.integrate_ms == acc.integrate_ms
+        e.frame_stats_reset()
+        assert e.frame_stats().accepted_steps == 0
+        e.stats_accumulate(False)
+        _frame(bh, torch, e, 256, 144, arith=1)
+        assert e.frame_stats().accepted_steps == one.accepted_steps
+
+
+def test_frame_call_returns_before_the_kernels_finish(bh, torch_mod):
+    """The device-pointer frame call queues its three kernels and returns: the host time of the
+    call is far below the device time of the frame (1080p STRICT is tens of milliseconds)."""
+    torch = torch_mod
+    W, H = 1920, 1080
+    with bh.PhysicsEngine(1.0, 0.999) as e:
+        cam = bh.camera_look_at(EYE, aspect=W / H)
+        p = bh.render_params(W, H, arith=0, profile=1)
+        rgba = torch.zeros(W * H, 4, dtype=torch.float32, device="cuda:0")
+        e.render_frame_device(cam, p, rgba=rgba)  # allocate workspace, LUT
+        e.frame_stats()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e.render_frame_device(cam, p, rgba=rgba)
+        host_ms = (time.perf_counter() - t0) * 1e3
+        st = e.frame_stats()
+    assert st.total_ms > 5.0, st.total_ms
+    assert host_ms < 0.25 * st.total_ms, (host_ms, st.total_ms)
+
+
+def test_tile_rank_out_of_range_is_refused(bh, torch_mod):
+    torch = torch_mod
+    with bh.PhysicsEngine(1.0, 0.5) as e:
+        cam = bh.camera_look_at(EYE, aspect=1.0)
+        p = bh.render_params(128, 128, tile_world=1, tile_rank=1)
+        rgba = torch.zeros(128 * 128, 4, dtype=torch.float32, device="cuda:0")
+        with pytest.raises(bh.GravitasError):
+            e.render_frame_device(cam, p, rgba=rgba)
+        p = bh.render_params(128, 128, disk_profile=7)
+        with pytest.raises(bh.GravitasError):
+            e.render_frame_device(cam, p, rgba=rgba)
+
+
+def test_fused_single_ray_equals_batch_and_oracle(bh, oracle):
+    """grv_integrate_ray_relativistic is one fused launch writing into pinned host memory; its
+    result is bitwise the 1-ray batch's (same advance_one) and the oracle's."""
+    rays = [
+        ([0.0, 20.0, np.pi / 2, 0.0, -1.0, -1.0, 0.0, 3.5], 0.9, 10000, 1e-8, True),   # doc-test ray
+        ([0.0, 20.0, np.pi / 2, 0.0, -1.0, -1.0, 0.0, 3.5], 0.9, 10000, 1e-8, False),
+        ([0.0, 15.0, 1.1, 0.3, -1.0, -0.9, 1.5, -2.0], 0.999, 500, 1e-9, True),
+        ([0.0, 8.0, 0.7, 0.0, -1.0, -1.0, 0.2, 0.1], 0.5, 3, 1e-8, True),               # MaxSteps
+        ([0.0, 1.0, 0.7, 0.0, -1.0, -1.0, 0.2, 0.1], 0.5, 50, 1e-8, True),              # inside the horizon
+        ([0.0, 30.0, 0.4, 0.0, -1.0, 1.0, 0.0, 1.0], 0.3, 0, 1e-8, True),               # zero steps
+    ]
+    lib = bh.load_library()
+    for v8, spin, steps, tol, ks in rays:
+        with bh.PhysicsEngine(1.0, spin) as e:
+            got = e.integrate_ray_relativistic(v8, steps, tol, ks)
+            o = bh.engine.default_options(metric_kind=bh.KERR_KS if ks else bh.KERR_BL, tolerance=tol,
+                                          max_steps=steps, arith=bh.ARITH_STRICT)
+            b = e.integrate_batch(np.array([v8]), o)
+            a = np.ascontiguousarray(v8, np.float64)
+            out = np.zeros(8)
+            ns, tm, dr = C.c_uint32(0), C.c_uint8(0), C.c_double(0.0)
+            n = lib.grv_integrate_ray_relativistic_ex(e._h, a.ctypes.data_as(C.c_void_p), 8, steps, tol,
+                                                      1 if ks else 0, out.ctypes.data_as(C.c_void_p),
+                                                      C.byref(ns), C.byref(tm), C.byref(dr))
+        assert n == 8
+        assert np.array_equal(got, b["states"][0]) and np.array_equal(out, got)
+        assert ns.value == b["steps"][0] and tm.value == b["term"][0] and dr.value == b["drift"][0]
+        ref = oracle.integrate_ray_relativistic(1.0, spin, v8, steps, tol, ks)
+        assert np.array_equal(got, np.asarray(ref)), (v8, got, ref)
+    # echo rule (lib.rs:429-431) and many calls in a row on one engine (sequence word wraps nothing)
+    with bh.PhysicsEngine(1.0, 0.9) as e:
+        assert list(e.integrate_ray_relativistic([1.0, 2.0, 3.0], 10, 1e-8, True)) == [1.0, 2.0, 3.0]
+        first = e.integrate_ray_relativistic(rays[0][0], 200, 1e-8, True)
+        for _ in range(300):
+            assert np.array_equal(e.integrate_ray_relativistic(rays[0][0], 200, 1e-8, True), first)
+
+
+def test_distributed_frame_on_one_gpu_is_the_plain_frame(bh, torch_mod):
+    """render_frame_distributed without a process group (world 1): the assembled image is the
+    row-major frame, not a tile permutation of it (the whole-frame render is already row-major)."""
+    torch = torch_mod
+    from blackhole_simulation_amd import distributed as D
+    W, H = 200, 130
+    with bh.PhysicsEngine(1.0, 0.999) as e:
+        cam = bh.camera_look_at(EYE, aspect=W / H)
+        p = bh.render_params(W, H, arith=1)
+        img, st = D.render_frame_distributed(e, cam, p)
+        ref = torch.zeros(W * H, 4, dtype=torch.float32, device="cuda:0")
+        e.render_frame_device(cam, p, rgba=ref)
+        torch.cuda.synchronize()
+    assert st.rays == W * H
+    assert torch.equal(img.reshape(-1, 4), ref)
+    assert float(img[..., :3].max()) > 0.0
+
+
+def test_f32_march_frames_accumulate_without_waiting(bh, torch_mod):
+    """config-4 plumbing: want_total=False queues the march; the step count is read once."""
+    torch = torch_mod
+    W, H = 256, 144
+    with bh.PhysicsEngine(1.0, 0.999) as e:
+        cam = bh.camera_look_at(EYE, aspect=W / H)
+        wp = bh.wgsl_params(W, H, cam, 1.0, 0.999, max_steps=1024, arith=bh.ARITH_FAST)
+        rgba = torch.zeros(W * H, 4, dtype=torch.float32, device="cuda:0")
+        one = e.render_frame_wgsl(wp, rgba)
+        e.stats_accumulate(True)
+        e.frame_stats_reset()
+        for _ in range(3):
+            assert e.render_frame_wgsl(wp, rgba, want_total=False) is None
+        assert e.frame_stats().accepted_steps == 3 * one

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(engine_mod):
     assert len(names) >= 25
     for n in names:
         assert hasattr(lib, n), "libgravitas_hip.so does not export %s" % n
-    assert lib.grv_abi_version() == 1
+    assert lib.grv_abi_version() == 2
 
 
 def test_no_device_fails_loudly(engine_mod):
@@ -44,7 +44,7 @@ def test_package_has_no_oracle_dependency():
                     assert "pyoracle" not in src and "gravitas_oracle" not in src and "orc_" not in src, f
     # bench.py touches the oracle in its cpu_baseline leg only
     src = open(os.path.join(ROOT, "bench.py")).read()
-    body = src[src.index("def cpu_baseline("):src.index("def load_committed_traffic(")]
+    body = src[src.index("def cpu_baseline_c3("):src.index("def committed_pmc(")]
     assert "pyoracle" in body and "pyoracle" not in src.replace(body, "")
 
 
@@ -128,8 +128,59 @@ def test_bench_helpers():
     spec.loader.exec_module(b)
     assert all(gx * gy == n for n, (gx, gy) in b.GRID.items()) and set(b.GRID) == {1, 2, 4, 8}
     assert 1 <= b.usable_cores() <= (os.cpu_count() or 1)
-    assert (b.B_STEP, b.B_RAY, b.HBM_PEAK_GBS) == (144, 96, 8000.0)       # SURVEY 8(d), microarch guide
-    t = b.load_committed_traffic()
-    assert t and t["hbm_bytes_per_launch"] > 1e9 and 0.5 < t["valu"]["issue_frac"] <= 1.0
-    # measured HBM bytes agree with the layout's 92 B read + 76 B written per slot to 2 %
-    assert abs(t["hbm_bytes_per_launch"] / t["expected_from_layout_bytes"] - 1.0) < 0.02
+    assert (b.B_STEP["c3"], b.B_RAY["c3"], b.HBM_PEAK_GBS) == (144, 96, 8000.0)  # SURVEY 8(d), microarch guide
+    assert b.B_STEP["c4"] == 72 and b.FP64_PEAK_TFLOPS == 78.6
+    assert b.cpu_model()
+    import blackhole_simulation_amd as bh
+    if not os.path.exists(bh.library_path()):
+        bh.build_library()
+    # the committed PMC figures are quoted only for the code object they were measured on
+    t, src = b.committed_pmc("integrate_segment_kernel<1,1,0>", bh.library_path())
+    if t is None:
+        assert src.startswith("stale"), src  # the kernel changed since the committed pass: dropped
+    else:
+        assert t["hbm_bytes_per_launch"] > 1e9 and 0.5 < t["valu"]["issue_frac"] <= 1.0
+        # measured HBM bytes agree with the layout's 92 B read + 76 B written per slot to 2 %
+        assert abs(t["hbm_bytes_per_launch"] / t["expected_from_layout_bytes"] - 1.0) < 0.02
+    none, why = b.committed_pmc("no_such_kernel", bh.library_path())
+    assert none is None and "no committed" in why
+
+
+def test_stale_pmc_figures_are_dropped(tmp_path, monkeypatch):
+    """A traffic.json stamped with another code hash must not be quoted."""
+    import importlib.util
+    import json
+    import shutil
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    import blackhole_simulation_amd as bh
+    fake = tmp_path / "repo"
+    (fake / "profiles").mkdir(parents=True)
+    shutil.copytree(os.path.join(ROOT, "tools"), fake / "tools")
+    json.dump({"format": 2, "kernels": {"integrate_segment_kernel<1,1,0>": {
+        "code_hash": "0123456789abcdef", "hbm_bytes_per_launch": 1}}}, open(fake / "profiles" / "traffic.json", "w"))
+    monkeypatch.setattr(b, "ROOT", str(fake))
+    t, why = b.committed_pmc("integrate_segment_kernel<1,1,0>", bh.library_path())
+    assert t is None and why.startswith("stale")
+
+
+def test_kernel_code_hash_tracks_the_code_object(engine_mod):
+    sys_path = os.path.join(ROOT, "tools")
+    import sys
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    import kernel_resources as kr
+    lib = engine_mod.library_path()
+    a = kr.kernel_code_hash(lib, "integrate_segment_kernel<1,1,0>")
+    b2 = kr.kernel_code_hash(lib, "integrate_segment_kernel<1,0,0>")
+    assert a and b2 and a != b2 and len(a) == 16
+    assert kr.kernel_code_hash(lib, "integrate_segment_kernel<1,1,0>") == a  # deterministic
+    assert kr.kernel_code_hash(lib, "no_such_kernel") is None
+
+
+def test_shadow_curve_capacity_is_honoured(engine_mod):
+    """grv_compute_shadow_curve never writes past out_capacity (on-axis observers double the curve)."""
+    lib = engine_mod.load_library()
+    # no engine without a device: the size query must tolerate a NULL handle (returns 0)
+    assert lib.grv_compute_shadow_curve(None, 0.0, 16, None, 0) == 0

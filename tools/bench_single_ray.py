@@ -1,7 +1,8 @@
 """Latency of the reference's path entry, integrate_ray_relativistic (lib.rs:422-464), one ray per
 call: a serial chain on one GPU lane.  Reports the per-call wall time for the doc-test ray
-(~220 accepted steps), for a 1-step call (fixed overhead: copies, three launches, syncs) and the
-per-ray time of the same rays in batches.  Run on the GPU box: python tools/bench_single_ray.py"""
+(~220 accepted steps), for 0-step and 1-step calls (fixed overhead of the fused launch: one kernel
+launch + the PCIe write of the result the host polls) and the per-ray time of the same rays in
+batches.  Run on the GPU box: python tools/bench_single_ray.py"""
 import json
 import os
 import sys
@@ -15,14 +16,18 @@ import blackhole_simulation_amd as bh  # noqa: E402
 if __name__ == "__main__":
     v = np.array([0, 20.0, np.pi / 2, 0, -1.0, -1.0, 0.0, 3.5])
     with bh.PhysicsEngine(1.0, 0.9) as e:
-        for steps, label in ((10000, "doc-test ray to termination"), (1, "one step (call overhead)")):
+        res = {}
+        for steps, label in ((10000, "doc-test ray to termination"), (1, "one step"), (0, "zero steps (call overhead)")):
             e.integrate_ray_relativistic(v, steps, 1e-8, True)
             t = time.perf_counter()
-            n = 200
+            n = 500
             for _ in range(n):
                 e.integrate_ray_relativistic(v, steps, 1e-8, True)
             dt = (time.perf_counter() - t) / n
+            res[steps] = dt
             print(json.dumps({"call": "integrate_ray_relativistic", "case": label, "us_per_call": round(dt * 1e6, 1)}), flush=True)
+        print(json.dumps({"call": "integrate_ray_relativistic", "case": "per accepted step (224 steps, overhead removed)",
+                          "us_per_step": round((res[10000] - res[0]) / 224 * 1e6, 3)}), flush=True)
         for nb in (1, 64, 4096, 262144):
             st = np.tile(v, (nb, 1))
             st[:, 7] = np.linspace(3.0, 4.0, nb) if nb > 1 else 3.5

@@ -49,6 +49,60 @@ def kernels(path):
                             out[kd[".name"]] = kd
 
 
+def code_objects(path):
+    """The embedded gfx950 ELF images of a bundle-carrying host library."""
+    data = open(path, "rb").read()
+    pos = 0
+    while True:
+        base = data.find(MAGIC, pos)
+        if base < 0:
+            return
+        pos = base + 1
+        (n,) = struct.unpack_from("<Q", data, base + 24)
+        off = base + 32
+        for _ in range(n):
+            o, s, t = struct.unpack_from("<QQQ", data, off)
+            off += 24
+            triple = data[off:off + t].decode()
+            off += t
+            if "amdgcn" in triple and s:
+                yield data[base + o:base + o + s]
+
+
+def kernel_code_hash(path, pretty_name):
+    """sha256 (first 16 hex digits) of one kernel's machine code + kernel descriptor, located
+    through the code object's symbol table.  `pretty_name` as printed by this tool, e.g.
+    'integrate_segment_kernel<1,1,0>'.  Changes whenever the compiled kernel changes and only then:
+    profiles/traffic.json is stamped with it and bench.py drops the committed PMC figures when
+    the stamp and the library on disk disagree."""
+    import hashlib
+    for elf in code_objects(path):
+        (shoff,) = struct.unpack_from("<Q", elf, 0x28)
+        shentsize, shnum, _ = struct.unpack_from("<HHH", elf, 0x3A)
+        secs = [struct.unpack_from("<IIQQQQIIQQ", elf, shoff + k * shentsize) for k in range(shnum)]
+        for sh in secs:
+            if sh[1] not in (2, 11):  # SHT_SYMTAB, SHT_DYNSYM
+                continue
+            strtab = secs[sh[6]]
+            h = None
+            parts = {}
+            for k in range(sh[5] // 24):
+                st_name, st_info, _o, st_shndx, st_value, st_size = struct.unpack_from(
+                    "<IBBHQQ", elf, sh[4] + k * 24)
+                end = elf.index(b"\0", strtab[4] + st_name)
+                name = elf[strtab[4] + st_name:end].decode()
+                base = name[:-3] if name.endswith(".kd") else name
+                if pretty(base) != pretty_name or st_shndx == 0 or st_shndx >= len(secs):
+                    continue
+                sec = secs[st_shndx]
+                o = st_value - sec[3] + sec[4]
+                parts["kd" if name.endswith(".kd") else "text"] = elf[o:o + st_size]
+            if "text" in parts:
+                h = hashlib.sha256(parts["text"] + parts.get("kd", b"")).hexdigest()[:16]
+                return h
+    return None
+
+
 def pretty(mangled):
     m = re.search(r"\d+([a-z_0-9]+_kernel)(I[A-Za-z0-9]*E)?", mangled)
     if not m:
@@ -58,8 +112,14 @@ def pretty(mangled):
 
 
 if __name__ == "__main__":
-    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "blackhole-simulation_amd", "libgravitas_hip.so")
+    args = [a for a in sys.argv[1:] if a != "--hashes"]
+    path = args[0] if args else os.path.join(ROOT, "blackhole-simulation_amd", "libgravitas_hip.so")
     ks = kernels(path)
+    if "--hashes" in sys.argv:  # {pretty name: code hash} of every kernel, for profiles/traffic.json
+        import json
+        names = sorted({pretty(n) for n in ks})
+        print(json.dumps({n: kernel_code_hash(path, n) for n in names}, indent=1))
+        sys.exit(0)
     print("# %s: %d kernels, gfx950, wave64.  waves/SIMD = floor(512 / ceil8(vgpr + agpr)), capped at 8" %
           (os.path.basename(path), len(ks)))
     print("# template arguments: <metric kind (0 BL, 1 KS, 2 Schwarzschild), arith (0 STRICT, 1 FAST), method (0 RKF45, 1 RK4, 2 symplectic)>"

@@ -75,40 +75,62 @@ for label, items in pm.items():
         if "integrate" in it["kernel"] or "finalize" in it["kernel"] or "init_from" in it["kernel"]:
             print(label, it)
 
-# HBM traffic of the dominant kernel per launch (bench.py reads profiles/traffic.json)
-def _avg(label, counter):
+# HBM traffic of the dominant kernels per launch (bench.py reads profiles/traffic.json).  Every
+# entry carries the code hash of the kernel it was measured on (code_hashes.json is written on the
+# GPU box by tools/profile_gpu.sh from the library that actually ran): bench.py quotes an entry
+# only for a library whose kernel hashes the same.
+def _avg(label, counter, needle):
     for it in pm.get(label, []):
-        if "integrate_segment_kernel" in it["kernel"] and it["counter"] == counter:
+        if needle in it["kernel"] and it["counter"] == counter:
             return it["avg"]
     return None
 
-f, w = _avg("pmc_fetch", "FETCH_SIZE"), _avg("pmc_write", "WRITE_SIZE")
-if f is not None and w is not None:
+
+hashes = {}
+hp = os.path.join(SRC, "code_hashes.json")
+if os.path.exists(hp):
+    hashes = json.load(open(hp))
+tpath = os.path.join(DST, "traffic.json")
+traffic = {"format": 2, "kernels": {}}
+if os.path.exists(tpath):
+    old = json.load(open(tpath))
+    if old.get("format") == 2:
+        traffic = old
+
+# (pretty name, substring of the demangled name in the trace, pass suffix, frame, layout bytes)
+CASES = [("integrate_segment_kernel<1,1,0>", "integrate_segment_kernel<1, 1, 0>", "", [3840, 2160], 8355840 * (92 + 76)),
+         ("integrate_segment_kernel<1,0,0>", "integrate_segment_kernel<1, 0, 0>", "_strict", [3840, 2160], 8355840 * (92 + 76)),
+         ("wgsl_symplectic_fast_kernel", "wgsl_symplectic_fast_kernel", "_c4", [7680, 4320], None)]
+for pretty, needle, sfx, frame, layout in CASES:
+    f, w = _avg("pmc_fetch" + sfx, "FETCH_SIZE", needle), _avg("pmc_write" + sfx, "WRITE_SIZE", needle)
+    if f is None or w is None:
+        continue
     # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  gfx950 correction
     # (/opt/skills/guides/MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 64 B per 128-B request
-    # on coalesced streaming reads -> x2.  Cross-check: 8 355 840 slots x 92 B read = 0.769 GB,
-    # x 76 B written = 0.635 GB.
-    traffic = {
-        "kernel": "integrate_segment_kernel<KerrSchild,FAST,RKF45>",
-        "command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline",
-        "fetch_size_kib_raw_avg_per_launch": f,
-        "write_size_kib_avg_per_launch": w,
-        "fetch_correction": 2.0,
-        "hbm_bytes_per_launch": int((2.0 * f + w) * 1024),
-        "expected_from_layout_bytes": 8355840 * (92 + 76),
-    }
-    f2, w2 = _avg("pmc_fetch_k16", "FETCH_SIZE"), _avg("pmc_write_k16", "WRITE_SIZE")
-    if f2 is not None and w2 is not None:
-        traffic["segment_tries_16"] = {"fetch_size_kib_raw_avg_per_launch": f2,
+    # on coalesced streaming reads -> x2.  Cross-check for the f64 frame: 8 355 840 slots x 92 B
+    # read = 0.769 GB, x 76 B written = 0.635 GB.
+    ent = {"name": needle, "code_hash": hashes.get(pretty), "frame": frame,
+           "command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline" +
+                      {"": "", "_strict": " --arith strict", "_c4": " --config c4"}[sfx],
+           "fetch_size_kib_raw_avg_per_launch": f, "write_size_kib_avg_per_launch": w,
+           "fetch_correction": 2.0, "hbm_bytes_per_launch": int((2.0 * f + w) * 1024)}
+    if layout:
+        ent["expected_from_layout_bytes"] = layout
+    if sfx == "":
+        f2, w2 = _avg("pmc_fetch_k16", "FETCH_SIZE", needle), _avg("pmc_write_k16", "WRITE_SIZE", needle)
+        if f2 is not None and w2 is not None:
+            ent["segment_tries_16"] = {"fetch_size_kib_raw_avg_per_launch": f2,
                                        "write_size_kib_avg_per_launch": w2,
                                        "hbm_bytes_per_launch": int((2.0 * f2 + w2) * 1024),
                                        "launches_per_frame": 32}
-    # what actually bounds the kernel: FP64 VALU issue.  SQ_INSTS_VALU wave-instructions x 4 cycles
-    # over 1024 SIMDs, against the elapsed cycles per XCD (GRBM_GUI_ACTIVE is summed over 8 XCDs)
-    insts, gui = _avg("pmc_sq", "SQ_INSTS_VALU"), _avg("pmc_sq", "GRBM_GUI_ACTIVE")
+    # what actually bounds the kernel: VALU issue.  SQ_INSTS_VALU wave-instructions x 4 cycles
+    # (f64; the f32 march issues most of its VALU work at 4 cycles per wave64 as well) over 1024
+    # SIMDs, against the elapsed cycles per XCD (GRBM_GUI_ACTIVE is summed over 8 XCDs)
+    insts, gui = _avg("pmc_sq" + sfx, "SQ_INSTS_VALU", needle), _avg("pmc_sq" + sfx, "GRBM_GUI_ACTIVE", needle)
     if insts and gui:
-        traffic["valu"] = {"sq_insts_valu_per_launch": insts, "cycles_per_xcd": gui / 8.0,
-                           "issue_frac": round(insts * 4.0 / 1024.0 / (gui / 8.0), 4),
-                           "note": "wave64 VALU instructions x 4 cycles / 1024 SIMDs / elapsed cycles"}
-    open(os.path.join(DST, "traffic.json"), "w").write(json.dumps(traffic, indent=1))
-    print(json.dumps(traffic, indent=1))
+        ent["valu"] = {"sq_insts_valu_per_launch": insts, "cycles_per_xcd": gui / 8.0,
+                       "issue_frac": round(insts * 4.0 / 1024.0 / (gui / 8.0), 4),
+                       "note": "wave64 VALU instructions x 4 cycles / 1024 SIMDs / elapsed cycles"}
+    traffic["kernels"][pretty] = ent
+open(tpath, "w").write(json.dumps(traffic, indent=1))
+print(json.dumps(traffic, indent=1))
