@@ -133,8 +133,8 @@ def cpu_baseline_c4(wp, width, height, target_seconds=12.0):
     cores = usable_cores()
     op = po.wgsl_params_from(wp)
     t = time.time()
-    probe = po.wgsl_frame(op, stride=(64, 64), nthreads=cores)
-    rate = float(np.sum(probe["steps"])) / max(time.time() - t, 1e-3)
+    _, psteps = po.wgsl_frame(op, stride=(64, 64), nthreads=cores)
+    rate = float(np.sum(psteps)) / max(time.time() - t, 1e-3)
     total = 900.0 * width * height
     sx = sy = 64
     for cand in ((4, 4), (6, 6), (8, 8), (12, 12), (16, 16), (24, 24), (32, 32), (48, 48), (64, 64)):
@@ -142,14 +142,14 @@ def cpu_baseline_c4(wp, width, height, target_seconds=12.0):
             sx, sy = cand
             break
     t = time.time()
-    out = po.wgsl_frame(op, stride=(sx, sy), nthreads=cores)
+    _, osteps = po.wgsl_frame(op, stride=(sx, sy), nthreads=cores)
     dt = time.time() - t
-    steps = int(np.sum(out["steps"]))
+    steps = int(np.sum(osteps))
     return {"value": round(steps / dt / 1e6, 4), "unit": "Mray-steps/s", "cores": cores,
             "cpu_model": cpu_model(), "kind": "port",
             "sample": "C restatement of the f32 compute march (compute.wgsl.ts; no TS/WGSL runtime "
                       "here), OpenMP over rays, 1/%d pixel-strided subset of the %dx%d frame: %d "
-                      "rays, %d steps in %.1f s" % (sx * sy, width, height, out["steps"].size, steps, dt)}
+                      "rays, %d steps in %.1f s" % (sx * sy, width, height, osteps.size, steps, dt)}
 
 
 def committed_pmc(kernel_pretty, lib_path):
@@ -189,6 +189,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: wait for each frame's gather before integrating the next frame")
+    ap.add_argument("--one-stream", action="store_true",
+                    help="queue every frame on one stream (default: even / odd frames on two streams, "
+                         "so one frame's tail runs under the next frame's head)")
     ap.add_argument("--profile-frames", type=int, default=3,
                     help="N > 1: profiled frames after the timed loop (roofline block)")
     args = ap.parse_args()
@@ -250,7 +253,14 @@ def main():
     if cfg == "c4":
         wp = bh.wgsl_params(W, H, cam, 1.0, 0.999, max_steps=1024, arith=arith,
                             tile_world=world, tile_rank=rank)
-    stream = torch.cuda.current_stream().cuda_stream
+    # two frames in flight: even and odd frames go to two streams (the engine alternates two ray
+    # workspaces and orders each behind its previous user), so the tail of one frame's integrate
+    # launch -- too few waves left to fill 256 CUs -- runs under the head of the next frame
+    # (N > 1 only: at N = 1 the tail is 1 % of a frame, and one stream keeps the in-loop HIP events
+    # bracketing one kernel at a time, which is what the roofline block is defined on)
+    two = world > 1 and not args.one_stream and not args.no_overlap
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()] if two else [torch.cuda.current_stream()] * 2
+    stream = streams[0].cuda_stream
     # all buffers live outside the frame loop: the padded send buffer doubles as the render
     # target, rank 0 additionally holds the receive slots and the assembled image
     tg = D.TileGather(params, world, rank, 4, torch.float32, torch.device("cuda", local_rank)) \
@@ -258,35 +268,38 @@ def main():
     overlap = tg is not None and not args.no_overlap
     if overlap:
         tg.enable_pipeline()  # second send buffer: frame i's gather runs under frame i+1's kernels
-    buf = tg.local_view(n_local) if tg else torch.empty((n_local, 4), dtype=torch.float32, device="cuda")
+    bufs = [tg.local_view(n_local)] * 2 if tg else \
+        [torch.empty((n_local, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
     eng.stats_accumulate(True)  # counters stay in HBM across frames: no read-back in the loop
 
     def dev_unpack(rparams, r, packed, image):
-        eng.unpack_tiles_device(rparams, r, packed, image, 16, stream)
+        eng.unpack_tiles_device(rparams, r, packed, image, 16, torch.cuda.current_stream().cuda_stream)
 
     # c4 at N = 1: bracket each march launch with events on the launch stream (torch's current
     # stream is the stream handed to the engine), resolved after the loop
     ev_pairs = []
 
     def render(target, profiled):
+        s = torch.cuda.current_stream().cuda_stream
         if cfg == "c3":
-            eng.render_frame_device(cam, prof_rp if profiled else rp, rgba=target, stream=stream)
+            eng.render_frame_device(cam, prof_rp if profiled else rp, rgba=target, stream=s)
         else:
             if profiled:
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
-            eng.render_frame_wgsl(wp, target, stream=stream, want_total=False)
+            eng.render_frame_wgsl(wp, target, stream=s, want_total=False)
             if profiled:
                 b.record()
                 ev_pairs.append((a, b))
 
     def one_frame(i, profiled):
-        target = tg.pipelined_view(i, n_local) if overlap else buf
-        render(target, profiled)
-        if overlap:
-            tg.submit(i, dev_unpack, force_collective=True)  # finish frame i-1's exchange, start frame i's
-        elif tg:
-            tg.run(dev_unpack, force_collective=True)  # the one exchange: gather tiles -> rank 0
+        with torch.cuda.stream(streams[i % 2]):
+            target = tg.pipelined_view(i, n_local) if overlap else bufs[i % 2]
+            render(target, profiled)
+            if overlap:
+                tg.submit(i, dev_unpack, force_collective=True)  # finish frame i-1's exchange, start frame i's
+            elif tg:
+                tg.run(dev_unpack, force_collective=True)  # the one exchange: gather tiles -> rank 0
 
     def fence():
         if overlap:
@@ -325,8 +338,9 @@ def main():
         # roofline of this rank's share from profiled frames outside the timed region
         eng.frame_stats_reset(stream)
         k = max(args.profile_frames, 1)
-        for i in range(k):
-            render(buf if not overlap else tg.pipelined_view(i, n_local), True)
+        for i in range(k):  # one stream: the events then bracket one kernel at a time
+            with torch.cuda.stream(streams[0]):
+                render(bufs[0], True)
         torch.cuda.synchronize()
         pst, integ_ms, launches = read_stats()
         prof_steps_per_frame = pst.accepted_steps / k
@@ -400,7 +414,8 @@ def main():
                                      % (", overlapped with the next frame" if overlap else ""))
                        if world > 1 else "single GPU",
                        "rays": total_rays, "accepted_steps_per_frame": int(total_steps / args.steps),
-                       "host_waits_in_frame_loop": 0 if not args.segment_tries else "one per segment"},
+                       "host_waits_in_frame_loop": 0 if not args.segment_tries else "one per segment",
+                       "frames_in_flight": 2 if two else 1},
             "roofline": roofline,
         }
         if cfg == "c3":

@@ -31,12 +31,25 @@ struct grv_engine {
     int n_cu = 256;
     std::string err;
 
-    // ray workspace (device)
-    void *ws_mem = nullptr;
-    size_t ws_slots = 0;
-    grvhip::RayWorkspace ws{};
+    // ray workspaces (device).  Two sets, used alternately by successive frame / batch calls, so a
+    // caller that alternates two streams keeps two frames in flight: the tail of one frame's
+    // integrate launch (too few waves left to fill the chip) runs under the head of the next.
+    // Each set carries an event recorded at the end of its last use; the next user's stream waits
+    // for it, so a set is never touched by two frames at once whatever streams the caller picks.
+    struct WorkSet {
+        void *mem = nullptr;
+        size_t slots = 0;
+        grvhip::RayWorkspace ws{};
+        uint32_t *live[2] = {nullptr, nullptr};
+        uint32_t *d_counters = nullptr; // [0],[1] live counts (ping-pong), [2] refill cursor
+        hipEvent_t done = nullptr;
+        bool used = false;
+    } wset[2];
+    int wturn = 0;
+    WorkSet *cur = nullptr;            // the set of the call in progress
+    grvhip::RayWorkspace ws{};         // == cur->ws
     uint32_t *live[2] = {nullptr, nullptr};
-    uint32_t *d_counters = nullptr; // [0],[1] live counts (ping-pong)
+    uint32_t *d_counters = nullptr;
     grvhip::FrameStatsDev *d_stats = nullptr;
     uint32_t *h_counters = nullptr; // pinned
     grvhip::FrameStatsDev *h_stats = nullptr; // pinned
@@ -108,7 +121,8 @@ double photon_sphere(double m, double a_star);
 double dilation(double m, double a_star, double r);
 double g_factor(double r, double mass, double spin, double lambda);
 
-int ensure_workspace(grv_engine *e, size_t slots);
+int ensure_workspace(grv_engine *e, size_t slots, hipStream_t s);
+int release_workspace(grv_engine *e, hipStream_t s);
 int ensure_stage(grv_engine *e, size_t bytes);
 int ensure_lut(grv_engine *e, uint32_t w, uint32_t h, double tmax, hipStream_t s);
 size_t align_up(size_t x, size_t a);
@@ -118,6 +132,7 @@ int run_segments(grv_engine *e, const GrvOptions &o, SegmentParams P, uint32_t s
                  bool profile);
 int begin_frame_stats(grv_engine *e, hipStream_t s);
 int resolve_frame_events(grv_engine *e);
+uint32_t tile_pitch(uint32_t width, uint32_t world);
 void frame_geometry(const GrvRenderParams &p, FrameGeom &G);
 void stats_to_abi(const grv_engine *e, const FrameStatsDev &d, GrvFrameStats *out);
 

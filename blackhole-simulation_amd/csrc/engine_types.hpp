@@ -49,7 +49,7 @@ struct SegmentParams {
 
 struct FrameGeom {
     uint32_t width, height;
-    uint32_t tiles_x, tiles_y;
+    uint32_t tiles_x, tiles_y; // tiles_x = row pitch of the tile ids (engine.hip: tile_pitch)
     uint32_t tile_world, tile_rank;
     uint32_t n_tiles_local;
 };

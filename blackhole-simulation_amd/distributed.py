@@ -1,6 +1,7 @@
 """Image-plane partition across the GPUs of one node: one process per GPU, each
 rank renders the 64x64 tiles k with k % world == rank (round-robin, so shadow and
-photon-ring tiles spread evenly; tile grid as physics-engine/_legacy_src/tiling.rs:38-56),
+photon-ring tiles spread evenly; tile grid as physics-engine/_legacy_src/tiling.rs:38-56;
+tile ids use a row pitch coprime with the rank count so the deal shifts from row to row),
 then ONE gather of the finished tiles to rank 0 (RCCL over xGMI when the backend
 is "nccl") and a de-interleave on rank 0.  No other collective touches the path.
 
@@ -13,17 +14,34 @@ from . import engine as _eng
 TILE = 64
 
 
-def tiles_total(width, height):
-    return ((width + TILE - 1) // TILE) * ((height + TILE - 1) // TILE)
+def tile_pitch(width, world):
+    """Row pitch of the tile ids: the first integer >= ceil(width / 64) coprime with `world`
+    (grv_tile_pitch, include/gravitas_abi.h).  Ids in the pad column(s) hold no pixels."""
+    import math
+    p = (width + TILE - 1) // TILE
+    while world > 1 and math.gcd(p, world) != 1:
+        p += 1
+    return p
+
+
+def tiles_total(width, height, world=1):
+    """Tile ids of the frame as `world` ranks number them (pad columns included)."""
+    return tile_pitch(width, world) * ((height + TILE - 1) // TILE)
 
 
 def tiles_of_rank(width, height, world, rank):
     """Global tile ids rendered by `rank`, in its packed order."""
-    return list(range(rank, tiles_total(width, height), world))
+    return list(range(rank, tiles_total(width, height, world), world))
+
+
+def tile_origin(tile, width, world):
+    """Pixel (x0, y0) of a tile id; x0 >= width for an id in a pad column."""
+    p = tile_pitch(width, world)
+    return (tile % p) * TILE, (tile // p) * TILE
 
 
 def max_tiles_per_rank(width, height, world):
-    return (tiles_total(width, height) + world - 1) // world
+    return (tiles_total(width, height, world) + world - 1) // world
 
 
 def rank_params(params, world, rank):
@@ -64,17 +82,25 @@ class TileGather:
     # Two send buffers alternate; the exchange is issued asynchronously (RCCL runs it on its own
     # stream over xGMI) and waited for only after the next frame's kernels are in the queue, so
     # the only exposed communication is the last frame's.  The data path still holds exactly one
-    # collective per frame.
+    # collective per frame.  The caller may put even and odd frames on two different streams (two
+    # frames in flight): every wait below is a wait of the CURRENT stream, and a send buffer is
+    # handed out again only behind the gather that last read it.
     def enable_pipeline(self):
         import torch
         if getattr(self, "sends", None) is None:
             self.sends = [self.send, torch.zeros_like(self.send)]
             self._pending = None  # (work, send buffer, collective?)
+            self._reader = [None, None]  # per send buffer: the gather that last read it
         return self
 
     def pipelined_view(self, frame_index, n_local):
-        """Render target for `frame_index` (no staging copy)."""
-        return self.sends[frame_index % 2][:n_local]
+        """Render target for `frame_index` (no staging copy).  Orders the current stream behind
+        the gather of frame_index - 2, which read the same buffer."""
+        b = frame_index % 2
+        if self._reader[b] is not None:
+            self._reader[b].wait()
+            self._reader[b] = None
+        return self.sends[b][:n_local]
 
     def submit(self, frame_index, unpack, force_collective=False):
         """Call after frame `frame_index` was rendered into pipelined_view(frame_index): completes
@@ -84,6 +110,7 @@ class TileGather:
         img = self.drain(unpack)
         buf = self.sends[frame_index % 2]
         self._pending = (self._gather(buf, force_collective, True), buf)
+        self._reader[frame_index % 2] = self._pending[0][0]
         return img
 
     def drain(self, unpack):

@@ -169,6 +169,8 @@ def load_library():
     L.grv_integrate_batch.argtypes = [p, sz, p, C.POINTER(Options), p, p, p, p]
     L.grv_integrate_batch_device.restype = i
     L.grv_integrate_batch_device.argtypes = [p, sz, p, C.POINTER(Options), p, p, p, p, p]
+    L.grv_tile_pitch.restype = C.c_uint32
+    L.grv_tile_pitch.argtypes = [C.c_uint32, C.c_uint32]
     L.grv_frame_ray_count.restype = sz
     L.grv_frame_ray_count.argtypes = [C.POINTER(RenderParams)]
     L.grv_render_frame.restype = i

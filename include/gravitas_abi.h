@@ -104,7 +104,10 @@ typedef struct {
     double lut_max_temp;
     /* image-plane partition for multi-GPU: this call renders the 64x64-pixel
      * tiles k with k % tile_world == tile_rank, packed in tile order
-     * (physics-engine/_legacy_src/tiling.rs:38-56 row-major grid). 1/0 = whole frame. */
+     * (physics-engine/_legacy_src/tiling.rs:38-56 row-major grid). 1/0 = whole frame.
+     * Tile (tx, ty) has id ty * P + tx, P = grv_tile_pitch(width, tile_world): the first integer
+     * >= ceil(width / 64) coprime with tile_world, so the deal shifts from row to row instead of
+     * handing a rank whole tile columns; ids in the pad columns hold no pixels. */
     uint32_t tile_world, tile_rank;
     uint32_t segment_tries; /* 0 = engine default: ONE integrate launch that runs every ray to its
                                end, queued on the stream without any host wait;
@@ -187,6 +190,7 @@ int grv_integrate_batch_device(grv_engine *e, size_t n, const double *d_states,
 
 /* ---- frame: pixel->state of src/shaders/compute.wgsl.ts:159-187 + integrate + shading ---- */
 size_t grv_frame_ray_count(const GrvRenderParams *p); /* rays this rank renders */
+uint32_t grv_tile_pitch(uint32_t width, uint32_t tile_world);
 int grv_render_frame(grv_engine *e, const GrvCamera *cam, const GrvRenderParams *p,
                      float *rgba_host, GrvFrameStats *stats);
 int grv_render_frame_device(grv_engine *e, const GrvCamera *cam, const GrvRenderParams *p,

@@ -32,10 +32,9 @@ def _worker(rank, world, port, w, h, out_path):
     try:
         p = bh.render_params(w, h)
         tiles = D.tiles_of_rank(w, h, world, rank)
-        tx = (w + 63) // 64
         packed = torch.zeros((len(tiles) * 4096, 4), dtype=torch.float32)
         for tl, t in enumerate(tiles):
-            x0, y0 = (t % tx) * 64, (t // tx) * 64
+            x0, y0 = D.tile_origin(t, w, world)
             ys, xs = np.meshgrid(np.arange(64) + y0, np.arange(64) + x0, indexing="ij")
             blk = np.stack([xs, ys, xs * 0 + rank, xs * 0 + 1], -1).astype(np.float32)
             packed[tl * 4096:(tl + 1) * 4096] = torch.from_numpy(blk.reshape(-1, 4))
@@ -78,8 +77,9 @@ def test_two_rank_tile_gather(tmp_path, w, h):
     ys, xs = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
     assert np.array_equal(img[..., 0], xs) and np.array_equal(img[..., 1], ys)
     assert np.all(img[..., 3] == 1.0)
-    tx = (w + 63) // 64
-    owner = ((ys // 64) * tx + xs // 64) % 2
+    sys.path.insert(0, ROOT)
+    from blackhole_simulation_amd import distributed as D
+    owner = ((ys // 64) * D.tile_pitch(w, 2) + xs // 64) % 2
     assert np.array_equal(img[..., 2], owner)  # round-robin tile -> rank map
 
 

@@ -181,3 +181,41 @@ def test_f32_march_frames_accumulate_without_waiting(bh, torch_mod):
         for _ in range(3):
             assert e.render_frame_wgsl(wp, rgba, want_total=False) is None
         assert e.frame_stats().accepted_steps == 3 * one
+
+
+def test_two_frames_in_flight_on_two_streams(bh, torch_mod):
+    """Even / odd frames on two streams: the engine alternates two ray workspaces and orders each
+    behind its previous user, so overlapping frames never share state.  Eight different frames
+    queued without a single wait equal the same frames rendered one at a time, bit for bit."""
+    torch = torch_mod
+    W, H = 384, 216
+    eyes = [(60.0 * np.sin(np.deg2rad(t)), 60.0 * np.cos(np.deg2rad(t)), 3.0 * k)
+            for k, t in enumerate((97.0, 80.0, 60.0, 110.0, 45.0, 97.0, 89.0, 135.0))]
+    with bh.PhysicsEngine(1.0, 0.999) as e:
+        p = bh.render_params(W, H, arith=1)
+        serial = []
+        for eye in eyes:
+            out = torch.zeros(W * H, 4, dtype=torch.float32, device="cuda:0")
+            fs = torch.zeros(W * H, 8, dtype=torch.float64, device="cuda:0")
+            e.render_frame_device(bh.camera_look_at(eye, aspect=W / H), p, rgba=out, final_state=fs)
+            torch.cuda.synchronize()
+            serial.append((out, fs))
+        one = e.frame_stats()
+        e.stats_accumulate(True)
+        e.frame_stats_reset()
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        flight = []
+        for k, eye in enumerate(eyes):
+            out = torch.zeros(W * H, 4, dtype=torch.float32, device="cuda:0")
+            fs = torch.zeros(W * H, 8, dtype=torch.float64, device="cuda:0")
+            flight.append((out, fs))
+        torch.cuda.synchronize()
+        for k, eye in enumerate(eyes):
+            with torch.cuda.stream(streams[k % 2]):
+                e.render_frame_device(bh.camera_look_at(eye, aspect=W / H), p, rgba=flight[k][0],
+                                      final_state=flight[k][1], stream=streams[k % 2].cuda_stream)
+        torch.cuda.synchronize()
+        acc = e.frame_stats()
+    assert acc.rays == len(eyes) * one.rays
+    for (a, fa), (b, fb) in zip(serial, flight):
+        assert torch.equal(a, b) and torch.equal(fa.view(torch.int64), fb.view(torch.int64))

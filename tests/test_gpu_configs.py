@@ -99,6 +99,6 @@ def test_config4_8k_tiled_over_8_ranks_fixed_1024(engine_mod):
             tsum += e.render_frame_wgsl(gpr, buf)
             e.unpack_tiles_device(D.rank_params(rp, R, r), r, buf, img, 16)
         torch.cuda.synchronize()
-        assert max(counts) - min(counts) <= 1 and sum(counts) == D.tiles_total(W, H)
+        assert max(counts) - min(counts) <= 1 and sum(counts) == D.tiles_total(W, H, R)
         assert tsum == tot
         assert torch.equal(img.reshape(-1, 4), whole)

@@ -95,7 +95,8 @@ def test_tile_partition_covers_every_pixel_once(engine_mod, w, h, world):
         packed = np.ones((n, 1), np.int32)
         counts += engine_mod.unpack_tiles(rp, r, packed, 1, np.int32)[..., 0]
     assert np.all(counts == 1)
-    assert sum(len(D.tiles_of_rank(w, h, world, r)) for r in range(world)) == D.tiles_total(w, h)
+    assert sum(len(D.tiles_of_rank(w, h, world, r)) for r in range(world)) == D.tiles_total(w, h, world)
+    assert engine_mod.load_library().grv_tile_pitch(w, world) == D.tile_pitch(w, world)
 
 
 def test_unpack_places_pixels_row_major(engine_mod):
@@ -104,19 +105,36 @@ def test_unpack_places_pixels_row_major(engine_mod):
     p = engine_mod.render_params(w, h)
     truth = np.arange(w * h, dtype=np.int32).reshape(h, w)
     img = np.zeros((h, w, 1), np.int32)
-    tx = (w + 63) // 64
     for r in range(world):
         rp = D.rank_params(p, world, r)
         tiles = D.tiles_of_rank(w, h, world, r)
         packed = np.zeros((len(tiles) * 4096, 1), np.int32)
         for tl, t in enumerate(tiles):
-            x0, y0 = (t % tx) * 64, (t // tx) * 64
+            x0, y0 = D.tile_origin(t, w, world)
             blk = np.zeros((64, 64), np.int32)
             sub = truth[y0:y0 + 64, x0:x0 + 64]
             blk[:sub.shape[0], :sub.shape[1]] = sub
             packed[tl * 4096:(tl + 1) * 4096, 0] = blk.reshape(-1)
         img += engine_mod.unpack_tiles(rp, r, packed, 1, np.int32)
     assert np.array_equal(img[..., 0], truth)
+
+
+@pytest.mark.parametrize("w,world", [(3840, 2), (3840, 4), (3840, 8), (7680, 8), (7680, 4), (1920, 8),
+                                     (200, 3), (640, 5), (64, 2), (3840, 1), (7680, 6)])
+def test_tile_deal_shifts_from_row_to_row(w, world):
+    """The pitch is coprime with the rank count, so no rank owns whole tile columns: every rank
+    meets every tile column within `world` consecutive rows, and the pad stays small."""
+    import math
+    from blackhole_simulation_amd import distributed as D
+    p = D.tile_pitch(w, world)
+    across = (w + 63) // 64
+    assert p >= across and math.gcd(p, world) == 1 and p - across < max(world, 2)
+    if world == 1:
+        assert p == across
+        return
+    for col in range(min(across, 9)):
+        owners = {(row * p + col) % world for row in range(world)}
+        assert owners == set(range(world)), (col, owners)
 
 
 def test_bench_helpers():

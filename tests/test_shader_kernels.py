@@ -237,8 +237,8 @@ def test_wgsl_packed_kernel_odd_sizes_and_tiles(engine_mod):
                 for arith in (1, 2):
                     gp = engine_mod.wgsl_params(W, H, cam, 1.0, 0.9, max_steps=200, arith=arith, stars=0,
                                                 tile_world=world, tile_rank=r)
-                    tiles = ((W + 63) // 64) * ((H + 63) // 64)
-                    n = W * H if world == 1 else ((tiles - r + world - 1) // world) * 4096
+                    gp_ray_count = engine_mod.render_params(W, H, tile_world=world, tile_rank=r)
+                    n = e.frame_ray_count(gp_ray_count)
                     rgba = torch.full((n, 4), -7.0, dtype=torch.float32, device="cuda:0")
                     steps = torch.zeros(n, dtype=torch.int32, device="cuda:0")
                     tot = e.render_frame_wgsl(gp, rgba, steps)

@@ -21,31 +21,34 @@ from blackhole_simulation_amd import distributed as D  # noqa: E402
 EYE = (60.0 * np.sin(np.deg2rad(97.0)), 60.0 * np.cos(np.deg2rad(97.0)), 0.0)
 
 
-def share(e, cfg, W, H, world, rank, frames):
+def share(e, cfg, W, H, world, rank, frames, two_streams=False):
     cam = bh.camera_look_at(EYE, aspect=W / H)
     params = bh.render_params(W, H, arith=bh.ARITH_FAST)
     rp = D.rank_params(params, world, rank)
     n = e.frame_ray_count(rp)
     wp = bh.wgsl_params(W, H, cam, 1.0, 0.999, max_steps=1024, arith=bh.ARITH_FAST,
                         tile_world=world, tile_rank=rank) if cfg == "c4" else None
-    rgba = torch.zeros(n, 4, dtype=torch.float32, device="cuda:0")
-    stream = torch.cuda.current_stream().cuda_stream
+    rgbas = [torch.zeros(n, 4, dtype=torch.float32, device="cuda:0") for _ in range(2)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()] if two_streams else [torch.cuda.current_stream()] * 2
+    stream = streams[0].cuda_stream
 
-    def go():
+    def go(i=0):
+        s = streams[i % 2].cuda_stream
         if cfg == "c3":
-            e.render_frame_device(cam, rp, rgba=rgba, stream=stream)
+            e.render_frame_device(cam, rp, rgba=rgbas[i % 2], stream=s)
         else:
-            e.render_frame_wgsl(wp, rgba, stream=stream, want_total=False)
+            e.render_frame_wgsl(wp, rgbas[i % 2], stream=s, want_total=False)
 
-    go()
+    go(0)
+    go(1)
     torch.cuda.synchronize()
     e.frame_stats_reset(stream)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     host = 0.0
-    for _ in range(frames):
+    for i in range(frames):
         h0 = time.perf_counter()
-        go()
+        go(i)
         host += time.perf_counter() - h0
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / frames
@@ -60,13 +63,13 @@ if __name__ == "__main__":
     with bh.PhysicsEngine(1.0, 0.999) as e:
         e.stats_accumulate(True)
         base = None
-        for world in (1, 2, 4, 8):
-            rows = [share(e, cfg, W, H, world, r, frames) for r in range(world)]
+        for world, two in ((1, False), (2, False), (4, False), (8, False), (1, True), (2, True), (4, True), (8, True)):
+            rows = [share(e, cfg, W, H, world, r, frames, two) for r in range(world)]
             ms = [r[0] for r in rows]
-            if world == 1:
+            if world == 1 and not two:
                 base = ms[0]
             print(json.dumps({
-                "config": cfg, "frame": [W, H], "n_gpus": world,
+                "config": cfg, "frame": [W, H], "n_gpus": world, "frames_in_flight": 2 if two else 1,
                 "ms_per_frame_by_rank": [round(x, 3) for x in ms],
                 "slowest_rank_ms": round(max(ms), 3),
                 "steps_by_rank": [int(r[2]) for r in rows],

@@ -22,8 +22,7 @@ EYE = (60.0 * np.sin(np.deg2rad(97.0)), 60.0 * np.cos(np.deg2rad(97.0)), 0.0)
 def run(name, W, H, make, call, reps=10, world=1):
     gp = make(W, H)
     gp.tile_world, gp.tile_rank = world, 0
-    tiles = ((W + 63) // 64) * ((H + 63) // 64)
-    n = ((tiles + world - 1) // world) * 4096 if world > 1 else W * H
+    n = bh.load_library().grv_frame_ray_count(bh.render_params(W, H, tile_world=world, tile_rank=0))
     rgba = torch.zeros(n, 4, dtype=torch.float32, device="cuda:0")
     with bh.PhysicsEngine(1.0, 0.999) as e:
         tot = call(e, gp, rgba)
