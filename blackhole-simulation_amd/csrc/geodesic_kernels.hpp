@@ -41,7 +41,23 @@ struct RayRegs {
                       // the post-step bookkeeping and reused as stage 1 of the next try
 };
 
-template <int KIND, int ARITH> constexpr bool kStage1Cache = (KIND == GRV_METRIC_KERR_KS && ARITH == GRV_ARITH_FAST);
+// The right-hand side at the current state is formed once, by the post-step bookkeeping, and reused
+// as stage 1 of the next try (also across rejected tries).  FAST Kerr-Schild builds it from the
+// shared geometry; the STRICT forms evaluate rhs_ref_at on the sine, cosine and inverse metric the
+// bookkeeping computed at that point -- the very operations stage 1 would repeat, so the bits are
+// those of the uncached form (GRV_STRICT_STAGE1_CACHE=0 compiles that form for comparison).
+#ifndef GRV_STRICT_STAGE1_CACHE
+#define GRV_STRICT_STAGE1_CACHE 1
+#endif
+template <int KIND, int ARITH> constexpr bool kFastKsCache = (KIND == GRV_METRIC_KERR_KS && ARITH == GRV_ARITH_FAST);
+template <int KIND, int ARITH> constexpr bool kStrictCache = (ARITH == GRV_ARITH_STRICT && GRV_STRICT_STAGE1_CACHE != 0);
+template <int KIND, int ARITH> constexpr bool kStage1Cache = kFastKsCache<KIND, ARITH> || kStrictCache<KIND, ARITH>;
+
+__device__ __forceinline__ Hole<double> make_hole(const SegmentParams &P) {
+    Hole<double> bh{P.M, P.a, P.a2, 2.0 * P.M};
+    bh.divs_ok = divs_ok_hole(P.M, P.a);
+    return bh;
+}
 
 __device__ __forceinline__ double clamp_rs(double x, double lo, double hi) {
     // Rust f64::clamp
@@ -60,7 +76,7 @@ __device__ __forceinline__ double rkf45_try(const Hole<double> &bh, const RayReg
     // right-hand side at a stage point; the FAST Kerr-Schild form takes the per-ray
     // constant products (rc) instead of recomputing them six times a try
     auto f = [&](double r_, double th_, double pr_, double pth_) {
-        if constexpr (kStage1Cache<KIND, ARITH>)
+        if constexpr (kFastKsCache<KIND, ARITH>)
             return rhs_ks_geom(bh, ks_geom(bh, r_, th_), r_, rc, pr_, pth_);
         else
             return rhs<KIND, ARITH>(bh, r_, th_, y.pt, pr_, pth_, y.pph);
@@ -190,7 +206,11 @@ __device__ __forceinline__ double rkf45_try(const Hole<double> &bh, const RayReg
 template <int KIND, int ARITH>
 __device__ __forceinline__ void rk4_step(const Hole<double> &bh, RayRegs &y, double h) {
     const double hh = 0.5 * h;
-    const Deriv<double> k1 = rhs<KIND, ARITH>(bh, y.r, y.th, y.pt, y.pr, y.pth, y.pph);
+    Deriv<double> k1;
+    if constexpr (kStage1Cache<KIND, ARITH>)
+        k1 = y.k1; // the right-hand side at the current state (post-step bookkeeping)
+    else
+        k1 = rhs<KIND, ARITH>(bh, y.r, y.th, y.pt, y.pr, y.pth, y.pph);
     const Deriv<double> k2 = rhs<KIND, ARITH>(bh, y.r + k1.dr * hh, y.th + k1.dth * hh, y.pt,
                                               y.pr + k1.dpr * hh, y.pth + k1.dpth * hh, y.pph);
     const Deriv<double> k3 = rhs<KIND, ARITH>(bh, y.r + k2.dr * hh, y.th + k2.dth * hh, y.pt,
@@ -213,7 +233,14 @@ __device__ __forceinline__ void symplectic_step(const Hole<double> &bh, RayRegs 
     double mr = y.r, mth = y.th, mpr = y.pr, mpth = y.pth;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-        const Deriv<double> d = rhs<KIND, ARITH>(bh, mr, mth, y.pt, mpr, mpth, y.pph);
+        Deriv<double> d;
+        if constexpr (kStage1Cache<KIND, ARITH>) {
+            // the first sweep evaluates the right-hand side at the current state: cached
+            if (it == 0) d = y.k1;
+            else d = rhs<KIND, ARITH>(bh, mr, mth, y.pt, mpr, mpth, y.pph);
+        } else {
+            d = rhs<KIND, ARITH>(bh, mr, mth, y.pt, mpr, mpth, y.pph);
+        }
         mr = 0.5 * (y.r + (y.r + d.dr * h));
         mth = 0.5 * (y.th + (y.th + d.dth * h));
         mpr = 0.5 * (y.pr + (y.pr + d.dpr * h));
@@ -255,6 +282,27 @@ __device__ __forceinline__ void ray_begin(const Hole<double> &bh, RayRegs &y,
     y.flags = (y.flags & ~kFlagTermMask) | term;
 }
 
+// STRICT post-step metric work at the new point: projection (on the renormalisation phase), H,
+// and the right-hand side there for the stage-1 cache.  Returns H.
+template <int KIND>
+__device__ __forceinline__ double post_step_ref(const Hole<double> &bh, RayRegs &y, bool renorm) {
+    double s, c;
+    sincos_t(y.th, &s, &c);
+    auto body = [&](auto div) {
+        using DIV = decltype(div);
+        const GInv<double> g = contravariant_ref<KIND, double, DIV>(bh, y.r, s, c);
+        if (renorm) y.pr = renormalized_pr<KIND, GRV_ARITH_STRICT, double>(g, y.pt, y.pr, y.pth, y.pph);
+        const double hv = hamiltonian_of<KIND, double>(g, y.pt, y.pr, y.pth, y.pph);
+        y.k1 = rhs_ref_at<KIND, double, DIV>(bh, y.r, s, c, g, y.pt, y.pr, y.pth, y.pph);
+        return hv;
+    };
+    if constexpr (KIND == GRV_METRIC_KERR_KS) {
+        const bool ok = bh.divs_ok && divs_ok_point(y.r, s, c);
+        if (__ballot(!ok) == 0ull) return body(SharedDiv{});
+    }
+    return body(IeeeDiv{});
+}
+
 // Everything integrate() does after a completed step (mod.rs:228-239), then the
 // next iteration's loop-top checks, plus the disk-plane crossing recorder.
 template <int KIND, int ARITH>
@@ -264,7 +312,7 @@ __device__ __forceinline__ void after_step(const Hole<double> &bh, RayRegs &y, d
                                            const KsRayConsts &rc) {
     const bool renorm = P.renorm_interval != 0 && y.phase == 0u; // steps % interval == 0
     double hv;
-    if constexpr (kStage1Cache<KIND, ARITH>) {
+    if constexpr (kFastKsCache<KIND, ARITH>) {
         // one geometry evaluation serves the projection, H and stage 1 of the next try
         const KsGeom geom = ks_geom(bh, y.r, y.th);
         if (renorm)
@@ -272,6 +320,10 @@ __device__ __forceinline__ void after_step(const Hole<double> &bh, RayRegs &y, d
                                                         y.pth, y.pph);
         y.k1 = rhs_ks_geom(bh, geom, y.r, rc, y.pr, y.pth, &hv);
         hv = fabs(hv);
+    } else if constexpr (kStrictCache<KIND, ARITH>) {
+        // reference order: contravariant() for the projection and for H (mod.rs:229-237), then the
+        // next iteration's first derivative at the same point -- one sine / cosine / metric for all
+        hv = fabs(post_step_ref<KIND>(bh, y, renorm));
     } else {
         const GInv<double> g = contravariant_at<KIND, ARITH, double>(bh, y.r, y.th);
         if (renorm) y.pr = renormalized_pr<KIND, ARITH, double>(g, y.pt, y.pr, y.pth, y.pph);
@@ -411,9 +463,11 @@ __device__ __forceinline__ void ray_resume(const Hole<double> &bh, RayRegs &y,
                                            const SegmentParams &P, bool live, KsRayConsts &rc) {
     y.phase = P.renorm_interval ? y.steps % P.renorm_interval : 1u;
     rc = ks_ray_consts(bh, y.pt, y.pph); // p_t, p_phi never change
-    if constexpr (kStage1Cache<KIND, ARITH>) {
+    if constexpr (kFastKsCache<KIND, ARITH>) {
         // rebuild the stage-1 cache
         if (live) y.k1 = rhs_ks_geom(bh, ks_geom(bh, y.r, y.th), y.r, rc, y.pr, y.pth);
+    } else if constexpr (kStrictCache<KIND, ARITH>) {
+        if (live) y.k1 = rhs<KIND, ARITH>(bh, y.r, y.th, y.pt, y.pr, y.pth, y.pph);
     }
 }
 
@@ -438,7 +492,7 @@ void integrate_segment_kernel(
     y.flags = 0;
     y.pt = y.pph = 0.0;
     if (have) load_ray(ws, slot, y);
-    const Hole<double> bh{P.M, P.a, P.a2, 2.0 * P.M};
+    const Hole<double> bh = make_hole(P);
 
     bool live = have && ray_live(y);
     KsRayConsts rc;
@@ -490,7 +544,7 @@ void integrate_refill_kernel(RayWorkspace ws, SegmentParams P,
                                                                   uint32_t *__restrict__ cursor) {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long below = (1ull << lane) - 1ull;
-    const Hole<double> bh{P.M, P.a, P.a2, 2.0 * P.M};
+    const Hole<double> bh = make_hole(P);
     RayRegs y;
     y.flags = 0;
     y.pt = y.pph = 0.0;
@@ -557,7 +611,7 @@ __global__ __launch_bounds__(64) void single_ray_kernel(SegmentParams P, SingleR
     y.steps = 0;
     y.tries = 0;
     y.flags = kFlagValid;
-    const Hole<double> bh{P.M, P.a, P.a2, 2.0 * P.M};
+    const Hole<double> bh = make_hole(P);
     ray_begin<KIND>(bh, y, P, true);
     bool live = ray_live(y);
     KsRayConsts rc;
@@ -605,7 +659,7 @@ __global__ __launch_bounds__(kBlock) void init_from_states_kernel(
     y.steps = 0;
     y.tries = 0;
     y.flags = kFlagValid;
-    const Hole<double> bh{P.M, P.a, P.a2, 2.0 * P.M};
+    const Hole<double> bh = make_hole(P);
     ray_begin<KIND>(bh, y, P, adaptive != 0);
     store_ray(ws, i, y);
     ws.pt[i] = y.pt;
@@ -692,7 +746,7 @@ __global__ __launch_bounds__(kBlock) void init_from_pixels_kernel(RayWorkspace w
     y.pth = pth_far * r0 * r0;
     y.pph = pph_far * r0 * r0 * st * st;
     y.flags = kFlagValid;
-    const Hole<double> bh{P.M, P.a, P.a2, 2.0 * P.M};
+    const Hole<double> bh = make_hole(P);
     ray_begin<KIND>(bh, y, P, adaptive != 0);
     store_ray(ws, slot, y);
     ws.pt[slot] = y.pt;

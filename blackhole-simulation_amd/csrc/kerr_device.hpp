@@ -32,6 +32,7 @@ template <typename T> struct Hole {
     T a;  // spin * mass
     T a2; // a * a
     T two_m; // 2 M
+    bool divs_ok = false; // M and a admit the shared-reciprocal division form (divs_ok_hole)
 };
 
 template <typename T> struct Deriv {
@@ -138,9 +139,66 @@ __device__ __forceinline__ double fast_pow_m1_4(double x) {
 }
 
 // ---------------------------------------------------------------------------
+// Division policies of the reference-order code.
+//
+// IeeeDiv: the language's `/` -- for f64 the compiler's correctly rounded expansion
+//   (v_div_scale x2, v_rcp, five fma, v_div_fmas, v_div_fixup: ten instructions a quotient).
+// SharedDiv (f64, STRICT Kerr-Schild): the SAME expansion with the part that depends on the
+//   denominator alone -- the reciprocal seed and its two Newton steps -- evaluated once per
+//   denominator and shared by every quotient over it (the Kerr-Schild right-hand side has fifteen
+//   quotients over five denominators).  Per quotient that leaves the product, the residual fma, the
+//   correction fma and v_div_fixup, which maps zero / infinite / NaN operands exactly as the full
+//   sequence does.  The two v_div_scale steps are dropped: they are the identity (and v_div_fmas a
+//   plain fma) whenever both operands are zero, non-finite or moderate in magnitude, and `divs_ok`
+//   below admits a right-hand side to this form only then.  Inside that range the instruction
+//   sequence per quotient is the compiler's own, so the quotient has the same bits; outside it the
+//   wave takes the IeeeDiv form.  Which form ran is therefore invisible in the results.
+// ---------------------------------------------------------------------------
+struct IeeeDiv {
+    template <typename T> struct Den { T d; };
+    template <typename T> static __device__ __forceinline__ Den<T> prep(T d) { return {d}; }
+    template <typename T> static __device__ __forceinline__ T div(T n, const Den<T> &D) { return n / D.d; }
+};
+struct SharedDiv {
+    template <typename T> struct Den { T d, r; };
+    static __device__ __forceinline__ Den<double> prep(double d) {
+        // r2 of the f64 fdiv expansion: rcp seed + two Newton steps
+        const double r0 = __builtin_amdgcn_rcp(d);
+        const double e0 = fma(-d, r0, 1.0);
+        const double r1 = fma(r0, e0, r0);
+        const double e1 = fma(-d, r1, 1.0);
+        return {d, fma(r1, e1, r1)};
+    }
+    static __device__ __forceinline__ double div(double n, const Den<double> &D) {
+        const double q0 = n * D.r;
+        const double res = fma(-D.d, q0, n);
+        return __builtin_amdgcn_div_fixup(fma(res, D.r, q0), D.d, n);
+    }
+};
+
+// x is zero or lo <= |x| <= hi  (false for NaN / infinities)
+__device__ __forceinline__ bool zero_or_within(double x, double lo, double hi) {
+    const double ax = fabs(x);
+    return ax == 0.0 || (ax >= lo && ax <= hi);
+}
+// Operand range in which every quotient of the Kerr-Schild metric and its derivatives keeps both
+// v_div_scale steps the identity: M, a, r zero or in [2^-20, 2^20]; sin, cos zero or >= 2^-70
+// (cos(pi/2) = 6e-17 = 2^-54 is the common equatorial value).  Then every denominator is zero or
+// in [2^-266, 2^82], every numerator zero or in [2^-290, 2^83] (differences of products are zero
+// or at least an ulp of their larger term): all normal, numerator exponents above the 2^-969 line
+// of v_div_scale, exponent differences far inside +-768.
+__device__ __forceinline__ bool divs_ok_hole(double M, double a) {
+    return zero_or_within(M, 0x1p-20, 0x1p20) && zero_or_within(a, 0x1p-20, 0x1p20);
+}
+__device__ __forceinline__ bool divs_ok_point(double r, double sin_theta, double cos_theta) {
+    return zero_or_within(r, 0x1p-20, 0x1p20) && zero_or_within(sin_theta, 0x1p-70, 1.0) &&
+           zero_or_within(cos_theta, 0x1p-70, 1.0);
+}
+
+// ---------------------------------------------------------------------------
 // Reference-order inverse metric.  KIND = GRV_METRIC_*.
 // ---------------------------------------------------------------------------
-template <int KIND, typename T>
+template <int KIND, typename T, typename DIV = IeeeDiv>
 __device__ __forceinline__ GInv<T> contravariant_ref(const Hole<T> &bh, T r, T sin_theta,
                                                      T cos_theta) {
     GInv<T> g;
@@ -154,12 +212,14 @@ __device__ __forceinline__ GInv<T> contravariant_ref(const Hole<T> &bh, T r, T s
         const T cos2 = T(1) - sin2;
         const T sigma = r2 + bh.a2 * cos2;
         const T delta = r2 - T(2) * m * r + bh.a2;
-        g.tt = -(T(1) + T(2) * m * r / sigma);
-        g.tr = T(2) * m * r / sigma;
-        g.rr = delta / sigma;
-        g.thth = T(1) / sigma;
-        g.phph = T(1) / (sigma * sin2);
-        g.rph = bh.a / sigma;
+        const auto by_sigma = DIV::prep(sigma);
+        const auto by_sigma_sin2 = DIV::prep(sigma * sin2);
+        g.tt = -(T(1) + DIV::div(T(2) * m * r, by_sigma));
+        g.tr = DIV::div(T(2) * m * r, by_sigma);
+        g.rr = DIV::div(delta, by_sigma);
+        g.thth = DIV::div(T(1), by_sigma);
+        g.phph = DIV::div(T(1), by_sigma_sin2);
+        g.rph = DIV::div(bh.a, by_sigma);
     } else if constexpr (KIND == GRV_METRIC_KERR_BL) {
         const T r2 = r * r;
         const T sin2 = sin_theta * sin_theta;
@@ -186,12 +246,11 @@ __device__ __forceinline__ GInv<T> contravariant_ref(const Hole<T> &bh, T r, T s
 // Reference-order right-hand side (used by the STRICT build for every metric
 // and by the FAST build for BL / Schwarzschild).
 // ---------------------------------------------------------------------------
-template <int KIND, typename T>
-__device__ __forceinline__ Deriv<T> rhs_ref(const Hole<T> &bh, T r, T theta, T p_t, T p_r,
-                                            T p_th, T p_ph) {
-    T sin_theta, cos_theta;
-    sincos_t(theta, &sin_theta, &cos_theta);
-    const GInv<T> g = contravariant_ref<KIND>(bh, r, sin_theta, cos_theta);
+// (the point's sine, cosine and inverse metric come from the caller: the post-step bookkeeping
+// has them already when it forms stage 1 of the next try)
+template <int KIND, typename T, typename DIV = IeeeDiv>
+__device__ __forceinline__ Deriv<T> rhs_ref_at(const Hole<T> &bh, T r, T sin_theta, T cos_theta,
+                                               const GInv<T> &g, T p_t, T p_r, T p_th, T p_ph) {
     Deriv<T> d;
     const T m = bh.M;
     const T a = bh.a;
@@ -217,19 +276,22 @@ __device__ __forceinline__ Deriv<T> rhs_ref(const Hole<T> &bh, T r, T theta, T p
         const T dsigma_dtheta = T(-2) * a2 * sin_theta * cos_theta;
         const T ddelta_dr = T(2) * r - T(2) * m;
 
-        const T dg_tt_dr = -(T(2) * m * (sigma - r * dsigma_dr)) / sigma2;
-        const T dg_tt_dtheta = (T(2) * m * r * dsigma_dtheta) / sigma2;
+        const auto by_sigma2 = DIV::prep(sigma2);
+        const auto by_sigma2_sin2 = DIV::prep(sigma2 * sin2);
+        const auto by_sigma2_sin4 = DIV::prep(sigma2 * sin2 * sin2);
+        const T dg_tt_dr = DIV::div(-(T(2) * m * (sigma - r * dsigma_dr)), by_sigma2);
+        const T dg_tt_dtheta = DIV::div(T(2) * m * r * dsigma_dtheta, by_sigma2);
         const T dg_tr_dr = -dg_tt_dr;
         const T dg_tr_dtheta = -dg_tt_dtheta;
-        const T dg_rr_dr = (ddelta_dr * sigma - delta * dsigma_dr) / sigma2;
-        const T dg_rr_dtheta = -(delta * dsigma_dtheta) / sigma2;
-        const T dg_thth_dr = -dsigma_dr / sigma2;
-        const T dg_thth_dtheta = -dsigma_dtheta / sigma2;
-        const T dg_phph_dr = -dsigma_dr / (sigma2 * sin2);
+        const T dg_rr_dr = DIV::div(ddelta_dr * sigma - delta * dsigma_dr, by_sigma2);
+        const T dg_rr_dtheta = DIV::div(-(delta * dsigma_dtheta), by_sigma2);
+        const T dg_thth_dr = DIV::div(-dsigma_dr, by_sigma2);
+        const T dg_thth_dtheta = DIV::div(-dsigma_dtheta, by_sigma2);
+        const T dg_phph_dr = DIV::div(-dsigma_dr, by_sigma2_sin2);
         const T dg_phph_dtheta =
-            -(dsigma_dtheta * sin2 + sigma * T(2) * sin_theta * cos_theta) / (sigma2 * sin2 * sin2);
-        const T dg_rph_dr = -(a * dsigma_dr) / sigma2;
-        const T dg_rph_dtheta = -(a * dsigma_dtheta) / sigma2;
+            DIV::div(-(dsigma_dtheta * sin2 + sigma * T(2) * sin_theta * cos_theta), by_sigma2_sin4);
+        const T dg_rph_dr = DIV::div(-(a * dsigma_dr), by_sigma2);
+        const T dg_rph_dtheta = DIV::div(-(a * dsigma_dtheta), by_sigma2);
 
         const T dh_dr = T(0.5) * (dg_tt_dr * p_t * p_t + dg_rr_dr * p_r * p_r +
                                   dg_thth_dr * p_th * p_th + dg_phph_dr * p_ph * p_ph +
@@ -327,6 +389,23 @@ __device__ __forceinline__ Deriv<T> rhs_ref(const Hole<T> &bh, T r, T theta, T p
         d.dpth = -dh_dtheta;
     }
     return d;
+}
+
+template <int KIND, typename T>
+__device__ __forceinline__ Deriv<T> rhs_ref(const Hole<T> &bh, T r, T theta, T p_t, T p_r,
+                                            T p_th, T p_ph) {
+    T sin_theta, cos_theta;
+    sincos_t(theta, &sin_theta, &cos_theta);
+    if constexpr (KIND == GRV_METRIC_KERR_KS && sizeof(T) == 8) {
+        // wave-uniform choice of the division form (see SharedDiv): same bits either way
+        const bool ok = bh.divs_ok && divs_ok_point(r, sin_theta, cos_theta);
+        if (__ballot(!ok) == 0ull) {
+            const GInv<T> g = contravariant_ref<KIND, T, SharedDiv>(bh, r, sin_theta, cos_theta);
+            return rhs_ref_at<KIND, T, SharedDiv>(bh, r, sin_theta, cos_theta, g, p_t, p_r, p_th, p_ph);
+        }
+    }
+    const GInv<T> g = contravariant_ref<KIND, T>(bh, r, sin_theta, cos_theta);
+    return rhs_ref_at<KIND, T>(bh, r, sin_theta, cos_theta, g, p_t, p_r, p_th, p_ph);
 }
 
 // ---------------------------------------------------------------------------
