@@ -7,7 +7,10 @@
  *                         pass sequence src/rendering/bloom.ts:443-583 (renderScale = 1)
  * TEST INFRASTRUCTURE ONLY.  The reference holds no test that executes these shaders
  * (its pipeline tests mock WebGL): parity unpinned upstream; pinned here
- * by closed-form properties (tests/test_post_chain.py).
+ * by closed-form properties (tests/test_post_chain.py) and, without going through the HIP twin,
+ * by hand-computed 3x3 / constant / impulse images evaluated in numpy f64 from the shaders'
+ * literal constants (tests/test_f32_oracle_pins.py: 1.5 sigma / 2 sigma clip boxes, the
+ * variance weight, feedback 0.92, luminance coefficients, the 9-tap weights, ACES, gamma).
  *
  * Images are RGBA f32, row-major.  Texture fetches are GL LINEAR + CLAMP_TO_EDGE with f32
  * weights; render targets are RGBA16F upstream, modelled by rounding every stored channel to

@@ -192,6 +192,20 @@ def lib():
         L.orc_wgsl_frame.argtypes = [C.POINTER(WgslParams), C.c_uint32, C.c_uint32, p, p, i]
         L.orc_glsl_frame.argtypes = [C.POINTER(GlslParams), C.c_uint32, C.c_uint32, p, p, i]
         L.orc_seeded_noise_rgba8.argtypes = [C.c_uint32, C.c_uint32, p]
+        # test hooks of the f32 shader oracle (single building blocks, shader_oracle.c)
+        f32 = C.c_float
+        L.orc_hook_wgsl_derivs.argtypes = [p, p, f32, f32, p, p]
+        L.orc_hook_wgsl_step.argtypes = [p, p, f32, f32, f32, p, p]
+        L.orc_hook_glsl_accel.argtypes = [p, p, f32, f32, p, p]
+        L.orc_hook_glsl_blackbody.argtypes = [f32, p]
+        L.orc_hook_glsl_verlet_oscillator.argtypes = [p, p, f32, f32, i]
+        for name, n in (("orc_hook_wgsl_horizon", 2), ("orc_hook_wgsl_isco", 2),
+                        ("orc_hook_glsl_horizon", 2), ("orc_hook_glsl_isco", 2),
+                        ("orc_hook_glsl_photon_sphere", 2), ("orc_hook_glsl_redshift_potential", 2),
+                        ("orc_hook_glsl_ergosphere_radius", 3), ("orc_hook_glsl_beaming", 1),
+                        ("orc_hook_glsl_disk_delta", 5)):
+            getattr(L, name).restype = f32
+            getattr(L, name).argtypes = [f32] * n
         L.orc_round_to_half.restype = C.c_float
         L.orc_round_to_half.argtypes = [C.c_float]
         L.orc_taa_resolve.argtypes = [C.c_uint32, C.c_uint32, p, p, C.c_float, i, i, p]

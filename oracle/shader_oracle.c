@@ -314,6 +314,36 @@ static v3 gl_kerr_accel(v3 p, v3 v, float M, float a, float *omega) {
     return acc;
 }
 
+/* fragment.glsl.ts:204 -- the expression advanced-physics.test.ts:12-14 mirrors */
+static float gl_redshift_potential(float rs, float r) { return sqrtf(fmaxf(0.0f, 1.0f - rs / r)); }
+/* fragment.glsl.ts:265 -- advanced-physics.test.ts:17-20 */
+static float gl_ergosphere_radius(float M, float a, float cosTheta) {
+    return M + sqrtf(fmaxf(0.0f, M * M - a * a * cosTheta * cosTheta));
+}
+/* chunks/disk.ts:95 (Doppler beaming of the disk emission) */
+static float gl_beaming(float delta) { return fmaxf(0.01f, orc_powf(delta, 3.5f)); }
+/* chunks/disk.ts:78-93: Keplerian emitter, equatorial metric, u^t, photon L, delta */
+static float gl_disk_delta(float M, float a, float spin, float sampleR, float L_photon) {
+    float r2 = sampleR * sampleR;
+    float sqrt_M = sqrtf(M);
+    float signSpin = signf(spin + 1e-8f);
+    float Omega = (signSpin * sqrt_M) / (sampleR * sqrtf(sampleR) + a * sqrt_M);
+    float g_tt = -(1.0f - 2.0f * M / sampleR);
+    float g_tphi = -2.0f * M * a / sampleR;
+    float g_phiphi = r2 + a * a + 2.0f * M * a * a / sampleR;
+    float u_t_sq = -(g_tt + 2.0f * Omega * g_tphi + Omega * Omega * g_phiphi);
+    float u_t = 1.0f / sqrtf(fmaxf(1e-6f, u_t_sq));
+    return 1.0f / fmaxf(0.01f, u_t * (1.0f - Omega * L_photon));
+}
+/* fragment.glsl.ts:176-191: the Velocity-Verlet update (advanced-physics.test.ts:196-218 runs the
+ * same two lines on a harmonic oscillator) */
+static v3 gl_verlet_position(v3 p, v3 v, v3 accel, float dt) {
+    return add3(p, add3(scale3(v, dt), scale3(scale3(scale3(accel, 0.5f), dt), dt)));
+}
+static v3 gl_verlet_velocity(v3 v, v3 accel, v3 accel_new, float dt) {
+    return add3(v, scale3(scale3(add3(accel, accel_new), 0.5f), dt));
+}
+
 /* chunks/blackbody.ts:9-34 */
 static void gl_blackbody(float temp, float rgb[3]) {
     float t = fmaxf(temp, 1.0f) / 100.0f;
@@ -467,18 +497,9 @@ static void gl_sample_disk(const orc_glsl_params *U, v3 p, v3 p_prev, v3 v, floa
     float baseDensity = turbulence * heightFalloff * radialFalloff;
     if (!(baseDensity > 0.001f)) return;
 
-    float r2 = sampleR * sampleR;
-    float sqrt_M = sqrtf(M);
-    float signSpin = signf(U->spin + 1e-8f);
-    float Omega = (signSpin * sqrt_M) / (sampleR * sqrtf(sampleR) + a * sqrt_M);
-    float g_tt = -(1.0f - 2.0f * M / sampleR);
-    float g_tphi = -2.0f * M * a / sampleR;
-    float g_phiphi = r2 + a * a + 2.0f * M * a * a / sampleR;
-    float u_t_sq = -(g_tt + 2.0f * Omega * g_tphi + Omega * Omega * g_phiphi);
-    float u_t = 1.0f / sqrtf(fmaxf(1e-6f, u_t_sq));
     float L_photon = p.z * v.x - p.x * v.z;
-    float delta = 1.0f / fmaxf(0.01f, u_t * (1.0f - Omega * L_photon));
-    float beaming = (U->features & ORC_GLSL_DOPPLER) ? fmaxf(0.01f, orc_powf(delta, 3.5f)) : 1.0f;
+    float delta = gl_disk_delta(M, a, U->spin, sampleR, L_photon);
+    float beaming = (U->features & ORC_GLSL_DOPPLER) ? gl_beaming(delta) : 1.0f;
     float isco_r = clampf(isco / sampleR, 0.0f, 1.0f);
     float nt_factor = fmaxf(0.0f, 1.0f - sqrtf(isco_r));
     float radialTempGradient = orc_powf(isco_r, 0.75f) * orc_powf(nt_factor, 0.25f);
@@ -633,12 +654,12 @@ uint32_t orc_glsl_pixel(const orc_glsl_params *U, uint32_t ix, uint32_t iy, floa
             accel = scale3(gl_kerr_accel(p, v, M, a, &omega), U->lensing_strength);
             gl_rot_apply(omega * currentDt, &v.x, &v.z); /* ZAMO twist of the velocity */
         }
-        p = add3(p, add3(scale3(v, currentDt), scale3(scale3(scale3(accel, 0.5f), currentDt), currentDt)));
+        p = gl_verlet_position(p, v, accel, currentDt);
         float r_new = length3(p);
         if ((F & ORC_GLSL_LENSING) && alpha < 0.95f) {
             float om2;
             v3 accel_new = scale3(gl_kerr_accel(p, v, M, a, &om2), U->lensing_strength);
-            v = add3(v, scale3(scale3(add3(accel, accel_new), 0.5f), currentDt));
+            v = gl_verlet_velocity(v, accel, accel_new, currentDt);
         }
         v = normalize3(v);
         steps++;
@@ -646,7 +667,7 @@ uint32_t orc_glsl_pixel(const orc_glsl_params *U, uint32_t ix, uint32_t iy, floa
         if (prevY * p.y < 0.0f && r_new < rph * 2.0f && r_new > rh)
             photonCrossings = photonCrossings + 1 < 3 ? photonCrossings + 1 : 3;
         if (U->show_redshift > 0.5f) {
-            float potential = sqrtf(fmaxf(0.0f, 1.0f - rs / r_new));
+            float potential = gl_redshift_potential(rs, r_new);
             if (!redshiftInitialized) {
                 maxRedshift = potential;
                 redshiftInitialized = 1;
@@ -697,7 +718,7 @@ uint32_t orc_glsl_pixel(const orc_glsl_params *U, uint32_t ix, uint32_t iy, floa
     if (absA > 0.1f && !hitHorizon) { /* fragment.glsl.ts:261-268 */
         float rFinal = length3(p);
         float cosTheta = p.y / fmaxf(rFinal, 0.001f);
-        float r_ergo = M + sqrtf(fmaxf(0.0f, M * M - a * a * cosTheta * cosTheta));
+        float r_ergo = gl_ergosphere_radius(M, a, cosTheta);
         float ergoGlow = orc_expf(-fabsf(rFinal - r_ergo) * 20.0f) * 0.35f * absA;
         ergo[0] = 0.3f * ergoGlow;
         ergo[1] = 0.35f * ergoGlow;
@@ -779,4 +800,59 @@ void orc_glsl_frame(const orc_glsl_params *p, uint32_t sx, uint32_t sy, float *r
         if (rgba) memcpy(&rgba[k * 4], px, sizeof px);
         if (steps) steps[k] = st;
     }
+}
+
+
+/* ========================================================================== */
+/* Test hooks: the building blocks above, callable one at a time, so that CPU  */
+/* tests can hold them to known answers WITHOUT going through a march:         */
+/*  - the reference's own tests of the shader expressions                      */
+/*    (src/__tests__/physics/advanced-physics.test.ts),                        */
+/*  - the pinned f64 oracle (gravitas_oracle.c), which the WGSL kernel's       */
+/*    get_derivatives claims to equal formula for formula                      */
+/*    (compute.wgsl.ts:42-120 vs kerr.rs:412-499),                             */
+/*  - closed forms.                                                            */
+/* ========================================================================== */
+void orc_hook_wgsl_derivs(const float x[4], const float p[4], float M, float spin, float dx[4], float dp[4]) {
+    ray32 s;
+    memcpy(s.x, x, sizeof s.x);
+    memcpy(s.p, p, sizeof s.p);
+    wgsl_derivs(&s, M, spin, dx, dp);
+}
+void orc_hook_wgsl_step(const float x[4], const float p[4], float h, float M, float spin, float ox[4], float op[4]) {
+    ray32 s;
+    memcpy(s.x, x, sizeof s.x);
+    memcpy(s.p, p, sizeof s.p);
+    ray32 o = wgsl_symplectic(&s, h, M, spin);
+    memcpy(ox, o.x, sizeof o.x);
+    memcpy(op, o.p, sizeof o.p);
+}
+float orc_hook_wgsl_horizon(float M, float a) { return wgsl_horizon(M, a); }
+float orc_hook_wgsl_isco(float M, float a) { return wgsl_isco(M, a); }
+void orc_hook_glsl_accel(const float p[3], const float v[3], float M, float a, float acc[3], float *omega) {
+    v3 r = gl_kerr_accel((v3){p[0], p[1], p[2]}, (v3){v[0], v[1], v[2]}, M, a, omega);
+    acc[0] = r.x;
+    acc[1] = r.y;
+    acc[2] = r.z;
+}
+float orc_hook_glsl_horizon(float M, float a) { return gl_horizon(M, a); }
+float orc_hook_glsl_isco(float M, float a) { return gl_isco(M, a); }
+float orc_hook_glsl_photon_sphere(float M, float a) { return gl_photon_sphere(M, a); }
+float orc_hook_glsl_redshift_potential(float rs, float r) { return gl_redshift_potential(rs, r); }
+float orc_hook_glsl_ergosphere_radius(float M, float a, float c) { return gl_ergosphere_radius(M, a, c); }
+float orc_hook_glsl_beaming(float delta) { return gl_beaming(delta); }
+float orc_hook_glsl_disk_delta(float M, float a, float spin, float r, float L) { return gl_disk_delta(M, a, spin, r, L); }
+void orc_hook_glsl_blackbody(float temp, float rgb[3]) { gl_blackbody(temp, rgb); }
+/* one Verlet update of (x, v) under the caller's acceleration field acc = -k x (the harmonic
+ * oscillator of advanced-physics.test.ts:199-218), through the march's own two update lines */
+void orc_hook_glsl_verlet_oscillator(float *x, float *v, float k, float dt, int steps) {
+    v3 p = {*x, 0.0f, 0.0f}, w = {*v, 0.0f, 0.0f};
+    for (int i = 0; i < steps; i++) {
+        v3 a0 = {-k * p.x, 0.0f, 0.0f};
+        p = gl_verlet_position(p, w, a0, dt);
+        v3 a1 = {-k * p.x, 0.0f, 0.0f};
+        w = gl_verlet_velocity(w, a0, a1, dt);
+    }
+    *x = p.x;
+    *v = w.x;
 }

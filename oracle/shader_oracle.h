@@ -4,9 +4,16 @@
  *   GLSL fragment march   src/shaders/blackhole/fragment.glsl.ts:40-221,
  *                         chunks/metric.ts:13-149 (a16), chunks/disk.ts:16-115 (a17),
  *                         chunks/blackbody.ts:9-34
- * TEST INFRASTRUCTURE ONLY.  "parity unpinned": the reference holds no image or
- * pixel test and its noise textures are unseeded Math.random();
- * see the .c file for what is restated and what is fixed to a constant.
+ * TEST INFRASTRUCTURE ONLY.  The reference holds no image or pixel test and its
+ * noise textures are unseeded Math.random(), so whole frames have no reference-held answer
+ * ("parity unpinned" for pixels).  What IS pinned (tests/test_f32_oracle_pins.py, through the
+ * orc_hook_* entry points below, none of it through the HIP twin): get_derivatives and
+ * symplectic_step against the pinned f64 oracle (compute.wgsl.ts:42-120 == kerr.rs:412-499),
+ * horizon / ISCO / photon sphere against kerr.rs:507-554, the disk Doppler factor against
+ * redshift.rs:65-95, the shader expressions the reference tests itself
+ * (src/__tests__/physics/advanced-physics.test.ts), kerr_geodesic_accel against its closed form,
+ * and both marches against the critical impact parameter of their own equation of motion
+ * (independent DOP853 integration).
  */
 #ifndef SHADER_ORACLE_H
 #define SHADER_ORACLE_H
@@ -78,6 +85,22 @@ void orc_seeded_noise_rgba8(uint32_t seed, uint32_t size, uint8_t *rgba);
 uint32_t orc_glsl_pixel(const orc_glsl_params *p, uint32_t ix, uint32_t iy, float rgba[4]);
 void orc_glsl_frame(const orc_glsl_params *p, uint32_t stride_x, uint32_t stride_y, float *rgba,
                     uint32_t *steps, int nthreads);
+
+/* test hooks (see the end of shader_oracle.c): single building blocks of the two marches */
+void orc_hook_wgsl_derivs(const float x[4], const float p[4], float M, float spin, float dx[4], float dp[4]);
+void orc_hook_wgsl_step(const float x[4], const float p[4], float h, float M, float spin, float ox[4], float op[4]);
+float orc_hook_wgsl_horizon(float M, float a);
+float orc_hook_wgsl_isco(float M, float a);
+void orc_hook_glsl_accel(const float p[3], const float v[3], float M, float a, float acc[3], float *omega);
+float orc_hook_glsl_horizon(float M, float a);
+float orc_hook_glsl_isco(float M, float a);
+float orc_hook_glsl_photon_sphere(float M, float a);
+float orc_hook_glsl_redshift_potential(float rs, float r);
+float orc_hook_glsl_ergosphere_radius(float M, float a, float cos_theta);
+float orc_hook_glsl_beaming(float delta);
+float orc_hook_glsl_disk_delta(float M, float a, float spin, float r, float L_photon);
+void orc_hook_glsl_blackbody(float temp, float rgb[3]);
+void orc_hook_glsl_verlet_oscillator(float *x, float *v, float k, float dt, int steps);
 
 #ifdef __cplusplus
 }
