@@ -336,6 +336,20 @@ int ensure_lut(grv_engine *e, uint32_t w, uint32_t h, double tmax, hipStream_t s
 // for N = 4) hands every rank whole tile COLUMNS, and the two ranks owning the columns through the
 // hole's image carry its divergent waves alone (measured: 3.9 ms against 2.8 ms at 8K / 8 ranks).
 // Ids in the pad column(s) hold no pixels.
+// Device copy of generate_disk_lut's table for the current (mass, spin): physics/disk.rs:175-201
+int ensure_disk_lut(grv_engine *e, hipStream_t s) {
+    if (e->disk_lut_valid && e->disk_lut_mass == e->mass && e->disk_lut_spin == e->spin_c) return GRV_OK;
+    constexpr size_t kScratchOff = 4096;
+    if (!e->d_disk_lut)
+        GRV_HIP(e, hipMalloc(reinterpret_cast<void **>(&e->d_disk_lut), kScratchOff + kDiskLutWidth * sizeof(double)));
+    double *scratch = reinterpret_cast<double *>(reinterpret_cast<char *>(e->d_disk_lut) + kScratchOff);
+    GRV_HIP(e, launch_disk_temperature_lut(e->d_disk_lut, scratch, kDiskLutWidth, e->mass, e->spin_c, s));
+    e->disk_lut_mass = e->mass;
+    e->disk_lut_spin = e->spin_c;
+    e->disk_lut_valid = true;
+    return GRV_OK;
+}
+
 uint32_t tile_pitch(uint32_t width, uint32_t world) {
     uint32_t p = (width + 63u) / 64u;
     if (world <= 1) return p;
@@ -433,6 +447,7 @@ void grv_engine_destroy(grv_engine *e) {
     }
     if (e->stage_mem) (void)hipFree(e->stage_mem);
     if (e->d_lut) (void)hipFree(e->d_lut);
+    if (e->d_disk_lut) (void)hipFree(e->d_disk_lut);
     if (e->d_noise) (void)hipFree(e->d_noise);
     if (e->post_mem) (void)hipFree(e->post_mem);
     if (e->rt.mem) (void)hipFree(e->rt.mem);
@@ -692,6 +707,10 @@ int grv_render_frame_device(grv_engine *e, const GrvCamera *cam, const GrvRender
         P.max_crossings = nmax;
         rc = ensure_lut(e, p->lut_width, p->lut_height, p->lut_max_temp, s);
         if (rc != GRV_OK) return rc;
+        if (p->disk_profile == GRV_DISK_PROFILE_PAGE_THORNE) {
+            rc = ensure_disk_lut(e, s);
+            if (rc != GRV_OK) return rc;
+        }
     }
 
     CameraDev cd;
@@ -740,6 +759,9 @@ int grv_render_frame_device(grv_engine *e, const GrvCamera *cam, const GrvRender
     S.lut_w = p->lut_width;
     S.lut_h = p->lut_height;
     S.lut_max_temp = p->lut_max_temp;
+    S.disk_profile = p->disk_profile;
+    S.pt_rin = isco_prograde(e->mass, e->spin_c); // physics/disk.rs:176-177
+    S.pt_rout = 50.0 * e->mass;
     if (p->shading) {
         // stage a band of g rows around g = 1 in LDS (128 KiB budget); the rest is
         // served from L2/HBM by the same lookup
@@ -752,7 +774,9 @@ int grv_render_frame_device(grv_engine *e, const GrvCamera *cam, const GrvRender
         S.lds_row0 = (uint32_t)r0;
     }
     if (profile) GRV_HIP(e, hipEventRecord(ev4[2], s));
-    GRV_HIP(e, launch_finalize_frame(e->ws, G, S, p->shading, e->d_lut, out->rgba,
+    GRV_HIP(e, launch_finalize_frame(e->ws, G, S, p->shading, e->d_lut,
+                                     p->disk_profile == GRV_DISK_PROFILE_PAGE_THORNE ? e->d_disk_lut : nullptr,
+                                     out->rgba,
                                      out->final_state, out->steps, out->termination, out->drift,
                                      e->d_stats, e->n_cu, s));
     if (profile) {

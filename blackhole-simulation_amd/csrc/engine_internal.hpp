@@ -68,6 +68,10 @@ struct grv_engine {
     float *d_lut = nullptr;
     uint32_t lut_w = 0, lut_h = 0;
     double lut_tmax = 0.0;
+    // cached Page-Thorne temperature table (device, 512 f32 + scratch), keyed by (mass, spin_c)
+    float *d_disk_lut = nullptr;
+    double disk_lut_mass = 0.0, disk_lut_spin = 0.0;
+    bool disk_lut_valid = false;
 
     // frame bookkeeping.  Counters live on the device (d_stats) and are read by grv_frame_stats
     // only; with stats_accum they are not cleared between frames (grv_stats_accumulate), so a
@@ -125,6 +129,7 @@ int ensure_workspace(grv_engine *e, size_t slots, hipStream_t s);
 int release_workspace(grv_engine *e, hipStream_t s);
 int ensure_stage(grv_engine *e, size_t bytes);
 int ensure_lut(grv_engine *e, uint32_t w, uint32_t h, double tmax, hipStream_t s);
+int ensure_disk_lut(grv_engine *e, hipStream_t s);
 size_t align_up(size_t x, size_t a);
 SegmentParams make_segment_params(const grv_engine *e, const GrvOptions &o);
 bool options_valid(const GrvOptions &o);

@@ -63,12 +63,18 @@ struct CameraDev {
     double r0, theta0, phi0, st, ct, sp, cp;
 };
 
+constexpr uint32_t kDiskLutWidth = 512; // lut_width of generate_disk_lut (lib.rs:65)
+
 struct ShadeParams {
     double M, spin;
     double disk_inner, disk_temp, disk_opacity, exposure;
     uint32_t lut_w, lut_h;
     double lut_max_temp;
     uint32_t lds_row0, lds_rows; // LUT rows staged in LDS
+    // radial temperature profile (GRV_DISK_PROFILE_*): the Page-Thorne table spans
+    // [pt_rin, pt_rout] = [prograde ISCO, 50 M] (physics/disk.rs:176-177)
+    uint32_t disk_profile;
+    double pt_rin, pt_rout;
 };
 
 // uniforms of the two f32 shader kernels (mirrors GrvWgslParams / GrvGlslParams)
@@ -131,7 +137,7 @@ hipError_t launch_finalize_batch(const RayWorkspace &ws, double *out_states, uin
                                  uint8_t *out_term, double *out_drift, FrameStatsDev *st,
                                  hipStream_t s);
 hipError_t launch_finalize_frame(const RayWorkspace &ws, const FrameGeom &G, const ShadeParams &S,
-                                 int shading, const float *lut, float *out_rgba,
+                                 int shading, const float *lut, const float *disk_lut, float *out_rgba,
                                  double *out_states, uint32_t *out_steps, uint8_t *out_term,
                                  double *out_drift, FrameStatsDev *st, int n_blocks,
                                  hipStream_t s);

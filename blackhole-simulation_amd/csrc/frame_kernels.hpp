@@ -138,6 +138,22 @@ __device__ __forceinline__ double disk_temp_profile_dev(double r, double disk_in
     return pow_rs(isco_r, 0.75) * pow_rs(nt, 0.25);
 }
 
+// Page-Thorne profile: the 512-entry table of generate_temperature_lut (physics/disk.rs:175-201),
+// entry i at r = rin + (i / 511)(rout - rin), normalised to its maximum; read as the LINEAR +
+// CLAMP_TO_EDGE texture the renderer uploads it as (src/rendering/webgl/renderer.ts:436-446), i.e.
+// linear interpolation between the two entries around the continuous index, clamped at both ends.
+__device__ __forceinline__ double disk_lut_profile_dev(const float *lut_s, double r, double rin,
+                                                       double rout) {
+    const double last = (double)(kDiskLutWidth - 1u);
+    double x = (r - rin) / (rout - rin) * last;
+    if (!(x > 0.0)) x = 0.0;
+    if (x > last) x = last;
+    const uint32_t i0 = (uint32_t)x;
+    const uint32_t i1 = (i0 + 1u < kDiskLutWidth) ? i0 + 1u : i0;
+    const double t0 = lut_s[i0], t1 = lut_s[i1];
+    return t0 + (t1 - t0) * (x - (double)i0);
+}
+
 // texel fetch: LDS for the staged rows [row0, row0+rows), HBM/L2 otherwise
 __device__ __forceinline__ float4 lut_texel(const float4 *__restrict__ lut_g, const float4 *lut_s,
                                             const ShadeParams &S, uint32_t x, uint32_t y) {
@@ -150,15 +166,20 @@ __device__ __forceinline__ float4 lut_texel(const float4 *__restrict__ lut_g, co
 // LDS once, then grid-strides over the slots.
 __global__ __launch_bounds__(1024) void finalize_frame_kernel(
     RayWorkspace ws, FrameGeom G, ShadeParams S, int shading, const float4 *__restrict__ lut,
-    float4 *__restrict__ out_rgba, double *__restrict__ out_states,
+    const float *__restrict__ disk_lut, float4 *__restrict__ out_rgba, double *__restrict__ out_states,
     uint32_t *__restrict__ out_steps, uint8_t *__restrict__ out_term,
     double *__restrict__ out_drift, FrameStatsDev *st) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float4 *lut_s = reinterpret_cast<float4 *>(smem_raw);
+    // the Page-Thorne table (2 KB) sits behind the staged Planck rows
+    float *disk_s = reinterpret_cast<float *>(lut_s + (size_t)S.lds_rows * S.lut_w);
+    const bool page_thorne = shading && lut && disk_lut && S.disk_profile == GRV_DISK_PROFILE_PAGE_THORNE;
     if (shading && lut) {
         const uint32_t n4 = S.lds_rows * S.lut_w;
         const float4 *src = lut + (size_t)S.lds_row0 * S.lut_w;
         for (uint32_t k = threadIdx.x; k < n4; k += blockDim.x) lut_s[k] = src[k];
+        if (page_thorne)
+            for (uint32_t k = threadIdx.x; k < kDiskLutWidth; k += blockDim.x) disk_s[k] = disk_lut[k];
     }
     __syncthreads();
 
@@ -196,7 +217,9 @@ __global__ __launch_bounds__(1024) void finalize_frame_kernel(
                     for (uint32_t c = 0; c < nc; ++c) {
                         const double r_c = ws.rc[(size_t)c * ws.n + slot];
                         const double g = kerr_g_factor_dev(r_c, S.M, S.spin, lambda);
-                        const double temp = S.disk_temp * disk_temp_profile_dev(r_c, S.disk_inner);
+                        const double temp =
+                            S.disk_temp * (page_thorne ? disk_lut_profile_dev(disk_s, r_c, S.pt_rin, S.pt_rout)
+                                                       : disk_temp_profile_dev(r_c, S.disk_inner));
                         // inverse LUT axes (spectrum.rs:82,85)
                         const double u = pow_rs(fmax(temp, 0.0) / S.lut_max_temp, 1.0 / 2.5);
                         double fx = u * (double)(S.lut_w > 1 ? S.lut_w - 1 : 1);

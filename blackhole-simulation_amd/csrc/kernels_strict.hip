@@ -118,12 +118,14 @@ hipError_t launch_finalize_batch(const RayWorkspace &ws, double *out_states, uin
 }
 
 hipError_t launch_finalize_frame(const RayWorkspace &ws, const FrameGeom &G, const ShadeParams &S,
-                                 int shading, const float *lut, float *out_rgba,
+                                 int shading, const float *lut, const float *disk_lut, float *out_rgba,
                                  double *out_states, uint32_t *out_steps, uint8_t *out_term,
                                  double *out_drift, FrameStatsDev *st, int n_blocks,
                                  hipStream_t s) {
     if (ws.n == 0) return hipSuccess;
-    const size_t lds = (shading && lut) ? (size_t)S.lds_rows * S.lut_w * sizeof(float4) : 0;
+    const size_t lds = (shading && lut)
+                           ? (size_t)S.lds_rows * S.lut_w * sizeof(float4) + kDiskLutWidth * sizeof(float)
+                           : 0;
     // the attribute belongs to the (function, device) pair: one bit per device, set once
     static std::atomic<uint64_t> attr_set{0};
     int dev = 0;
@@ -141,7 +143,7 @@ hipError_t launch_finalize_frame(const RayWorkspace &ws, const FrameGeom &G, con
     if (grid > need) grid = need;
     if (grid == 0) grid = 1;
     hipLaunchKernelGGL(finalize_frame_kernel, dim3(grid), dim3(1024), lds, s, ws, G, S, shading,
-                       reinterpret_cast<const float4 *>(lut), reinterpret_cast<float4 *>(out_rgba),
+                       reinterpret_cast<const float4 *>(lut), disk_lut, reinterpret_cast<float4 *>(out_rgba),
                        out_states, out_steps, out_term, out_drift, st);
     return hipGetLastError();
 }

@@ -523,6 +523,16 @@ static napi_value m_render_frame(napi_env env, napi_callback_info info) {
     p.opt.tolerance = obj_f64(env, argv[0], "tolerance", p.opt.tolerance);
     p.shading = (int32_t)obj_f64(env, argv[0], "shading", (double)p.shading);
     bool has = false;
+    if (napi_has_named_property(env, argv[0], "diskProfile", &has) == napi_ok && has) {
+        /* "pageThorne": the generate_disk_lut table as the radial temperature profile (disk.rs:175-201) */
+        napi_value v;
+        char buf[16] = {0};
+        size_t len = 0;
+        if (napi_get_named_property(env, argv[0], "diskProfile", &v) == napi_ok &&
+            napi_get_value_string_utf8(env, v, buf, sizeof buf, &len) == napi_ok)
+            p.disk_profile = strcmp(buf, "pageThorne") == 0 ? GRV_DISK_PROFILE_PAGE_THORNE : GRV_DISK_PROFILE_SHORTCUT;
+    }
+    has = false;
     if (napi_has_named_property(env, argv[0], "arith", &has) == napi_ok && has) {
         napi_value v;
         char buf[16] = {0};

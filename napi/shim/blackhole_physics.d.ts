@@ -25,6 +25,9 @@ export interface RenderFrameOptions {
   /** 0 endpoints only, 1 thin-disk (T x g) Planck-LUT shading */
   shading?: number;
   arith?: "fast" | "strict";
+  /** radial temperature profile of the disk: the shader's closed form (default) or the
+   *  Page-Thorne table generate_disk_lut() returns (physics/disk.rs:175-201) */
+  diskProfile?: "shortcut" | "pageThorne";
 }
 
 export interface RenderFrameResult {

@@ -3,6 +3,7 @@
  * ONLY; see frame_oracle.h for what is restated vs defined ("parity unpinned").
  */
 #include "frame_oracle.h"
+#include "control_oracle.h"
 #include "ref_libm.h"
 
 #include <math.h>
@@ -117,6 +118,19 @@ double orc_disk_temp_profile(double r, double disk_inner) {
     return orc_pow(isco_r, 0.75) * orc_pow(nt_factor, 0.25);
 }
 
+/* physics/disk.rs:175-201 stores entry i at r = rin + (i/(width-1))(rout-rin); a LINEAR,
+ * CLAMP_TO_EDGE fetch interpolates between the two entries around the continuous index */
+double orc_disk_lut_profile(const float *lut, uint32_t width, double r, double rin, double rout) {
+    double last = (double)(width - 1u);
+    double x = (r - rin) / (rout - rin) * last;
+    if (!(x > 0.0)) x = 0.0;
+    if (x > last) x = last;
+    uint32_t i0 = (uint32_t)x;
+    uint32_t i1 = (i0 + 1u < width) ? i0 + 1u : i0;
+    double t0 = lut[i0], t1 = lut[i1];
+    return t0 + (t1 - t0) * (x - (double)i0);
+}
+
 /* inverse of the LUT axes of physics/spectrum.rs:82,85:
  *   g = 0.05 + 4.95 * y/(H-1) ; T = (x/(W-1))^2.5 * Tmax */
 void orc_lut_sample(const float *lut, uint32_t w, uint32_t h, double max_temp, double temp,
@@ -207,7 +221,12 @@ int orc_trace_pixel(const orc_camera *cam, const orc_frame_params *fp, const flo
                 if (r_c > disk_inner && r_c < fp->disk_outer) {
                     double lambda = state.p[3] / (-state.p[0]);
                     double g = orc_kerr_g_factor(r_c, fp->mass, m.spin, lambda);
-                    double temp = fp->disk_temp * orc_disk_temp_profile(r_c, disk_inner);
+                    double prof;
+                    if (fp->disk_profile == 1 && fp->disk_lut)
+                        prof = orc_disk_lut_profile(fp->disk_lut, 512u, r_c, orc_isco(&mk, 0), 50.0 * mk.mass);
+                    else
+                        prof = orc_disk_temp_profile(r_c, disk_inner);
+                    double temp = fp->disk_temp * prof;
                     double rgb[3] = {0.0, 0.0, 0.0};
                     if (lut)
                         orc_lut_sample(lut, fp->lut_width, fp->lut_height, fp->lut_max_temp, temp,
@@ -257,6 +276,15 @@ void orc_render_frame(const orc_camera *cam, const orc_frame_params *fp, const f
         orc_generate_blackbody_lut(fp->lut_width, fp->lut_height, fp->lut_max_temp, lut_own);
         lut = lut_own;
     }
+
+    float disk_lut_own[512];
+    orc_frame_params fp_local = *fp;
+    if (fp->shading && fp->disk_profile == 1 && !fp->disk_lut) {
+        orc_metric mk = orc_metric_make(ORC_KERR_BL, fp->mass, fp->spin);
+        orc_generate_temperature_lut(mk.mass, mk.spin, 512, disk_lut_own);
+        fp_local.disk_lut = disk_lut_own;
+    }
+    fp = &fp_local;
 
     uint64_t acc_steps = 0, acc_tries = 0, acc_cross = 0;
     uint64_t tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0, tc4 = 0;

@@ -45,6 +45,11 @@ typedef struct {
     double exposure;        /* multiplies LUT rgb */
     uint32_t lut_width, lut_height;
     double lut_max_temp;
+    int disk_profile;       /* 0: the shader's closed form (disk.ts:100-102); 1: the 512-entry
+                               Page-Thorne table of generate_temperature_lut (physics/disk.rs:175-201)
+                               read with linear interpolation, clamped (the LINEAR / CLAMP_TO_EDGE
+                               texture of src/rendering/webgl/renderer.ts:436-446) */
+    const float *disk_lut;  /* 512 entries for disk_profile 1; NULL: orc_render_frame generates it */
 } orc_frame_params;
 
 typedef struct {
@@ -84,6 +89,8 @@ void orc_lut_sample(const float *lut, uint32_t w, uint32_t h, double max_temp, d
 
 /* temperature profile, src/shaders/blackhole/chunks/disk.ts:100-102 in f64 */
 double orc_disk_temp_profile(double r, double disk_inner);
+/* Page-Thorne profile: linear read of the normalised table over [rin, rout] (width entries) */
+double orc_disk_lut_profile(const float *lut, uint32_t width, double r, double rin, double rout);
 
 #ifdef __cplusplus
 }

@@ -47,7 +47,7 @@ class FrameParams(C.Structure):
                 ("shading", C.c_int), ("disk_inner", C.c_double), ("disk_outer", C.c_double),
                 ("disk_temp", C.c_double), ("disk_opacity", C.c_double), ("exposure", C.c_double),
                 ("lut_width", C.c_uint32), ("lut_height", C.c_uint32),
-                ("lut_max_temp", C.c_double)]
+                ("lut_max_temp", C.c_double), ("disk_profile", C.c_int), ("disk_lut", C.c_void_p)]
 
 
 class FrameStats(C.Structure):
@@ -376,12 +376,12 @@ def pixel_state(cam, width, height, i, j):
 
 def frame_params(width, height, mass=1.0, spin=0.999, metric_kind=KERR_KS, opt=None, shading=1,
                  disk_inner=0.0, disk_outer=30.0, disk_temp=9500.0, disk_opacity=0.6,
-                 exposure=1.0, lut_width=512, lut_height=64, lut_max_temp=1e5):
+                 exposure=1.0, lut_width=512, lut_height=64, lut_max_temp=1e5, disk_profile=0):
     if opt is None:
         opt = options(max_steps=2048)
     return FrameParams(width, height, metric_kind, mass, spin, opt, shading, disk_inner,
                        disk_outer, disk_temp, disk_opacity, exposure, lut_width, lut_height,
-                       lut_max_temp)
+                       lut_max_temp, disk_profile, None)
 
 
 def render_frame(cam, fp, lut=None, stride=(1, 1), nthreads=1, want_states=True):

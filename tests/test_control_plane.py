@@ -139,3 +139,85 @@ def test_engine_tick_sab_matches_oracle(engine_mod, oracle):
         e.attach_sab(ext)
         e.tick_sab(0.016)
         assert ext[128] == view[128] and ext[143] == 64.0
+
+
+# ---- 8f-1 in the shading: the Page-Thorne table as the disk's radial temperature profile ------
+def test_page_thorne_profile_reader(oracle):
+    """orc_disk_lut_profile reads the 512-entry table of generate_temperature_lut
+    (physics/disk.rs:175-201) the way its LINEAR / CLAMP_TO_EDGE texture is read: entry i sits at
+    r = rin + i/511 (rout - rin), halfway between two entries is their mean, both ends clamp; and
+    the profile it yields keeps disk.rs:284-308 (peak within 3 r_isco, positive)."""
+    import ctypes as C
+    L = oracle.lib()
+    L.orc_disk_lut_profile.restype = C.c_double
+    L.orc_disk_lut_profile.argtypes = [C.c_void_p, C.c_uint32, C.c_double, C.c_double, C.c_double]
+    for spin in (0.0, 0.9, 0.999):
+        lut = oracle.temperature_lut(1.0, spin)
+        rin = L.orc_isco(oracle.metric(oracle.KERR_BL, 1.0, spin), 0)
+        rout = 50.0
+        ptr = lut.ctypes.data_as(C.c_void_p)
+        for i in (0, 1, 17, 255, 510, 511):
+            r = rin + i / 511.0 * (rout - rin)
+            assert abs(L.orc_disk_lut_profile(ptr, 512, r, rin, rout) - float(lut[i])) < 1e-6
+        for i in (0, 100, 300):
+            r = rin + (i + 0.5) / 511.0 * (rout - rin)
+            want = 0.5 * (float(lut[i]) + float(lut[i + 1]))
+            assert abs(L.orc_disk_lut_profile(ptr, 512, r, rin, rout) - want) < 1e-6
+        assert L.orc_disk_lut_profile(ptr, 512, rin - 3.0, rin, rout) == float(lut[0]) == 0.0
+        assert L.orc_disk_lut_profile(ptr, 512, 80.0, rin, rout) == float(lut[511])
+        rs = np.linspace(rin, rout, 2000)
+        prof = np.array([L.orc_disk_lut_profile(ptr, 512, float(r), rin, rout) for r in rs])
+        assert prof.max() > 0.99 and prof.min() >= 0.0
+        if spin == 0.0:   # disk.rs:284-308 is stated for Schwarzschild
+            assert rs[prof.argmax()] < 3.0 * rin
+
+
+def test_page_thorne_profile_changes_the_shaded_frame(oracle):
+    W, H = 64, 36
+    th = np.deg2rad(80.0)
+    cam = oracle.camera_look_at((60 * np.sin(th), 60 * np.cos(th), 0.0), aspect=W / H)
+    a = oracle.render_frame(cam, oracle.frame_params(W, H, spin=0.9), None, nthreads=4)
+    b = oracle.render_frame(cam, oracle.frame_params(W, H, spin=0.9, disk_profile=1), None, nthreads=4)
+    assert np.array_equal(a["states"], b["states"]) and np.array_equal(a["steps"], b["steps"])
+    lit = a["rgba"][..., :3].sum(-1) > 0
+    assert lit.any() and np.array_equal(lit, b["rgba"][..., :3].sum(-1) > 0)     # same disk pixels
+    assert not np.array_equal(a["rgba"], b["rgba"])
+    # the table is normalised to its peak, the closed form peaks at 0.49: hotter -> brighter overall
+    assert b["rgba"][..., :3].sum() > a["rgba"][..., :3].sum()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spin,theta_deg", [(0.999, 97.0), (0.5, 75.0), (0.0, 60.0)])
+def test_page_thorne_shaded_frame_is_bit_exact(engine_mod, oracle, spin, theta_deg):
+    """GrvRenderParams.disk_profile = PAGE_THORNE: finalize_frame_kernel reads the device table
+    (staged in LDS beside the Planck rows); pixels equal the oracle's bit for bit (STRICT) and
+    to 1e-5 of the peak (FAST)."""
+    import torch
+    bh = engine_mod
+    W, H = 160, 90
+    th = np.deg2rad(theta_deg)
+    eye = (60 * np.sin(th), 60 * np.cos(th), 0.0)
+    ref = oracle.render_frame(oracle.camera_look_at(eye, aspect=W / H),
+                              oracle.frame_params(W, H, spin=spin, disk_profile=1), None, nthreads=8)
+    peak = float(ref["rgba"][..., :3].max())
+    assert peak > 0
+    with bh.PhysicsEngine(1.0, spin) as e:
+        cam = bh.camera_look_at(eye, aspect=W / H)
+        for arith in (bh.ARITH_STRICT, bh.ARITH_FAST):
+            p = bh.render_params(W, H, arith=arith, disk_profile=bh.DISK_PROFILE_PAGE_THORNE)
+            rgba = torch.zeros(W * H, 4, dtype=torch.float32, device="cuda:0")
+            e.render_frame_device(cam, p, rgba=rgba)
+            torch.cuda.synchronize()
+            got = rgba.cpu().numpy().reshape(H, W, 4)
+            if arith == bh.ARITH_STRICT:
+                assert np.array_equal(got, ref["rgba"])
+            else:
+                assert np.abs(got - ref["rgba"]).max() <= 1e-5 * peak
+        # the table follows update_params (it is keyed by mass and spin)
+        e.update_params(1.0, 0.3)
+        ref2 = oracle.render_frame(oracle.camera_look_at(eye, aspect=W / H),
+                                   oracle.frame_params(W, H, spin=0.3, disk_profile=1), None, nthreads=8)
+        p = bh.render_params(W, H, arith=bh.ARITH_STRICT, disk_profile=bh.DISK_PROFILE_PAGE_THORNE)
+        e.render_frame_device(cam, p, rgba=rgba)
+        torch.cuda.synchronize()
+        assert np.array_equal(rgba.cpu().numpy().reshape(H, W, 4), ref2["rgba"])
