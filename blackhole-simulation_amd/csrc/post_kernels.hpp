@@ -49,6 +49,17 @@ __device__ __forceinline__ float4 post_sample(const float4 *__restrict__ tex, ui
                        w00 * t00.w + w10 * t10.w + w01 * t01.w + w11 * t11.w);
 }
 
+// texture(tex, uv) at the centre of texel (px, py) of a w x h image.  A LINEAR sampler returns the
+// texel itself there; shader order still evaluates the f32 bilinear arithmetic (a weight of ~1e-7 can
+// leak from a neighbour when the tap position does not round back onto the centre), the FAST
+// contract reads the texel.
+template <int ARITH>
+__device__ __forceinline__ float4 post_fetch_centre(const float4 *__restrict__ tex, uint32_t w, uint32_t h,
+                                                    uint32_t px, uint32_t py) {
+    if constexpr (ARITH == GRV_ARITH_FAST) return tex[(size_t)py * w + px];
+    else return post_sample(tex, w, h, ((float)px + 0.5f) / (float)w, ((float)py + 0.5f) / (float)h);
+}
+
 // ---- LDS-staged tile of the current frame: 64x4 pixels + halo -------------------------------
 constexpr int kTileW = 64, kTileH = 4;
 template <int HALO> struct PostTile {
@@ -265,6 +276,26 @@ __global__ __launch_bounds__(256) void bloom_blur_kernel(uint32_t sw, uint32_t s
     uint32_t px, py;
     if (!post_pixel(dw, dh, px, py)) return;
     const float wts[5] = {0.227027f, 0.1945946f, 0.1216216f, 0.054054f, 0.016216f};
+    if constexpr (ARITH == GRV_ARITH_FAST) {
+        if (sw == dw && sh == dh) { // every tap sits on a texel centre: nine texel reads
+            const float4 c = src[(size_t)py * sw + px];
+            float r = c.x * wts[0], g = c.y * wts[0], b = c.z * wts[0];
+#pragma unroll
+            for (int i = 1; i < 5; ++i) {
+                const int xa = vertical ? (int)px : post_clampi((int)px + i, 0, (int)sw - 1);
+                const int xb = vertical ? (int)px : post_clampi((int)px - i, 0, (int)sw - 1);
+                const int ya = vertical ? post_clampi((int)py + i, 0, (int)sh - 1) : (int)py;
+                const int yb = vertical ? post_clampi((int)py - i, 0, (int)sh - 1) : (int)py;
+                const float4 p = src[(size_t)ya * sw + xa], m = src[(size_t)yb * sw + xb];
+                r += (p.x + m.x) * wts[i];
+                g += (p.y + m.y) * wts[i];
+                b += (p.z + m.z) * wts[i];
+            }
+            dst[(size_t)py * dw + px] = make_float4(post_store(r, half_storage), post_store(g, half_storage),
+                                                    post_store(b, half_storage), 1.0f);
+            return;
+        }
+    }
     const float tx = 1.0f / (float)dw, ty = 1.0f / (float)dh;
     const float u = ((float)px + 0.5f) / (float)dw, v = ((float)py + 0.5f) / (float)dh;
     const float4 c0 = post_sample(src, sw, sh, u, v);
@@ -303,11 +334,183 @@ __global__ __launch_bounds__(256) void bloom_combine_kernel(uint32_t w, uint32_t
     uint32_t px, py;
     if (!post_pixel(w, h, px, py)) return;
     const float u = ((float)px + 0.5f) / (float)w, v = ((float)py + 0.5f) / (float)h;
-    const float4 s = post_sample(scene, w, h, u, v);
+    const float4 s = post_fetch_centre<ARITH>(scene, w, h, px, py);
     const float4 b = post_sample(bloom, bw, bh, u, v);
     out[(size_t)py * w + px] = make_float4(post_pow<ARITH>(post_aces(s.x + b.x * intensity), 0.4545f),
                                            post_pow<ARITH>(post_aces(s.y + b.y * intensity), 0.4545f),
                                            post_pow<ARITH>(post_aces(s.z + b.z * intensity), 0.4545f), 1.0f);
+}
+
+// ---- fused bloom passes ------------------------------------------------------------------------
+// BloomManager.applyBloomToTexture (bloom.ts:443-583) is bright -> passes x (H, V) -> combine, every
+// pass a full round trip of its render target.  Two of those round trips carry no reuse across the
+// image and are fused away when the sizes nest (w = 4 bw, h = 4 bh, hw = 2 bw, hh = 2 bh):
+//   bright + first H blur : the block builds the thresholded half-resolution tile it needs in LDS
+//                           straight from the scene (the same per-texel expression as
+//                           bloom_bright_kernel) and blurs out of LDS -- the half-resolution bright
+//                           target is never written or read;
+//   last V blur + combine : the block blurs the 18 x 6 quarter-resolution texels its 64 x 16 output
+//                           pixels will tap into LDS, then combines -- the last blur target is never
+//                           written or read.
+// Both evaluate the very expressions of the separate kernels (post_sample's arithmetic through a
+// window accessor), so the STRICT forms stay bit-identical to the unfused chain and to the oracle.
+struct LdsWindow {      // texel (i, j) of an image, i in [x0, x0 + W), j in [y0, y0 + H), row pitch W
+    const float4 *t;
+    int x0, y0, W;
+    __device__ __forceinline__ float4 at(int i, int j) const { return t[(j - y0) * W + (i - x0)]; }
+};
+// texture(tex, uv) LINEAR + CLAMP_TO_EDGE on a w x h image whose texels come from the window:
+// post_sample's arithmetic, texel for texel
+__device__ __forceinline__ float4 post_sample_win(const LdsWindow &L, uint32_t w, uint32_t h, float u, float v) {
+    const float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+    const float fx = floorf(x), fy = floorf(y);
+    const float a = x - fx, b = y - fy;
+    const int i0 = post_clampi((int)fx, 0, (int)w - 1), i1 = post_clampi((int)fx + 1, 0, (int)w - 1);
+    const int j0 = post_clampi((int)fy, 0, (int)h - 1), j1 = post_clampi((int)fy + 1, 0, (int)h - 1);
+    const float4 t00 = L.at(i0, j0), t10 = L.at(i1, j0), t01 = L.at(i0, j1), t11 = L.at(i1, j1);
+    const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    return make_float4(w00 * t00.x + w10 * t10.x + w01 * t01.x + w11 * t11.x,
+                       w00 * t00.y + w10 * t10.y + w01 * t01.y + w11 * t11.y,
+                       w00 * t00.z + w10 * t10.z + w01 * t01.z + w11 * t11.z,
+                       w00 * t00.w + w10 * t10.w + w01 * t01.w + w11 * t11.w);
+}
+// the 9-tap blur of bloom.glsl.ts:64-89 at (u, v) over a windowed source
+__device__ __forceinline__ float4 post_blur9_win(const LdsWindow &L, uint32_t sw, uint32_t sh, float u, float v,
+                                                 float tx, float ty, int vertical, int half_storage) {
+    const float wts[5] = {0.227027f, 0.1945946f, 0.1216216f, 0.054054f, 0.016216f};
+    const float4 c0 = post_sample_win(L, sw, sh, u, v);
+    float r = c0.x * wts[0], g = c0.y * wts[0], b = c0.z * wts[0];
+#pragma unroll
+    for (int i = 1; i < 5; ++i) {
+        const float ox = (vertical ? 0.0f : 1.0f) * tx * (float)i, oy = (vertical ? 1.0f : 0.0f) * ty * (float)i;
+        const float4 p = post_sample_win(L, sw, sh, u + ox, v + oy);
+        const float4 m = post_sample_win(L, sw, sh, u - ox, v - oy);
+        r += p.x * wts[i];
+        r += m.x * wts[i];
+        g += p.y * wts[i];
+        g += m.y * wts[i];
+        b += p.z * wts[i];
+        b += m.z * wts[i];
+    }
+    return make_float4(post_store(r, half_storage), post_store(g, half_storage), post_store(b, half_storage), 1.0f);
+}
+
+// bright pass + first horizontal blur.  Block = 64 x 4 texels of the quarter-size target; with
+// hw = 2 bw a tap at (px + k) reads bright texels 2 (px + k) and 2 (px + k) + 1 (one more on either
+// side is kept for f32 rounding of the tap position), rows 2 py and 2 py + 1.
+constexpr int kBrightWinW = 2 * (kTileW + 8) + 4, kBrightWinH = 2 * kTileH + 2;
+template <int ARITH>
+__global__ __launch_bounds__(256) void bloom_bright_hblur_kernel(uint32_t w, uint32_t h,
+                                                                 const float4 *__restrict__ scene, uint32_t hw,
+                                                                 uint32_t hh, uint32_t bw, uint32_t bh,
+                                                                 float threshold, int half_storage,
+                                                                 float4 *__restrict__ dst) {
+    __shared__ float4 win[kBrightWinH * kBrightWinW];
+    const int x0 = 2 * ((int)(blockIdx.x * kTileW) - 4) - 2, y0 = 2 * (int)(blockIdx.y * kTileH) - 1;
+    const int tid = threadIdx.y * kTileW + threadIdx.x;
+    for (int k = tid; k < kBrightWinW * kBrightWinH; k += kTileW * kTileH) {
+        const int gx = x0 + k % kBrightWinW, gy = y0 + k / kBrightWinW;
+        float4 o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (gx >= 0 && gy >= 0 && gx < (int)hw && gy < (int)hh) { // bloom_bright_kernel's texel (gx, gy)
+            const float4 c = post_sample(scene, w, h, ((float)gx + 0.5f) / (float)hw, ((float)gy + 0.5f) / (float)hh);
+            const float lum = c.x * 0.299f + c.y * 0.587f + c.z * 0.114f;
+            if (lum > threshold)
+                o = make_float4(post_store(c.x, half_storage), post_store(c.y, half_storage),
+                                post_store(c.z, half_storage), post_store(c.w, half_storage));
+        }
+        win[k] = o;
+    }
+    __syncthreads();
+    const uint32_t px = blockIdx.x * kTileW + threadIdx.x, py = blockIdx.y * kTileH + threadIdx.y;
+    if (px >= bw || py >= bh) return;
+    const LdsWindow L{win, x0, y0, kBrightWinW};
+    dst[(size_t)py * bw + px] = post_blur9_win(L, hw, hh, ((float)px + 0.5f) / (float)bw, ((float)py + 0.5f) / (float)bh,
+                                               1.0f / (float)bw, 1.0f / (float)bh, 0, half_storage);
+}
+
+// a middle (V, H) pair of the blur chain in one launch: the block blurs the 74 x 6 texels its
+// 64 x 4 outputs tap (4 texels either side along x, one more for f32 rounding of the tap position)
+// vertically into LDS, then horizontally out of it -- the intermediate target of the pair stays on
+// chip.  Both steps are bloom_blur_kernel's expressions.
+constexpr int kMvW = kTileW + 10, kMvH = kTileH + 2, kMsW = kMvW + 2, kMsH = kMvH + 10;
+template <int ARITH>
+__global__ __launch_bounds__(256) void bloom_vh_blur_kernel(uint32_t bw, uint32_t bh,
+                                                            const float4 *__restrict__ src, int half_storage,
+                                                            float4 *__restrict__ dst) {
+    __shared__ float4 src_s[kMsH * kMsW];
+    __shared__ float4 v_s[kMvH * kMvW];
+    const int vx0 = (int)(blockIdx.x * kTileW) - 5, vy0 = (int)(blockIdx.y * kTileH) - 1;
+    const int sx0 = vx0 - 1, sy0 = vy0 - 5;
+    const int tid = threadIdx.y * kTileW + threadIdx.x;
+    for (int k = tid; k < kMsW * kMsH; k += kTileW * kTileH) {
+        const int gx = sx0 + k % kMsW, gy = sy0 + k / kMsW;
+        src_s[k] = (gx >= 0 && gy >= 0 && gx < (int)bw && gy < (int)bh) ? src[(size_t)gy * bw + gx]
+                                                                        : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    __syncthreads();
+    const float tx = 1.0f / (float)bw, ty = 1.0f / (float)bh;
+    const LdsWindow S{src_s, sx0, sy0, kMsW};
+    for (int k = tid; k < kMvW * kMvH; k += kTileW * kTileH) {
+        const int gx = vx0 + k % kMvW, gy = vy0 + k / kMvW;
+        float4 o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (gx >= 0 && gy >= 0 && gx < (int)bw && gy < (int)bh)
+            o = post_blur9_win(S, bw, bh, ((float)gx + 0.5f) / (float)bw, ((float)gy + 0.5f) / (float)bh, tx, ty, 1,
+                               half_storage);
+        v_s[k] = o;
+    }
+    __syncthreads();
+    const uint32_t px = blockIdx.x * kTileW + threadIdx.x, py = blockIdx.y * kTileH + threadIdx.y;
+    if (px >= bw || py >= bh) return;
+    const LdsWindow V{v_s, vx0, vy0, kMvW};
+    dst[(size_t)py * bw + px] = post_blur9_win(V, bw, bh, ((float)px + 0.5f) / (float)bw, ((float)py + 0.5f) / (float)bh,
+                                               tx, ty, 0, half_storage);
+}
+
+// last vertical blur + combine.  Block = 64 x 16 output pixels = 16 x 4 quarter-size texels; the
+// combine's bilinear taps reach one texel further on every side (18 x 6), each of those is a 9-tap
+// vertical blur whose own taps may round one texel sideways (source window 20 x 16).
+constexpr int kVbW = kTileW / 4 + 2, kVbH = 4 + 2, kVsW = kVbW + 2, kVsH = kVbH + 10;
+template <int ARITH>
+__global__ __launch_bounds__(256) void bloom_vblur_combine_kernel(uint32_t w, uint32_t h,
+                                                                  const float4 *__restrict__ scene, uint32_t bw,
+                                                                  uint32_t bh, const float4 *__restrict__ hblur,
+                                                                  float intensity, int half_storage,
+                                                                  float4 *__restrict__ out) {
+    __shared__ float4 src_s[kVsH * kVsW];
+    __shared__ float4 vb_s[kVbH * kVbW];
+    const int qx0 = (int)(blockIdx.x * (kTileW / 4)), qy0 = (int)(blockIdx.y * 4);
+    const int sx0 = qx0 - 2, sy0 = qy0 - 6, vx0 = qx0 - 1, vy0 = qy0 - 1;
+    const int tid = threadIdx.y * kTileW + threadIdx.x;
+    for (int k = tid; k < kVsW * kVsH; k += kTileW * kTileH) {
+        const int gx = sx0 + k % kVsW, gy = sy0 + k / kVsW;
+        src_s[k] = (gx >= 0 && gy >= 0 && gx < (int)bw && gy < (int)bh) ? hblur[(size_t)gy * bw + gx]
+                                                                        : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    __syncthreads();
+    if (tid < kVbW * kVbH) {
+        const int gx = vx0 + tid % kVbW, gy = vy0 + tid / kVbW;
+        float4 o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (gx >= 0 && gy >= 0 && gx < (int)bw && gy < (int)bh) { // bloom_blur_kernel's (vertical) texel (gx, gy)
+            const LdsWindow L{src_s, sx0, sy0, kVsW};
+            o = post_blur9_win(L, bw, bh, ((float)gx + 0.5f) / (float)bw, ((float)gy + 0.5f) / (float)bh,
+                               1.0f / (float)bw, 1.0f / (float)bh, 1, half_storage);
+        }
+        vb_s[tid] = o;
+    }
+    __syncthreads();
+    const LdsWindow V{vb_s, vx0, vy0, kVbW};
+    const uint32_t px = blockIdx.x * kTileW + threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t py = blockIdx.y * 16u + (uint32_t)r * 4u + threadIdx.y;
+        if (px >= w || py >= h) continue;
+        const float u = ((float)px + 0.5f) / (float)w, v = ((float)py + 0.5f) / (float)h;
+        const float4 s = post_fetch_centre<ARITH>(scene, w, h, px, py);
+        const float4 b = post_sample_win(V, bw, bh, u, v);
+        out[(size_t)py * w + px] = make_float4(post_pow<ARITH>(post_aces(s.x + b.x * intensity), 0.4545f),
+                                               post_pow<ARITH>(post_aces(s.y + b.y * intensity), 0.4545f),
+                                               post_pow<ARITH>(post_aces(s.z + b.z * intensity), 0.4545f), 1.0f);
+    }
 }
 
 // A compute / fragment pass that writes an RGBA16F target: round the stored channels in place

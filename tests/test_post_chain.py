@@ -137,7 +137,7 @@ def _close(got, ref, fast=False):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("half", [True, False])
-@pytest.mark.parametrize("size", [(135, 240), (37, 53)])
+@pytest.mark.parametrize("size", [(135, 240), (37, 53), (136, 240)])
 def test_fast_post_chain_matches_oracle(engine_mod, oracle, half, size):
     """The FAST contract of the post kernels (kernels_fast.hip) against the same oracle."""
     import torch
@@ -199,7 +199,10 @@ def test_taa_and_ataa_kernels_match_oracle(engine_mod, oracle, half, size):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("half", [True, False])
-@pytest.mark.parametrize("size,passes", [((135, 240), 2), ((64, 64), 0), ((37, 53), 3), ((3, 5), 1)])
+@pytest.mark.parametrize("size,passes", [((135, 240), 2), ((64, 64), 0), ((37, 53), 3), ((3, 5), 1),
+                                         # w, h multiples of 4: the fused launches (bright + H, (V, H) pairs, V + combine)
+                                         ((128, 256), 2), ((64, 64), 1), ((36, 52), 3), ((4, 8), 1), ((8, 4), 2),
+                                         ((136, 200), 4), ((540, 960), 2)])
 def test_bloom_kernels_match_oracle(engine_mod, oracle, half, size, passes):
     import torch
     h, w = size
