@@ -28,15 +28,35 @@
 #define SAB_BYTES (2048u * 4u)
 #define LUT_BYTES (512u * 4u)
 
+#define SLOT_BYTES (SAB_BYTES + LUT_BYTES)
+#define N_SLOTS (ARENA_BYTES / SLOT_BYTES)
+
 static uint8_t *g_arena = NULL;
-static size_t g_arena_used = 0;
+static uint8_t g_slot_used[N_SLOTS]; /* one SAB + LUT region per live engine, reused after free() / GC */
 static napi_ref g_arena_ref = NULL;
 
 typedef struct {
     grv_engine *h;
+    int slot;       /* arena slot, -1 once released */
     size_t sab_off;
     size_t lut_off; /* 512-float disk LUT copy (get_disk_lut_ptr, lib.rs:112) */
 } engine_box;
+
+static int slot_acquire(void) {
+    for (unsigned k = 0; k < N_SLOTS; ++k)
+        if (!g_slot_used[k]) {
+            g_slot_used[k] = 1;
+            return (int)k;
+        }
+    return -1;
+}
+static void slot_release(engine_box *box) {
+    if (box->slot >= 0) {
+        g_slot_used[box->slot] = 0;
+        if (g_arena) memset(g_arena + box->sab_off, 0, SLOT_BYTES); /* the next owner starts from zeros */
+        box->slot = -1;
+    }
+}
 
 #define NAPI_OK(call)                                                        \
     do {                                                                     \
@@ -87,6 +107,7 @@ static void engine_finalize(napi_env env, void *data, void *hint) {
     engine_box *box = (engine_box *)data;
     if (box) {
         if (box->h) grv_engine_destroy(box->h);
+        slot_release(box);
         free(box);
     }
 }
@@ -112,12 +133,16 @@ static napi_value engine_new(napi_env env, napi_callback_info info) {
         return NULL;
     }
     (void)get_arena(env);
-    if (g_arena && g_arena_used + SAB_BYTES + LUT_BYTES <= ARENA_BYTES) {
-        box->sab_off = g_arena_used;
-        box->lut_off = g_arena_used + SAB_BYTES;
-        g_arena_used += SAB_BYTES + LUT_BYTES;
-        grv_attach_sab(box->h, (float *)(g_arena + box->sab_off)); /* attach_sab lib.rs:74 */
+    box->slot = g_arena ? slot_acquire() : -1;
+    if (box->slot < 0) { /* no silent fallback onto another engine's region */
+        grv_engine_destroy(box->h);
+        free(box);
+        napi_throw_error(env, NULL, "PhysicsEngine: memory arena exhausted (free() engines no longer in use)");
+        return NULL;
     }
+    box->sab_off = (size_t)box->slot * SLOT_BYTES;
+    box->lut_off = box->sab_off + SAB_BYTES;
+    grv_attach_sab(box->h, (float *)(g_arena + box->sab_off)); /* attach_sab lib.rs:74 */
     NAPI_OK(napi_wrap(env, self, box, engine_finalize, NULL, NULL));
     return self;
 }
@@ -176,7 +201,7 @@ static napi_value m_integrate_ray(napi_env env, napi_callback_info info) {
             napi_throw_type_error(env, NULL, "initial_state must be a Float64Array");
             return NULL;
         }
-        n = len > 64 ? 64 : len;
+        n = len > 64 ? 64 : len; /* only [0, 8) is read once len >= 8 (lib.rs:429-442); shorter inputs are echoed */
         memcpy(in, data, n * sizeof(double));
     } else {
         uint32_t len = 0;
@@ -234,7 +259,7 @@ static napi_value m_generate_disk_lut(napi_env env, napi_callback_info info) {
     void *dst;
     NAPI_OK(napi_create_arraybuffer(env, 512 * sizeof(float), &dst, &ab));
     grv_generate_disk_lut(b->h, (float *)dst);
-    if (g_arena && b->lut_off) memcpy(g_arena + b->lut_off, dst, LUT_BYTES); /* self.lut_buffer */
+    if (g_arena && b->slot >= 0) memcpy(g_arena + b->lut_off, dst, LUT_BYTES); /* self.lut_buffer */
     NAPI_OK(napi_create_typedarray(env, napi_float32_array, 512, ab, 0, &ta));
     return ta;
 }
@@ -662,6 +687,7 @@ static napi_value m_free(napi_env env, napi_callback_info info) { /* wasm-bindge
     if (napi_unwrap(env, self, (void **)&box) == napi_ok && box && box->h) {
         grv_engine_destroy(box->h);
         box->h = NULL;
+        slot_release(box);
     }
     return NULL;
 }

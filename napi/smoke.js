@@ -43,6 +43,26 @@ const wasm = require(path.join(__dirname, "blackhole_physics.node"));
   let glMax = 0;
   for (let i = 0; i < gl.length; i += 4) glMax = Math.max(glMax, gl[i], gl[i + 1], gl[i + 2]);
   res.webgl = { len: gl.length, max: glMax, alpha: gl[3] };
+  // arena slots: hot reload / repeated construction reuses the slots of freed engines, and running
+  // out of slots is an exception, never another engine's region
+  const firstPtr = engine.get_sab_ptr();
+  const seen = new Set();
+  for (let k = 0; k < 300; k++) {
+    const e2 = new mod.PhysicsEngine(1.0, 0.1);
+    seen.add(e2.get_sab_ptr());
+    e2.free();
+  }
+  const live = [];
+  let exhausted = null;
+  try {
+    for (let k = 0; k < 200; k++) live.push(new mod.PhysicsEngine(1.0, 0.2));
+  } catch (e) {
+    exhausted = String(e.message);
+  }
+  const ptrs = new Set(live.map((e2) => e2.get_sab_ptr()));
+  res.arena = { reusedSlots: seen.size, reuseAvoidsLive: !seen.has(firstPtr), liveEngines: live.length,
+                distinctLivePtrs: ptrs.size, liveAvoidFirst: !ptrs.has(firstPtr), exhausted: exhausted };
+  live.forEach((e2) => e2.free());
   console.log(JSON.stringify(res));
   engine.free();
 })().catch((e) => { console.error("FAILED", e); process.exit(1); });

@@ -137,6 +137,12 @@ def test_smoke_js_matches_oracle(oracle):
     assert res["frame"]["rays"] == 96 * 54 and res["frame"]["alpha0"] == 1.0
     assert res["frame"]["acceptedSteps"] == int(fr["steps"].sum())
     assert res["frame"]["lit"] == int((fr["rgba"].reshape(-1, 4)[:, :3].sum(axis=1) > 0).sum())
+    # arena slots (1 MiB / 10 KiB = 102): freed engines give their slot back, live engines never share
+    # one, and running out is an exception instead of an alias of slot 0
+    ar = res["arena"]
+    assert ar["reusedSlots"] == 1 and ar["reuseAvoidsLive"]
+    assert ar["liveEngines"] == 101 and ar["distinctLivePtrs"] == 101 and ar["liveAvoidFirst"]
+    assert ar["exhausted"] and "arena exhausted" in ar["exhausted"]
 
 
 @pytest.mark.gpu
