@@ -7,9 +7,23 @@
 // checker in oracle/ -- the STRICT kernels evaluate them by the published fdlibm / FreeBSD msun
 // algorithms written out here (k_sin, k_cos, the medium-range Cody-Waite rem_pio2, e_pow, e_exp, s_atan, e_log, e_acos, e_atan2): IEEE
 // add / multiply / divide / sqrt only, round-to-nearest, no FMA (this header is only used from
-// translation units built with -ffp-contract=off).  < 1 ulp, see tests/test_ref_libm.py.
+// translation units built with -ffp-contract=off).  Errors against mpmath, tests/test_ref_libm.py:
+// < 1 ulp for sin, cos, pow, exp, log, atan, acos (worst seen 0.86); atan2 up to 1.12 ulp (the
+// quotient y/x is rounded before s_atan sees it, as in e_atan2.c -- kept, the result is specified).
 // Not restated: rem_pio2's Payne-Hanek branch; |x| >= 2^20 pi/2 goes through the same
 // three-term reduction and loses accuracy gradually (a geodesic's theta is O(1..100)).
+//
+// The algorithms, their polynomial coefficients and split constants are those of fdlibm (k_sin.c,
+// k_cos.c, e_rem_pio2.c, e_pow.c, e_exp.c, e_log.c, s_atan.c, e_atan2.c, e_acos.c), whose files
+// carry this notice:
+//   ====================================================
+//   Copyright (C) 1993, 2004 by Sun Microsystems, Inc. All rights reserved.
+//
+//   Developed at SunSoft / SunPro, a Sun Microsystems, Inc. business.
+//   Permission to use, copy, modify, and distribute this
+//   software is freely granted, provided that this notice
+//   is preserved.
+//   ====================================================
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -1,7 +1,20 @@
 /* ref_libm.c -- see ref_libm.h.  TEST INFRASTRUCTURE ONLY.
  * Restates the published fdlibm / FreeBSD msun algorithms (k_sin.c, k_cos.c, e_rem_pio2.c medium
  * range, e_pow.c).  Plain IEEE double arithmetic, round-to-nearest, no FMA (the Makefile passes
- * -ffp-contract=off). */
+ * -ffp-contract=off).
+ *
+ * The algorithms, their polynomial coefficients and split constants are those of fdlibm (k_sin.c,
+ * k_cos.c, e_rem_pio2.c, e_pow.c, e_exp.c, e_log.c, s_atan.c, e_atan2.c, e_acos.c), whose files
+ * carry this notice:
+ *   ====================================================
+ *   Copyright (C) 1993, 2004 by Sun Microsystems, Inc. All rights reserved.
+ *
+ *   Developed at SunSoft / SunPro, a Sun Microsystems, Inc. business.
+ *   Permission to use, copy, modify, and distribute this
+ *   software is freely granted, provided that this notice
+ *   is preserved.
+ *   ====================================================
+ */
 #include "ref_libm.h"
 
 #include <math.h>

@@ -1,0 +1,55 @@
+#!/bin/bash
+# ASan + UBSan pass over the PRODUCT's host code on the CPU box (GPU ASan is not available on this
+# pool): the host side of libgravitas_hip.so -- every engine*.hip entry point, control_plane.hip's
+# host twins, grv_strict_math_host, the tile (un)pack helpers -- and napi/gravitas_napi.c.
+#   device code : compiled for gfx950 as shipped (-Xarch_host keeps the sanitizers off it)
+#   host code   : -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=undefined
+# The sanitized library takes the in-tree library's place for the run (restored on exit); the tests
+# are the no-device ones: host logic, the C-ABI surface, control plane / viz host twins, the gloo
+# world-size-2 assembly, and the CPU half of the N-API tests (node loads the sanitized addon with the
+# ASan runtime preloaded).  Usage: bash oracle/sanitize_host.sh
+set -eu
+R=$(cd "$(dirname "$0")/.." && pwd)
+CS="$R/blackhole-simulation_amd/csrc"
+LIB="$R/blackhole-simulation_amd/libgravitas_hip.so"
+ADDON="$R/napi/blackhole_physics.node"
+B=/tmp/grv_host_san
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+CLANG=/opt/rocm/lib/llvm/bin/clang
+RT=$($CLANG -print-file-name=libclang_rt.asan-x86_64.so)
+SAN="-fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer"
+XSAN=""; for f in $SAN; do XSAN="$XSAN -Xarch_host $f"; done
+TESTS=${SAN_TESTS:-"tests/test_host_logic.py tests/test_control_plane.py tests/test_spacetime_viz.py tests/test_ref_libm.py \
+tests/test_dist_cpu.py tests/test_napi_addon.py tests/test_closed_form_properties.py"}
+
+mkdir -p $B
+cp "$LIB" $B/libgravitas_hip.keep
+[ -f "$ADDON" ] && cp "$ADDON" $B/addon.keep
+restore() {
+  cp $B/libgravitas_hip.keep "$LIB"; touch "$LIB"
+  [ -f $B/addon.keep ] && { cp $B/addon.keep "$ADDON"; touch "$ADDON"; }
+  return 0
+}
+trap restore EXIT
+
+for tu in kernels_strict kernels_fast control_plane spacetime_viz engine engine_shaders engine_control; do
+  fp="-ffp-contract=off"
+  [ $tu = kernels_fast ] && fp="-ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt"
+  (cd "$CS" && $HIPCC -O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $fp $XSAN \
+      -c $tu.hip -o $B/$tu.o) &
+done
+wait
+$HIPCC --offload-arch=gfx950 -shared -fPIC $SAN -shared-libsan -o "$LIB" $B/kernels_strict.o $B/kernels_fast.o \
+    $B/control_plane.o $B/spacetime_viz.o $B/engine.o $B/engine_shaders.o $B/engine_control.o
+# -asan-globals=0 on the addon only: its merged string literals land on odd addresses, which ASan's
+# global registration refuses under node; stack and heap checking (the argument buffers, the arena)
+# stay on
+if [ -f /usr/include/node/node_api.h ]; then
+  $CLANG -O1 -g -std=c11 -fPIC -shared -Wall -Wextra $SAN -mllvm -asan-globals=0 -shared-libsan -I/usr/include/node \
+      "$R/napi/gravitas_napi.c" -o "$ADDON" -L"$R/blackhole-simulation_amd" -lgravitas_hip \
+      -Wl,-rpath,'$ORIGIN/../blackhole-simulation_amd'
+fi
+echo "== host code of libgravitas_hip.so + N-API addon under ASan + UBSan"
+cd "$R"
+ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1 \
+  LD_PRELOAD=$RT python -m pytest $TESTS -x -q -m "not gpu" -p no:cacheprovider 2>&1 | tail -${SAN_TAIL:-3}
