@@ -9,6 +9,7 @@
 
 #include "glsl_fragment.hpp"
 #include "post_kernels.hpp"
+#include "post_fast_kernels.hpp"
 
 namespace grvhip {
 
@@ -86,7 +87,9 @@ inline uint32_t at_least_1(uint32_t x) { return x ? x : 1u; }
 } // namespace
 #define GRV_POST_ARITH GRV_ARITH_FAST
 #define GRV_POST_FN(name) name##_fast
+#define GRV_POST_FAST_FORMS
 #include "post_launch.inc"
+#undef GRV_POST_FAST_FORMS
 #undef GRV_POST_ARITH
 #undef GRV_POST_FN
 
