@@ -48,14 +48,14 @@ const wasm = require(path.join(__dirname, "blackhole_physics.node"));
   const firstPtr = engine.get_sab_ptr();
   const seen = new Set();
   for (let k = 0; k < 300; k++) {
-    const e2 = new mod.PhysicsEngine(1.0, 0.1);
+    const e2 = new wasm.PhysicsEngine(1.0, 0.1);
     seen.add(e2.get_sab_ptr());
     e2.free();
   }
   const live = [];
   let exhausted = null;
   try {
-    for (let k = 0; k < 200; k++) live.push(new mod.PhysicsEngine(1.0, 0.2));
+    for (let k = 0; k < 200; k++) live.push(new wasm.PhysicsEngine(1.0, 0.2));
   } catch (e) {
     exhausted = String(e.message);
   }
