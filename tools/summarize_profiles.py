@@ -52,11 +52,12 @@ def pmc_summary(dbpath):
 
 
 out = {}
-for label in ("trace", "trace_k16"):
+TRACE_CMD = {"trace": "--steps 10 --warmup 2", "trace_k16": "--steps 10 --warmup 2 --segment-tries 16",
+             "trace_strict": "--steps 5 --warmup 1 --arith strict", "trace_c4": "--steps 5 --warmup 1 --config c4"}
+for label in ("trace", "trace_k16", "trace_strict", "trace_c4"):
     p = os.path.join(SRC, label, "bench_results.db")
     if os.path.exists(p):
-        txt, rows = trace_summary(p, "python bench.py --steps 10 --warmup 2 --no-cpu-baseline" +
-                                  (" --segment-tries 16" if label.endswith("k16") else ""))
+        txt, rows = trace_summary(p, "python bench.py %s --no-cpu-baseline" % TRACE_CMD[label])
         bj = os.path.join(SRC, label + "_bench.json")
         if os.path.exists(bj):
             txt += "\n# bench.py line of the same run\n" + open(bj).read().strip() + "\n"
@@ -64,7 +65,8 @@ for label in ("trace", "trace_k16"):
         print(txt)
 
 pm = {}
-for label in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_fetch_k16", "pmc_write_k16"):
+for label in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_fetch_k16", "pmc_write_k16", "pmc_fetch_strict", "pmc_write_strict",
+              "pmc_sq_strict", "pmc_fetch_c4", "pmc_write_c4", "pmc_sq_c4"):
     p = os.path.join(SRC, label, "bench_results.db")
     if os.path.exists(p):
         for k, c, n, avg, tot in pmc_summary(p):
@@ -72,7 +74,7 @@ for label in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_fetch_k16", "pmc_write_k1
 open(os.path.join(DST, "%s_pmc_counters.json" % TAG), "w").write(json.dumps(pm, indent=1))
 for label, items in pm.items():
     for it in items:
-        if "integrate" in it["kernel"] or "finalize" in it["kernel"] or "init_from" in it["kernel"]:
+        if "integrate" in it["kernel"] or "finalize" in it["kernel"] or "init_from" in it["kernel"] or "wgsl" in it["kernel"]:
             print(label, it)
 
 # HBM traffic of the dominant kernels per launch (bench.py reads profiles/traffic.json).  Every
@@ -123,14 +125,18 @@ for pretty, needle, sfx, frame, layout in CASES:
                                        "write_size_kib_avg_per_launch": w2,
                                        "hbm_bytes_per_launch": int((2.0 * f2 + w2) * 1024),
                                        "launches_per_frame": 32}
-    # what actually bounds the kernel: VALU issue.  SQ_INSTS_VALU wave-instructions x 4 cycles
-    # (f64; the f32 march issues most of its VALU work at 4 cycles per wave64 as well) over 1024
-    # SIMDs, against the elapsed cycles per XCD (GRBM_GUI_ACTIVE is summed over 8 XCDs)
+    # what actually bounds the kernel: VALU issue.  SQ_INSTS_VALU wave-instructions x issue cycles over
+    # 1024 SIMDs, against the elapsed cycles per XCD (GRBM_GUI_ACTIVE is summed over 8 XCDs).  An f64
+    # wave64 instruction occupies its SIMD for 4 cycles; an f32 one for 2 (MI355X_MICROARCH.md:
+    # `v_fma_f32` (wave64) 2 cyc, SIMD-32) -- for the f32 march that is a LOWER bound of the issue
+    # occupancy: its v_rcp_f32, conversions, selects and integer ops take 4 or 8.
     insts, gui = _avg("pmc_sq" + sfx, "SQ_INSTS_VALU", needle), _avg("pmc_sq" + sfx, "GRBM_GUI_ACTIVE", needle)
     if insts and gui:
+        cyc = 2.0 if sfx == "_c4" else 4.0
         ent["valu"] = {"sq_insts_valu_per_launch": insts, "cycles_per_xcd": gui / 8.0,
-                       "issue_frac": round(insts * 4.0 / 1024.0 / (gui / 8.0), 4),
-                       "note": "wave64 VALU instructions x 4 cycles / 1024 SIMDs / elapsed cycles"}
+                       "issue_frac": round(insts * cyc / 1024.0 / (gui / 8.0), 4),
+                       "note": "wave64 VALU instructions x %d cycles / 1024 SIMDs / elapsed cycles%s" % (
+                           cyc, " (lower bound: every instruction priced as a 2-cycle f32 op)" if sfx == "_c4" else "")}
     traffic["kernels"][pretty] = ent
 open(tpath, "w").write(json.dumps(traffic, indent=1))
 print(json.dumps(traffic, indent=1))
