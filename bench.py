@@ -181,7 +181,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", choices=["c3", "c4"], default="c3")
-    ap.add_argument("--arith", choices=["fast", "strict", "packed"], default="fast")
+    ap.add_argument("--arith", choices=["fast", "strict", "packed"], default=None,
+                    help="arithmetic contract (default: fast for c3; packed = the FAST contract with two rays per "
+                         "lane on the packed-f32 ops for c4)")
     ap.add_argument("--segment-tries", type=int, default=0)
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--width", type=int, default=0)
@@ -196,6 +198,8 @@ def main():
                     help="N > 1: profiled frames after the timed loop (roofline block)")
     args = ap.parse_args()
     cfg = args.config
+    if args.arith is None:
+        args.arith = "fast" if cfg == "c3" else "packed"
     if cfg == "c3" and args.arith == "packed":
         raise SystemExit("--arith packed is the two-rays-per-lane form of the f32 march (--config c4)")
     base_w = args.width or (3840 if cfg == "c3" else 7680)

@@ -4,7 +4,7 @@ exactly as bench.py's loop does (minus the RCCL gather, which overlaps the next 
 slowest rank's time per N: the strong-scaling efficiency the compute side allows,
 t(1) / (N * max_r t_r(N)), and the host time of a frame call (the budget that must stay below the
 device time for the queue never to run dry).
-    python tools/bench_rank_share.py [c3|c4] > profiles/r02_rank_share_<cfg>.jsonl"""
+    python tools/bench_rank_share.py [c3|c4] [fast|packed] > profiles/r02_rank_share_<cfg>.jsonl"""
 import json
 import os
 import sys
@@ -21,12 +21,15 @@ from blackhole_simulation_amd import distributed as D  # noqa: E402
 EYE = (60.0 * np.sin(np.deg2rad(97.0)), 60.0 * np.cos(np.deg2rad(97.0)), 0.0)
 
 
+WGSL_ARITH = bh.ARITH_FAST
+
+
 def share(e, cfg, W, H, world, rank, frames, two_streams=False):
     cam = bh.camera_look_at(EYE, aspect=W / H)
     params = bh.render_params(W, H, arith=bh.ARITH_FAST)
     rp = D.rank_params(params, world, rank)
     n = e.frame_ray_count(rp)
-    wp = bh.wgsl_params(W, H, cam, 1.0, 0.999, max_steps=1024, arith=bh.ARITH_FAST,
+    wp = bh.wgsl_params(W, H, cam, 1.0, 0.999, max_steps=1024, arith=WGSL_ARITH,
                         tile_world=world, tile_rank=rank) if cfg == "c4" else None
     rgbas = [torch.zeros(n, 4, dtype=torch.float32, device="cuda:0") for _ in range(2)]
     streams = [torch.cuda.Stream(), torch.cuda.Stream()] if two_streams else [torch.cuda.current_stream()] * 2
@@ -60,6 +63,8 @@ if __name__ == "__main__":
     cfg = sys.argv[1] if len(sys.argv) > 1 else "c3"
     W, H = (3840, 2160) if cfg == "c3" else (7680, 4320)
     frames = 10 if cfg == "c3" else 4
+    if len(sys.argv) > 2 and sys.argv[2] == "packed":
+        WGSL_ARITH = bh.ARITH_FAST_PACKED
     with bh.PhysicsEngine(1.0, 0.999) as e:
         e.stats_accumulate(True)
         base = None
@@ -69,7 +74,7 @@ if __name__ == "__main__":
             if world == 1 and not two:
                 base = ms[0]
             print(json.dumps({
-                "config": cfg, "frame": [W, H], "n_gpus": world, "frames_in_flight": 2 if two else 1,
+                "config": cfg, "arith": "packed" if WGSL_ARITH == bh.ARITH_FAST_PACKED else "fast", "frame": [W, H], "n_gpus": world, "frames_in_flight": 2 if two else 1,
                 "ms_per_frame_by_rank": [round(x, 3) for x in ms],
                 "slowest_rank_ms": round(max(ms), 3),
                 "steps_by_rank": [int(r[2]) for r in rows],

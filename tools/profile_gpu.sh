@@ -3,7 +3,8 @@
 # and each PMC set are separate runs, as the guide prescribes.  Passes per dominant kernel:
 #   ""        bench.py                 integrate_segment_kernel<1,1,0>  (FAST f64, the bench line)
 #   _strict   bench.py --arith strict  integrate_segment_kernel<1,0,0>  (reference order, the FFI's contract)
-#   _c4       bench.py --config c4     wgsl_symplectic_fast_kernel      (f32 march of the scaling config)
+#   _c4       bench.py --config c4     wgsl_symplectic_pk_kernel        (f32 march of the scaling config, two rays per lane)
+#   _c4fast   bench.py --config c4 --arith fast   wgsl_symplectic_fast_kernel  (one ray per lane)
 # code_hashes.json stamps the passes with the code objects of the library that ran them
 # (tools/summarize_profiles.py -> profiles/traffic.json; bench.py drops figures whose stamp differs).
 set -u
@@ -16,7 +17,8 @@ import json, sys
 sys.path.insert(0, "$R"); sys.path.insert(0, "$R/tools")
 import kernel_resources as kr
 lib = "$R/blackhole-simulation_amd/libgravitas_hip.so"
-names = ["integrate_segment_kernel<1,1,0>", "integrate_segment_kernel<1,0,0>", "wgsl_symplectic_fast_kernel"]
+names = ["integrate_segment_kernel<1,1,0>", "integrate_segment_kernel<1,0,0>", "wgsl_symplectic_fast_kernel",
+         "wgsl_symplectic_pk_kernel"]
 json.dump({n: kr.kernel_code_hash(lib, n) for n in names}, open("$OUT/code_hashes.json", "w"), indent=1)
 PY
 run() { # label, rocprof args..., -- bench args
@@ -31,8 +33,8 @@ run trace_k16    --kernel-trace --stats -- --steps 10 --warmup 2 --segment-tries
 run trace_strict --kernel-trace --stats -- --steps 5 --warmup 1 --arith strict
 run trace_c4     --kernel-trace --stats -- --steps 5 --warmup 1 --config c4
 SQ="SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
-for sfx in "" _strict _c4; do
-  case "$sfx" in "") extra="";; _strict) extra="--arith strict";; _c4) extra="--config c4";; esac
+for sfx in "" _strict _c4 _c4fast; do
+  case "$sfx" in "") extra="";; _strict) extra="--arith strict";; _c4) extra="--config c4";; _c4fast) extra="--config c4 --arith fast";; esac
   run pmc_fetch$sfx --pmc FETCH_SIZE -- --steps 2 --warmup 1 $extra
   run pmc_write$sfx --pmc WRITE_SIZE -- --steps 2 --warmup 1 $extra
   run pmc_sq$sfx    --pmc $SQ -- --steps 2 --warmup 1 $extra

@@ -66,7 +66,8 @@ for label in ("trace", "trace_k16", "trace_strict", "trace_c4"):
 
 pm = {}
 for label in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_fetch_k16", "pmc_write_k16", "pmc_fetch_strict", "pmc_write_strict",
-              "pmc_sq_strict", "pmc_fetch_c4", "pmc_write_c4", "pmc_sq_c4"):
+              "pmc_sq_strict", "pmc_fetch_c4", "pmc_write_c4", "pmc_sq_c4", "pmc_fetch_c4fast", "pmc_write_c4fast",
+              "pmc_sq_c4fast"):
     p = os.path.join(SRC, label, "bench_results.db")
     if os.path.exists(p):
         for k, c, n, avg, tot in pmc_summary(p):
@@ -102,7 +103,8 @@ if os.path.exists(tpath):
 # (pretty name, substring of the demangled name in the trace, pass suffix, frame, layout bytes)
 CASES = [("integrate_segment_kernel<1,1,0>", "integrate_segment_kernel<1, 1, 0>", "", [3840, 2160], 8355840 * (92 + 76)),
          ("integrate_segment_kernel<1,0,0>", "integrate_segment_kernel<1, 0, 0>", "_strict", [3840, 2160], 8355840 * (92 + 76)),
-         ("wgsl_symplectic_fast_kernel", "wgsl_symplectic_fast_kernel", "_c4", [7680, 4320], None)]
+         ("wgsl_symplectic_pk_kernel", "wgsl_symplectic_pk_kernel", "_c4", [7680, 4320], None),
+         ("wgsl_symplectic_fast_kernel", "wgsl_symplectic_fast_kernel", "_c4fast", [7680, 4320], None)]
 for pretty, needle, sfx, frame, layout in CASES:
     f, w = _avg("pmc_fetch" + sfx, "FETCH_SIZE", needle), _avg("pmc_write" + sfx, "WRITE_SIZE", needle)
     if f is None or w is None:
@@ -113,7 +115,7 @@ for pretty, needle, sfx, frame, layout in CASES:
     # read = 0.769 GB, x 76 B written = 0.635 GB.
     ent = {"name": needle, "code_hash": hashes.get(pretty), "frame": frame,
            "command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline" +
-                      {"": "", "_strict": " --arith strict", "_c4": " --config c4"}[sfx],
+                      {"": "", "_strict": " --arith strict", "_c4": " --config c4", "_c4fast": " --config c4 --arith fast"}[sfx],
            "fetch_size_kib_raw_avg_per_launch": f, "write_size_kib_avg_per_launch": w,
            "fetch_correction": 2.0, "hbm_bytes_per_launch": int((2.0 * f + w) * 1024)}
     if layout:
@@ -132,11 +134,11 @@ for pretty, needle, sfx, frame, layout in CASES:
     # occupancy: its v_rcp_f32, conversions, selects and integer ops take 4 or 8.
     insts, gui = _avg("pmc_sq" + sfx, "SQ_INSTS_VALU", needle), _avg("pmc_sq" + sfx, "GRBM_GUI_ACTIVE", needle)
     if insts and gui:
-        cyc = 2.0 if sfx == "_c4" else 4.0
+        cyc = 2.0 if sfx.startswith("_c4") else 4.0
         ent["valu"] = {"sq_insts_valu_per_launch": insts, "cycles_per_xcd": gui / 8.0,
                        "issue_frac": round(insts * cyc / 1024.0 / (gui / 8.0), 4),
                        "note": "wave64 VALU instructions x %d cycles / 1024 SIMDs / elapsed cycles%s" % (
-                           cyc, " (lower bound: every instruction priced as a 2-cycle f32 op)" if sfx == "_c4" else "")}
+                           cyc, " (lower bound: every instruction priced as a 2-cycle f32 op; a packed op occupies 4)" if sfx.startswith("_c4") else "")}
     traffic["kernels"][pretty] = ent
 open(tpath, "w").write(json.dumps(traffic, indent=1))
 print(json.dumps(traffic, indent=1))
