@@ -323,6 +323,11 @@ def main():
         return st, ms, n
 
     in_loop_profile = world == 1  # no events in a multi-rank timed loop
+    if tg is not None:
+        # communicator set-up (RCCL opens its xGMI peer connections on first use) belongs to
+        # initialisation, not to a frame: one exchange of the still empty buffers, whatever --warmup is
+        tg.run(dev_unpack, force_collective=True)
+        torch.cuda.synchronize()
     for i in range(args.warmup):
         one_frame(i, False)
     fence()

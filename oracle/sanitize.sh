@@ -6,7 +6,7 @@ set -eu
 R=$(cd "$(dirname "$0")/.." && pwd)
 SRC="gravitas_oracle.c frame_oracle.c control_oracle.c shader_oracle.c viz_oracle.c post_oracle.c ref_libm.c"
 TESTS="tests/test_oracle_pins.py tests/test_oracle_physics.py tests/test_golden_cpu.py tests/test_golden_shaders.py \
-tests/test_post_chain.py tests/test_spacetime_viz.py tests/test_control_plane.py tests/test_shader_kernels.py tests/test_ref_libm.py"
+tests/test_post_chain.py tests/test_spacetime_viz.py tests/test_control_plane.py tests/test_shader_kernels.py tests/test_ref_libm.py tests/test_f32_oracle_pins.py"
 cp "$R/oracle/libgravitas_oracle.so" /tmp/libgravitas_oracle.keep
 restore() { cp /tmp/libgravitas_oracle.keep "$R/oracle/libgravitas_oracle.so"; touch "$R/oracle/libgravitas_oracle.so"; }
 trap restore EXIT
