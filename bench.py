@@ -230,14 +230,24 @@ def main():
         else:
             while not os.path.exists(bh.library_path()):
                 time.sleep(1.0)
+    # Test hooks (tests/test_gpu_dist_shared_device.py): GRV_BENCH_ONE_DEVICE=1 puts every rank on
+    # cuda:0 and GRV_BENCH_BACKEND=gloo exchanges the device buffers through gloo, so that the N > 1
+    # control flow of this file (strong split, two frames in flight, pipelined gather, timing
+    # reductions) runs for real on a one-GPU box; RCCL refuses two ranks on one device.
+    backend = os.environ.get("GRV_BENCH_BACKEND", "nccl")
+    if os.environ.get("GRV_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or "RANK" in os.environ  # under torchrun even a 1-rank job walks the RCCL path
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     gx, gy = GRID.get(world, (world, 1)) if args.scaling == "weak" else (1, 1)
     W, H = base_w * gx, base_h * gy
@@ -424,7 +434,8 @@ def main():
                        if world > 1 else "single GPU",
                        "rays": total_rays, "accepted_steps_per_frame": int(total_steps / args.steps),
                        "host_waits_in_frame_loop": 0 if not args.segment_tries else "one per segment",
-                       "frames_in_flight": 2 if two else 1},
+                       "frames_in_flight": 2 if two else 1,
+                       **({"exchange_backend": backend} if backend != "nccl" else {})},
             "roofline": roofline,
         }
         if cfg == "c3":

@@ -1,0 +1,142 @@
+"""The N > 1 path on ONE GPU: several processes share cuda:0, render their tile shares with the HIP
+engine into the gather's send buffers and exchange the device buffers through gloo (RCCL refuses
+two ranks on one device; the pool hands out one-GPU boxes).  Everything but the transport is the
+path bench.py and render_frame_distributed run on eight GPUs: rank_params, the packed render
+targets, TileGather (synchronous and pipelined, two frames in flight on two streams), the
+de-interleave kernel on rank 0, the timing reductions.  The assembled image must equal a
+whole-frame render bit for bit."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, w, h, arith, out_path):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import blackhole_simulation_amd as bh
+    from blackhole_simulation_amd import distributed as D
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        th = np.deg2rad(97.0)
+        eye = (60.0 * np.sin(th), 60.0 * np.cos(th), 0.0)
+        cam = bh.camera_look_at(eye, aspect=w / h)
+        params = bh.render_params(w, h, arith=arith)
+        rp = D.rank_params(params, world, rank)
+        with bh.PhysicsEngine(1.0, 0.999, device=0) as eng:
+            n_local = eng.frame_ray_count(rp)
+
+            def dev_unpack(rparams, r, packed, image):
+                eng.unpack_tiles_device(rparams, r, packed, image, 16, torch.cuda.current_stream().cuda_stream)
+
+            # synchronous form
+            tg = D.TileGather(params, world, rank, 4, torch.float32, dev)
+            eng.render_frame_device(cam, rp, rgba=tg.local_view(n_local),
+                                    stream=torch.cuda.current_stream().cuda_stream)
+            img = tg.run(dev_unpack)
+            torch.cuda.synchronize()
+            images = [img.cpu().numpy().copy()] if rank == 0 else []
+            # pipelined form, even / odd frames on two streams (bench.py's default for N > 1):
+            # four frames of the same camera must come back identical to the synchronous one
+            tg2 = D.TileGather(params, world, rank, 4, torch.float32, dev).enable_pipeline()
+            streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+            eng.stats_accumulate(True)
+            eng.frame_stats_reset(streams[0].cuda_stream)
+            torch.cuda.synchronize()
+            for f in range(4):
+                with torch.cuda.stream(streams[f % 2]):
+                    target = tg2.pipelined_view(f, n_local)
+                    eng.render_frame_device(cam, rp, rgba=target, stream=streams[f % 2].cuda_stream)
+                    prev = tg2.submit(f, dev_unpack)
+                    if prev is not None and rank == 0:
+                        torch.cuda.current_stream().synchronize()
+                        images.append(prev.cpu().numpy().copy())
+            last = tg2.drain(dev_unpack)
+            torch.cuda.synchronize()
+            if rank == 0:
+                images.append(last.cpu().numpy().copy())
+            st = eng.frame_stats(streams[0].cuda_stream)
+            steps = torch.tensor([float(st.accepted_steps)], dtype=torch.float64, device=dev)
+            dist.all_reduce(steps)
+            if rank == 0:
+                # the whole frame on this GPU, one rank
+                whole = torch.zeros(w * h, 4, dtype=torch.float32, device=dev)
+                eng.stats_accumulate(False)
+                eng.render_frame_device(cam, params, rgba=whole, stream=torch.cuda.current_stream().cuda_stream)
+                wst = eng.frame_stats()
+                torch.cuda.synchronize()
+                np.savez(out_path, whole=whole.cpu().numpy().reshape(h, w, 4), images=np.stack(images),
+                         steps_sum=float(steps.item()), steps_whole=float(wst.accepted_steps))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,w,h,arith", [(2, 200, 130, 0), (4, 512, 288, 1), (8, 960, 540, 1)])
+def test_ranks_sharing_one_gpu_assemble_the_whole_frame_bitwise(tmp_path, engine_mod, world, w, h, arith):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "r.npz")
+    mp.spawn(_worker, args=(world, _free_port(), w, h, arith, out), nprocs=world, join=True)
+    r = np.load(out)
+    assert r["images"].shape[0] == 5  # one synchronous frame + four pipelined ones
+    for img in r["images"]:
+        assert np.array_equal(img.view(np.uint32), r["whole"].view(np.uint32))
+    assert r["steps_sum"] == 4 * r["steps_whole"]  # four accumulated frames, every ray counted once
+
+
+def _bench(world, *args):
+    env = dict(os.environ, GRV_BENCH_BACKEND="gloo", GRV_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+           "--gpus", str(world)] + list(args)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_strong_split_runs_with_several_ranks(world):
+    """bench.py's own N > 1 loop (strong split of the fixed frame, two frames in flight, pipelined
+    gather, max-over-ranks timing, summed steps) against the one-rank run of the same frame."""
+    one = _bench(1, "--width", "640", "--height", "360", "--steps", "4", "--warmup", "1", "--no-cpu-baseline")
+    many = _bench(world, "--width", "640", "--height", "360", "--steps", "4", "--warmup", "1")
+    assert many["n_gpus"] == world and many["scaling"] == "strong" and many["steps"] == 4
+    assert many["config"]["rays"] == one["config"]["rays"] == 640 * 360
+    assert many["config"]["accepted_steps_per_frame"] == one["config"]["accepted_steps_per_frame"]
+    assert many["config"]["frames_in_flight"] == 2 and many["config"]["host_waits_in_frame_loop"] == 0
+    assert "split over %d GPUs" % world in many["config"]["workload"]
+    assert many["value"] > 0 and many["roofline"]["avg_launch_ms"] > 0
+    assert "cpu_baseline" not in many
+
+
+def test_bench_config4_runs_with_several_ranks():
+    one = _bench(1, "--config", "c4", "--width", "512", "--height", "288", "--steps", "3", "--warmup", "1",
+                 "--no-cpu-baseline")
+    many = _bench(2, "--config", "c4", "--width", "512", "--height", "288", "--steps", "3", "--warmup", "1")
+    assert many["n_gpus"] == 2 and many["dtype"] == "f32" and many["config"]["arith"] == "packed"
+    # the packed march pairs horizontally adjacent slots; a tile share pairs the same pixels
+    assert many["config"]["accepted_steps_per_frame"] == one["config"]["accepted_steps_per_frame"]
+    assert many["config"]["rays"] == 512 * 288
