@@ -219,3 +219,55 @@ def test_two_frames_in_flight_on_two_streams(bh, torch_mod):
     assert acc.rays == len(eyes) * one.rays
     for (a, fa), (b, fb) in zip(serial, flight):
         assert torch.equal(a, b) and torch.equal(fa.view(torch.int64), fb.view(torch.int64))
+
+
+def test_engines_on_two_host_threads_are_independent(bh, torch_mod):
+    """a handle is not thread-safe, distinct handles are independent.  Two host
+    threads, each with its own engine (different spins) and its own stream, render frames and
+    integrate batches at the same time (ctypes releases the GIL around every C call); each must
+    get the bits its engine produces alone."""
+    import threading
+    torch = torch_mod
+    W, H = 320, 180
+    rng = np.random.default_rng(11)
+    states = np.tile(np.array([0.0, 20.0, np.pi / 2, 0.0, -1.0, -1.0, 0.0, 3.5]), (512, 1))
+    states[:, 7] = rng.uniform(2.0, 6.0, 512)
+
+    def work(spin, stream, reps, out):
+        torch.cuda.set_device(0)
+        with bh.PhysicsEngine(1.0, spin) as e:
+            cam = bh.camera_look_at(EYE, aspect=W / H)
+            p = bh.render_params(W, H, arith=0)
+            n = e.frame_ray_count(p)
+            with torch.cuda.stream(stream):
+                imgs = []
+                for _ in range(reps):
+                    rgba = torch.zeros(n, 4, dtype=torch.float32, device="cuda:0")
+                    fs = torch.zeros(n, 8, dtype=torch.float64, device="cuda:0")
+                    e.render_frame_device(cam, p, rgba, fs, stream=stream.cuda_stream)
+                    imgs.append((rgba, fs))
+                stream.synchronize()
+                res = e.integrate_batch(states, bh.engine.default_options(metric_kind=bh.KERR_KS))
+            out.append(([(a.cpu().numpy(), b.cpu().numpy()) for a, b in imgs], res))
+
+    s_main = torch.cuda.current_stream()
+    alone = {}
+    for spin in (0.999, 0.3):
+        got = []
+        work(spin, s_main, 1, got)
+        alone[spin] = got[0]
+    results = {0.999: [], 0.3: []}
+    threads = [threading.Thread(target=work, args=(spin, torch.cuda.Stream(), 3, results[spin])) for spin in results]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for spin in results:
+        assert len(results[spin]) == 1, "worker thread died"
+        imgs, res = results[spin][0]
+        ref_imgs, ref_res = alone[spin]
+        for rgba, fs in imgs:
+            assert np.array_equal(rgba.view(np.uint32), ref_imgs[0][0].view(np.uint32))
+            assert np.array_equal(fs.view(np.uint64), ref_imgs[0][1].view(np.uint64))
+        for k in ref_res:
+            assert np.array_equal(res[k], ref_res[k]), k
