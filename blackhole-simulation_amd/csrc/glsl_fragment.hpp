@@ -130,6 +130,18 @@ __device__ __forceinline__ F3 glsl_accel(F3 p, F3 v, float M, float a, float &om
 // sin / cos of the FAST contract: two-term Cody-Waite reduction by pi/2 + cephes minimax
 // polynomials on [-pi/4, pi/4] (~1 ulp f32 for the O(1) angles of the march)
 __device__ __forceinline__ void glsl_fast_sincos(float ang, float &s, float &c) {
+    if (__ballot(!(fabsf(ang) <= 0.78539816f)) == 0ull) {
+        // the whole wave is inside [-pi/4, pi/4] (the ZAMO twist omega * dt of a march step always is):
+        // j = 0, the reduction returns the argument and the quadrant logic is the identity -- same bits
+        const float z = ang * ang;
+        float ps = fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+        ps = fmaf(z, ps, -1.6666654611e-1f);
+        s = fmaf(ang * z, ps, ang);
+        float pc = fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+        pc = fmaf(z, pc, 4.166664568298827e-2f);
+        c = fmaf(z * z, pc, fmaf(z, -0.5f, 1.0f));
+        return;
+    }
     const float j = rintf(ang * 0.636619772367581343f);
     float x = fmaf(-j, 1.57079637050628662109375f, ang);
     x = fmaf(-j, -4.37113900018624283e-8f, x);
@@ -296,20 +308,24 @@ __device__ void glsl_starfield(const GlslParams &U, F3 dir, float stars[3]) {
 }
 
 // chunks/disk.ts:16-115
+// (r_p = |p|, which the march has already: the FAST contract takes the sample radius from it when
+// the step did not cross the plane and the sample point is p itself)
 template <int ARITH>
 __device__ __forceinline__ void glsl_sample_disk(const GlslParams &U, F3 p, F3 p_prev, F3 v,
                                                  float isco, float M, float a, float dt,
-                                                 float col[3], float &alpha) {
+                                                 float col[3], float &alpha, float r_p) {
     if (!(U.show_redshift < 0.5f)) return;
     const bool crossed = (p_prev.y * p.y < 0.0f);
     F3 sp = p;
+    float sampleR = r_p;
     if (crossed) {
         const float t = fabsf(p_prev.y) / fmaxf(0.0001f, fabsf(p_prev.y) + fabsf(p.y));
         sp.x = p_prev.x * (1.0f - t) + p.x * t;
         sp.y = p_prev.y * (1.0f - t) + p.y * t;
         sp.z = p_prev.z * (1.0f - t) + p.z * t;
+        if constexpr (ARITH == GRV_ARITH_FAST) sampleR = length_t<ARITH>(sp);
     }
-    const float sampleR = length_t<ARITH>(sp);
+    if constexpr (ARITH != GRV_ARITH_FAST) sampleR = length_t<ARITH>(sp);
     const float effH = fminf(U.disk_scale_height, 0.45f);
     const float diskHeight = sampleR * effH;
     const float diskInner = isco;
@@ -579,7 +595,7 @@ __device__ uint32_t glsl_fragment(const GlslParams &U, uint32_t width, uint32_t 
         }
         prevY = p.y;
         if (disk) {
-            glsl_sample_disk<ARITH>(U, p, p_prev, v, isco, M, a, cdt, col, alpha);
+            glsl_sample_disk<ARITH>(U, p, p_prev, v, isco, M, a, cdt, col, alpha, r_new);
             if (alpha > 0.99f) break;
         }
         if (jets) glsl_sample_jets<ARITH>(U, p, v, rh, dt, col, alpha); // un-refined dt (fragment.glsl.ts:219)
