@@ -35,7 +35,8 @@ template <int ARITH> __device__ __forceinline__ F3 normalize_t(F3 a) {
 }
 template <int ARITH> __device__ __forceinline__ float smoothstep_t(float e0, float e1, float x) {
     if constexpr (ARITH == GRV_ARITH_FAST) {
-        const float t = clampf_d((x - e0) * __builtin_amdgcn_rcpf(e1 - e0), 0.0f, 1.0f);
+        // (1 / (e1 - e0) folds at compile time for the literal edges of the march; v_rcp_f32 otherwise)
+        const float t = clampf_d((x - e0) * (1.0f / (e1 - e0)), 0.0f, 1.0f);
         return t * t * (3.0f - 2.0f * t);
     } else {
         return smoothstep_d(e0, e1, x);
@@ -549,14 +550,21 @@ __device__ uint32_t glsl_fragment(const GlslParams &U, uint32_t width, uint32_t 
         if (lensing) {
             float omega;
             if constexpr (ARITH == GRV_ARITH_FAST && GRV_GLSL_CARRY_GEOM) {
-                accel = scale_f3(glsl_accel_from_geom(geom, p, v, a), U.lensing_strength);
+                accel = glsl_accel_from_geom(geom, p, v, a); // unscaled: u_lensing_strength rides in k2 / kv below
                 omega = geom.drag;
             } else {
                 accel = scale_f3(glsl_accel<ARITH>(p, v, M, a, omega), U.lensing_strength);
             }
             glsl_rot<ARITH>(omega * cdt, v.x, v.z);
         }
-        p = add_f3(p, add_f3(scale_f3(v, cdt), scale_f3(scale_f3(scale_f3(accel, 0.5f), cdt), cdt)));
+        if constexpr (ARITH == GRV_ARITH_FAST && GRV_GLSL_CARRY_GEOM) {
+            // p + v dt + (a / 2) dt^2 with the three scalings of a folded into one factor
+            const float k2 = 0.5f * cdt * cdt * U.lensing_strength;
+            p = F3{fmaf(accel.x, k2, fmaf(v.x, cdt, p.x)), fmaf(accel.y, k2, fmaf(v.y, cdt, p.y)),
+                   fmaf(accel.z, k2, fmaf(v.z, cdt, p.z))};
+        } else {
+            p = add_f3(p, add_f3(scale_f3(v, cdt), scale_f3(scale_f3(scale_f3(accel, 0.5f), cdt), cdt)));
+        }
         float r_new;
         if constexpr (ARITH == GRV_ARITH_FAST && GRV_GLSL_CARRY_GEOM) {
             if (lensing) {
@@ -570,14 +578,16 @@ __device__ uint32_t glsl_fragment(const GlslParams &U, uint32_t width, uint32_t 
             r_new = length_t<ARITH>(p);
         }
         if (lensing && alpha < 0.95f) {
-            F3 accel_new;
             if constexpr (ARITH == GRV_ARITH_FAST && GRV_GLSL_CARRY_GEOM) {
-                accel_new = scale_f3(glsl_accel_from_geom(geom, p, v, a), U.lensing_strength);
+                const F3 accel_new = glsl_accel_from_geom(geom, p, v, a);
+                const float kv = 0.5f * cdt * U.lensing_strength;
+                v = F3{fmaf(accel.x + accel_new.x, kv, v.x), fmaf(accel.y + accel_new.y, kv, v.y),
+                       fmaf(accel.z + accel_new.z, kv, v.z)};
             } else {
                 float om2;
-                accel_new = scale_f3(glsl_accel<ARITH>(p, v, M, a, om2), U.lensing_strength);
+                const F3 accel_new = scale_f3(glsl_accel<ARITH>(p, v, M, a, om2), U.lensing_strength);
+                v = add_f3(v, scale_f3(scale_f3(add_f3(accel, accel_new), 0.5f), cdt));
             }
-            v = add_f3(v, scale_f3(scale_f3(add_f3(accel, accel_new), 0.5f), cdt));
         }
         v = normalize_t<ARITH>(v);
         ++steps;
