@@ -188,6 +188,9 @@ def test_wgsl_kernel_star_density(engine_mod, arith):
     (-0.7, 1, dict(features=7 | 64, show_redshift=1.0)),        # redshift overlay, retrograde spin
     (0.9, 0, dict(quality=0)),                                  # RAY_QUALITY_LOW indicator path
     (0.9, 1, dict(cam_pos=(0.0, 6.0, -60.0), cam_quat=(0.05, 0.0, 0.0, 0.99875))),  # SAB camera
+    (0.9, 0, dict(features=6, turbulence=0.75)),                # lensing off: straight rays through the disk
+    (0.999, 0, dict(features=1)),                               # lensing only (the march without any sampling)
+    (0.9, 1, dict(lensing_strength=0.5, time=1.3)),             # u_lensing_strength != 1 (folded scalings of FAST)
 ])
 @pytest.mark.parametrize("arith", [0, 1])  # shader operation order / FAST contract
 def test_glsl_kernel_matches_oracle(engine_mod, oracle, spin, tone, kw, arith):
