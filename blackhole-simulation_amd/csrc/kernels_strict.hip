@@ -214,6 +214,8 @@ __global__ __launch_bounds__(kBlock) void strict_math_kernel(int op, uint32_t n,
     case 6: out[i] = strictm::sl_atan(x[i]); break;
     case 7: out[i] = strictm::sl_log(x[i]); break;
     case 8: out[i] = strictm::sl_acos(x[i]); break;
+    case 10: out[i] = IeeeDiv::div(x[i], IeeeDiv::prep(y[i])); break;
+    case 11: out[i] = SharedDiv::div(x[i], SharedDiv::prep(y[i])); break;
     default: out[i] = strictm::sl_atan2(x[i], y[i]); break;
     }
 }

@@ -374,6 +374,11 @@ int grv_generate_spectrum_lut_device(grv_engine *e, size_t width, size_t height,
 enum { GRV_MATH_SINCOS_SIN = 0, GRV_MATH_SINCOS_COS = 1, GRV_MATH_SIN = 2, GRV_MATH_COS = 3,
        GRV_MATH_POW = 4, GRV_MATH_EXP = 5, GRV_MATH_ATAN = 6, GRV_MATH_LOG = 7, GRV_MATH_ACOS = 8,
        GRV_MATH_ATAN2 = 9 /* atan2(x[i], y[i]) */,
+       GRV_MATH_DIV = 10 /* x[i] / y[i] as the compiler expands it on the device (correctly rounded) */,
+       GRV_MATH_DIV_SHARED = 11 /* x[i] / y[i] through the STRICT Kerr-Schild kernels' shared-reciprocal form
+                                   (csrc/kerr_device.hpp SharedDiv): the same bits as GRV_MATH_DIV whenever
+                                   both operands are zero or moderate in magnitude, which is the only case in
+                                   which the kernels use it */,
        GRV_MATH_F32 = 16 /* or-ed in: the f32 form (float)op((double)(float)x) of the shader-order kernels */ };
 int grv_strict_math(grv_engine *e, int op, size_t n, const double *x, const double *y, double *out);
 /* the same routines compiled for the host (they also serve the engine's host-side closed forms):

@@ -257,3 +257,48 @@ def test_device_routines_return_the_same_bits(engine_mod, oracle):
         ok = ~np.isnan(want)
         assert np.array_equal(got.view(np.uint64)[ok], want.view(np.uint64)[ok])
         assert np.array_equal(np.isnan(got), np.isnan(want))
+
+
+@pytest.mark.gpu
+def test_shared_reciprocal_quotient_is_the_ieee_quotient_inside_its_range(engine_mod):
+    """SharedDiv (csrc/kerr_device.hpp): the STRICT Kerr-Schild kernels evaluate the reciprocal
+    refinement of the compiler's f64 division once per denominator and share it between the quotients
+    over it.  The kernels admit a right-hand side to that form only when every operand is zero or
+    moderate in magnitude (divs_ok_hole / divs_ok_point: denominators in [2^-266, 2^82], numerators zero
+    or in [2^-290, 2^83]); inside that range the form must return the bits of the device's own `/`
+    and of the host's IEEE quotient.  4 M random operand pairs over the whole admitted range, the
+    range's corners, signed zeros."""
+    bh = engine_mod
+    E = bh.engine
+    rng = np.random.default_rng(20260930)
+    n = 4_000_000
+
+    def operands(k, lo, hi, zero_frac):
+        mant = 1.0 + rng.random(k)
+        mant[rng.random(k) < 0.02] = 1.0                       # exact powers of two
+        mant[rng.random(k) < 0.02] = np.nextafter(2.0, 1.0)    # all-ones mantissa
+        x = np.ldexp(mant, rng.integers(lo, hi, k)) * rng.choice([-1.0, 1.0], k)
+        x[rng.random(k) < zero_frac] = 0.0
+        return x
+    num = operands(n, -290, 83, 0.03)
+    den = operands(n, -266, 82, 0.0)
+    corners = np.array([(a, b) for a in (2.0 ** -290, np.nextafter(2.0 ** 83, 0), 0.0, -0.0, 1.0, 3.0)
+                        for b in (2.0 ** -266, -np.nextafter(2.0 ** 82, 0), 1.0, 3.0, 2.0 ** -54)])
+    num = np.concatenate([num, corners[:, 0]])
+    den = np.concatenate([den, corners[:, 1]])
+    with bh.PhysicsEngine(1.0, 0.9) as e:
+        ieee = e.strict_math(E.MATH_DIV, num, den)
+        shared = e.strict_math(E.MATH_DIV_SHARED, num, den)
+    host = E.strict_math_host(E.MATH_DIV, num, den)
+    assert np.array_equal(host.view(np.uint64), (num / den).view(np.uint64))
+    assert np.array_equal(ieee.view(np.uint64), host.view(np.uint64))
+    bad = np.flatnonzero(shared.view(np.uint64) != ieee.view(np.uint64))
+    assert bad.size == 0, (bad.size, num[bad[:4]], den[bad[:4]], shared[bad[:4]], ieee[bad[:4]])
+    # outside the admitted range the two forms need not agree (subnormal quotients lose the scaling the
+    # full sequence applies): that is what the kernels' range test is for.  Only finiteness of the
+    # statement is checked here -- a zero denominator or non-finite operand maps like the full sequence
+    sp_n = np.array([1.0, -1.0, 0.0, np.inf, np.nan, 1.0])
+    sp_d = np.array([0.0, 0.0, 0.0, 2.0, 1.0, np.inf])
+    with bh.PhysicsEngine(1.0, 0.9) as e:
+        a, b = e.strict_math(E.MATH_DIV, sp_n, sp_d), e.strict_math(E.MATH_DIV_SHARED, sp_n, sp_d)
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
