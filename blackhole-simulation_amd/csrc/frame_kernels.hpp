@@ -281,6 +281,21 @@ __global__ __launch_bounds__(kBlock) void unpack_tiles_kernel(FrameGeom G,
     }
 }
 
+// 16-byte pixels (RGBA f32, the frame path's format): one thread moves one pixel, a wave one 1-KiB tile
+// row -- a coalesced read and a coalesced write, index arithmetic in shifts.
+__global__ __launch_bounds__(kBlock) void unpack_tiles16_kernel(FrameGeom G, const uint4 *__restrict__ packed,
+                                                                uint4 *__restrict__ image) {
+    const size_t total = (size_t)G.n_tiles_local * 4096u;
+    for (size_t pix = (size_t)blockIdx.x * kBlock + threadIdx.x; pix < total; pix += (size_t)gridDim.x * kBlock) {
+        const uint32_t tile_local = (uint32_t)(pix >> 12);
+        const uint32_t within = (uint32_t)(pix & 4095u);
+        const uint32_t px = within & 63u, py = within >> 6;
+        const uint32_t tile = tile_local * G.tile_world + G.tile_rank;
+        const uint32_t X = (tile % G.tiles_x) * 64u + px, Y = (tile / G.tiles_x) * 64u + py;
+        if (X < G.width && Y < G.height) image[(size_t)Y * G.width + X] = packed[pix];
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Planck (T x g) LUT: one thread per texel, 201-sample CIE integration
 // ---------------------------------------------------------------------------

@@ -152,6 +152,14 @@ hipError_t launch_unpack_tiles(const FrameGeom &G, const void *packed, void *ima
                                uint32_t words_per_pixel, hipStream_t s) {
     const size_t total = (size_t)G.n_tiles_local * 4096u * words_per_pixel;
     if (total == 0) return hipSuccess;
+    if (words_per_pixel == 4 && (reinterpret_cast<uintptr_t>(packed) & 15u) == 0 &&
+        (reinterpret_cast<uintptr_t>(image) & 15u) == 0) { // RGBA f32: one 16-byte move per thread
+        size_t g16 = (total / 4 + kBlock - 1) / kBlock;
+        if (g16 > 16384) g16 = 16384;
+        hipLaunchKernelGGL(unpack_tiles16_kernel, dim3((uint32_t)g16), dim3(kBlock), 0, s, G,
+                           static_cast<const uint4 *>(packed), static_cast<uint4 *>(image));
+        return hipGetLastError();
+    }
     size_t grid = (total + kBlock - 1) / kBlock;
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(unpack_tiles_kernel, dim3((uint32_t)grid), dim3(kBlock), 0, s, G,
