@@ -684,8 +684,15 @@ __device__ uint32_t glsl_fragment(const GlslParams &U, uint32_t width, uint32_t 
 }
 
 // one thread per pixel of this rank's tile set; a wave is one 8x8 pixel block
+// FAST form compiled for five waves per SIMD (96 VGPRs; 72 B of scratch, all in the disk / jet sampling
+// branches): +2-3 % over the 120 registers / four waves the compiler takes on its own, measured A/B;
+// six waves (80 VGPRs, 132 B of scratch) loses on the default preset
+#ifndef GRV_GLSL_FAST_WAVES
+#define GRV_GLSL_FAST_WAVES 5
+#endif
 template <int ARITH>
-__global__ __launch_bounds__(kBlock) void glsl_fragment_kernel(FrameGeom G, GlslParams U,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ARITH == GRV_ARITH_FAST ? GRV_GLSL_FAST_WAVES : 1)))
+void glsl_fragment_kernel(FrameGeom G, GlslParams U,
                                                                float4 *__restrict__ out_rgba,
                                                                uint32_t *__restrict__ out_steps,
                                                                unsigned long long *total_steps,
