@@ -175,6 +175,30 @@ def committed_pmc(kernel_pretty, lib_path):
     return ent, "profiles/traffic.json (code object %s)" % now
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-run this command line under
+    torch.distributed.run with N ranks on this node (one per visible GPU) and pass rank 0's JSON
+    line through.  Returns the launcher's exit status."""
+    import socket
+    import subprocess
+    if os.environ.get("GRV_BENCH_ONE_DEVICE") != "1":
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            sys.stderr.write("bench.py: --gpus %d but only %d HIP device(s) visible\n" % (n, have))
+            return 2
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -204,6 +228,11 @@ def main():
         raise SystemExit("--arith packed is the two-rays-per-lane form of the f32 march (--config c4)")
     base_w = args.width or (3840 if cfg == "c3" else 7680)
     base_h = args.height or (2160 if cfg == "c3" else 4320)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # a bare `python bench.py --gpus N`: launch the N ranks ourselves (one process per GPU)
+        raise SystemExit(spawn_ranks(args.gpus))
 
     # stdout carries exactly one line, the JSON result: libraries that print banners on load
     # (RCCL prints its version / host / library path) get stderr until that line is written
@@ -220,10 +249,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:  # never an N = 1 line for a --gpus 8 command (or the reverse)
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    one_device = os.environ.get("GRV_BENCH_ONE_DEVICE") == "1"
+    n_dev = torch.cuda.device_count()
+    if not one_device and n_dev < world:
+        raise SystemExit("--gpus %d but only %d HIP device(s) visible" % (world, n_dev))
     if not os.path.exists(bh.library_path()):
         if local_rank == 0:
             bh.build_library()  # checkout without the built artefact: compile it (hipcc)
@@ -235,7 +268,7 @@ def main():
     # control flow of this file (strong split, two frames in flight, pipelined gather, timing
     # reductions) runs for real on a one-GPU box; RCCL refuses two ranks on one device.
     backend = os.environ.get("GRV_BENCH_BACKEND", "nccl")
-    if os.environ.get("GRV_BENCH_ONE_DEVICE") == "1":
+    if one_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or "RANK" in os.environ  # under torchrun even a 1-rank job walks the RCCL path
@@ -248,6 +281,16 @@ def main():
                                     device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("--gpus %d but the process group has %d ranks" % (args.gpus, dist.get_world_size()))
+    # which device every rank sits on (goes into the JSON line: the judge of a scaling curve should
+    # not have to trust n_gpus)
+    rank_devices = [local_rank]
+    if use_dist:
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, local_rank)
+        if not one_device and len(set(rank_devices)) != world:
+            raise SystemExit("ranks share devices: %s" % (rank_devices,))
 
     gx, gy = GRID.get(world, (world, 1)) if args.scaling == "weak" else (1, 1)
     W, H = base_w * gx, base_h * gy
@@ -423,7 +466,8 @@ def main():
                                                         else " (%dx%d per GPU x %d)" % (base_w, base_h, world))))
         line = {
             "metric": "Mray-steps/s", "value": round(value, 2), "unit": "Mray-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "ranks": dist.get_world_size() if use_dist else 1,
+            "rank_devices": rank_devices, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64" if cfg == "c3" else "f32", "data": "synthetic",

@@ -105,16 +105,54 @@ def test_ranks_sharing_one_gpu_assemble_the_whole_frame_bitwise(tmp_path, engine
     assert r["steps_sum"] == 4 * r["steps_whole"]  # four accumulated frames, every ray counted once
 
 
-def _bench(world, *args):
+def _bench(world, *args, launcher=False):
+    """bench.py as the driver invokes it.  Default: the BARE command `python bench.py --gpus N ...`
+    (bench.py launches its own N ranks); launcher=True: under `python -m torch.distributed.run`."""
     env = dict(os.environ, GRV_BENCH_BACKEND="gloo", GRV_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
-           "--gpus", str(world)] + list(args)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    if launcher:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")]
+    else:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")]
+    cmd += ["--gpus", str(world)] + list(args)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]  # rank 0 prints ONE JSON line
     return json.loads(lines[0])
+
+
+def test_bare_bench_command_launches_its_own_ranks():
+    """`python bench.py --gpus 2 --steps 5 --warmup 2` with no launcher around it must run two ranks
+    and say so; the same command line under torch.distributed.run must give the same workload."""
+    bare = _bench(2, "--width", "640", "--height", "360", "--steps", "5", "--warmup", "2")
+    assert bare["n_gpus"] == 2 and bare["ranks"] == 2 and bare["rank_devices"] == [0, 0]
+    under = _bench(2, "--width", "640", "--height", "360", "--steps", "5", "--warmup", "2", launcher=True)
+    assert under["n_gpus"] == 2 and under["ranks"] == 2
+    assert bare["config"]["accepted_steps_per_frame"] == under["config"]["accepted_steps_per_frame"]
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """Without the one-device test hook a --gpus 8 command on a smaller box must fail, loudly and
+    with the device count -- never print a line for fewer GPUs than asked."""
+    import torch
+    have = torch.cuda.device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK",
+                                                            "GRV_BENCH_ONE_DEVICE", "GRV_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(have + 1), "--steps", "1",
+                        "--warmup", "0"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "only %d HIP device" % have in r.stderr
+    # a launcher whose world size disagrees with --gpus is refused as well
+    env2 = dict(env, GRV_BENCH_BACKEND="gloo", GRV_BENCH_ONE_DEVICE="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env2)
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 
 
 @pytest.mark.parametrize("world", [2, 8])

@@ -202,3 +202,18 @@ def test_shadow_curve_capacity_is_honoured(engine_mod):
     lib = engine_mod.load_library()
     # no engine without a device: the size query must tolerate a NULL handle (returns 0)
     assert lib.grv_compute_shadow_curve(None, 0.0, 16, None, 0) == 0
+
+
+def test_bench_gpus_n_is_never_silently_one_gpu():
+    """`python bench.py --gpus N` without a launcher starts its own N ranks; with fewer devices
+    than N it must exit non-zero and print no result line (a bare --gpus 8 used to run
+    one GPU and print n_gpus 1)."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "GRV_BENCH_ONE_DEVICE", "GRV_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1",
+                        "--warmup", "0"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0
+    assert "HIP device(s) visible" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
