@@ -82,19 +82,24 @@ int fail(grv_engine *e, int code, const char *fmt, ...) {
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-// Takes the next workspace set for a frame / batch of `slots` rays queued on `s` (allocating or
-// growing it) and orders `s` behind the set's previous user.
+// Takes the workspace set for a frame / batch of `slots` rays queued on `s` (allocating or growing
+// it) and orders `s` behind the set's previous user.  The previous call's set is taken again unless
+// that call sits on another stream: only then does the other set come into play (two frames in
+// flight); a one-stream caller never allocates it.
 int ensure_workspace(grv_engine *e, size_t slots, hipStream_t s) {
-    grv_engine::WorkSet &W = e->wset[e->wturn];
-    e->wturn ^= 1;
-    e->cur = &W;
+    int pick = e->wlast;
+    if (e->wset[pick].used && e->wset[pick].last_stream != s) pick ^= 1;
+    grv_engine::WorkSet &W = e->wset[pick];
+    e->wlast = pick;
     GRV_HIP(e, hipSetDevice(e->device));
     if (!W.done) GRV_HIP(e, hipEventCreateWithFlags(&W.done, hipEventDisableTiming));
+    e->cur = &W;
     if (!(slots <= W.slots && W.mem)) {
         if (W.mem) {
             (void)hipFree(W.mem); // implicit device synchronise: no frame still uses it
             W.mem = nullptr;
             W.slots = 0;
+            W.bytes = 0;
             W.used = false;
         }
         // 10 f64 components + crossing records + 3 u32 + two live lists, each 256-B aligned, + counters
@@ -104,6 +109,7 @@ int ensure_workspace(grv_engine *e, size_t slots, hipStream_t s) {
         const size_t total = f64b * (10 + kMaxCrossRec) + u32b * 5 + 256;
         void *mem = nullptr;
         GRV_HIP(e, hipMalloc(&mem, total));
+        W.bytes = total;
         char *p = static_cast<char *>(mem);
         auto take64 = [&](size_t n) {
             double *q = reinterpret_cast<double *>(p);
@@ -138,7 +144,8 @@ int ensure_workspace(grv_engine *e, size_t slots, hipStream_t s) {
         W.slots = cap;
         W.ws = w;
     }
-    if (W.used) GRV_HIP(e, hipStreamWaitEvent(s, W.done, 0));
+    if (W.used && W.last_stream != s) GRV_HIP(e, hipStreamWaitEvent(s, W.done, 0));
+    W.last_stream = s;
     W.ws.n = (uint32_t)slots;
     e->ws = W.ws;
     e->live[0] = W.live[0];
@@ -150,9 +157,10 @@ int ensure_workspace(grv_engine *e, size_t slots, hipStream_t s) {
 // End of the call that took the current set: its later users wait for everything queued so far.
 int release_workspace(grv_engine *e, hipStream_t s) {
     if (!e->cur) return GRV_OK;
-    GRV_HIP(e, hipEventRecord(e->cur->done, s));
-    e->cur->used = true;
+    grv_engine::WorkSet *W = e->cur;
     e->cur = nullptr;
+    W->used = true; // even if the record below fails: the next user then waits on the older event
+    GRV_HIP(e, hipEventRecord(W->done, s));
     return GRV_OK;
 }
 
@@ -181,6 +189,8 @@ SegmentParams make_segment_params(const grv_engine *e, const GrvOptions &o) {
     P.renorm_interval =
         o.renormalize_interval > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)o.renormalize_interval;
     P.max_tries = 0;
+    P.final_launch = 0;
+    P.try_cap = 0xFFFFFFFFu;
     P.shading = 0;
     P.disk_inner = 0.0;
     P.disk_outer = 0.0;
@@ -219,31 +229,53 @@ hipError_t launch_refill(int arith, int kind, int method, const RayWorkspace &ws
 // tries between two refill checks of a wave in the refill kernel
 constexpr uint32_t kRefillPeriod = 8;
 
+// Hard bound on the integrator tries one ray can take.  Every completed step costs a bounded number
+// of tries: a reject shrinks |h| by >= 10 % (integrator.rs:97: factor max(0.9 ratio^-1/4, 0.1), ratio
+// > 1), |h| <= 10 after the clamp, and below 1e-5 the forced step of integrator.rs:99-104 is taken
+// unconditionally -- at most ln(1e6) / ln(1 / 0.9) = 132 rejects, one forced try.  steps <= max_steps,
+// so 160 max_steps + 64 is never reached by a correct kernel; a ray still live there (a NaN the
+// argument missed, a future stepper) is ended as TERM_MAXSTEPS instead of hanging the GPU.
+uint32_t try_bound(uint64_t max_steps) {
+    // test hook: a tiny bound makes the "never a hang" exit reachable (tests/test_gpu_async.py)
+    if (const char *dbg = std::getenv("GRV_DEBUG_TRY_BOUND")) {
+        const long v = std::strtol(dbg, nullptr, 10);
+        if (v > 0) return (uint32_t)v;
+    }
+    const uint64_t b = (max_steps > (0xFFFFFFFFull - 64u) / 160u) ? 0xFFFFFFFFull : 160u * max_steps + 64u;
+    return (uint32_t)b;
+}
+
 // One integrate pass over the initialised workspace.
-//   seg_tries == 0 (default): ONE launch that runs every ray to its end.  A ray always ends: each
-//     completed step costs a bounded number of tries (a reject shrinks |h| by >= 10 % and the
-//     forced 1e-5 step of integrator.rs:99-104 is taken unconditionally) and steps <= max_steps,
-//     so the kernel needs no try budget, no live list, no counter read-back -- and the host does
-//     not wait for it: the call returns with the work queued on `s`.
+//   seg_tries == 0 (default): ONE launch that runs every ray to its end (or to try_bound): no live
+//     list, no counter read-back -- and the host does not wait for it: the call returns with the
+//     work queued on `s`.
 //   seg_tries  > 0: the compacting wavefront schedule.  Every launch appends its survivors to the
 //     next live list; the host reads the count back (one stream synchronise per launch) to size
 //     the next launch.  Results are bitwise those of the single launch.
 int run_segments(grv_engine *e, const GrvOptions &o, SegmentParams P, uint32_t seg_tries,
                  hipStream_t s, bool profile) {
+    const uint32_t bound = try_bound(o.max_steps);
     if (seg_tries == 0) {
-        P.max_tries = 0xFFFFFFFFu;
+        P.max_tries = bound;
+        P.final_launch = 1;
         GRV_HIP(e, launch_segment(o.arith, o.metric_kind, o.method, e->ws, P, nullptr, e->ws.n,
                                   nullptr, nullptr, s));
         e->last_launches += 1;
         return GRV_OK;
     }
     P.max_tries = seg_tries;
+    P.final_launch = 0;
     uint32_t n_live = e->ws.n;
     const uint32_t *live_in = nullptr;
     int cur = 0;
     float integ_ms = 0.f;
+    const uint64_t hard_cap = (uint64_t)bound / seg_tries + 2u; // launches a correct kernel can need
+    uint64_t launches = 0;
     GRV_HIP(e, hipMemsetAsync(e->d_counters, 0, 4 * sizeof(uint32_t), s));
     while (n_live > 0) {
+        if (++launches > hard_cap)
+            return fail(e, GRV_ERR_HIP, "integrate: %u rays still live after %llu launches of %u tries "
+                        "(bound %u tries per ray)", n_live, (unsigned long long)hard_cap, seg_tries, bound);
         const int nxt = cur ^ 1;
         GRV_HIP(e, hipMemsetAsync(e->d_counters + nxt, 0, sizeof(uint32_t), s));
         if (profile) GRV_HIP(e, hipEventRecord(e->ev[2], s));
@@ -267,13 +299,36 @@ int run_segments(grv_engine *e, const GrvOptions &o, SegmentParams P, uint32_t s
     return GRV_OK;
 }
 
-// Start of a frame / batch: clear the device counters unless the caller accumulates them.
+// Start of a frame / batch: take a counter block.  Accumulating callers keep adding to the current
+// one; otherwise the call takes the other block and clears it on its own stream, ordered behind
+// that block's previous user (whose finalize kernel may still be adding to it on another stream).
 int begin_frame_stats(grv_engine *e, hipStream_t s) {
-    if (e->stats_accum) return GRV_OK;
+    e->stats_open = true;
+    if (e->stats_accum) {
+        // adds to the current block: only a clear of it (grv_frame_stats_reset on another stream)
+        // has to come first
+        if (e->stats_cleared_rec) GRV_HIP(e, hipStreamWaitEvent(s, e->stats_cleared, 0));
+        return GRV_OK;
+    }
+    e->stats_turn ^= 1;
+    const int b = e->stats_turn;
+    e->d_stats = e->stats_blocks + b;
+    if (e->stats_used[b]) GRV_HIP(e, hipStreamWaitEvent(s, e->stats_done[b], 0));
+    if (e->stats_cleared_rec) GRV_HIP(e, hipStreamWaitEvent(s, e->stats_cleared, 0));
     GRV_HIP(e, hipMemsetAsync(e->d_stats, 0, sizeof(FrameStatsDev), s));
     for (float &m : e->last_ms) m = 0.f;
     e->last_launches = 0;
     e->ev_frames = 0; // unresolved events of earlier frames describe counters that are gone
+    return GRV_OK;
+}
+
+int end_frame_stats(grv_engine *e, hipStream_t s) {
+    if (!e->stats_open) return GRV_OK;
+    e->stats_open = false;
+    if (e->stats_accum) return GRV_OK; // accumulating calls on two streams must not order each other
+    const int b = (int)(e->d_stats - e->stats_blocks);
+    e->stats_used[b] = true;
+    GRV_HIP(e, hipEventRecord(e->stats_done[b], s));
     return GRV_OK;
 }
 
@@ -317,12 +372,17 @@ int resolve_frame_events(grv_engine *e) {
 }
 
 int ensure_lut(grv_engine *e, uint32_t w, uint32_t h, double tmax, hipStream_t s) {
-    if (e->d_lut && e->lut_w == w && e->lut_h == h && e->lut_tmax == tmax) return GRV_OK;
+    if (e->d_lut && e->lut_w == w && e->lut_h == h && e->lut_tmax == tmax) {
+        GRV_HIP(e, hipStreamWaitEvent(s, e->lut_ready, 0)); // generated on another stream, perhaps
+        return GRV_OK;
+    }
     if (w == 0 || h == 0 || (uint64_t)w * h > (1ull << 26)) return fail(e, GRV_ERR_INVALID, "bad LUT shape");
-    if (e->d_lut) (void)hipFree(e->d_lut);
+    if (e->d_lut) (void)hipFree(e->d_lut); // implicit device synchronise: no queued frame still reads it
     e->d_lut = nullptr;
     GRV_HIP(e, hipMalloc(reinterpret_cast<void **>(&e->d_lut), (size_t)w * h * 4 * sizeof(float)));
+    e->lut_w = e->lut_h = 0;
     GRV_HIP(e, launch_spectrum_lut(e->d_lut, w, h, tmax, s));
+    GRV_HIP(e, hipEventRecord(e->lut_ready, s));
     e->lut_w = w;
     e->lut_h = h;
     e->lut_tmax = tmax;
@@ -338,12 +398,22 @@ int ensure_lut(grv_engine *e, uint32_t w, uint32_t h, double tmax, hipStream_t s
 // Ids in the pad column(s) hold no pixels.
 // Device copy of generate_disk_lut's table for the current (mass, spin): physics/disk.rs:175-201
 int ensure_disk_lut(grv_engine *e, hipStream_t s) {
-    if (e->disk_lut_valid && e->disk_lut_mass == e->mass && e->disk_lut_spin == e->spin_c) return GRV_OK;
+    if (e->disk_lut_valid && e->disk_lut_mass == e->mass && e->disk_lut_spin == e->spin_c) {
+        GRV_HIP(e, hipStreamWaitEvent(s, e->disk_lut_ready, 0));
+        return GRV_OK;
+    }
     constexpr size_t kScratchOff = 4096;
     if (!e->d_disk_lut)
         GRV_HIP(e, hipMalloc(reinterpret_cast<void **>(&e->d_disk_lut), kScratchOff + kDiskLutWidth * sizeof(double)));
+    // regenerated in place (mass / spin changed): frames still queued on other streams read the old
+    // table in their finalize kernels -- the rewrite goes behind the end of every workspace set's
+    // last call
+    for (auto &W : e->wset)
+        if (W.used && &W != e->cur) GRV_HIP(e, hipStreamWaitEvent(s, W.done, 0));
+    e->disk_lut_valid = false;
     double *scratch = reinterpret_cast<double *>(reinterpret_cast<char *>(e->d_disk_lut) + kScratchOff);
     GRV_HIP(e, launch_disk_temperature_lut(e->d_disk_lut, scratch, kDiskLutWidth, e->mass, e->spin_c, s));
+    GRV_HIP(e, hipEventRecord(e->disk_lut_ready, s));
     e->disk_lut_mass = e->mass;
     e->disk_lut_spin = e->spin_c;
     e->disk_lut_valid = true;
@@ -424,11 +494,21 @@ int grv_engine_create(double mass, double spin, int device, grv_engine **out) {
     if (hipSetDevice(device) != hipSuccess) return bail(GRV_ERR_NO_DEVICE);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) e->n_cu = prop.multiProcessorCount;
-    if (hipMalloc(reinterpret_cast<void **>(&e->d_stats), sizeof(FrameStatsDev)) != hipSuccess) return bail(GRV_ERR_OOM);
+    if (hipMalloc(reinterpret_cast<void **>(&e->stats_blocks), 2 * sizeof(FrameStatsDev)) != hipSuccess) return bail(GRV_ERR_OOM);
+    if (hipMemset(e->stats_blocks, 0, 2 * sizeof(FrameStatsDev)) != hipSuccess) return bail(GRV_ERR_HIP);
+    e->d_stats = e->stats_blocks;
+    for (auto &ev : e->stats_done)
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return bail(GRV_ERR_HIP);
+    if (hipEventCreateWithFlags(&e->lut_ready, hipEventDisableTiming) != hipSuccess) return bail(GRV_ERR_HIP);
+    if (hipEventCreateWithFlags(&e->stats_cleared, hipEventDisableTiming) != hipSuccess) return bail(GRV_ERR_HIP);
+    if (hipEventCreateWithFlags(&e->disk_lut_ready, hipEventDisableTiming) != hipSuccess) return bail(GRV_ERR_HIP);
     if (hipHostMalloc(reinterpret_cast<void **>(&e->h_counters), 4 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return bail(GRV_ERR_OOM);
     if (hipHostMalloc(reinterpret_cast<void **>(&e->h_stats), sizeof(FrameStatsDev), hipHostMallocDefault) != hipSuccess) return bail(GRV_ERR_OOM);
     std::memset(e->h_stats, 0, sizeof(FrameStatsDev));
-    if (hipHostMalloc(reinterpret_cast<void **>(&e->ray_out), sizeof(SingleRayOut), hipHostMallocDefault) != hipSuccess) return bail(GRV_ERR_OOM);
+    // polled by the host while the kernel writes it: fine-grained (coherent) mapping spelled out, so
+    // the poll does not depend on HIP_HOST_COHERENT
+    if (hipHostMalloc(reinterpret_cast<void **>(&e->ray_out), sizeof(SingleRayOut),
+                      hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) return bail(GRV_ERR_OOM);
     std::memset(e->ray_out, 0, sizeof(SingleRayOut));
     if (hipStreamCreateWithFlags(&e->ray_stream, hipStreamNonBlocking) != hipSuccess) return bail(GRV_ERR_HIP);
     e->ev_ok = true;
@@ -451,7 +531,12 @@ void grv_engine_destroy(grv_engine *e) {
     if (e->d_noise) (void)hipFree(e->d_noise);
     if (e->post_mem) (void)hipFree(e->post_mem);
     if (e->rt.mem) (void)hipFree(e->rt.mem);
-    if (e->d_stats) (void)hipFree(e->d_stats);
+    if (e->stats_blocks) (void)hipFree(e->stats_blocks);
+    for (auto &ev : e->stats_done)
+        if (ev) (void)hipEventDestroy(ev);
+    if (e->lut_ready) (void)hipEventDestroy(e->lut_ready);
+    if (e->stats_cleared) (void)hipEventDestroy(e->stats_cleared);
+    if (e->disk_lut_ready) (void)hipEventDestroy(e->disk_lut_ready);
     if (e->h_counters) (void)hipHostFree(e->h_counters);
     if (e->h_stats) (void)hipHostFree(e->h_stats);
     if (e->ray_stream) {
@@ -507,6 +592,7 @@ int grv_integrate_batch_device(grv_engine *e, size_t n, const double *d_states,
     if (n > 0x7FFFFFFFull) return fail(e, GRV_ERR_INVALID, "batch too large");
     hipStream_t s = static_cast<hipStream_t>(stream);
     GRV_HIP(e, hipSetDevice(e->device));
+    CallScope scope(e, s); // hands the workspace set and the counter block back on every exit path
     int rc = ensure_workspace(e, n, s);
     if (rc != GRV_OK) return rc;
     SegmentParams P = make_segment_params(e, *opt);
@@ -523,13 +609,14 @@ int grv_integrate_batch_device(grv_engine *e, size_t n, const double *d_states,
         if (rc != GRV_OK) return rc;
     } else {
         P.max_tries = opt->segment_tries < 0 ? (uint32_t)(-(int64_t)opt->segment_tries) : kRefillPeriod;
+        P.try_cap = try_bound(opt->max_steps);
         GRV_HIP(e, launch_refill(opt->arith, opt->metric_kind, opt->method, e->ws, P,
                                  e->d_counters + 2, e->n_cu, s));
         e->last_launches += 1;
     }
     GRV_HIP(e, launch_finalize_batch(e->ws, d_out_states, d_steps, d_termination, d_drift,
                                      e->d_stats, s));
-    return release_workspace(e, s);
+    return GRV_OK;
 }
 
 int grv_integrate_batch(grv_engine *e, size_t n, const double *states, const GrvOptions *opt,
@@ -582,6 +669,11 @@ size_t grv_integrate_ray_relativistic_ex(grv_engine *e, const double *initial_st
     o.escape_radius = 1000.0;
     o.renormalize_interval = 10;
     o.arith = GRV_ARITH_STRICT;
+    if (!options_valid(o)) { // cannot fail for the fixed options above; kept so a later edit of them is checked
+        fail(e, GRV_ERR_INVALID, "integrate_ray_relativistic: invalid options");
+        for (int i = 0; i < 8; ++i) out[i] = std::nan("");
+        return 8;
+    }
     // no Result in the reference FFI: on any failure hand back NaNs so the caller's finite-guard
     // (src/engine/physics-bridge.ts:174-180) trips; the error text stays on the handle
     auto nan_out = [&](const char *why, hipError_t st) {
@@ -592,6 +684,7 @@ size_t grv_integrate_ray_relativistic_ex(grv_engine *e, const double *initial_st
     hipError_t st = hipSetDevice(e->device);
     if (st != hipSuccess) return nan_out("hipSetDevice", st);
     SegmentParams P = make_segment_params(e, o);
+    P.try_cap = try_bound(o.max_steps);
     SingleRayIn in;
     std::memcpy(in.v, initial_state, sizeof in.v);
     const uint32_t seq = ++e->ray_seq ? e->ray_seq : ++e->ray_seq; // never 0 (the block starts zeroed)
@@ -677,10 +770,11 @@ int grv_render_frame_device(grv_engine *e, const GrvCamera *cam, const GrvRender
     FrameGeom G;
     frame_geometry(*p, G);
     const size_t slots = (size_t)G.n_tiles_local * 4096u;
+    if (slots > 0x7FFFFFFFull) return fail(e, GRV_ERR_INVALID, "frame too large for one rank");
+    CallScope scope(e, s); // hands the workspace set and the counter block back on every exit path
     int rc = begin_frame_stats(e, s);
     if (rc != GRV_OK) return rc;
     if (slots == 0) return GRV_OK;
-    if (slots > 0x7FFFFFFFull) return fail(e, GRV_ERR_INVALID, "frame too large for one rank");
     rc = ensure_workspace(e, slots, s);
     if (rc != GRV_OK) return rc;
 
@@ -787,19 +881,37 @@ int grv_render_frame_device(grv_engine *e, const GrvCamera *cam, const GrvRender
         e->ev_loop[e->ev_frames] = p->segment_tries != 0;
         e->ev_frames += 1;
     }
-    return release_workspace(e, s);
+    return GRV_OK;
 }
 
 int grv_frame_stats(grv_engine *e, void *stream, GrvFrameStats *stats) {
     if (!e || !stats) return GRV_ERR_INVALID;
     hipStream_t s = static_cast<hipStream_t>(stream);
     GRV_HIP(e, hipSetDevice(e->device));
+    // the counters belong to calls that may sit on other streams than `s`
+    if (e->stats_accum) {
+        GRV_HIP(e, hipDeviceSynchronize()); // every call since the reset added to this block
+    } else {
+        const int b = (int)(e->d_stats - e->stats_blocks);
+        if (e->stats_used[b]) GRV_HIP(e, hipStreamWaitEvent(s, e->stats_done[b], 0));
+    }
     GRV_HIP(e, hipMemcpyAsync(e->h_stats, e->d_stats, sizeof(FrameStatsDev), hipMemcpyDeviceToHost, s));
     GRV_HIP(e, hipStreamSynchronize(s));
     const int rc = resolve_frame_events(e);
     if (rc != GRV_OK) return rc;
     stats_to_abi(e, *e->h_stats, stats);
     return GRV_OK;
+}
+
+size_t grv_engine_device_bytes(const grv_engine *e) {
+    if (!e) return 0;
+    size_t b = 2 * sizeof(FrameStatsDev) + e->stage_bytes + e->post_bytes;
+    for (const auto &W : e->wset) b += W.bytes;
+    if (e->d_lut) b += (size_t)e->lut_w * e->lut_h * 4 * sizeof(float);
+    if (e->d_disk_lut) b += 4096 + kDiskLutWidth * sizeof(double);
+    if (e->d_noise) b += 2u * 256u * 256u;
+    if (e->rt.mem) b += (size_t)3 * e->rt.w * e->rt.h * 4 * sizeof(float);
+    return b;
 }
 
 int grv_stats_accumulate(grv_engine *e, int enable) {
@@ -812,7 +924,14 @@ int grv_frame_stats_reset(grv_engine *e, void *stream) {
     if (!e) return GRV_ERR_INVALID;
     hipStream_t s = static_cast<hipStream_t>(stream);
     GRV_HIP(e, hipSetDevice(e->device));
+    // behind every call that may still be adding to the block (they may sit on other streams)
+    for (int b = 0; b < 2; ++b)
+        if (e->stats_used[b]) GRV_HIP(e, hipStreamWaitEvent(s, e->stats_done[b], 0));
+    for (auto &W : e->wset)
+        if (W.used) GRV_HIP(e, hipStreamWaitEvent(s, W.done, 0));
     GRV_HIP(e, hipMemsetAsync(e->d_stats, 0, sizeof(FrameStatsDev), s));
+    GRV_HIP(e, hipEventRecord(e->stats_cleared, s)); // later calls on other streams start behind the clear
+    e->stats_cleared_rec = true;
     for (float &m : e->last_ms) m = 0.f;
     e->last_launches = 0;
     e->ev_frames = 0;

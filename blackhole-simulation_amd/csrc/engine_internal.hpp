@@ -31,25 +31,40 @@ struct grv_engine {
     int n_cu = 256;
     std::string err;
 
-    // ray workspaces (device).  Two sets, used alternately by successive frame / batch calls, so a
-    // caller that alternates two streams keeps two frames in flight: the tail of one frame's
-    // integrate launch (too few waves left to fill the chip) runs under the head of the next.
-    // Each set carries an event recorded at the end of its last use; the next user's stream waits
-    // for it, so a set is never touched by two frames at once whatever streams the caller picks.
+    // ray workspaces (device).  Up to two sets, so a caller that alternates two streams keeps two
+    // frames in flight: the tail of one frame's integrate launch (too few waves left to fill the
+    // chip) runs under the head of the next.  A call reuses the set of the previous call when it
+    // arrives on the same stream (stream order already serialises them); only a call on a
+    // DIFFERENT stream takes -- and on first use allocates -- the other set, so one-stream and
+    // host-pointer callers hold one workspace.  Each set carries an event recorded at the end of its
+    // last use; the next user's stream waits for it, so a set is never touched by two calls at once
+    // whatever streams the caller picks.
     struct WorkSet {
         void *mem = nullptr;
-        size_t slots = 0;
+        size_t slots = 0, bytes = 0;
         grvhip::RayWorkspace ws{};
         uint32_t *live[2] = {nullptr, nullptr};
         uint32_t *d_counters = nullptr; // [0],[1] live counts (ping-pong), [2] refill cursor
         hipEvent_t done = nullptr;
+        hipStream_t last_stream = nullptr;
         bool used = false;
     } wset[2];
-    int wturn = 0;
+    int wlast = 0;                     // the set the previous call used
     WorkSet *cur = nullptr;            // the set of the call in progress
     grvhip::RayWorkspace ws{};         // == cur->ws
     uint32_t *live[2] = {nullptr, nullptr};
     uint32_t *d_counters = nullptr;
+    // frame counters: two device blocks.  Without grv_stats_accumulate successive calls alternate
+    // them (a call clears its block behind the block's previous user, so the clear never lands under
+    // another stream's still-running finalize kernel); with it every call adds to the current block.
+    // d_stats is the block of the call in progress / the last call: what grv_frame_stats reads.
+    grvhip::FrameStatsDev *stats_blocks = nullptr; // [2]
+    hipEvent_t stats_done[2] = {nullptr, nullptr};
+    bool stats_used[2] = {false, false};
+    hipEvent_t stats_cleared = nullptr; // end of the last grv_frame_stats_reset
+    bool stats_cleared_rec = false;
+    int stats_turn = 0;
+    bool stats_open = false;           // a call holds d_stats (begin_frame_stats .. end_frame_stats)
     grvhip::FrameStatsDev *d_stats = nullptr;
     uint32_t *h_counters = nullptr; // pinned
     grvhip::FrameStatsDev *h_stats = nullptr; // pinned
@@ -72,6 +87,9 @@ struct grv_engine {
     float *d_disk_lut = nullptr;
     double disk_lut_mass = 0.0, disk_lut_spin = 0.0;
     bool disk_lut_valid = false;
+    // the tables are generated on whichever stream the frame call that needed them received; every
+    // frame stream that reads one is ordered behind its generation through these events
+    hipEvent_t lut_ready = nullptr, disk_lut_ready = nullptr;
 
     // frame bookkeeping.  Counters live on the device (d_stats) and are read by grv_frame_stats
     // only; with stats_accum they are not cleared between frames (grv_stats_accumulate), so a
@@ -136,6 +154,23 @@ bool options_valid(const GrvOptions &o);
 int run_segments(grv_engine *e, const GrvOptions &o, SegmentParams P, uint32_t seg_tries, hipStream_t s,
                  bool profile);
 int begin_frame_stats(grv_engine *e, hipStream_t s);
+int end_frame_stats(grv_engine *e, hipStream_t s);
+// Ends a frame / batch call on every exit path, early error returns included: the workspace set and
+// the counter block the call took are handed back with their events recorded on the call's stream, so
+// a later call on another stream can never run on them concurrently with kernels this call queued.
+struct CallScope {
+    grv_engine *e;
+    hipStream_t s;
+    CallScope(grv_engine *e_, hipStream_t s_) : e(e_), s(s_) {}
+    CallScope(const CallScope &) = delete;
+    CallScope &operator=(const CallScope &) = delete;
+    ~CallScope() {
+        (void)release_workspace(e, s);
+        (void)end_frame_stats(e, s);
+    }
+};
+// hard bound on the integrator tries of one ray (see run_segments)
+uint32_t try_bound(uint64_t max_steps);
 int resolve_frame_events(grv_engine *e);
 uint32_t tile_pitch(uint32_t width, uint32_t world);
 void frame_geometry(const GrvRenderParams &p, FrameGeom &G);
@@ -158,11 +193,12 @@ int run_shader_frame(grv_engine *e, uint32_t width, uint32_t height, uint32_t tw
     FrameGeom G;
     frame_geometry(q, G);
     const size_t slots = (size_t)G.n_tiles_local * 4096u;
+    if (slots > 0x7FFFFFFFull) return fail(e, GRV_ERR_INVALID, "frame too large for one rank");
+    CallScope scope(e, s);
     {
         const int rc = begin_frame_stats(e, s);
         if (rc != GRV_OK) return rc;
     }
-    if (slots > 0x7FFFFFFFull) return fail(e, GRV_ERR_INVALID, "frame too large for one rank");
     GRV_HIP(e, launch(G, (uint32_t)slots, &e->d_stats->accepted_steps));
     if (total_steps) {
         GRV_HIP(e, hipMemcpyAsync(e->h_stats, e->d_stats, sizeof(FrameStatsDev), hipMemcpyDeviceToHost, s));

@@ -41,6 +41,9 @@ struct SegmentParams {
     uint32_t max_steps;
     uint32_t renorm_interval;
     uint32_t max_tries; // per launch
+    uint32_t final_launch; // segment kernel: no launch follows -- a ray still live after max_tries
+                           // (the hard bound of engine.hip try_bound) is ended as TERM_MAXSTEPS
+    uint32_t try_cap;      // refill / single-ray kernels: the same bound on a ray's total tries
     // disk-plane crossing recorder (shading)
     int32_t shading;
     double disk_inner, disk_outer;

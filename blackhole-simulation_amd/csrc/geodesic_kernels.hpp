@@ -502,6 +502,11 @@ void integrate_segment_kernel(
         if (live) live = advance_one<KIND, ARITH, METHOD>(bh, y, P, ws, slot, rc);
     }
 
+    // one-launch schedule: max_tries is the hard bound no ray of a correct kernel reaches
+    if (P.final_launch && live) {
+        y.flags = (y.flags & ~kFlagTermMask) | GRV_TERM_MAXSTEPS;
+        live = false;
+    }
     if (have) store_ray(ws, slot, y);
 
     // block-aggregated append of the survivors (ray compaction for the next launch):
@@ -581,6 +586,10 @@ void integrate_refill_kernel(RayWorkspace ws, SegmentParams P,
             if (live) live = advance_one<KIND, ARITH, METHOD>(bh, y, P, ws, slot, rc);
             if (__ballot(live) == 0ull) break;
         }
+        if (live && y.tries >= P.try_cap) { // hard bound (engine.hip try_bound): never a hang
+            y.flags = (y.flags & ~kFlagTermMask) | GRV_TERM_MAXSTEPS;
+            live = false;
+        }
     }
     if (have) store_ray(ws, slot, y);
 }
@@ -617,7 +626,8 @@ __global__ __launch_bounds__(64) void single_ray_kernel(SegmentParams P, SingleR
     KsRayConsts rc;
     ray_resume<KIND, ARITH>(bh, y, P, live, rc);
     RayWorkspace ws{}; // only the crossing recorder writes to it, and P.shading == 0 here
-    while (live) live = advance_one<KIND, ARITH, GRV_METHOD_RKF45>(bh, y, P, ws, 0u, rc);
+    while (live && y.tries < P.try_cap) live = advance_one<KIND, ARITH, GRV_METHOD_RKF45>(bh, y, P, ws, 0u, rc);
+    if (live) y.flags = (y.flags & ~kFlagTermMask) | GRV_TERM_MAXSTEPS; // hard bound reached: never a hang
     out->state[0] = y.t;
     out->state[1] = y.r;
     out->state[2] = y.th;

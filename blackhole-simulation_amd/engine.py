@@ -186,6 +186,8 @@ def load_library():
     L.grv_stats_accumulate.argtypes = [p, i]
     L.grv_frame_stats_reset.restype = i
     L.grv_frame_stats_reset.argtypes = [p, p]
+    L.grv_engine_device_bytes.restype = sz
+    L.grv_engine_device_bytes.argtypes = [p]
     L.grv_integrate_ray_relativistic_ex.restype = sz
     L.grv_integrate_ray_relativistic_ex.argtypes = [p, p, sz, sz, d, i, p, p, p, p]
     L.grv_unpack_tiles.restype = i
@@ -552,6 +554,9 @@ class PhysicsEngine:
         self._check(self._lib.grv_frame_stats(self._h, C.c_void_p(stream) if stream else None,
                                               C.byref(st)), "frame_stats")
         return st
+
+    def device_bytes(self):
+        return int(self._lib.grv_engine_device_bytes(self._h))
 
     def stats_accumulate(self, enable=True):
         """Frames stop clearing the device-side counters: one frame_stats() after a loop of

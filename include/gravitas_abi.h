@@ -202,6 +202,10 @@ int grv_frame_stats(grv_engine *e, void *stream, GrvFrameStats *stats);
  * loop of frames accumulates them in HBM and one grv_frame_stats after the loop reads the sums */
 int grv_stats_accumulate(grv_engine *e, int enable);
 int grv_frame_stats_reset(grv_engine *e, void *stream);
+/* device memory the handle holds right now (ray workspaces, tables, staging, render targets), bytes.
+ * A caller that keeps every frame / batch call on ONE stream holds one ray workspace (~170 B per ray
+ * slot); the second one exists only once calls have arrived on two different streams. */
+size_t grv_engine_device_bytes(const grv_engine *e);
 /* host-only: scatter packed tile-order pixels of `rank` into a row-major W x H x C image */
 int grv_unpack_tiles(const GrvRenderParams *p, uint32_t rank, const void *packed, void *image,
                      size_t bytes_per_pixel);

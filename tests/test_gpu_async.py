@@ -271,3 +271,118 @@ def test_engines_on_two_host_threads_are_independent(bh, torch_mod):
             assert np.array_equal(fs.view(np.uint64), ref_imgs[0][1].view(np.uint64))
         for k in ref_res:
             assert np.array_equal(res[k], ref_res[k]), k
+
+
+# ---- round 3: the ADVICE items of round 2 --------------------------------------------------------
+
+def test_one_stream_callers_hold_one_workspace(bh, torch_mod):
+    """The second ray workspace exists only once calls have arrived on two different streams."""
+    torch = torch_mod
+    W, H = 512, 288
+    with bh.PhysicsEngine(1.0, 0.999) as e:
+        base = e.device_bytes()
+        for _ in range(3):
+            _frame(bh, torch, e, W, H, arith=1)
+        torch.cuda.synchronize()
+        one = e.device_bytes() - base
+        per_slot = one / (W * H)  # ceil to 64x64 tiles: 8 x 5 tiles = 163840 slots for 147456 pixels
+        assert 100 < per_slot < 260
+        # two streams: the other set is allocated, and only then
+        cam = bh.camera_look_at(EYE, aspect=W / H)
+        p = bh.render_params(W, H, arith=1)
+        n = e.frame_ray_count(p)
+        bufs = [torch.zeros(n, 4, dtype=torch.float32, device="cuda:0") for _ in range(2)]
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        for f in range(4):
+            with torch.cuda.stream(streams[f % 2]):
+                e.render_frame_device(cam, p, rgba=bufs[f % 2], stream=streams[f % 2].cuda_stream)
+        torch.cuda.synchronize()
+        two = e.device_bytes() - base
+        assert one * 1.9 < two < one * 2.1 + (1 << 21)
+        assert torch.equal(bufs[0].view(torch.int32), bufs[1].view(torch.int32))
+
+
+def test_two_streams_without_accumulate_report_the_last_frame(bh, torch_mod):
+    """Frames alternate two streams and the counters are NOT accumulated: each call clears its own
+    counter block behind that block's previous user, so grv_frame_stats returns exactly the last
+    frame's counts (the single block of round 2 could be cleared under a running finalize)."""
+    torch = torch_mod
+    with bh.PhysicsEngine(1.0, 0.999) as e:
+        small = bh.render_params(192, 108, arith=1)
+        big = bh.render_params(640, 360, arith=1)
+        cams = {192: bh.camera_look_at(EYE, aspect=192 / 108), 640: bh.camera_look_at(EYE, aspect=640 / 360)}
+        _frame(bh, torch, e, 192, 108, arith=1)
+        ref_small = e.frame_stats()
+        _frame(bh, torch, e, 640, 360, arith=1)
+        ref_big = e.frame_stats()
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        outs = [torch.zeros(e.frame_ray_count(big), 4, dtype=torch.float32, device="cuda:0") for _ in range(2)]
+        for rep in range(6):
+            for f, p in enumerate((big, small)):  # the long frame first, the short one right behind it
+                with torch.cuda.stream(streams[f]):
+                    e.render_frame_device(cams[p.width], p, rgba=outs[f], stream=streams[f].cuda_stream)
+            st = e.frame_stats(streams[1].cuda_stream)
+            assert (st.rays, st.accepted_steps, st.rkf_tries) == \
+                (ref_small.rays, ref_small.accepted_steps, ref_small.rkf_tries), rep
+        torch.cuda.synchronize()
+        assert ref_big.accepted_steps > ref_small.accepted_steps
+
+
+def test_tables_generated_on_one_stream_are_ordered_for_the_other(bh, torch_mod):
+    """Page-Thorne shading: the table is (re)generated on the stream of the frame that needs it.
+    Frames on two streams around an update_params must each be shaded with the table of their own
+    (mass, spin) -- compared with the same frames rendered one by one with a synchronise between."""
+    torch = torch_mod
+    W, H = 384, 216
+    cam = bh.camera_look_at(EYE, aspect=W / H)
+    kw = dict(arith=1, disk_profile=1, lut_width=256, lut_height=32)
+    spins = [0.999, 0.5, 0.9, 0.1, 0.7, 0.3]
+    with bh.PhysicsEngine(1.0, spins[0]) as e:
+        p = bh.render_params(W, H, **kw)
+        n = e.frame_ray_count(p)
+        want = []
+        for a in spins:
+            e.update_params(1.0, a)
+            o = torch.zeros(n, 4, dtype=torch.float32, device="cuda:0")
+            e.render_frame_device(cam, p, rgba=o)
+            torch.cuda.synchronize()
+            want.append(o)
+    for trial in range(3):
+        with bh.PhysicsEngine(1.0, spins[0]) as e:  # fresh engine: first frame generates both tables
+            streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+            got = [torch.zeros(n, 4, dtype=torch.float32, device="cuda:0") for _ in spins]
+            for f, a in enumerate(spins):
+                e.update_params(1.0, a)
+                with torch.cuda.stream(streams[f % 2]):
+                    e.render_frame_device(cam, p, rgba=got[f], stream=streams[f % 2].cuda_stream)
+            torch.cuda.synchronize()
+            for f in range(len(spins)):
+                assert torch.equal(got[f].view(torch.int32), want[f].view(torch.int32)), (trial, f)
+
+
+def test_try_bound_ends_rays_instead_of_hanging(bh, torch_mod, monkeypatch):
+    """The one-launch schedule, the refill kernel and the single-ray kernel carry a hard bound on a
+    ray's tries (160 max_steps + 64, never reached by a correct kernel).  With the bound forced down
+    to 40 tries every ray that would need more comes back as TERM_MAXSTEPS with fewer than max_steps
+    accepted steps -- and the call returns."""
+    torch = torch_mod
+    monkeypatch.setenv("GRV_DEBUG_TRY_BOUND", "40")
+    with bh.PhysicsEngine(1.0, 0.999) as e:
+        o = _frame(bh, torch, e, 128, 72, arith=1)
+        torch.cuda.synchronize()
+        term, steps = o["term"].cpu().numpy(), o["steps"].cpu().numpy()
+        assert (term == 3).sum() > 0.9 * term.size and steps.max() <= 40
+        # batch (refill kernel) and the single-ray entry
+        st = np.tile(np.array([0.0, 20.0, np.pi / 2, 0.0, -1.0, -1.0, 0.0, 3.5]), (256, 1))
+        b = e.integrate_batch(st, bh.default_options(max_steps=2048))
+        assert (b["term"] == 3).all() and (b["steps"] <= 48).all()  # the check runs every 8 tries
+        ex = C.c_uint32(0), C.c_uint8(0), C.c_double(0)
+        out = np.zeros(8)
+        e._lib.grv_integrate_ray_relativistic_ex(e._h, st[0].ctypes.data_as(C.c_void_p), 8, 2048, 1e-8, 1,
+                                                 out.ctypes.data_as(C.c_void_p), C.byref(ex[0]), C.byref(ex[1]),
+                                                 C.byref(ex[2]))
+        assert ex[1].value == 3 and ex[0].value <= 40 and np.isfinite(out).all()
+    monkeypatch.delenv("GRV_DEBUG_TRY_BOUND")
+    with bh.PhysicsEngine(1.0, 0.999) as e:  # and without the hook nothing is cut short
+        o = _frame(bh, torch, e, 128, 72, arith=1)
+        assert (o["term"].cpu().numpy() == 3).sum() == 0
