@@ -258,6 +258,34 @@ def load_library():
     L.grv_generate_embedding_mesh.argtypes = [p, d, d, sz, sz, p]
     L.grv_generate_ergosphere_mesh.restype = i
     L.grv_generate_ergosphere_mesh.argtypes = [p, sz, sz, p]
+    L.grv_engine_create_multi.restype = i
+    L.grv_engine_create_multi.argtypes = [d, d, C.c_uint64, i, C.POINTER(p)]
+    L.grv_engine_create_multi_virtual.restype = i
+    L.grv_engine_create_multi_virtual.argtypes = [d, d, i, i, C.POINTER(p)]
+    L.grv_multi_destroy.argtypes = [p]
+    L.grv_multi_last_error.restype = C.c_char_p
+    L.grv_multi_last_error.argtypes = [p]
+    for name in ("grv_multi_rank_count", "grv_multi_transport", "grv_multi_synchronize",
+                 "grv_multi_frame_stats_reset"):
+        getattr(L, name).restype = i
+        getattr(L, name).argtypes = [p]
+    L.grv_multi_rank_device.restype = i
+    L.grv_multi_rank_device.argtypes = [p, i]
+    L.grv_multi_engine.restype = p
+    L.grv_multi_engine.argtypes = [p, i]
+    L.grv_multi_update_params.restype = i
+    L.grv_multi_update_params.argtypes = [p, d, d]
+    L.grv_render_frame_multi_device.restype = i
+    L.grv_render_frame_multi_device.argtypes = [p, C.POINTER(Camera), C.POINTER(RenderParams), p, p]
+    L.grv_render_frame_multi.restype = i
+    L.grv_render_frame_multi.argtypes = [p, C.POINTER(Camera), C.POINTER(RenderParams), p,
+                                         C.POINTER(FrameStats)]
+    L.grv_render_frame_wgsl_multi_device.restype = i
+    L.grv_render_frame_wgsl_multi_device.argtypes = [p, C.POINTER(WgslParams), p, p]
+    L.grv_multi_stats_accumulate.restype = i
+    L.grv_multi_stats_accumulate.argtypes = [p, i]
+    L.grv_multi_frame_stats.restype = i
+    L.grv_multi_frame_stats.argtypes = [p, C.POINTER(FrameStats)]
     L.grv_attach_sab.restype = i
     L.grv_attach_sab.argtypes = [p, p]
     L.grv_set_camera_state.argtypes = [p, d, d, d]
@@ -687,3 +715,90 @@ class PhysicsEngine:
         a = (C.c_size_t * 5)()
         self._lib.grv_get_sab_layout(a)
         return list(a)
+
+
+TRANSPORT_AUTO, TRANSPORT_RCCL, TRANSPORT_PEER_COPY = 0, 1, 2
+
+
+class MultiEngine:
+    """The image plane across the GPUs of one node through the C ABI (grv_engine_create_multi):
+    one process, one host thread and two streams per device, one gather of finished tiles per
+    frame (RCCL over xGMI, or peer copies).  `virtual_ranks=G` puts G ranks on ONE device."""
+
+    def __init__(self, mass, spin, devices=None, transport=TRANSPORT_AUTO, virtual_ranks=0, device=0):
+        self._lib = load_library()
+        h = C.c_void_p()
+        if virtual_ranks:
+            rc = self._lib.grv_engine_create_multi_virtual(float(mass), float(spin), int(device),
+                                                           int(virtual_ranks), C.byref(h))
+        else:
+            mask = 0
+            for dv in (devices if devices is not None else [0]):
+                mask |= 1 << int(dv)
+            rc = self._lib.grv_engine_create_multi(float(mass), float(spin), mask, int(transport), C.byref(h))
+        if rc != 0:
+            raise GravitasError("grv_engine_create_multi: %s (no CPU fallback exists)" % _STATUS.get(rc, rc))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.grv_multi_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self._lib.grv_multi_last_error(self._h)
+            raise GravitasError("%s: %s: %s" % (what, _STATUS.get(rc, rc), msg.decode() if msg else ""))
+
+    @property
+    def ranks(self):
+        return self._lib.grv_multi_rank_count(self._h)
+
+    @property
+    def transport(self):
+        return self._lib.grv_multi_transport(self._h)
+
+    def rank_devices(self):
+        return [self._lib.grv_multi_rank_device(self._h, r) for r in range(self.ranks)]
+
+    def update_params(self, mass, spin):
+        self._check(self._lib.grv_multi_update_params(self._h, float(mass), float(spin)), "update_params")
+
+    def render_frame_device(self, camera, params, rgba, stream=None):
+        self._check(self._lib.grv_render_frame_multi_device(
+            self._h, C.byref(camera), C.byref(params), _dev_ptr(rgba),
+            C.c_void_p(stream) if stream else None), "render_frame_multi_device")
+
+    def render_frame_wgsl_device(self, params, rgba, stream=None):
+        self._check(self._lib.grv_render_frame_wgsl_multi_device(
+            self._h, C.byref(params), _dev_ptr(rgba), C.c_void_p(stream) if stream else None),
+            "render_frame_wgsl_multi_device")
+
+    def render_frame(self, camera, params):
+        rgba = np.zeros((params.height, params.width, 4), np.float32)
+        st = FrameStats()
+        self._check(self._lib.grv_render_frame_multi(self._h, C.byref(camera), C.byref(params),
+                                                     _np_ptr(rgba), C.byref(st)), "render_frame_multi")
+        return rgba, st
+
+    def synchronize(self):
+        self._check(self._lib.grv_multi_synchronize(self._h), "multi_synchronize")
+
+    def stats_accumulate(self, enable=True):
+        self._check(self._lib.grv_multi_stats_accumulate(self._h, 1 if enable else 0), "multi_stats_accumulate")
+
+    def frame_stats_reset(self):
+        self._check(self._lib.grv_multi_frame_stats_reset(self._h), "multi_frame_stats_reset")
+
+    def frame_stats(self):
+        st = FrameStats()
+        self._check(self._lib.grv_multi_frame_stats(self._h, C.byref(st)), "multi_frame_stats")
+        return st

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GRV_ABI_VERSION 2
+#define GRV_ABI_VERSION 3
 
 typedef struct grv_engine grv_engine;
 
@@ -215,6 +215,43 @@ int grv_unpack_tiles_device(grv_engine *e, const GrvRenderParams *p, uint32_t ra
                             const void *d_packed, void *d_image, size_t bytes_per_pixel,
                             void *stream);
 
+/* ---- the image plane across the GPUs of one node (SURVEY 8(b) device_mask, 8(e)) ----
+ * One handle = G ranks, one per device of `device_mask` (bit d = HIP device d; rank order =
+ * ascending device index, rank 0 assembles), each with its own engine, host thread and two streams.
+ * A frame is cut in 64x64 tiles dealt round-robin (tile k -> rank k mod G, the row-major grid of
+ * physics-engine/_legacy_src/tiling.rs:38-56 on the pitch of grv_tile_pitch); every rank renders
+ * its share, ONE gather brings the finished tiles to rank 0, rank 0 de-interleaves them into the
+ * caller's row-major image.  The calls queue their work and return; the image is complete in the
+ * order of `root_stream` (a hipStream_t of rank 0's device, NULL = default).  Successive frames
+ * alternate two sets of streams and buffers: two frames are in flight. */
+typedef struct grv_multi grv_multi;
+enum { GRV_TRANSPORT_AUTO = 0,      /* RCCL for G > 1 real devices, else peer copy */
+       GRV_TRANSPORT_RCCL = 1,      /* one ncclGroup of G-1 ncclSend / ncclRecv pairs over xGMI
+                                       (librccl is bound with dlopen when a handle asks for it) */
+       GRV_TRANSPORT_PEER_COPY = 2  /* each rank pushes its tiles with hipMemcpyPeerAsync */ };
+int grv_engine_create_multi(double mass, double spin, uint64_t device_mask, int transport,
+                            grv_multi **out);
+/* G virtual ranks on ONE device (peer-copy transport): the whole assembly path on a one-GPU box */
+int grv_engine_create_multi_virtual(double mass, double spin, int device, int ranks, grv_multi **out);
+void grv_multi_destroy(grv_multi *m);
+const char *grv_multi_last_error(const grv_multi *m);
+int grv_multi_rank_count(const grv_multi *m);
+int grv_multi_rank_device(const grv_multi *m, int rank);
+int grv_multi_transport(const grv_multi *m);
+grv_engine *grv_multi_engine(grv_multi *m, int rank); /* rank's engine: closed forms, LUT entry points ... */
+int grv_multi_update_params(grv_multi *m, double mass, double spin);
+/* p->tile_world must be 0 or 1 (the handle deals the tiles).  d_rgba: W x H x 4 f32 on rank 0's device */
+int grv_render_frame_multi_device(grv_multi *m, const GrvCamera *cam, const GrvRenderParams *p,
+                                  float *d_rgba, void *root_stream);
+/* same into host memory (one D2H copy of the assembled image), optional summed statistics */
+int grv_render_frame_multi(grv_multi *m, const GrvCamera *cam, const GrvRenderParams *p,
+                           float *rgba_host, GrvFrameStats *stats);
+int grv_multi_synchronize(grv_multi *m);
+int grv_multi_stats_accumulate(grv_multi *m, int enable);
+int grv_multi_frame_stats_reset(grv_multi *m);
+/* waits for every rank, then sums the ranks' counters (max for max_drift and the event times) */
+int grv_multi_frame_stats(grv_multi *m, GrvFrameStats *stats);
+
 /* ---- f32 march loops of the reference's GPU shaders ----
  * Uniform blocks as the shaders receive them.  Outputs are device pointers: RGBA f32
  * [n][4] and (optional) per-pixel step counts, in this rank's pixel order. */
@@ -288,6 +325,10 @@ int grv_render_frame_wgsl(grv_engine *e, const GrvWgslParams *p, float *d_rgba, 
                           uint64_t *total_steps, void *stream);
 int grv_render_frame_glsl(grv_engine *e, const GrvGlslParams *p, float *d_rgba, uint32_t *d_steps,
                           uint64_t *total_steps, void *stream);
+/* the WGSL compute march over the ranks of a multi-GPU handle (BASELINE configs[3]); as
+ * grv_render_frame_multi_device.  Accepted steps: grv_multi_frame_stats().accepted_steps */
+int grv_render_frame_wgsl_multi_device(grv_multi *m, const GrvWgslParams *p, float *d_rgba,
+                                       void *root_stream);
 
 /* ---- post chain: device RGBA f32 images [height][width][4], row-major ----
  * Texture fetches are GL LINEAR + CLAMP_TO_EDGE with f32 weights; half_storage != 0 rounds every

@@ -374,7 +374,7 @@ def test_try_bound_ends_rays_instead_of_hanging(bh, torch_mod, monkeypatch):
         assert (term == 3).sum() > 0.9 * term.size and steps.max() <= 40
         # batch (refill kernel) and the single-ray entry
         st = np.tile(np.array([0.0, 20.0, np.pi / 2, 0.0, -1.0, -1.0, 0.0, 3.5]), (256, 1))
-        b = e.integrate_batch(st, bh.default_options(max_steps=2048))
+        b = e.integrate_batch(st, bh.engine.default_options(max_steps=2048))
         assert (b["term"] == 3).all() and (b["steps"] <= 48).all()  # the check runs every 8 tries
         ex = C.c_uint32(0), C.c_uint8(0), C.c_double(0)
         out = np.zeros(8)

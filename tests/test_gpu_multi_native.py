@@ -1,0 +1,184 @@
+"""The multi-GPU frame behind the C ABI (grv_engine_create_multi*, csrc/engine_multi.hip) on ONE GPU:
+G virtual ranks share cuda:0, each with its own engine, host thread and two streams; every rank
+renders its round-robin tile share, the peer-copy transport pushes the shares into rank 0's receive
+slots, rank 0 de-interleaves.  The assembled image must equal grv_render_frame_device's whole frame
+bit for bit -- same kernels, same rays, another schedule.  The RCCL transport is walked with one
+device (communicator set-up, one self send/recv group per frame); more than one rank per device is
+something RCCL refuses, and the pool hands out one-GPU boxes."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EYE = (60.0 * np.sin(np.deg2rad(97.0)), 60.0 * np.cos(np.deg2rad(97.0)), 0.0)
+
+
+@pytest.fixture(scope="module")
+def bh(engine_mod):
+    return engine_mod
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _whole(bh, torch, w, h, spin=0.999, **kw):
+    cam = bh.camera_look_at(EYE, aspect=w / h)
+    p = bh.render_params(w, h, **kw)
+    with bh.PhysicsEngine(1.0, spin) as e:
+        out = torch.zeros(h, w, 4, dtype=torch.float32, device="cuda:0")
+        e.render_frame_device(cam, p, rgba=out)
+        st = e.frame_stats()
+        torch.cuda.synchronize()
+    return cam, p, out, st
+
+
+@pytest.mark.parametrize("ranks,w,h,arith", [(2, 200, 130, 0), (4, 512, 288, 1), (8, 960, 540, 1), (3, 333, 77, 1),
+                                             (8, 64, 64, 1)])
+def test_virtual_ranks_assemble_the_whole_frame_bitwise(bh, torch, ranks, w, h, arith):
+    cam, p, want, wst = _whole(bh, torch, w, h, arith=arith)
+    with bh.MultiEngine(1.0, 0.999, virtual_ranks=ranks) as m:
+        assert m.ranks == ranks and m.rank_devices() == [0] * ranks and m.transport == bh.TRANSPORT_PEER_COPY
+        got = torch.full((h, w, 4), -7.0, dtype=torch.float32, device="cuda:0")
+        m.render_frame_device(cam, p, got)
+        st = m.frame_stats()
+        assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+        assert (st.rays, st.accepted_steps, st.rkf_tries) == (wst.rays, wst.accepted_steps, wst.rkf_tries)
+        assert list(st.term_count) == list(wst.term_count) and st.max_drift == wst.max_drift
+        # host-pointer entry
+        img, st2 = m.render_frame(cam, p)
+        assert np.array_equal(img.view(np.uint32), want.cpu().numpy().view(np.uint32))
+        assert st2.accepted_steps == wst.accepted_steps
+
+
+def test_frames_in_flight_and_changing_cameras(bh, torch):
+    """Eight frames queued back to back (even / odd frames on the two stream sets, no host wait
+    between them), each with its own camera and its own output buffer: every image equals the
+    single-engine render of that camera; accumulated counters are the sums."""
+    w, h, ranks = 384, 216, 4
+    eyes = [(60.0 * np.sin(t), 60.0 * np.cos(t), 3.0 * k) for k, t in enumerate(np.deg2rad(np.linspace(60, 120, 8)))]
+    p = bh.render_params(w, h, arith=1)
+    want, steps = [], 0
+    with bh.PhysicsEngine(1.0, 0.999) as e:
+        for eye in eyes:
+            o = torch.zeros(h, w, 4, dtype=torch.float32, device="cuda:0")
+            e.render_frame_device(bh.camera_look_at(eye, aspect=w / h), p, rgba=o)
+            steps += e.frame_stats().accepted_steps
+            want.append(o)
+    with bh.MultiEngine(1.0, 0.999, virtual_ranks=ranks) as m:
+        m.stats_accumulate(True)
+        m.frame_stats_reset()
+        got = [torch.zeros(h, w, 4, dtype=torch.float32, device="cuda:0") for _ in eyes]
+        for eye, o in zip(eyes, got):
+            m.render_frame_device(bh.camera_look_at(eye, aspect=w / h), p, o)
+        st = m.frame_stats()
+        torch.cuda.synchronize()
+        for k in range(len(eyes)):
+            assert torch.equal(got[k].view(torch.int32), want[k].view(torch.int32)), k
+        assert st.accepted_steps == steps
+        # the frame size may change between frames (buffers grow on demand)
+        cam2, p2, want2, _ = _whole(bh, torch, 700, 400, arith=1)
+        big = torch.zeros(400, 700, 4, dtype=torch.float32, device="cuda:0")
+        m.render_frame_device(cam2, p2, big)
+        m.synchronize()
+        assert torch.equal(big.view(torch.int32), want2.view(torch.int32))
+
+
+def test_update_params_reaches_every_rank(bh, torch):
+    w, h = 256, 144
+    cam, p, want, _ = _whole(bh, torch, w, h, spin=0.5, arith=1, disk_profile=1)
+    with bh.MultiEngine(1.0, 0.999, virtual_ranks=3) as m:
+        got = torch.zeros(h, w, 4, dtype=torch.float32, device="cuda:0")
+        m.render_frame_device(cam, p, got)
+        m.update_params(1.0, 0.5)
+        m.render_frame_device(cam, p, got)
+        m.synchronize()
+        assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+
+
+def test_wgsl_march_over_virtual_ranks(bh, torch):
+    """BASELINE configs[3]'s kernel (f32 compute march, packed two-rays-per-lane form) over ranks."""
+    w, h = 512, 288
+    cam = bh.camera_look_at(EYE, aspect=w / h)
+    for arith in (bh.ARITH_STRICT, bh.ARITH_FAST_PACKED):
+        wp = bh.wgsl_params(w, h, cam, 1.0, 0.999, max_steps=300, arith=arith)
+        with bh.PhysicsEngine(1.0, 0.999) as e:
+            want = torch.zeros(h, w, 4, dtype=torch.float32, device="cuda:0")
+            total = e.render_frame_wgsl(wp, want)
+        with bh.MultiEngine(1.0, 0.999, virtual_ranks=4) as m:
+            got = torch.zeros(h, w, 4, dtype=torch.float32, device="cuda:0")
+            m.render_frame_wgsl_device(wp, got)
+            st = m.frame_stats()
+            assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+            assert st.accepted_steps == total
+
+
+def test_single_rank_handle_is_the_plain_frame(bh, torch):
+    cam, p, want, wst = _whole(bh, torch, 320, 180, arith=1)
+    with bh.MultiEngine(1.0, 0.999, devices=[0]) as m:
+        assert m.ranks == 1
+        got = torch.zeros(180, 320, 4, dtype=torch.float32, device="cuda:0")
+        m.render_frame_device(cam, p, got)
+        assert m.frame_stats().accepted_steps == wst.accepted_steps
+        assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+
+
+def test_bad_requests_are_refused(bh, torch):
+    L = bh.load_library()
+    h = C.c_void_p()
+    assert L.grv_engine_create_multi(1.0, 0.5, 0, 0, C.byref(h)) == 1           # empty mask
+    assert L.grv_engine_create_multi(1.0, 0.5, 1 << 40, 0, C.byref(h)) == 2     # no such device
+    assert L.grv_engine_create_multi_virtual(1.0, 0.5, 0, 0, C.byref(h)) == 1   # zero ranks
+    with bh.MultiEngine(1.0, 0.999, virtual_ranks=2) as m:
+        cam = bh.camera_look_at(EYE, aspect=2.0)
+        p = bh.render_params(128, 64, arith=1, tile_world=2, tile_rank=1)
+        out = torch.zeros(64, 128, 4, dtype=torch.float32, device="cuda:0")
+        with pytest.raises(bh.GravitasError, match="tile_world"):
+            m.render_frame_device(cam, p, out)
+        with pytest.raises(bh.GravitasError):
+            m.render_frame_device(cam, bh.render_params(128, 64, arith=7), out)
+        # the handle is still usable afterwards
+        m.render_frame_device(cam, bh.render_params(128, 64, arith=1), out)
+        m.synchronize()
+
+
+_RCCL_WALK = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch
+import blackhole_simulation_amd as bh
+EYE = (60.0 * np.sin(np.deg2rad(97.0)), 60.0 * np.cos(np.deg2rad(97.0)), 0.0)
+w, h = 320, 180
+cam = bh.camera_look_at(EYE, aspect=w / h)
+p = bh.render_params(w, h, arith=1)
+with bh.PhysicsEngine(1.0, 0.999) as e:
+    want = torch.zeros(h, w, 4, dtype=torch.float32, device="cuda:0")
+    e.render_frame_device(cam, p, rgba=want)
+    torch.cuda.synchronize()
+with bh.MultiEngine(1.0, 0.999, devices=[0], transport=bh.TRANSPORT_RCCL) as m:
+    assert m.transport == bh.TRANSPORT_RCCL
+    for k in range(3):
+        got = torch.zeros(h, w, 4, dtype=torch.float32, device="cuda:0")
+        m.render_frame_device(cam, p, got)
+        m.synchronize()
+        assert torch.equal(got.view(torch.int32), want.view(torch.int32)), k
+print("RCCL_WALK_OK")
+"""
+
+
+def test_rccl_transport_walk_on_one_device():
+    """ncclCommInitAll on one device and, with GRV_MULTI_SELF_EXCHANGE, rank 0's share travelling
+    through one ncclSend / ncclRecv group per frame before the unpack: every RCCL call of the
+    transport runs, on the one device this pool has."""
+    env = dict(os.environ, GRV_MULTI_SELF_EXCHANGE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _RCCL_WALK % {"root": ROOT}], capture_output=True, text=True,
+                       timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0 and "RCCL_WALK_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
