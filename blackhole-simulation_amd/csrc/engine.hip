@@ -914,6 +914,16 @@ size_t grv_engine_device_bytes(const grv_engine *e) {
     return b;
 }
 
+void *grv_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void grv_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
 int grv_stats_accumulate(grv_engine *e, int enable) {
     if (!e) return GRV_ERR_INVALID;
     e->stats_accum = enable != 0;

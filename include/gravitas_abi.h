@@ -206,6 +206,12 @@ int grv_frame_stats_reset(grv_engine *e, void *stream);
  * A caller that keeps every frame / batch call on ONE stream holds one ray workspace (~170 B per ray
  * slot); the second one exists only once calls have arrived on two different streams. */
 size_t grv_engine_device_bytes(const grv_engine *e);
+/* Page-locked host memory for the host-pointer entry points (grv_render_frame, grv_integrate_batch,
+ * grv_render_frame_multi, *_render_host): a frame rendered into it leaves the device in one DMA at
+ * the full PCIe rate instead of going through the runtime's pageable staging.  The N-API addon hands
+ * it to JS as an external ArrayBuffer (renderFrame({out})).  NULL on failure. */
+void *grv_host_alloc(size_t bytes);
+void grv_host_free(void *p);
 /* host-only: scatter packed tile-order pixels of `rank` into a row-major W x H x C image */
 int grv_unpack_tiles(const GrvRenderParams *p, uint32_t rank, const void *packed, void *image,
                      size_t bytes_per_pixel);

@@ -18,7 +18,9 @@
  * Build: make -C napi   (gcc against /usr/include/node/node_api.h)
  */
 #include <node_api.h>
+#include <pthread.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -40,6 +42,19 @@ typedef struct {
     int slot;       /* arena slot, -1 once released */
     size_t sab_off;
     size_t lut_off; /* 512-float disk LUT copy (get_disk_lut_ptr, lib.rs:112) */
+    double mass, spin; /* as last given (constructor / update_params): what the lazily created handles below start from */
+    /* renderFrame({devices: n}) / ({virtualRanks: n}): the multi-GPU handle of the C ABI, created on
+     * first use and re-created when n changes */
+    grv_multi *multi;
+    int multi_ranks, multi_virtual;
+    /* the *Async methods run on the libuv pool.  A handle is not thread-safe, so they get handles of
+     * their own (never touched by the synchronous methods) and one mutex serialises them. */
+    grv_engine *async_h;
+    grv_multi *async_multi;
+    int async_multi_ranks, async_multi_virtual;
+    pthread_mutex_t async_mu;
+    int async_pending; /* works queued or running (main thread only) */
+    int freed;         /* free() was called while works were pending: the last one to complete cleans up */
 } engine_box;
 
 static int slot_acquire(void) {
@@ -101,13 +116,24 @@ static napi_value mk_f64(napi_env env, double d) {
     return v;
 }
 
+static void box_destroy_handles(engine_box *box) {
+    if (box->multi) grv_multi_destroy(box->multi);
+    if (box->async_multi) grv_multi_destroy(box->async_multi);
+    if (box->async_h) grv_engine_destroy(box->async_h);
+    if (box->h) grv_engine_destroy(box->h);
+    box->multi = box->async_multi = NULL;
+    box->async_h = box->h = NULL;
+}
+
 static void engine_finalize(napi_env env, void *data, void *hint) {
     (void)env;
     (void)hint;
     engine_box *box = (engine_box *)data;
     if (box) {
-        if (box->h) grv_engine_destroy(box->h);
+        /* a pending async work holds a reference to the JS object, so none is pending here */
+        box_destroy_handles(box);
         slot_release(box);
+        pthread_mutex_destroy(&box->async_mu);
         free(box);
     }
 }
@@ -124,8 +150,12 @@ static napi_value engine_new(napi_env env, napi_callback_info info) {
         napi_throw_error(env, NULL, "PhysicsEngine: out of memory");
         return NULL;
     }
+    box->mass = mass;
+    box->spin = spin;
+    pthread_mutex_init(&box->async_mu, NULL);
     int rc = grv_engine_create(mass, spin, 0, &box->h);
     if (rc != GRV_OK) {
+        pthread_mutex_destroy(&box->async_mu);
         free(box);
         napi_throw_error(env, NULL, rc == GRV_ERR_NO_DEVICE
                                         ? "PhysicsEngine: no HIP device (this engine has no CPU path)"
@@ -136,6 +166,7 @@ static napi_value engine_new(napi_env env, napi_callback_info info) {
     box->slot = g_arena ? slot_acquire() : -1;
     if (box->slot < 0) { /* no silent fallback onto another engine's region */
         grv_engine_destroy(box->h);
+        pthread_mutex_destroy(&box->async_mu);
         free(box);
         napi_throw_error(env, NULL, "PhysicsEngine: memory arena exhausted (free() engines no longer in use)");
         return NULL;
@@ -152,7 +183,11 @@ static napi_value m_update_params(napi_env env, napi_callback_info info) { /* li
     napi_value argv[2];
     engine_box *b = unwrap(env, info, &argc, argv);
     if (!b) return NULL;
-    grv_update_params(b->h, arg_f64(env, argv[0]), arg_f64(env, argv[1]));
+    b->mass = arg_f64(env, argv[0]);
+    b->spin = arg_f64(env, argv[1]);
+    grv_update_params(b->h, b->mass, b->spin);
+    if (b->multi) grv_multi_update_params(b->multi, b->mass, b->spin);
+    /* the async handles take (mass, spin) with every work item */
     return NULL;
 }
 
@@ -513,16 +548,214 @@ static void obj_vec3(napi_env env, napi_value obj, const char *key, double out[3
         if (napi_get_element(env, arr, i, &e) == napi_ok) out[i] = arg_f64(env, e);
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * The path's two bulk entries -- frames and batches of geodesics -- in a synchronous and an
+ * asynchronous form.  A work item is filled on the JS thread (arguments parsed, output ArrayBuffers
+ * created or taken from the caller), executed either in place or on the libuv pool, and turned into
+ * the result object on the JS thread again.
+ * ------------------------------------------------------------------------------------------- */
+static int obj_str(napi_env env, napi_value obj, const char *key, char *buf, size_t cap) {
+    bool has = false;
+    napi_value v;
+    size_t len = 0;
+    buf[0] = 0;
+    if (napi_has_named_property(env, obj, key, &has) != napi_ok || !has) return 0;
+    if (napi_get_named_property(env, obj, key, &v) != napi_ok) return 0;
+    return napi_get_value_string_utf8(env, v, buf, cap, &len) == napi_ok;
+}
+
+typedef struct {
+    engine_box *box;
+    int kind;       /* 0 frame, 1 batch */
+    int is_async;
+    double mass, spin;
+    /* frame */
+    GrvCamera cam;
+    GrvRenderParams p;
+    int devices, virtual_ranks;
+    float *rgba;    /* W*H*4, memory of the result's ArrayBuffer */
+    GrvFrameStats st;
+    /* batch */
+    size_t n;
+    GrvOptions opt;
+    double *in, *out_states, *drift;
+    uint32_t *steps;
+    uint8_t *term;
+    /* result */
+    int rc;
+    char err[256];
+    napi_ref keep[5]; /* typed arrays of the result (and the caller's input) kept alive while queued */
+    int n_keep;
+    napi_ref self_ref;
+    napi_deferred deferred;
+    napi_async_work work;
+} bulk_work;
+
+/* the multi-GPU handle for `ranks` ranks (virtual: all on device 0), cached in *slot */
+static int multi_for(grv_multi **slot, int *cur_ranks, int *cur_virtual, int ranks, int virt, double mass,
+                     double spin, char *err, size_t cap) {
+    if (*slot && (*cur_ranks != ranks || *cur_virtual != virt)) {
+        grv_multi_destroy(*slot);
+        *slot = NULL;
+    }
+    if (!*slot) {
+        int rc = virt ? grv_engine_create_multi_virtual(mass, spin, 0, ranks, slot)
+                      : grv_engine_create_multi(mass, spin, ranks >= 64 ? ~0ull : ((1ull << ranks) - 1ull),
+                                                GRV_TRANSPORT_AUTO, slot);
+        if (rc != GRV_OK) {
+            snprintf(err, cap, "renderFrame: cannot open %d %s (status %d)", ranks,
+                     virt ? "virtual ranks" : "HIP devices", rc);
+            return rc;
+        }
+        *cur_ranks = ranks;
+        *cur_virtual = virt;
+    }
+    return grv_multi_update_params(*slot, mass, spin);
+}
+
+/* runs on the JS thread (sync form) or on a pool thread (async form) */
+static void bulk_execute(bulk_work *w) {
+    engine_box *b = w->box;
+    grv_engine *h = b->h;
+    grv_multi **mslot = &b->multi;
+    int *mr = &b->multi_ranks, *mv = &b->multi_virtual;
+    if (w->is_async) {
+        pthread_mutex_lock(&b->async_mu);
+        if (!b->async_h && grv_engine_create(w->mass, w->spin, 0, &b->async_h) != GRV_OK) {
+            w->rc = GRV_ERR_NO_DEVICE;
+            snprintf(w->err, sizeof w->err, "async: grv_engine_create failed");
+            pthread_mutex_unlock(&b->async_mu);
+            return;
+        }
+        h = b->async_h;
+        grv_update_params(h, w->mass, w->spin);
+        mslot = &b->async_multi;
+        mr = &b->async_multi_ranks;
+        mv = &b->async_multi_virtual;
+    }
+    if (w->kind == 0) {
+        const int ranks = w->virtual_ranks > 0 ? w->virtual_ranks : w->devices;
+        if (ranks > 1 || w->virtual_ranks > 0) {
+            w->rc = multi_for(mslot, mr, mv, ranks, w->virtual_ranks > 0, w->mass, w->spin, w->err, sizeof w->err);
+            if (w->rc == GRV_OK) {
+                w->rc = grv_render_frame_multi(*mslot, &w->cam, &w->p, w->rgba, &w->st);
+                if (w->rc != GRV_OK) snprintf(w->err, sizeof w->err, "%s", grv_multi_last_error(*mslot));
+            }
+        } else {
+            w->rc = grv_render_frame(h, &w->cam, &w->p, w->rgba, &w->st);
+            if (w->rc != GRV_OK) snprintf(w->err, sizeof w->err, "%s", grv_last_error(h));
+        }
+    } else {
+        w->rc = grv_integrate_batch(h, w->n, w->in, &w->opt, w->out_states, w->steps, w->term, w->drift);
+        if (w->rc != GRV_OK) snprintf(w->err, sizeof w->err, "%s", grv_last_error(h));
+    }
+    if (w->is_async) pthread_mutex_unlock(&b->async_mu);
+}
+
+static napi_value bulk_result(napi_env env, bulk_work *w) {
+    napi_value out, v[5];
+    for (int k = 0; k < w->n_keep; k++)
+        if (napi_get_reference_value(env, w->keep[k], &v[k]) != napi_ok) return NULL;
+    if (napi_create_object(env, &out) != napi_ok) return NULL;
+    if (w->kind == 0) {
+        napi_set_named_property(env, out, "rgba", v[0]);
+        napi_set_named_property(env, out, "width", mk_f64(env, w->p.width));
+        napi_set_named_property(env, out, "height", mk_f64(env, w->p.height));
+        napi_set_named_property(env, out, "rays", mk_f64(env, (double)w->st.rays));
+        napi_set_named_property(env, out, "acceptedSteps", mk_f64(env, (double)w->st.accepted_steps));
+        napi_set_named_property(env, out, "launches", mk_f64(env, (double)w->st.launches));
+        napi_set_named_property(env, out, "devices",
+                                mk_f64(env, w->virtual_ranks > 0 ? w->virtual_ranks : (w->devices > 1 ? w->devices : 1)));
+    } else {
+        napi_set_named_property(env, out, "states", v[0]);
+        napi_set_named_property(env, out, "steps", v[1]);
+        napi_set_named_property(env, out, "term", v[2]);
+        napi_set_named_property(env, out, "drift", v[3]);
+    }
+    return out;
+}
+
+static void bulk_release(napi_env env, bulk_work *w) {
+    for (int k = 0; k < w->n_keep; k++) napi_delete_reference(env, w->keep[k]);
+    if (w->self_ref) napi_delete_reference(env, w->self_ref);
+    free(w);
+}
+
+static void bulk_async_execute(napi_env env, void *data) {
+    (void)env;
+    bulk_execute((bulk_work *)data);
+}
+
+static void bulk_async_complete(napi_env env, napi_status status, void *data) {
+    bulk_work *w = (bulk_work *)data;
+    engine_box *b = w->box;
+    napi_value res = NULL;
+    if (status == napi_ok && w->rc == GRV_OK) res = bulk_result(env, w);
+    if (res) {
+        napi_resolve_deferred(env, w->deferred, res);
+    } else {
+        napi_value msg, err;
+        napi_create_string_utf8(env, w->err[0] ? w->err : "async work failed", NAPI_AUTO_LENGTH, &msg);
+        napi_create_error(env, NULL, msg, &err);
+        napi_reject_deferred(env, w->deferred, err);
+    }
+    napi_delete_async_work(env, w->work);
+    b->async_pending--;
+    if (b->freed && b->async_pending == 0) box_destroy_handles(b); /* free() came while works were queued */
+    bulk_release(env, w);
+}
+
+/* queue (async) or run (sync) a filled work item; returns the promise / the result object */
+static napi_value bulk_dispatch(napi_env env, napi_value self, bulk_work *w) {
+    if (!w->is_async) {
+        bulk_execute(w);
+        napi_value res = w->rc == GRV_OK ? bulk_result(env, w) : NULL;
+        if (!res) napi_throw_error(env, NULL, w->err[0] ? w->err : "call failed");
+        bulk_release(env, w);
+        return res;
+    }
+    napi_value promise, name;
+    if (napi_create_promise(env, &w->deferred, &promise) != napi_ok ||
+        napi_create_reference(env, self, 1, &w->self_ref) != napi_ok || /* the engine outlives its queued works */
+        napi_create_string_utf8(env, "gravitas.bulk", NAPI_AUTO_LENGTH, &name) != napi_ok ||
+        napi_create_async_work(env, NULL, name, bulk_async_execute, bulk_async_complete, w, &w->work) != napi_ok ||
+        napi_queue_async_work(env, w->work) != napi_ok) {
+        napi_throw_error(env, NULL, "cannot queue async work");
+        bulk_release(env, w);
+        return NULL;
+    }
+    w->box->async_pending++;
+    return promise;
+}
+
+static int keep_ref(napi_env env, bulk_work *w, napi_value v) {
+    if (napi_create_reference(env, v, 1, &w->keep[w->n_keep]) != napi_ok) return 0;
+    w->n_keep++;
+    return 1;
+}
+
 /* renderFrame({width, height, eye:[x,y,z], target?, up?, fovY?, maxSteps?, tolerance?, shading?,
- *              arith?: "fast"|"strict"}) -> {rgba: Float32Array[w*h*4], width, height, rays,
- *              acceptedSteps, launches}
+ *              arith?: "fast"|"strict", diskProfile?, devices?: n, virtualRanks?: n,
+ *              out?: Float32Array(w*h*4)})
+ *   -> {rgba: Float32Array[w*h*4], width, height, rays, acceptedSteps, launches, devices}
  * The frame the reference only produces in its WebGPU compute pass (compute.wgsl.ts:147-258),
- * integrated by the f64 RKF45 kernel; pixel->ray of compute.wgsl.ts:159-187. */
-static napi_value m_render_frame(napi_env env, napi_callback_info info) {
+ * integrated by the f64 RKF45 kernel; pixel->ray of compute.wgsl.ts:159-187.
+ *   devices: n      the image plane is tiled over the first n HIP devices (one gather of finished
+ *                   tiles to device 0, RCCL over xGMI; include/gravitas_abi.h grv_engine_create_multi);
+ *   virtualRanks: n the same assembly path with n ranks on device 0 (one-GPU hosts, tests);
+ *   out             render into a caller-owned array -- with allocPinned() memory the frame
+ *                   leaves the device in one DMA and no copy is made on the JS side.
+ * renderFrameAsync(opts) -> Promise of the same object: the frame runs on the libuv pool with an
+ * engine handle of its own, so a worker's tick (physics.worker.ts:111-176) is never held. */
+static napi_value render_frame_common(napi_env env, napi_callback_info info, int is_async) {
     size_t argc = 1;
-    napi_value argv[1];
-    engine_box *b = unwrap(env, info, &argc, argv);
-    if (!b) return NULL;
+    napi_value argv[1], self;
+    engine_box *b = NULL;
+    if (napi_get_cb_info(env, info, &argc, argv, &self, NULL) != napi_ok) return NULL;
+    if (napi_unwrap(env, self, (void **)&b) != napi_ok || !b || !b->h) {
+        napi_throw_error(env, NULL, "PhysicsEngine: invalid receiver");
+        return NULL;
+    }
     napi_valuetype t;
     if (argc < 1 || napi_typeof(env, argv[0], &t) != napi_ok || t != napi_object) {
         napi_throw_type_error(env, NULL, "renderFrame expects an options object");
@@ -534,57 +767,195 @@ static napi_value m_render_frame(napi_env env, napi_callback_info info) {
         napi_throw_range_error(env, NULL, "renderFrame: width/height out of range");
         return NULL;
     }
+    const double devices = obj_f64(env, argv[0], "devices", 1.0), vranks = obj_f64(env, argv[0], "virtualRanks", 0.0);
+    if (!(devices >= 1.0 && devices <= 64.0) || !(vranks >= 0.0 && vranks <= 64.0)) {
+        napi_throw_range_error(env, NULL, "renderFrame: devices / virtualRanks out of range (1..64)");
+        return NULL;
+    }
+    bulk_work *wk = (bulk_work *)calloc(1, sizeof *wk);
+    if (!wk) {
+        napi_throw_error(env, NULL, "out of memory");
+        return NULL;
+    }
+    wk->box = b;
+    wk->kind = 0;
+    wk->is_async = is_async;
+    wk->mass = b->mass;
+    wk->spin = b->spin;
+    wk->devices = (int)devices;
+    wk->virtual_ranks = (int)vranks;
     double eye[3] = {0.0, 0.0, 60.0}, target[3] = {0.0, 0.0, 0.0}, up[3] = {0.0, 1.0, 0.0};
     obj_vec3(env, argv[0], "eye", eye);
     obj_vec3(env, argv[0], "target", target);
     obj_vec3(env, argv[0], "up", up);
-    GrvCamera cam;
     /* fovY in degrees (WebGPUCanvas.tsx:143-151 uses 60); the C ABI takes radians */
     grv_camera_look_at(eye, target, up, obj_f64(env, argv[0], "fovY", 60.0) * (3.14159265358979323846 / 180.0),
-                       (double)w / (double)h, &cam);
-    GrvRenderParams p;
-    grv_render_params_default(w, h, &p);
-    p.opt.max_steps = (uint64_t)obj_f64(env, argv[0], "maxSteps", (double)p.opt.max_steps);
-    p.opt.tolerance = obj_f64(env, argv[0], "tolerance", p.opt.tolerance);
-    p.shading = (int32_t)obj_f64(env, argv[0], "shading", (double)p.shading);
-    bool has = false;
-    if (napi_has_named_property(env, argv[0], "diskProfile", &has) == napi_ok && has) {
-        /* "pageThorne": the generate_disk_lut table as the radial temperature profile (disk.rs:175-201) */
-        napi_value v;
-        char buf[16] = {0};
-        size_t len = 0;
-        if (napi_get_named_property(env, argv[0], "diskProfile", &v) == napi_ok &&
-            napi_get_value_string_utf8(env, v, buf, sizeof buf, &len) == napi_ok)
-            p.disk_profile = strcmp(buf, "pageThorne") == 0 ? GRV_DISK_PROFILE_PAGE_THORNE : GRV_DISK_PROFILE_SHORTCUT;
-    }
-    has = false;
-    if (napi_has_named_property(env, argv[0], "arith", &has) == napi_ok && has) {
-        napi_value v;
-        char buf[16] = {0};
-        size_t len = 0;
-        if (napi_get_named_property(env, argv[0], "arith", &v) == napi_ok &&
-            napi_get_value_string_utf8(env, v, buf, sizeof buf, &len) == napi_ok)
-            p.opt.arith = strcmp(buf, "strict") == 0 ? GRV_ARITH_STRICT : GRV_ARITH_FAST;
-    }
+                       (double)w / (double)h, &wk->cam);
+    GrvRenderParams *p = &wk->p;
+    grv_render_params_default(w, h, p);
+    p->opt.max_steps = (uint64_t)obj_f64(env, argv[0], "maxSteps", (double)p->opt.max_steps);
+    p->opt.tolerance = obj_f64(env, argv[0], "tolerance", p->opt.tolerance);
+    p->shading = (int32_t)obj_f64(env, argv[0], "shading", (double)p->shading);
+    char buf[16];
+    /* "pageThorne": the generate_disk_lut table as the radial temperature profile (disk.rs:175-201) */
+    if (obj_str(env, argv[0], "diskProfile", buf, sizeof buf))
+        p->disk_profile = strcmp(buf, "pageThorne") == 0 ? GRV_DISK_PROFILE_PAGE_THORNE : GRV_DISK_PROFILE_SHORTCUT;
+    if (obj_str(env, argv[0], "arith", buf, sizeof buf))
+        p->opt.arith = strcmp(buf, "strict") == 0 ? GRV_ARITH_STRICT : GRV_ARITH_FAST;
     const size_t n = (size_t)w * h * 4;
-    napi_value ab, rgba, out;
-    void *dst;
-    NAPI_OK(napi_create_arraybuffer(env, n * sizeof(float), &dst, &ab));
-    GrvFrameStats st;
-    memset(&st, 0, sizeof st);
-    if (grv_render_frame(b->h, &cam, &p, (float *)dst, &st) != GRV_OK) {
-        napi_throw_error(env, NULL, grv_last_error(b->h));
+    napi_value rgba;
+    bool has = false;
+    if (napi_has_named_property(env, argv[0], "out", &has) == napi_ok && has) {
+        napi_typedarray_type ty;
+        size_t len = 0;
+        void *data = NULL;
+        bool is_ta = false;
+        if (napi_get_named_property(env, argv[0], "out", &rgba) != napi_ok ||
+            napi_is_typedarray(env, rgba, &is_ta) != napi_ok || !is_ta ||
+            napi_get_typedarray_info(env, rgba, &ty, &len, &data, NULL, NULL) != napi_ok ||
+            ty != napi_float32_array || len < n) {
+            free(wk);
+            napi_throw_type_error(env, NULL, "renderFrame: out must be a Float32Array of width*height*4 elements");
+            return NULL;
+        }
+        wk->rgba = (float *)data;
+    } else {
+        napi_value ab;
+        void *dst;
+        if (napi_create_arraybuffer(env, n * sizeof(float), &dst, &ab) != napi_ok ||
+            napi_create_typedarray(env, napi_float32_array, n, ab, 0, &rgba) != napi_ok) {
+            free(wk);
+            napi_throw_error(env, NULL, "renderFrame: cannot allocate the image");
+            return NULL;
+        }
+        wk->rgba = (float *)dst;
+    }
+    if (!keep_ref(env, wk, rgba)) {
+        free(wk);
+        napi_throw_error(env, NULL, "renderFrame: reference failed");
         return NULL;
     }
-    NAPI_OK(napi_create_typedarray(env, napi_float32_array, n, ab, 0, &rgba));
-    NAPI_OK(napi_create_object(env, &out));
-    NAPI_OK(napi_set_named_property(env, out, "rgba", rgba));
-    NAPI_OK(napi_set_named_property(env, out, "width", mk_f64(env, w)));
-    NAPI_OK(napi_set_named_property(env, out, "height", mk_f64(env, h)));
-    NAPI_OK(napi_set_named_property(env, out, "rays", mk_f64(env, (double)st.rays)));
-    NAPI_OK(napi_set_named_property(env, out, "acceptedSteps", mk_f64(env, (double)st.accepted_steps)));
-    NAPI_OK(napi_set_named_property(env, out, "launches", mk_f64(env, (double)st.launches)));
-    return out;
+    return bulk_dispatch(env, self, wk);
+}
+static napi_value m_render_frame(napi_env env, napi_callback_info info) { return render_frame_common(env, info, 0); }
+static napi_value m_render_frame_async(napi_env env, napi_callback_info info) { return render_frame_common(env, info, 1); }
+
+/* integrate_batch(states: Float64Array(8 n), {method?: "rkf45"|"rk4"|"symplectic", metric?: "ks"|"bl"|
+ *                 "schwarzschild", tolerance?, initialStep?, maxSteps?, escapeRadius?, renormalizeInterval?,
+ *                 stepSize?, arith?: "strict"|"fast"})
+ *   -> {states: Float64Array(8 n), steps: Uint32Array(n), term: Uint8Array(n), drift: Float64Array(n)}
+ * n independent integrate() calls (geodesic/mod.rs:180-253) in one launch: what a consumer of
+ * integrate_ray_relativistic (lib.rs:422-464, one ray per call) should use for more than a few rays.
+ * Defaults are IntegrationOptions::default (integrator.rs:35-47); the Trajectory scalars
+ * (mod.rs:150-161) come back per ray.  integrateBatchAsync: the same on the libuv pool. */
+static napi_value integrate_batch_common(napi_env env, napi_callback_info info, int is_async) {
+    size_t argc = 2;
+    napi_value argv[2], self;
+    engine_box *b = NULL;
+    if (napi_get_cb_info(env, info, &argc, argv, &self, NULL) != napi_ok) return NULL;
+    if (napi_unwrap(env, self, (void **)&b) != napi_ok || !b || !b->h) {
+        napi_throw_error(env, NULL, "PhysicsEngine: invalid receiver");
+        return NULL;
+    }
+    napi_typedarray_type ty;
+    size_t len = 0;
+    void *data = NULL;
+    bool is_ta = false;
+    if (argc < 1 || napi_is_typedarray(env, argv[0], &is_ta) != napi_ok || !is_ta ||
+        napi_get_typedarray_info(env, argv[0], &ty, &len, &data, NULL, NULL) != napi_ok ||
+        ty != napi_float64_array || len % 8 != 0) {
+        napi_throw_type_error(env, NULL, "integrate_batch: states must be a Float64Array of 8 n elements");
+        return NULL;
+    }
+    bulk_work *wk = (bulk_work *)calloc(1, sizeof *wk);
+    if (!wk) {
+        napi_throw_error(env, NULL, "out of memory");
+        return NULL;
+    }
+    wk->box = b;
+    wk->kind = 1;
+    wk->is_async = is_async;
+    wk->mass = b->mass;
+    wk->spin = b->spin;
+    wk->n = len / 8;
+    wk->in = (double *)data;
+    GrvOptions *o = &wk->opt;
+    grv_options_default(o);
+    napi_valuetype t;
+    if (argc > 1 && napi_typeof(env, argv[1], &t) == napi_ok && t == napi_object) {
+        char buf[24];
+        if (obj_str(env, argv[1], "method", buf, sizeof buf))
+            o->method = strcmp(buf, "rk4") == 0 ? GRV_METHOD_RK4
+                        : strcmp(buf, "symplectic") == 0 ? GRV_METHOD_SYMPLECTIC : GRV_METHOD_RKF45;
+        if (obj_str(env, argv[1], "metric", buf, sizeof buf))
+            o->metric_kind = strcmp(buf, "bl") == 0 ? GRV_METRIC_KERR_BL
+                             : strcmp(buf, "schwarzschild") == 0 ? GRV_METRIC_SCHWARZSCHILD : GRV_METRIC_KERR_KS;
+        if (obj_str(env, argv[1], "arith", buf, sizeof buf))
+            o->arith = strcmp(buf, "fast") == 0 ? GRV_ARITH_FAST : GRV_ARITH_STRICT;
+        o->tolerance = obj_f64(env, argv[1], "tolerance", o->tolerance);
+        o->initial_step = obj_f64(env, argv[1], "initialStep", o->initial_step);
+        o->max_steps = (uint64_t)obj_f64(env, argv[1], "maxSteps", (double)o->max_steps);
+        o->escape_radius = obj_f64(env, argv[1], "escapeRadius", o->escape_radius);
+        o->renormalize_interval = (uint64_t)obj_f64(env, argv[1], "renormalizeInterval", (double)o->renormalize_interval);
+        o->step_size = obj_f64(env, argv[1], "stepSize", o->step_size);
+    }
+    const size_t n = wk->n;
+    napi_value ab[4], ta[4];
+    void *mem[4] = {NULL, NULL, NULL, NULL};
+    const size_t bytes[4] = {n * 64, n * 4, n, n * 8};
+    const napi_typedarray_type tys[4] = {napi_float64_array, napi_uint32_array, napi_uint8_array, napi_float64_array};
+    const size_t counts[4] = {n * 8, n, n, n};
+    for (int k = 0; k < 4; k++) {
+        if (napi_create_arraybuffer(env, bytes[k], &mem[k], &ab[k]) != napi_ok ||
+            napi_create_typedarray(env, tys[k], counts[k], ab[k], 0, &ta[k]) != napi_ok || !keep_ref(env, wk, ta[k])) {
+            bulk_release(env, wk);
+            napi_throw_error(env, NULL, "integrate_batch: cannot allocate the outputs");
+            return NULL;
+        }
+    }
+    if (!keep_ref(env, wk, argv[0])) { /* the input stays alive (and should stay unmodified) while queued */
+        bulk_release(env, wk);
+        napi_throw_error(env, NULL, "integrate_batch: reference failed");
+        return NULL;
+    }
+    wk->out_states = (double *)mem[0];
+    wk->steps = (uint32_t *)mem[1];
+    wk->term = (uint8_t *)mem[2];
+    wk->drift = (double *)mem[3];
+    if (n == 0) wk->is_async = is_async; /* an empty batch still resolves (with empty arrays) */
+    return bulk_dispatch(env, self, wk);
+}
+static napi_value m_integrate_batch(napi_env env, napi_callback_info info) { return integrate_batch_common(env, info, 0); }
+static napi_value m_integrate_batch_async(napi_env env, napi_callback_info info) { return integrate_batch_common(env, info, 1); }
+
+/* allocPinned(bytes) -> ArrayBuffer over page-locked host memory (grv_host_alloc): a
+ * `new Float32Array(buf)` passed as renderFrame({out}) receives the frame in one DMA, with no copy
+ * on the JS side.  Freed when the ArrayBuffer is collected. */
+static void pinned_finalize(napi_env env, void *data, void *hint) {
+    (void)env;
+    (void)hint;
+    grv_host_free(data);
+}
+static napi_value f_alloc_pinned(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1], buf;
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    const double bytes = argc > 0 ? arg_f64(env, argv[0]) : 0.0;
+    if (!(bytes >= 1.0 && bytes <= 68719476736.0)) {
+        napi_throw_range_error(env, NULL, "allocPinned: size out of range");
+        return NULL;
+    }
+    void *p = grv_host_alloc((size_t)bytes);
+    if (!p) {
+        napi_throw_error(env, NULL, "allocPinned: hipHostMalloc failed (no HIP device?)");
+        return NULL;
+    }
+    if (napi_create_external_arraybuffer(env, p, (size_t)bytes, pinned_finalize, NULL, &buf) != napi_ok) {
+        grv_host_free(p);
+        napi_throw_error(env, NULL, "allocPinned: cannot wrap the allocation");
+        return NULL;
+    }
+    return buf;
 }
 
 /* renderWebGPUFrame(cameraUniforms: Float32Array(88), physicsParams: Float32Array(8),
@@ -685,8 +1056,17 @@ static napi_value m_free(napi_env env, napi_callback_info info) { /* wasm-bindge
     engine_box *box = NULL;
     NAPI_OK(napi_get_cb_info(env, info, &argc, NULL, &self, NULL));
     if (napi_unwrap(env, self, (void **)&box) == napi_ok && box && box->h) {
-        grv_engine_destroy(box->h);
-        box->h = NULL;
+        if (box->async_pending > 0) {
+            /* works are queued on the pool: the synchronous handle goes now (the object is unusable
+             * from here on), the async handles when the last work completes */
+            grv_engine_destroy(box->h);
+            box->h = NULL;
+            if (box->multi) grv_multi_destroy(box->multi);
+            box->multi = NULL;
+            box->freed = 1;
+        } else {
+            box_destroy_handles(box);
+        }
         slot_release(box);
     }
     return NULL;
@@ -749,6 +1129,10 @@ static napi_value module_init(napi_env env, napi_value exports) {
         METHOD("compute_proper_distance", m_compute_proper_distance),
         METHOD("renderFrame", m_render_frame),
         METHOD("render_frame", m_render_frame),
+        METHOD("renderFrameAsync", m_render_frame_async),
+        METHOD("integrate_batch", m_integrate_batch),
+        METHOD("integrateBatch", m_integrate_batch),
+        METHOD("integrateBatchAsync", m_integrate_batch_async),
         METHOD("renderWebGPUFrame", m_render_webgpu_frame),
         METHOD("renderWebGLFrame", m_render_webgl_frame),
         METHOD("free", m_free),
@@ -762,6 +1146,8 @@ static napi_value module_init(napi_env env, napi_value exports) {
     NAPI_OK(napi_set_named_property(env, exports, "init", fn));
     NAPI_OK(napi_create_function(env, "init_hooks", NAPI_AUTO_LENGTH, f_init_hooks, NULL, &fn));
     NAPI_OK(napi_set_named_property(env, exports, "init_hooks", fn));
+    NAPI_OK(napi_create_function(env, "allocPinned", NAPI_AUTO_LENGTH, f_alloc_pinned, NULL, &fn));
+    NAPI_OK(napi_set_named_property(env, exports, "allocPinned", fn));
     return exports;
 }
 

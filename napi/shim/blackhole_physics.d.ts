@@ -10,6 +10,9 @@ export interface InitOutput {
 
 export default function init(): Promise<InitOutput>;
 export function init_hooks(): void;
+/** ArrayBuffer over page-locked host memory: `new Float32Array(allocPinned(w*h*16))` passed as
+ *  renderFrame({out}) receives the frame in one DMA and no copy is made on the JS side */
+export function allocPinned(bytes: number): ArrayBuffer;
 
 export interface RenderFrameOptions {
   width: number;
@@ -28,6 +31,34 @@ export interface RenderFrameOptions {
   /** radial temperature profile of the disk: the shader's closed form (default) or the
    *  Page-Thorne table generate_disk_lut() returns (physics/disk.rs:175-201) */
   diskProfile?: "shortcut" | "pageThorne";
+  /** tile the image plane over the first n HIP devices of the node: each renders its round-robin
+   *  share of 64x64 tiles, one gather of finished tiles to device 0 (RCCL over xGMI) */
+  devices?: number;
+  /** the same assembly path with n ranks on device 0 (one-GPU hosts, tests) */
+  virtualRanks?: number;
+  /** render into this array (width*height*4) instead of a fresh one */
+  out?: Float32Array;
+}
+
+export interface IntegrateBatchOptions {
+  method?: "rkf45" | "rk4" | "symplectic";
+  metric?: "ks" | "bl" | "schwarzschild";
+  /** IntegrationOptions (geodesic/integrator.rs:24-47); defaults are IntegrationOptions::default */
+  tolerance?: number;
+  initialStep?: number;
+  maxSteps?: number;
+  escapeRadius?: number;
+  renormalizeInterval?: number;
+  stepSize?: number;
+  arith?: "strict" | "fast";
+}
+
+/** per ray: Trajectory.final_state / steps_taken / termination / max_hamiltonian_drift (geodesic/mod.rs:150-161) */
+export interface IntegrateBatchResult {
+  states: Float64Array;
+  steps: Uint32Array;
+  term: Uint8Array;
+  drift: Float64Array;
 }
 
 export interface RenderFrameResult {
@@ -38,6 +69,7 @@ export interface RenderFrameResult {
   rays: number;
   acceptedSteps: number;
   launches: number;
+  devices: number;
 }
 
 export interface WebGLFrameOptions {
@@ -105,6 +137,12 @@ export class PhysicsEngine {
   /** f64 RKF45 frame (pixel -> ray of compute.wgsl.ts:159-187) */
   renderFrame(options: RenderFrameOptions): RenderFrameResult;
   render_frame(options: RenderFrameOptions): RenderFrameResult;
+  /** the same frame on the libuv pool (an engine handle of its own): the caller's loop is not held */
+  renderFrameAsync(options: RenderFrameOptions): Promise<RenderFrameResult>;
+  /** n independent integrate() calls (geodesic/mod.rs:180-253) in one launch; states = 8 n f64 */
+  integrate_batch(states: Float64Array, options?: IntegrateBatchOptions): IntegrateBatchResult;
+  integrateBatch(states: Float64Array, options?: IntegrateBatchOptions): IntegrateBatchResult;
+  integrateBatchAsync(states: Float64Array, options?: IntegrateBatchOptions): Promise<IntegrateBatchResult>;
   /** WebGPURenderer.render with the 352-byte / 32-byte uniform blocks (src/types/webgpu.ts:67-116) */
   renderWebGPUFrame(
     cameraUniforms: Float32Array, physicsParams: Float32Array,

@@ -32,6 +32,8 @@ WASM_METHODS = [
     "integratePhotonGeodesic", "renderFrame", "free",
     # the renderers' frame surfaces
     "renderWebGPUFrame", "renderWebGLFrame",
+    # bulk / non-blocking entries
+    "integrate_batch", "integrateBatch", "integrateBatchAsync", "renderFrameAsync",
 ]
 
 pytestmark = pytest.mark.skipif(NODE is None or not os.path.exists(ADDON),
@@ -48,7 +50,7 @@ def test_addon_loads_and_exports_the_wasm_bindgen_surface():
               "p:Object.getOwnPropertyNames(m.PhysicsEngine.prototype),d:typeof m.default}))" % ADDON)
     assert r.returncode == 0, r.stderr
     got = json.loads(r.stdout)
-    assert {"PhysicsEngine", "default", "init_hooks"} <= set(got["k"]) and got["d"] == "function"
+    assert {"PhysicsEngine", "default", "init_hooks", "allocPinned"} <= set(got["k"]) and got["d"] == "function"
     missing = [m for m in WASM_METHODS if m not in got["p"]]
     assert not missing, missing
 
@@ -163,3 +165,50 @@ def test_worker_and_bridge_sab_protocol(oracle):
         assert t["finite"] and t["inputs_consumed"]
         assert np.allclose(t["camera"], want[64:76], rtol=1e-6, atol=1e-6)
         assert np.allclose(t["physics"], want[128:256], rtol=1e-6, atol=1e-6)
+
+
+def _bulk_rays(n):
+    """The initial states napi/bulk.js builds (same IEEE operations)."""
+    s = np.zeros((n, 8))
+    for i in range(n):
+        u = (i + 0.5) / n
+        s[i] = [0, 20 + 40 * ((i * 7919) % n) / n, math.pi / 2 - 0.4 + 0.8 * u, 0.1 * i, -1, -1, 0.3 - 0.6 * u,
+                -8 + 16 * u]
+    return s
+
+
+@pytest.mark.gpu
+def test_bulk_js_batch_async_and_multi_device_entries(oracle, tmp_path):
+    """napi/bulk.js: 4096 geodesics through ONE integrate_batch call equal the oracle's integrate()
+    bit for bit (STRICT is the default contract of the entry, as for integrate_ray_relativistic); the
+    *Async forms return the same bits while the caller's timer keeps ticking; renderFrame over
+    virtual ranks / into caller-owned pinned memory equals the one-device frame bit for bit."""
+    out = tmp_path / "bulk.json"
+    r = subprocess.run([NODE, os.path.join(ROOT, "napi", "bulk.js"), str(out)], capture_output=True, text=True,
+                       timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr + r.stdout[-2000:]
+    res = json.loads(out.read_text())
+    n = res["batch"]["n"]
+    init = _bulk_rays(n)
+    assert np.array_equal(np.array(res["batch"]["init"]), init.reshape(-1)[:64])
+    ref = oracle.integrate_batch(oracle.metric(oracle.KERR_KS, 1.0, 0.9),
+                                 oracle.options(max_steps=2000, tolerance=1e-8), init, nthreads=8)
+    got = np.array(res["batch"]["states"]).reshape(n, 8)
+    assert np.array_equal(got.view(np.uint64), ref["states"].view(np.uint64))
+    assert np.array_equal(np.array(res["batch"]["steps"], np.uint32), ref["steps"])
+    assert np.array_equal(np.array(res["batch"]["term"], np.uint8), ref["term"])
+    assert np.array_equal(np.array(res["batch"]["drift"]).view(np.uint64), ref["drift"].view(np.uint64))
+    assert len(set(res["batch"]["term"])) >= 2  # captured and escaped rays both present
+    # the one-ray FFI entry agrees with the batch on the same rays (same kernel body)
+    assert np.array_equal(np.array(res["single"]), got[:32])
+    a = res["async"]
+    assert a["batch_equal"] and a["frame_rays"] == 640 * 360 and a["frame_steps"] > 0
+    assert a["ticks_during"] >= 1  # the event loop ran while the pool thread waited for the GPU
+    f = res["frames"]
+    assert f["ranks_equal"] and f["async_ranks_equal"] and f["pinned_equal"] and f["pinned_is_out"]
+    assert f["steps1"] == f["steps4"] and f["devices4"] == 4 and f["update_reaches_ranks"]
+    e = res["errors"]
+    assert all(e["sync"]) and "8 n" in e["sync"][0] and "out of range" in e["sync"][1] and "out must be" in e["sync"][2]
+    assert e["async_rejected"] and res["empty"] == 0 and res["free_while_pending"] == 800
+    # per-ray cost from JS: a 4096-ray call must beat the one-ray entry by two orders of magnitude
+    assert res["us_per_ray_batch"] * 100 < res["single_ms_per_ray"] * 1e3
