@@ -199,6 +199,124 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+def workload_text(cfg, W, H, split):
+    if cfg == "c3":
+        return ("%dx%d frame%s, a=0.999 Kerr-Schild, adaptive RKF45 tol=1e-8 h0=0.01 escape=1000 "
+                "renorm=10 max_steps=2048, Planck LUT 512x64 Tmax=1e5 redshift shading, camera "
+                "r0=60M theta=97deg fov=60deg" % (W, H, split))
+    return ("%dx%d frame%s, a=0.999, f32 compute march (Kerr-Schild implicit-midpoint, "
+            "compute.wgsl.ts) at a fixed 1024-step budget, disk g-factor shading + star field "
+            "(packed / fast arithmetic: the star hash takes a FAST-contract sin, so individual stars "
+            "differ from the shader-order sky; parity tests compare with stars off), "
+            "camera r0=60M theta=97deg fov=60deg" % (W, H, split))
+
+
+def main_native(args, cfg, base_w, base_h):
+    """--native: one process, the C ABI's multi-GPU handle (csrc/engine_multi.hip).  Same workloads,
+    same timing contract (K frames bracketed by a full synchronise of every rank's streams)."""
+    if args.scaling != "strong":
+        raise SystemExit("--native splits the one frame (strong scaling)")
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
+        raise SystemExit("--native is one process: do not launch it under torch.distributed.run")
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
+    import torch
+
+    import blackhole_simulation_amd as bh
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    if not os.path.exists(bh.library_path()):
+        bh.build_library()
+    G = args.gpus
+    one_device = os.environ.get("GRV_BENCH_ONE_DEVICE") == "1"
+    if not one_device and torch.cuda.device_count() < G:
+        raise SystemExit("--gpus %d but only %d HIP device(s) visible" % (G, torch.cuda.device_count()))
+    transport = {"auto": bh.TRANSPORT_AUTO, "rccl": bh.TRANSPORT_RCCL, "peer": bh.TRANSPORT_PEER_COPY}[args.transport]
+    m = (bh.MultiEngine(1.0, 0.999, virtual_ranks=G) if one_device
+         else bh.MultiEngine(1.0, 0.999, devices=list(range(G)), transport=transport))
+    if m.ranks != G:
+        raise SystemExit("--gpus %d but the handle has %d ranks" % (G, m.ranks))
+    torch.cuda.set_device(0)
+    W, H = base_w, base_h
+    th = np.deg2rad(97.0)
+    eye = (60.0 * np.sin(th), 60.0 * np.cos(th), 0.0)
+    arith = {"fast": bh.ARITH_FAST, "strict": bh.ARITH_STRICT, "packed": bh.ARITH_FAST_PACKED}[args.arith]
+    cam = bh.camera_look_at(eye, aspect=W / H)
+    params = bh.render_params(W, H, arith=arith if cfg == "c3" else bh.ARITH_FAST, segment_tries=args.segment_tries)
+    prof = bh.render_params(W, H, arith=arith if cfg == "c3" else bh.ARITH_FAST, segment_tries=args.segment_tries,
+                            profile=1)
+    wp = bh.wgsl_params(W, H, cam, 1.0, 0.999, max_steps=1024, arith=arith) if cfg == "c4" else None
+    images = [torch.empty((H, W, 4), dtype=torch.float32, device="cuda:0") for _ in range(2)]
+    m.stats_accumulate(True)
+
+    def frame(i, p):
+        if cfg == "c3":
+            m.render_frame_device(cam, p, images[i % 2])
+        else:
+            m.render_frame_wgsl_device(wp, images[i % 2])
+
+    for i in range(args.warmup):
+        frame(i, params)
+    m.synchronize()
+    m.frame_stats_reset()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        frame(args.warmup + i, params)
+    m.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    st = m.frame_stats()
+    total_steps = float(st.accepted_steps)
+    # the dominant kernel of one rank's share, from profiled frames after the timed loop (c3: HIP
+    # events recorded by the library on each rank's launch stream; the slowest rank counts)
+    roofline = None
+    if cfg == "c3":
+        k = max(args.profile_frames, 1)
+        m.frame_stats_reset()
+        for i in range(k):
+            frame(i, prof)
+            m.synchronize()  # one frame at a time: the events then bracket one launch per rank
+        pst = m.frame_stats()
+        launches_per_rank = max(pst.launches / G, 1.0)
+        avg_launch_ms = pst.integrate_ms / max(launches_per_rank, 1.0)
+        share_bytes = (pst.accepted_steps / k * B_STEP[cfg] + W * H * B_RAY[cfg]) / G / max(launches_per_rank / k, 1.0)
+        achieved = share_bytes / (avg_launch_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "traffic_source": "not applicable to this run (committed pass: 1 GPU, whole frame)",
+                    "kernel": KERNEL_OF[(cfg, args.arith)], "avg_launch_ms": round(avg_launch_ms, 4),
+                    "launches_per_frame": launches_per_rank / k,
+                    "algorithmic_bytes_per_launch": int(share_bytes),
+                    "timing": "%d profiled frames after the timed loop, slowest rank's share (mean share bytes)" % k,
+                    "bound_actual": "fp64_valu"}
+    line = {
+        "metric": "Mray-steps/s", "value": round(total_steps / elapsed / 1e6, 2), "unit": "Mray-steps/s",
+        "n_gpus": G, "ranks": m.ranks, "rank_devices": m.rank_devices(), "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64" if cfg == "c3" else "f32", "data": "synthetic",
+        "config": {"workload": workload_text(cfg, W, H, "" if G == 1 else " split over %d GPUs" % G),
+                   "baseline_config": "configs[2]" if cfg == "c3" else "configs[3]", "arith": args.arith,
+                   "segment_tries": args.segment_tries or "one launch",
+                   "host": "one process through the C ABI (grv_engine_create_multi): a host thread and two "
+                           "streams per device",
+                   "partition": "64x64 tiles round-robin, one %s gather to rank 0 per frame, two frames in flight"
+                                % ("RCCL send/recv-group" if m.transport == bh.TRANSPORT_RCCL else "peer-copy")
+                   if G > 1 else "single GPU",
+                   "virtual_ranks_on_one_device": bool(one_device),
+                   "rays": W * H, "accepted_steps_per_frame": int(total_steps / args.steps),
+                   "host_waits_in_frame_loop": 0 if not args.segment_tries else "one per segment",
+                   "frames_in_flight": 2},
+        "roofline": roofline,
+    }
+    m.close()
+    sys.stdout.flush()
+    os.dup2(stdout_fd, 1)
+    print(json.dumps(line), flush=True)
+    os.dup2(2, 1)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,6 +338,12 @@ def main():
                          "so one frame's tail runs under the next frame's head)")
     ap.add_argument("--profile-frames", type=int, default=3,
                     help="N > 1: profiled frames after the timed loop (roofline block)")
+    ap.add_argument("--native", action="store_true",
+                    help="ONE process drives all N GPUs through the C ABI's multi-GPU handle "
+                         "(grv_engine_create_multi: a host thread and two streams per device, one RCCL "
+                         "send/recv group per frame) instead of N torch.distributed ranks")
+    ap.add_argument("--transport", choices=["auto", "rccl", "peer"], default="auto",
+                    help="--native: exchange transport (auto: RCCL between real devices)")
     args = ap.parse_args()
     cfg = args.config
     if args.arith is None:
@@ -230,6 +354,8 @@ def main():
     base_h = args.height or (2160 if cfg == "c3" else 4320)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.native:
+        return main_native(args, cfg, base_w, base_h)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # a bare `python bench.py --gpus N`: launch the N ranks ourselves (one process per GPU)
         raise SystemExit(spawn_ranks(args.gpus))
@@ -452,18 +578,9 @@ def main():
             roofline["hbm_measured_GBps"] = round(usable_pmc["hbm_bytes_per_launch"] / (avg_launch_ms * 1e-3) / 1e9, 1)
             if "valu" in usable_pmc:
                 roofline["valu_issue_frac"] = usable_pmc["valu"]["issue_frac"]
-        if cfg == "c3":
-            workload = ("%dx%d frame%s, a=0.999 Kerr-Schild, adaptive RKF45 tol=1e-8 h0=0.01 escape=1000 "
-                        "renorm=10 max_steps=2048, Planck LUT 512x64 Tmax=1e5 redshift shading, camera "
-                        "r0=60M theta=97deg fov=60deg"
-                        % (W, H, "" if world == 1 else (" split over %d GPUs" % world if args.scaling == "strong"
-                                                        else " (%dx%d per GPU x %d)" % (base_w, base_h, world))))
-        else:
-            workload = ("%dx%d frame%s, a=0.999, f32 compute march (Kerr-Schild implicit-midpoint, "
-                        "compute.wgsl.ts) at a fixed 1024-step budget, disk g-factor shading + star field, "
-                        "camera r0=60M theta=97deg fov=60deg"
-                        % (W, H, "" if world == 1 else (" split over %d GPUs" % world if args.scaling == "strong"
-                                                        else " (%dx%d per GPU x %d)" % (base_w, base_h, world))))
+        split = "" if world == 1 else (" split over %d GPUs" % world if args.scaling == "strong"
+                                         else " (%dx%d per GPU x %d)" % (base_w, base_h, world))
+        workload = workload_text(cfg, W, H, split)
         line = {
             "metric": "Mray-steps/s", "value": round(value, 2), "unit": "Mray-steps/s",
             "n_gpus": world, "ranks": dist.get_world_size() if use_dist else 1,

@@ -182,3 +182,30 @@ def test_rccl_transport_walk_on_one_device():
     r = subprocess.run([sys.executable, "-c", _RCCL_WALK % {"root": ROOT}], capture_output=True, text=True,
                        timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0 and "RCCL_WALK_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def _bench_native(*args):
+    import json
+    env = dict(os.environ, GRV_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--native"] + list(args),
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_native_drives_the_c_abi_multi_handle():
+    """bench.py --native: one process, grv_engine_create_multi (here: virtual ranks on the one GPU),
+    same frame and the same accepted steps per frame as the one-rank run."""
+    one = _bench_native("--gpus", "1", "--width", "640", "--height", "360", "--steps", "4", "--warmup", "1")
+    four = _bench_native("--gpus", "4", "--width", "640", "--height", "360", "--steps", "4", "--warmup", "1")
+    assert one["n_gpus"] == 1 and four["n_gpus"] == 4 and four["ranks"] == 4 and four["rank_devices"] == [0] * 4
+    assert four["config"]["accepted_steps_per_frame"] == one["config"]["accepted_steps_per_frame"]
+    assert four["config"]["virtual_ranks_on_one_device"] and four["config"]["frames_in_flight"] == 2
+    assert four["roofline"]["avg_launch_ms"] > 0 and four["value"] > 0
+    c4 = _bench_native("--gpus", "2", "--config", "c4", "--width", "512", "--height", "288", "--steps", "3",
+                       "--warmup", "1")
+    assert c4["dtype"] == "f32" and c4["n_gpus"] == 2 and c4["config"]["accepted_steps_per_frame"] > 0
