@@ -5,9 +5,8 @@ The shader-order (STRICT) kernels evaluate the shaders' transcendental functions
 specified f32 forms as the restatement (csrc/strict_libm.hpp <-> oracle/ref_libm.c) and must return
 its step counts and pixels bit for bit, stars included.  The FAST kernels (FMA, hardware
 rcp/rsq/exp2/log2, polynomial sin/cos) amplify their rounding differences over hundreds of f32
-steps, so their pixel parity is statistical.  Stated tolerance (written in the tests):
-  step counts equal on >= 99 % of pixels, |d steps| <= 2 on >= 99.9 %;
-  colour: |d| <= 2e-3 * frame peak on >= 99 % of pixels, <= 5e-2 * peak on >= 99.9 %."""
+steps, so their pixel parity is statistical: the stated tolerance is FAST_BARS below (what is measured, plus a bounded tail), and BASELINE configs[3] is checked in the very form
+the bench runs it (test_config4_bench_form_against_the_oracle)."""
 import numpy as np
 import pytest
 
@@ -122,19 +121,65 @@ def test_glsl_oracle_compositing_terms(oracle, engine_mod):
     assert (cam[..., :3].sum(-1) > 0).mean() > 0.01
 
 
-def _compare(got_rgba, got_steps, ref_rgba, ref_steps, exact=False):
+# FAST contract, stated tolerance (round 3: what is measured, plus a bounded tail).  Measured on MI355X
+# (tools/f32_fast_tail.py -> profiles/r03_f32_fast_tail.json; WGSL march, FAST and packed, 480x270 and
+# every 16th pixel of the 7680x4320 / 1024-step frame of BASELINE configs[3]): step counts equal on
+# 99.98 % of the pixels; |d colour| / peak: p50 = p90 = 0 (91 % of the pixels are bit-identical), p99
+# 2.3e-7, p99.9 3.4e-6, p99.99 4e-5, max 3.9e-2; no pixel beyond 5e-2.  The pixels that differ at all
+# in step count are the rays next to the critical curve (they orbit: up to the whole step budget of
+# difference) -- they end in the hole or far away either way, so their colour barely moves.
+FAST_BARS = dict(steps_equal=0.999, steps_within_2=0.9995, colour_1e4=0.999, colour_2e3=0.9995, beyond_5e2=1e-4)
+# The GLSL fragment shader (FAST) measures tighter still on its nine cases at 480x270: step counts
+# equal on >= 99.997 %, |d colour| / peak <= 1e-4 on >= 99.99 %, max 1.1e-2 -- it is held to the same bars.
+
+
+def _compare(got_rgba, got_steps, ref_rgba, ref_steps, exact=False, bars=FAST_BARS):
     if exact:   # shader order with the specified f32 functions: the checker's bits
         assert np.array_equal(got_steps, ref_steps)
         assert np.array_equal(got_rgba, ref_rgba, equal_nan=True)
-        return
+        return None
     ds = np.abs(got_steps.astype(np.int64) - ref_steps.astype(np.int64))
     peak = max(float(ref_rgba[..., :3].max()), 1e-12)
     dc = np.abs(got_rgba - ref_rgba)[..., :3].max(-1) / peak
-    print("steps equal %.5f, |ds|<=2 %.5f ; colour <=2e-3 %.5f, <=5e-2 %.5f, max %.3g ; identical pixels %.6f" %
-          ((ds == 0).mean(), (ds <= 2).mean(), (dc <= 2e-3).mean(), (dc <= 5e-2).mean(), dc.max(),
-           (got_rgba == ref_rgba).all(-1).mean()))
-    assert (ds == 0).mean() >= 0.99 and (ds <= 2).mean() >= 0.999
-    assert (dc <= 2e-3).mean() >= 0.99 and (dc <= 5e-2).mean() >= 0.999
+    m = dict(steps_equal=float((ds == 0).mean()), steps_within_2=float((ds <= 2).mean()),
+             colour_1e4=float((dc <= 1e-4).mean()), colour_2e3=float((dc <= 2e-3).mean()),
+             beyond_5e2=float((dc > 5e-2).mean()), colour_max=float(dc.max()),
+             colour_p99=float(np.percentile(dc, 99)), colour_p9999=float(np.percentile(dc, 99.99)),
+             identical=float((got_rgba == ref_rgba).all(-1).mean()))
+    print("FAST vs oracle:", m)
+    for k in ("steps_equal", "steps_within_2", "colour_1e4", "colour_2e3"):
+        assert m[k] >= bars[k], (k, m[k], bars[k])
+    assert m["beyond_5e2"] <= bars["beyond_5e2"], m
+    return m
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arith", [1, 2])
+def test_config4_bench_form_against_the_oracle(engine_mod, oracle, arith):
+    """BASELINE configs[3] exactly as `bench.py --config c4` runs it -- 7680x4320, fixed 1024-step
+    budget, FAST contract (arith 2 = two rays per lane on the packed-f32 ops, the bench default) --
+    against the shader-order oracle on every 16th pixel in x and y (129 600 rays), stars off (one ulp
+    of the hash's sin lights a different star: the bench line's sky differs star by star from the
+    shader-order sky, and config.workload says so).  The FAST checks otherwise stop at 480x270."""
+    import torch
+    W, H, stride = 7680, 4320, 16
+    cam = engine_mod.camera_look_at(EYE, aspect=W / H)
+    gp = engine_mod.wgsl_params(W, H, cam, 1.0, 0.999, max_steps=1024, arith=arith, stars=0)
+    with engine_mod.PhysicsEngine(1.0, 0.999) as e:
+        rgba = torch.zeros(W * H, 4, dtype=torch.float32, device="cuda:0")
+        steps = torch.zeros(W * H, dtype=torch.int32, device="cuda:0")
+        tot = e.render_frame_wgsl(gp, rgba, steps)
+        assert tot == int(steps.sum(dtype=torch.int64).item())
+        g = rgba.view(H, W, 4)[::stride, ::stride].cpu().numpy()
+        s = steps.view(H, W)[::stride, ::stride].cpu().numpy()
+    ref_rgba, ref_steps = oracle.wgsl_frame(oracle.wgsl_params_from(gp), stride=(stride, stride), nthreads=16)
+    assert ref_steps.shape == s.shape == (270, 480)
+    m = _compare(g, s, ref_rgba, ref_steps)
+    assert m["colour_max"] <= 5e-2
+    # rays still marching when the budget runs out orbit next to the critical curve, where one ulp
+    # decides between another turn and falling in: a handful of the 129 600 on either side (measured
+    # 13 here against 3 in the oracle)
+    assert int((s == 1024).sum()) <= 40 and int((ref_steps == 1024).sum()) <= 40
 
 
 @pytest.mark.gpu
