@@ -4,7 +4,8 @@ Runs on the GPU box.  For the WGSL compute march (FAST and two-rays-per-lane PAC
 size and at BASELINE configs[3] (7680x4320, 1024 steps, every 16th pixel in x and y), stars off:
 percentiles of |d steps| and |d colour| / peak, the fractions beyond the two colour bars, and a
 classification of the pixels beyond 5e-2 (step count differs / lit-dark flip at a disk edge / other).
--> profiles/r03_f32_fast_tail.json"""
+-> profiles/r03_f32_fast_tail.json
+(a checker-side measurement: it lives under tests/ because it calls the oracle)"""
 import json
 import os
 import sys

@@ -122,7 +122,7 @@ def test_glsl_oracle_compositing_terms(oracle, engine_mod):
 
 
 # FAST contract, stated tolerance (round 3: what is measured, plus a bounded tail).  Measured on MI355X
-# (tools/f32_fast_tail.py -> profiles/r03_f32_fast_tail.json; WGSL march, FAST and packed, 480x270 and
+# (tests/measure_f32_fast_tail.py -> profiles/r03_f32_fast_tail.json; WGSL march, FAST and packed, 480x270 and
 # every 16th pixel of the 7680x4320 / 1024-step frame of BASELINE configs[3]): step counts equal on
 # 99.98 % of the pixels; |d colour| / peak: p50 = p90 = 0 (91 % of the pixels are bit-identical), p99
 # 2.3e-7, p99.9 3.4e-6, p99.99 4e-5, max 3.9e-2; no pixel beyond 5e-2.  The pixels that differ at all
