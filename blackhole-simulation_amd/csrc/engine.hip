@@ -202,6 +202,7 @@ bool options_valid(const GrvOptions &o) {
     if (o.method < GRV_METHOD_RKF45 || o.method > GRV_METHOD_SYMPLECTIC) return false;
     if (o.metric_kind < GRV_METRIC_KERR_BL || o.metric_kind > GRV_METRIC_SCHWARZSCHILD) return false;
     if (o.arith != GRV_ARITH_STRICT && o.arith != GRV_ARITH_FAST) return false;
+    if (o.reserved != 0) return false;
     // STRICT takes any tolerance, as the reference does: 0 or NaN rejects every try and walks the
     // forced 1e-5 steps, a negative one accepts every try (integrator.rs:76-104).  The FAST
     // contract multiplies by 1 / tolerance and is defined for positive tolerances only.
@@ -218,6 +219,14 @@ hipError_t launch_segment(int arith, int kind, int method, const RayWorkspace &w
     return arith == GRV_ARITH_FAST
                ? launch_segment_fast(kind, method, ws, P, live_in, n_live, live_out, cnt, s)
                : launch_segment_strict(kind, method, ws, P, live_in, n_live, live_out, cnt, s);
+}
+
+hipError_t launch_path(int arith, int kind, int method, const RayWorkspace &ws, const SegmentParams &P,
+                       const double *states_in, double *paths, uint32_t *counts, uint32_t max_points,
+                       hipStream_t s) {
+    return arith == GRV_ARITH_FAST
+               ? launch_path_fast(kind, method, ws, P, states_in, paths, counts, max_points, s)
+               : launch_path_strict(kind, method, ws, P, states_in, paths, counts, max_points, s);
 }
 
 hipError_t launch_refill(int arith, int kind, int method, const RayWorkspace &ws,
@@ -640,6 +649,95 @@ int grv_integrate_batch(grv_engine *e, size_t n, const double *states, const Grv
     if (rc != GRV_OK) return rc;
     GRV_HIP(e, hipDeviceSynchronize());
     GRV_HIP(e, hipMemcpy(out_states, d_out, n * 64, hipMemcpyDeviceToHost));
+    if (steps) GRV_HIP(e, hipMemcpy(steps, d_steps, n * 4, hipMemcpyDeviceToHost));
+    if (termination) GRV_HIP(e, hipMemcpy(termination, d_term, n, hipMemcpyDeviceToHost));
+    if (drift) GRV_HIP(e, hipMemcpy(drift, d_drift, n * 8, hipMemcpyDeviceToHost));
+    return GRV_OK;
+}
+
+// Trajectory.path (geodesic/mod.rs:160): the batch call with the recorded path of every ray.
+int grv_integrate_paths_device(grv_engine *e, size_t n, const double *d_states, const GrvOptions *opt,
+                               size_t max_points, double *d_paths, uint32_t *d_counts,
+                               double *d_out_states, uint32_t *d_steps, uint8_t *d_termination,
+                               double *d_drift, void *stream) {
+    if (!e) return GRV_ERR_INVALID;
+    if (!opt || !options_valid(*opt)) return fail(e, GRV_ERR_INVALID, "invalid GrvOptions");
+    if (n == 0) return GRV_OK;
+    if (!d_states) return fail(e, GRV_ERR_INVALID, "null states");
+    if (!d_counts) return fail(e, GRV_ERR_INVALID, "null counts");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!opt->record_path) { // path: None -- the plain batch call, and every Vec has length 0
+        const int rc = grv_integrate_batch_device(e, n, d_states, opt, d_out_states, d_steps, d_termination,
+                                                  d_drift, stream);
+        if (rc != GRV_OK) return rc;
+        GRV_HIP(e, hipMemsetAsync(d_counts, 0, n * sizeof(uint32_t), s));
+        return GRV_OK;
+    }
+    if (n > 0x7FFFFFFFull) return fail(e, GRV_ERR_INVALID, "batch too large");
+    if (max_points > 0xFFFFFFFFull) return fail(e, GRV_ERR_INVALID, "max_points too large");
+    if (max_points > 0 && !d_paths) return fail(e, GRV_ERR_INVALID, "null paths");
+    GRV_HIP(e, hipSetDevice(e->device));
+    CallScope scope(e, s);
+    int rc = ensure_workspace(e, n, s);
+    if (rc != GRV_OK) return rc;
+    SegmentParams P = make_segment_params(e, *opt);
+    rc = begin_frame_stats(e, s);
+    if (rc != GRV_OK) return rc;
+    GRV_HIP(e, launch_init_states(opt->metric_kind, e->ws, P, d_states, opt->initial_step,
+                                  opt->method == GRV_METHOD_RKF45, s));
+    P.max_tries = try_bound(opt->max_steps);
+    P.final_launch = 1;
+    GRV_HIP(e, launch_path(opt->arith, opt->metric_kind, opt->method, e->ws, P, d_states, d_paths, d_counts,
+                           (uint32_t)max_points, s));
+    e->last_launches += 1;
+    GRV_HIP(e, launch_finalize_batch(e->ws, d_out_states, d_steps, d_termination, d_drift, e->d_stats, s));
+    return GRV_OK;
+}
+
+int grv_integrate_paths(grv_engine *e, size_t n, const double *states, const GrvOptions *opt,
+                        size_t max_points, double *out_paths, uint32_t *out_counts, double *out_states,
+                        uint32_t *steps, uint8_t *termination, double *drift) {
+    if (!e) return GRV_ERR_INVALID;
+    if (n == 0) return GRV_OK;
+    if (!states || !out_counts) return fail(e, GRV_ERR_INVALID, "null states / counts");
+    if (!opt) return fail(e, GRV_ERR_INVALID, "invalid GrvOptions");
+    const bool rec = opt->record_path != 0;
+    if (rec && max_points > 0 && !out_paths) return fail(e, GRV_ERR_INVALID, "null paths");
+    if (max_points > 0xFFFFFFFFull || (rec && max_points && n > ((size_t)1 << 40) / 64 / max_points))
+        return fail(e, GRV_ERR_INVALID, "path buffer too large"); // more than 1 TiB of path rows
+    GRV_HIP(e, hipSetDevice(e->device));
+    const size_t sb = align_up(n * 64, 256), ub = align_up(n * 4, 256), bb = align_up(n, 256),
+                 db = align_up(n * 8, 256), pb = rec ? align_up(n * max_points * 64, 256) : 0;
+    int rc = ensure_stage(e, 2 * sb + 2 * ub + bb + db + pb);
+    if (rc != GRV_OK) return rc;
+    char *p = static_cast<char *>(e->stage_mem);
+    double *d_in = reinterpret_cast<double *>(p);
+    double *d_out = reinterpret_cast<double *>(p + sb);
+    uint32_t *d_steps = reinterpret_cast<uint32_t *>(p + 2 * sb);
+    uint32_t *d_counts = reinterpret_cast<uint32_t *>(p + 2 * sb + ub);
+    uint8_t *d_term = reinterpret_cast<uint8_t *>(p + 2 * sb + 2 * ub);
+    double *d_drift = reinterpret_cast<double *>(p + 2 * sb + 2 * ub + bb);
+    double *d_paths = reinterpret_cast<double *>(p + 2 * sb + 2 * ub + bb + db);
+    GRV_HIP(e, hipMemcpy(d_in, states, n * 64, hipMemcpyHostToDevice));
+    rc = grv_integrate_paths_device(e, n, d_in, opt, max_points, d_paths, d_counts, d_out, d_steps, d_term,
+                                    d_drift, nullptr);
+    if (rc != GRV_OK) return rc;
+    GRV_HIP(e, hipDeviceSynchronize());
+    GRV_HIP(e, hipMemcpy(out_counts, d_counts, n * 4, hipMemcpyDeviceToHost));
+    if (rec && max_points) {
+        // a ray's row holds min(count, max_points) points; the rest of the caller's row stays untouched
+        bool full = true;
+        for (size_t i = 0; i < n; ++i) full = full && out_counts[i] >= max_points;
+        if (full) {
+            GRV_HIP(e, hipMemcpy(out_paths, d_paths, n * max_points * 64, hipMemcpyDeviceToHost));
+        } else {
+            for (size_t i = 0; i < n; ++i) {
+                const size_t k = out_counts[i] < max_points ? out_counts[i] : max_points;
+                if (k) GRV_HIP(e, hipMemcpy(out_paths + i * max_points * 8, d_paths + i * max_points * 8, k * 64, hipMemcpyDeviceToHost));
+            }
+        }
+    }
+    if (out_states) GRV_HIP(e, hipMemcpy(out_states, d_out, n * 64, hipMemcpyDeviceToHost));
     if (steps) GRV_HIP(e, hipMemcpy(steps, d_steps, n * 4, hipMemcpyDeviceToHost));
     if (termination) GRV_HIP(e, hipMemcpy(termination, d_term, n, hipMemcpyDeviceToHost));
     if (drift) GRV_HIP(e, hipMemcpy(drift, d_drift, n * 8, hipMemcpyDeviceToHost));

@@ -129,6 +129,9 @@ hipError_t launch_segment_strict(int kind, int method, const RayWorkspace &ws,
                                  uint32_t *live_out, uint32_t *live_out_count, hipStream_t s);
 hipError_t launch_refill_strict(int kind, int method, const RayWorkspace &ws, const SegmentParams &P,
                                 uint32_t *cursor, int n_cu, hipStream_t s);
+hipError_t launch_path_strict(int kind, int method, const RayWorkspace &ws, const SegmentParams &P,
+                              const double *states_in, double *paths, uint32_t *counts, uint32_t max_points,
+                              hipStream_t s);
 hipError_t launch_single_ray(int kind, const SegmentParams &P, const SingleRayIn &in, double h0,
                              SingleRayOut *out_pinned, uint32_t seq, hipStream_t s);
 hipError_t launch_init_states(int kind, const RayWorkspace &ws, const SegmentParams &P,
@@ -195,5 +198,8 @@ hipError_t launch_segment_fast(int kind, int method, const RayWorkspace &ws,
                                uint32_t *live_out, uint32_t *live_out_count, hipStream_t s);
 hipError_t launch_refill_fast(int kind, int method, const RayWorkspace &ws, const SegmentParams &P,
                               uint32_t *cursor, int n_cu, hipStream_t s);
+hipError_t launch_path_fast(int kind, int method, const RayWorkspace &ws, const SegmentParams &P,
+                            const double *states_in, double *paths, uint32_t *counts, uint32_t max_points,
+                            hipStream_t s);
 
 } // namespace grvhip

@@ -534,6 +534,64 @@ void integrate_segment_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// The path kernel: integrate() with IntegrationOptions.record_path (integrator.rs:32), i.e.
+// Trajectory.path (mod.rs:160).  One launch runs every ray of a (small) batch to its end and
+// appends the state after every completed loop body (mod.rs:241-243: after the step, the periodic
+// renormalisation and `steps += 1`) to the ray's row of `paths`, AoS GeodesicState like the
+// reference's Vec<GeodesicState>.  Point 0 is the state as handed in, BEFORE the initial
+// renormalize_null (mod.rs:193-197 pushes it ahead of mod.rs:200), so it comes from the caller's
+// array, not from the workspace.  counts[i] = points the reference's Vec would hold (1 + steps
+// taken); at most max_points of them are stored.  Same advance_one as every other schedule.
+// ---------------------------------------------------------------------------
+template <int KIND, int ARITH, int METHOD>
+__global__ __launch_bounds__(kBlock) void integrate_path_kernel(
+    RayWorkspace ws, SegmentParams P, const double *__restrict__ states_in, double *__restrict__ paths,
+    uint32_t *__restrict__ counts, uint32_t max_points) {
+    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+    const bool have = slot < ws.n;
+    RayRegs y;
+    y.flags = 0;
+    y.pt = y.pph = 0.0;
+    if (have) load_ray(ws, slot, y);
+    const Hole<double> bh = make_hole(P);
+    double2 *row = reinterpret_cast<double2 *>(paths + (size_t)slot * max_points * 8);
+    uint32_t npts = 0;
+    if (have) {
+        if (max_points > 0u) {
+            const double2 *src = reinterpret_cast<const double2 *>(states_in + (size_t)slot * 8);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) row[q] = src[q];
+        }
+        npts = 1;
+    }
+    bool live = have && ray_live(y);
+    KsRayConsts rc;
+    ray_resume<KIND, ARITH>(bh, y, P, live, rc);
+    for (uint32_t it = 0; it < P.max_tries; ++it) {
+        if (__ballot(live) == 0ull) break;
+        if (live) {
+            const uint32_t before = y.steps;
+            live = advance_one<KIND, ARITH, METHOD>(bh, y, P, ws, slot, rc);
+            if (y.steps != before) {
+                if (npts < max_points) {
+                    double2 *dst = row + (size_t)npts * 4;
+                    dst[0] = make_double2(y.t, y.r);
+                    dst[1] = make_double2(y.th, y.ph);
+                    dst[2] = make_double2(y.pt, y.pr);
+                    dst[3] = make_double2(y.pth, y.pph);
+                }
+                npts += 1;
+            }
+        }
+    }
+    if (live) y.flags = (y.flags & ~kFlagTermMask) | GRV_TERM_MAXSTEPS; // hard try bound: never a hang
+    if (have) {
+        store_ray(ws, slot, y);
+        counts[slot] = npts;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // The refill kernel: a resident grid (one launch) whose waves pull rays from a
 // global cursor.  Every `P.max_tries` tries a wave hands its finished lanes' rays
 // back to HBM and gives those lanes the next unclaimed slots (one wave-aggregated

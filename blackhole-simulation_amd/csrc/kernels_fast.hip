@@ -53,6 +53,12 @@ hipError_t launch_segment_fast(int kind, int method, const RayWorkspace &ws,
 #undef GRV_REFILL_ARITH
 #undef GRV_REFILL_FN
 
+#define GRV_PATH_ARITH GRV_ARITH_FAST
+#define GRV_PATH_FN launch_path_fast
+#include "path_launch.inc"
+#undef GRV_PATH_ARITH
+#undef GRV_PATH_FN
+
 hipError_t launch_wgsl_symplectic_fast(const FrameGeom &G, const WgslParams &P, float *out_rgba,
                                        uint32_t *out_steps, unsigned long long *total_steps,
                                        uint32_t n_slots, hipStream_t s) {

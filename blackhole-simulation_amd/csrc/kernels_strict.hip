@@ -50,6 +50,12 @@ hipError_t launch_segment_strict(int kind, int method, const RayWorkspace &ws,
 #undef GRV_REFILL_ARITH
 #undef GRV_REFILL_FN
 
+#define GRV_PATH_ARITH GRV_ARITH_STRICT
+#define GRV_PATH_FN launch_path_strict
+#include "path_launch.inc"
+#undef GRV_PATH_ARITH
+#undef GRV_PATH_FN
+
 hipError_t launch_single_ray(int kind, const SegmentParams &P, const SingleRayIn &in, double h0,
                              SingleRayOut *out_pinned, uint32_t seq, hipStream_t s) {
     switch (kind) {

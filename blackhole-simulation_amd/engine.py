@@ -35,7 +35,8 @@ class Options(C.Structure):
     _fields_ = [("method", C.c_int32), ("metric_kind", C.c_int32), ("tolerance", C.c_double),
                 ("initial_step", C.c_double), ("max_steps", C.c_uint64),
                 ("escape_radius", C.c_double), ("renormalize_interval", C.c_uint64),
-                ("step_size", C.c_double), ("arith", C.c_int32), ("segment_tries", C.c_int32)]
+                ("step_size", C.c_double), ("arith", C.c_int32), ("segment_tries", C.c_int32),
+                ("record_path", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Camera(C.Structure):
@@ -170,6 +171,10 @@ def load_library():
     L.grv_integrate_batch.argtypes = [p, sz, p, C.POINTER(Options), p, p, p, p]
     L.grv_integrate_batch_device.restype = i
     L.grv_integrate_batch_device.argtypes = [p, sz, p, C.POINTER(Options), p, p, p, p, p]
+    L.grv_integrate_paths.restype = i
+    L.grv_integrate_paths.argtypes = [p, sz, p, C.POINTER(Options), sz, p, p, p, p, p, p]
+    L.grv_integrate_paths_device.restype = i
+    L.grv_integrate_paths_device.argtypes = [p, sz, p, C.POINTER(Options), sz, p, p, p, p, p, p, p]
     L.grv_tile_pitch.restype = C.c_uint32
     L.grv_tile_pitch.argtypes = [C.c_uint32, C.c_uint32]
     L.grv_frame_ray_count.restype = sz
@@ -481,6 +486,37 @@ class PhysicsEngine:
             self._h, int(n), _dev_ptr(d_states), C.byref(options), _dev_ptr(d_out),
             _dev_ptr(d_steps), _dev_ptr(d_term), _dev_ptr(d_drift),
             C.c_void_p(stream) if stream else None), "integrate_batch_device")
+
+    # ---- Trajectory.path (geodesic/mod.rs:150-161, IntegrationOptions.record_path) ----
+    def integrate_paths(self, states, options, max_points=None):
+        """integrate() with record_path: returns the batch dict plus `paths` (a list of [k, 8] arrays,
+        the reference's Vec<GeodesicState> per ray: the initial state as handed in, then the state
+        after every completed step) and `counts` (1 + steps_taken; a ray's array holds
+        min(count, max_points) of them).  With options.record_path == 0 `paths` is None (path: None).
+        max_points defaults to max_steps + 1, the longest path a ray can have."""
+        a = np.ascontiguousarray(states, dtype=np.float64).reshape(-1, 8)
+        n = a.shape[0]
+        rec = bool(options.record_path)
+        if max_points is None:
+            max_points = int(options.max_steps) + 1
+        out = np.zeros_like(a)
+        steps = np.zeros(n, np.uint32)
+        term = np.zeros(n, np.uint8)
+        drift = np.zeros(n, np.float64)
+        counts = np.zeros(n, np.uint32)
+        rows = np.zeros((n, max_points, 8), np.float64) if rec else None
+        self._check(self._lib.grv_integrate_paths(self._h, n, _np_ptr(a), C.byref(options), int(max_points),
+                                                  _np_ptr(rows) if rec else None, _np_ptr(counts), _np_ptr(out),
+                                                  _np_ptr(steps), _np_ptr(term), _np_ptr(drift)), "integrate_paths")
+        paths = [rows[i, :min(int(counts[i]), max_points)].copy() for i in range(n)] if rec else None
+        return dict(states=out, steps=steps, term=term, drift=drift, counts=counts, paths=paths)
+
+    def integrate_paths_device(self, n, d_states, options, max_points, d_paths, d_counts, d_out=None,
+                               d_steps=None, d_term=None, d_drift=None, stream=None):
+        self._check(self._lib.grv_integrate_paths_device(
+            self._h, int(n), _dev_ptr(d_states), C.byref(options), int(max_points), _dev_ptr(d_paths),
+            _dev_ptr(d_counts), _dev_ptr(d_out), _dev_ptr(d_steps), _dev_ptr(d_term), _dev_ptr(d_drift),
+            C.c_void_p(stream) if stream else None), "integrate_paths_device")
 
     # ---- frame ----
     def frame_ray_count(self, params):

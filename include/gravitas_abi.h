@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GRV_ABI_VERSION 3
+#define GRV_ABI_VERSION 4
 
 typedef struct grv_engine grv_engine;
 
@@ -77,6 +77,10 @@ typedef struct {
                                       >0 = relaunch with live-ray compaction every segment_tries
                                            tries (one host read-back per launch).
                                       Results do not depend on this field. */
+    int32_t record_path;           /* integrator.rs:32 IntegrationOptions.record_path: read by
+                                      grv_integrate_paths only (the other entry points have no path
+                                      output, as a Trajectory with path: None) */
+    int32_t reserved;              /* must be 0 */
 } GrvOptions;
 
 /* f64 mirror of the CameraUniforms fields the compute kernel reads
@@ -187,6 +191,26 @@ int grv_integrate_batch(grv_engine *e, size_t n, const double *states, const Grv
 int grv_integrate_batch_device(grv_engine *e, size_t n, const double *d_states,
                                const GrvOptions *opt, double *d_out_states, uint32_t *d_steps,
                                uint8_t *d_termination, double *d_drift, void *stream);
+
+/* ---- Trajectory.path: geodesic/mod.rs:150-161 (the visualised geodesics) ----
+ * n independent integrate() calls that also return what the reference collects under
+ * IntegrationOptions.record_path (integrator.rs:32): point 0 is the initial state as handed in,
+ * pushed BEFORE the initial renormalize_null (mod.rs:193-197, 200), then the state after every
+ * completed loop body (mod.rs:241-243) -- 1 + steps_taken points.
+ *   out_paths  [n][max_points][8]  AoS GeodesicState rows (the Vec<GeodesicState> of each ray);
+ *   out_counts [n]                 length of the reference's Vec: 1 + steps_taken, or 0 when
+ *                                  opt->record_path == 0 (path: None; out_paths is not touched).
+ * Only the first min(count, max_points) points of a ray are stored; the rest of its row is not
+ * written.  out_states / steps / termination / drift as grv_integrate_batch (any may be NULL).
+ * One launch runs every ray to its end: meant for the few rays a scene draws, not for frames. */
+int grv_integrate_paths(grv_engine *e, size_t n, const double *states, const GrvOptions *opt,
+                        size_t max_points, double *out_paths, uint32_t *out_counts,
+                        double *out_states, uint32_t *steps, uint8_t *termination, double *drift);
+/* same with device pointers, asynchronous on `stream` */
+int grv_integrate_paths_device(grv_engine *e, size_t n, const double *d_states, const GrvOptions *opt,
+                               size_t max_points, double *d_paths, uint32_t *d_counts,
+                               double *d_out_states, uint32_t *d_steps, uint8_t *d_termination,
+                               double *d_drift, void *stream);
 
 /* ---- frame: pixel->state of src/shaders/compute.wgsl.ts:159-187 + integrate + shading ---- */
 size_t grv_frame_ray_count(const GrvRenderParams *p); /* rays this rank renders */

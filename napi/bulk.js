@@ -73,6 +73,10 @@ const now = () => { const t = process.hrtime(); return t[0] * 1e3 + t[1] / 1e6; 
   try { await engine.renderFrameAsync({ width: 8, height: 8, devices: 63 }); } catch (e) { rejected = String(e.message); }
   res.errors = { sync: errs, async_rejected: rejected };
   res.empty = engine.integrate_batch(new Float64Array(0)).steps.length;
+  // recordPath: Trajectory.path of the first 16 rays (engine is at spin 0.5 here), 64 rows per ray
+  const pp = engine.integrate_batch(init.slice(0, 128), { maxSteps: 2000, tolerance: 1e-8, recordPath: true, maxPoints: 64 });
+  res.paths = { init: Array.from(init.slice(0, 128)), counts: Array.from(pp.counts), maxPoints: pp.maxPoints,
+                rows: Array.from(pp.paths), steps: Array.from(pp.steps) };
   // free() with a work still queued: the promise still settles
   const e2 = new wasm.PhysicsEngine(1.0, 0.7);
   const late = e2.integrateBatchAsync(init.slice(0, 800), opts);

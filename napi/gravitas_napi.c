@@ -539,6 +539,18 @@ static double obj_f64(napi_env env, napi_value obj, const char *key, double dflt
     return arg_f64(env, v);
 }
 
+/* a boolean option (true / false, or a number compared with 0) */
+static int obj_flag(napi_env env, napi_value obj, const char *key) {
+    bool has = false, b = false;
+    napi_value v;
+    napi_valuetype t;
+    if (napi_has_named_property(env, obj, key, &has) != napi_ok || !has) return 0;
+    if (napi_get_named_property(env, obj, key, &v) != napi_ok || napi_typeof(env, v, &t) != napi_ok) return 0;
+    if (t == napi_boolean) return napi_get_value_bool(env, v, &b) == napi_ok && b;
+    if (t == napi_number) return arg_f64(env, v) != 0.0;
+    return 0;
+}
+
 static void obj_vec3(napi_env env, napi_value obj, const char *key, double out[3]) {
     bool has = false;
     napi_value arr, e;
@@ -581,10 +593,13 @@ typedef struct {
     double *in, *out_states, *drift;
     uint32_t *steps;
     uint8_t *term;
+    size_t max_points;  /* recordPath: rows of `paths` per ray */
+    double *paths;      /* [n][max_points][8] */
+    uint32_t *counts;   /* [n] */
     /* result */
     int rc;
     char err[256];
-    napi_ref keep[5]; /* typed arrays of the result (and the caller's input) kept alive while queued */
+    napi_ref keep[7]; /* typed arrays of the result (and the caller's input) kept alive while queued */
     int n_keep;
     napi_ref self_ref;
     napi_deferred deferred;
@@ -646,14 +661,18 @@ static void bulk_execute(bulk_work *w) {
             if (w->rc != GRV_OK) snprintf(w->err, sizeof w->err, "%s", grv_last_error(h));
         }
     } else {
-        w->rc = grv_integrate_batch(h, w->n, w->in, &w->opt, w->out_states, w->steps, w->term, w->drift);
+        if (w->opt.record_path)
+            w->rc = grv_integrate_paths(h, w->n, w->in, &w->opt, w->max_points, w->paths, w->counts, w->out_states,
+                                        w->steps, w->term, w->drift);
+        else
+            w->rc = grv_integrate_batch(h, w->n, w->in, &w->opt, w->out_states, w->steps, w->term, w->drift);
         if (w->rc != GRV_OK) snprintf(w->err, sizeof w->err, "%s", grv_last_error(h));
     }
     if (w->is_async) pthread_mutex_unlock(&b->async_mu);
 }
 
 static napi_value bulk_result(napi_env env, bulk_work *w) {
-    napi_value out, v[5];
+    napi_value out, v[7];
     for (int k = 0; k < w->n_keep; k++)
         if (napi_get_reference_value(env, w->keep[k], &v[k]) != napi_ok) return NULL;
     if (napi_create_object(env, &out) != napi_ok) return NULL;
@@ -671,6 +690,11 @@ static napi_value bulk_result(napi_env env, bulk_work *w) {
         napi_set_named_property(env, out, "steps", v[1]);
         napi_set_named_property(env, out, "term", v[2]);
         napi_set_named_property(env, out, "drift", v[3]);
+        if (w->opt.record_path) { /* Trajectory.path (mod.rs:160): row i holds min(counts[i], maxPoints) states */
+            napi_set_named_property(env, out, "paths", v[4]);
+            napi_set_named_property(env, out, "counts", v[5]);
+            napi_set_named_property(env, out, "maxPoints", mk_f64(env, (double)w->max_points));
+        }
     }
     return out;
 }
@@ -898,14 +922,25 @@ static napi_value integrate_batch_common(napi_env env, napi_callback_info info, 
         o->escape_radius = obj_f64(env, argv[1], "escapeRadius", o->escape_radius);
         o->renormalize_interval = (uint64_t)obj_f64(env, argv[1], "renormalizeInterval", (double)o->renormalize_interval);
         o->step_size = obj_f64(env, argv[1], "stepSize", o->step_size);
+        /* IntegrationOptions.record_path (integrator.rs:32): the result gains `paths` and `counts` */
+        o->record_path = obj_flag(env, argv[1], "recordPath");
+        const double mp = obj_f64(env, argv[1], "maxPoints", (double)o->max_steps + 1.0);
+        wk->max_points = o->record_path ? (size_t)(mp < 0.0 ? 0.0 : mp > 4294967295.0 ? 4294967295.0 : mp) : 0;
     }
     const size_t n = wk->n;
-    napi_value ab[4], ta[4];
-    void *mem[4] = {NULL, NULL, NULL, NULL};
-    const size_t bytes[4] = {n * 64, n * 4, n, n * 8};
-    const napi_typedarray_type tys[4] = {napi_float64_array, napi_uint32_array, napi_uint8_array, napi_float64_array};
-    const size_t counts[4] = {n * 8, n, n, n};
-    for (int k = 0; k < 4; k++) {
+    if (o->record_path && wk->max_points && n > ((size_t)1 << 33) / 64 / wk->max_points) { /* 8 GiB of rows */
+        free(wk);
+        napi_throw_range_error(env, NULL, "integrate_batch: n x maxPoints is too large; pass a smaller maxPoints");
+        return NULL;
+    }
+    napi_value ab[6], ta[6];
+    void *mem[6] = {NULL, NULL, NULL, NULL, NULL, NULL};
+    const size_t bytes[6] = {n * 64, n * 4, n, n * 8, n * wk->max_points * 64, n * 4};
+    const napi_typedarray_type tys[6] = {napi_float64_array, napi_uint32_array, napi_uint8_array, napi_float64_array,
+                                         napi_float64_array, napi_uint32_array};
+    const size_t counts[6] = {n * 8, n, n, n, n * wk->max_points * 8, n};
+    const int n_out = o->record_path ? 6 : 4;
+    for (int k = 0; k < n_out; k++) {
         if (napi_create_arraybuffer(env, bytes[k], &mem[k], &ab[k]) != napi_ok ||
             napi_create_typedarray(env, tys[k], counts[k], ab[k], 0, &ta[k]) != napi_ok || !keep_ref(env, wk, ta[k])) {
             bulk_release(env, wk);
@@ -922,6 +957,8 @@ static napi_value integrate_batch_common(napi_env env, napi_callback_info info, 
     wk->steps = (uint32_t *)mem[1];
     wk->term = (uint8_t *)mem[2];
     wk->drift = (double *)mem[3];
+    wk->paths = (double *)mem[4];
+    wk->counts = (uint32_t *)mem[5];
     if (n == 0) wk->is_async = is_async; /* an empty batch still resolves (with empty arrays) */
     return bulk_dispatch(env, self, wk);
 }

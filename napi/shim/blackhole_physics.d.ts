@@ -51,6 +51,10 @@ export interface IntegrateBatchOptions {
   renormalizeInterval?: number;
   stepSize?: number;
   arith?: "strict" | "fast";
+  /** IntegrationOptions.record_path (integrator.rs:32): the result gains `paths`, `counts`, `maxPoints` */
+  recordPath?: boolean;
+  /** rows of `paths` kept per ray (default maxSteps + 1, the longest path there is) */
+  maxPoints?: number;
 }
 
 /** per ray: Trajectory.final_state / steps_taken / termination / max_hamiltonian_drift (geodesic/mod.rs:150-161) */
@@ -59,6 +63,12 @@ export interface IntegrateBatchResult {
   steps: Uint32Array;
   term: Uint8Array;
   drift: Float64Array;
+  /** with recordPath: Trajectory.path (geodesic/mod.rs:160) as [n][maxPoints][8] f64 rows -- ray i holds
+   *  min(counts[i], maxPoints) states: the initial state as passed in, then the state after every step */
+  paths?: Float64Array;
+  /** 1 + steps_taken: the length of the reference's Vec<GeodesicState> */
+  counts?: Uint32Array;
+  maxPoints?: number;
 }
 
 export interface RenderFrameResult {

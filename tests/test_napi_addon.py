@@ -212,3 +212,14 @@ def test_bulk_js_batch_async_and_multi_device_entries(oracle, tmp_path):
     assert e["async_rejected"] and res["empty"] == 0 and res["free_while_pending"] == 100
     # per-ray cost from JS: a 4096-ray call must beat the one-ray entry by two orders of magnitude
     assert res["us_per_ray_batch"] * 100 < res["single_ms_per_ray"] * 1e3
+    # recordPath: Trajectory.path from JS = the oracle's orc_integrate_path rows, bit for bit (spin 0.5 by then)
+    pth = res["paths"]
+    mp = pth["maxPoints"]
+    rows = np.array(pth["rows"]).reshape(16, mp, 8)
+    m5 = oracle.metric(oracle.KERR_KS, 1.0, 0.5)
+    for i in range(16):
+        t, ref_path = oracle.integrate_path(np.array(pth["init"][8 * i:8 * i + 8]), m5,
+                                            oracle.options(max_steps=2000, tolerance=1e-8), cap=2001)
+        assert pth["counts"][i] == ref_path.shape[0] == pth["steps"][i] + 1
+        k = min(mp, ref_path.shape[0])
+        assert np.array_equal(rows[i, :k].view(np.uint64), ref_path[:k].view(np.uint64)), i

@@ -39,6 +39,29 @@ for sfx in "" _strict _c4 _c4fast; do
   run pmc_write$sfx --pmc WRITE_SIZE -- --steps 2 --warmup 1 $extra
   run pmc_sq$sfx    --pmc $SQ -- --steps 2 --warmup 1 $extra
 done
+# dynamic VALU mix by hardware class counter (tools/issue_floor.py prices it with the microbenchmark's costs)
+CLS32="SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64"
+# flops as the hardware counts them, and the issue-occupancy pair of one and the same run
+OCC="SQ_INSTS_VALU_FLOPS_FP32 SQ_INSTS_VALU_FLOPS_FP64 SQ_INSTS_VALU_FLOPS_FP32_TRANS SQ_INSTS_VALU_FLOPS_FP64_TRANS SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VALU2 GRBM_GUI_ACTIVE"
+CLS64="SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU2 SQ_THREAD_CYCLES_VALU"
+for sfx in "" _strict _c4 _c4fast; do
+  case "$sfx" in "") extra="";; _strict) extra="--arith strict";; _c4) extra="--config c4";; _c4fast) extra="--config c4 --arith fast";; esac
+  run pmc_cls32$sfx --pmc $CLS32 -- --steps 2 --warmup 1 $extra
+  run pmc_cls64$sfx --pmc $CLS64 -- --steps 2 --warmup 1 $extra
+  run pmc_occ$sfx --pmc $OCC -- --steps 2 --warmup 1 $extra
+done
+# the microbenchmark: costs in shader cycles (plain runs), and the same binary under the class counters
+# (which counter does a mnemonic land in, what do SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES say per instruction)
+if hipcc -O2 --offload-arch=gfx950 $R/tools/valu_microbench.hip -o /tmp/valu_microbench 2> $OUT/valu_microbench_build.err; then
+  for w in 1 2 4 8; do /tmp/valu_microbench $w > $OUT/valu_costs_w$w.json 2>> $OUT/valu_microbench.err; done
+  mb() { local label=$1; shift
+    rocprofv3 "$@" -d $OUT/$label -o bench -- /tmp/valu_microbench 4 > /dev/null 2> $OUT/$label.err
+    db=$(find $OUT/$label -name "bench_results.db" | head -1); [ -n "$db" ] && [ "$db" != "$OUT/$label/bench_results.db" ] && mv "$db" $OUT/$label/bench_results.db; }
+  mb mb_cls32 --pmc $CLS32
+  mb mb_cls64 --pmc $CLS64
+  mb mb_sq --pmc $SQ
+  mb mb_occ --pmc $OCC
+fi
 run pmc_fetch_k16 --pmc FETCH_SIZE -- --steps 2 --warmup 1 --segment-tries 16
 run pmc_write_k16 --pmc WRITE_SIZE -- --steps 2 --warmup 1 --segment-tries 16
 find $OUT -name "*.csv" -delete
