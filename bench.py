@@ -42,7 +42,9 @@ FP32_PEAK_TFLOPS = 157.3  # same guide: vector FP32
 # algorithmic bytes and flops per unit: SURVEY.md 8(d) / DESIGN.md section 4
 B_STEP = {"c3": 144, "c4": 72}
 B_RAY = {"c3": 96, "c4": 56}
-FLOP_STEP = {"c3": 1300.0, "c4": 500.0}
+# flops are no longer estimated: they are the hardware's own count of the profiled launch
+# (SQ_INSTS_VALU_FLOPS_* x 64 lanes, profiles/traffic.json -> valu.flops_counted_per_launch), quoted
+# only when the library on disk holds the very kernel the counters were read on
 KERNEL_OF = {("c3", "fast"): "integrate_segment_kernel<1,1,0>",
              ("c3", "strict"): "integrate_segment_kernel<1,0,0>",
              ("c4", "fast"): "wgsl_symplectic_fast_kernel",
@@ -289,7 +291,7 @@ def main_native(args, cfg, base_w, base_h):
                     "launches_per_frame": launches_per_rank / k,
                     "algorithmic_bytes_per_launch": int(share_bytes),
                     "timing": "%d profiled frames after the timed loop, slowest rank's share (mean share bytes)" % k,
-                    "bound_actual": "fp64_valu"}
+                    "bound_actual": "fp64_valu_issue"}
     line = {
         "metric": "Mray-steps/s", "value": round(total_steps / elapsed / 1e6, 2), "unit": "Mray-steps/s",
         "n_gpus": G, "ranks": m.ranks, "rank_devices": m.rank_devices(), "steps": args.steps,
@@ -558,10 +560,10 @@ def main():
         pmc, pmc_src = committed_pmc(kernel_pretty, bh.library_path())
         usable_pmc = pmc if (pmc and world == 1 and not args.segment_tries and
                              (W, H) == tuple(pmc.get("frame", (W, H)))) else None
-        flops = prof_steps_per_frame * FLOP_STEP[cfg] / launches_per_frame / (avg_launch_ms * 1e-3) / 1e12
         peak_tf = FP64_PEAK_TFLOPS if cfg == "c3" else FP32_PEAK_TFLOPS
+        nominal_frac = achieved / HBM_PEAK_GBS
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "unit": "GB/s", "frac": round(nominal_frac, 4) if nominal_frac <= 1.0 else None,
                     "traffic": usable_pmc.get("hbm_bytes_per_launch") if usable_pmc else None,
                     "traffic_source": pmc_src if usable_pmc or not pmc else
                     "not applicable to this run (committed pass: 1 GPU, default schedule, %s)" % pmc_src,
@@ -571,13 +573,24 @@ def main():
                     "algorithmic_bytes_per_launch": int(per_frame_bytes / launches_per_frame),
                     "timing": prof_note,
                     # what actually bounds the register-resident kernel: vector-ALU issue
-                    "bound_actual": "fp64_valu" if cfg == "c3" else "fp32_valu",
-                    "algorithmic_tflops": round(flops, 2), "peak_tflops": peak_tf,
-                    "flops_frac": round(flops / peak_tf, 4)}
+                    "bound_actual": "fp64_valu_issue" if cfg == "c3" else "fp32_valu_issue"}
+        if nominal_frac > 1.0:
+            roofline["frac_reason"] = ("SURVEY 8(d)'s %d B per ray-step would be %.1f TB/s, above the HBM peak: the march is "
+                                       "register-resident and does not move them; the kernel is judged on valu_issue_frac"
+                                       % (B_STEP[cfg], achieved / 1e3))
         if usable_pmc:
             roofline["hbm_measured_GBps"] = round(usable_pmc["hbm_bytes_per_launch"] / (avg_launch_ms * 1e-3) / 1e9, 1)
-            if "valu" in usable_pmc:
-                roofline["valu_issue_frac"] = usable_pmc["valu"]["issue_frac"]
+            v = usable_pmc.get("valu") or {}
+            if "issue_frac" in v:
+                # fraction of the chip's VALU issue slots the profiled launch filled:
+                # (SQ_ACTIVE_INST_VALU - SQ_ACTIVE_INST_VALU2) x 4 cycles / (1024 SIMDs x elapsed cycles)
+                roofline["valu_issue_frac"] = v["issue_frac"]
+            if v.get("flops_counted_per_launch"):
+                tf = v["flops_counted_per_launch"] / (avg_launch_ms * 1e-3) / 1e12
+                roofline.update({"counted_tflops": round(tf, 2), "peak_tflops": peak_tf,
+                                 "flops_frac": round(tf / peak_tf, 4),
+                                 "flops_per_ray_step": round(v["flops_counted_per_launch"] / max(prof_steps_per_frame, 1.0), 1),
+                                 "flops_source": "SQ_INSTS_VALU_FLOPS_* x 64 lanes of the profiled launch (%s)" % pmc_src})
         split = "" if world == 1 else (" split over %d GPUs" % world if args.scaling == "strong"
                                          else " (%dx%d per GPU x %d)" % (base_w, base_h, world))
         workload = workload_text(cfg, W, H, split)
