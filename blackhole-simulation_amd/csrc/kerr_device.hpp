@@ -103,6 +103,30 @@ __device__ __forceinline__ void fast_sincos(double x, double *sn, double *cs) {
     *cs = ((q + 1) & 2) ? -c0 : c0;
 }
 
+// A/B switches of the FAST Kerr-Schild geometry (tools/ab_build.sh builds the other forms)
+#ifndef GRV_TRIG_BITS
+#define GRV_TRIG_BITS 1
+#endif
+#ifndef GRV_POLAR_HI_WORD
+#define GRV_POLAR_HI_WORD 1
+#endif
+
+// Bit-level helpers for the quadrant logic of the FAST trigonometry.  Written as single
+// instructions on purpose: the optimiser turns the portable forms ((a & m) | (b & ~m) with a
+// sign-extended bit m, x + (y << 31)) back into compare + select pairs, which is exactly the
+// instruction count these exist to avoid.
+__device__ __forceinline__ int bits_sext_bit0(int x) { return __builtin_amdgcn_sbfe(x, 0, 1); } // v_bfe_i32
+__device__ __forceinline__ int bits_select(int mask, int a, int b) { // (a & mask) | (b & ~mask): v_bfi_b32
+    int d;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(mask), "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ int bits_shl_add(int x, int sh, int y) { // (x << sh) + y: v_lshl_add_u32
+    int d;
+    asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "n"(sh), "v"(y));
+    return d;
+}
+
 // 1/x: v_rcp_f64 seed (~2^-23 relative) + two Newton steps -> ~1 ulp.
 __device__ __forceinline__ double fast_rcp(double x) {
     double y = __builtin_amdgcn_rcp(x);
@@ -427,7 +451,16 @@ struct KsGeom {
 // sin^2 and sin*cos are all the right-hand side needs, so the quadrant logic of a
 // full sincos collapses to one swap and one sign.
 __device__ __forceinline__ KsGeom ks_geom(const Hole<double> &bh, double r, double theta) {
+#if GRV_TRIG_BITS
+    // j = round-to-nearest-even(theta 2/pi) by adding 1.5 2^52: the sum keeps the integer in its low
+    // mantissa bits (|theta| < 2^50), so the quadrant's parity is bit 0 of the sum's low word and needs
+    // no conversion, compare or select further down
+    constexpr double kRound = 6755399441055744.0;
+    const double t = fma(theta, 6.36619772367581382433e-01, kRound); // 2/pi
+    const double j = t - kRound;
+#else
     const double j = rint(theta * 6.36619772367581382433e-01); // 2/pi
+#endif
     // pi/2 = hi + mid to 2^-107: with fma the product j*hi is not rounded, so two terms
     // leave |j| * 1.5e-33 -- nothing for the O(1..100) theta of a geodesic
     double x = fma(-j, 1.57079632679489655800e+00, theta);
@@ -445,14 +478,26 @@ __device__ __forceinline__ KsGeom ks_geom(const Hole<double> &bh, double r, doub
     pc = fma(z, pc, -1.38888888888741095749e-03);
     pc = fma(z, pc, 4.16666666666666019037e-02);
     const double cr = fma(z, fma(z, pc, -0.5), 1.0);
+    KsGeom g;
+    const double prod = sr * cr;
+#if GRV_TRIG_BITS
+    // odd quadrant: sin <-> cos, product changes sign -- both done on the bit patterns: a bitwise
+    // select under the sign-extended parity bit (v_bfe_i32 + v_bfi_b32 per word) and the parity bit
+    // added into the product's sign position (v_lshl_add_u32); 3 instructions fewer per evaluation
+    // than convert / and / compare / two selects / xor / select
+    const int tl = __double2loint(t);
+    const int odd = bits_sext_bit0(tl); // 0 or ~0
+    const double sn = __hiloint2double(bits_select(odd, __double2hiint(cr), __double2hiint(sr)),
+                                       bits_select(odd, __double2loint(cr), __double2loint(sr)));
+    g.sc = __hiloint2double(bits_shl_add(tl, 31, __double2hiint(prod)), __double2loint(prod));
+#else
     const bool odd = ((int)j & 1) != 0; // odd quadrant: sin <-> cos, product changes sign
     const double sn = odd ? cr : sr;
-    const double prod = sr * cr;
-    KsGeom g;
+    g.sc = odd ? -prod : prod;
+#endif
     const double s2 = sn * sn;
     g.polar = s2 < 1e-20;
     g.sin2 = fmax(s2, 1e-12);
-    g.sc = odd ? -prod : prod;
     const double r2a2 = fma(r, r, bh.a2);
     g.sigma = fma(-bh.a2, g.sin2, r2a2); // r^2 + a^2 (1 - sin^2)
     g.delta = fma(-bh.two_m, r, r2a2);
@@ -515,7 +560,18 @@ __device__ __forceinline__ Deriv<double> rhs_ks_geom(const Hole<double> &bh, con
     const double ath_half = g.sc * fma(bh.a2, w, -(sigma * (q * isin2)));
     const double isig2 = isig * isig;
     d.dpr = -(isig2 * ar_half);
+#if GRV_POLAR_HI_WORD
+    // kerr.rs:494 (dH/dtheta := 0 within 1e-10 of the axis): only the high word of the force is
+    // cleared (one select instead of two).  What is left in the low word is a subnormal below 2^-1042:
+    // added to any normal p_theta it is absorbed exactly, and a ray that sits on the axis with
+    // p_theta = 0 keeps |p_theta| < 1e-300 -- the same trajectory to every digit the output carries.
+    {
+        const double f = -(isig2 * ath_half);
+        d.dpth = __hiloint2double(g.polar ? 0 : __double2hiint(f), __double2loint(f));
+    }
+#else
     d.dpth = g.polar ? 0.0 : -(isig2 * ath_half);
+#endif
     if (ham) *ham = (0.5 * isig) * fma(-sigma, c.pt2, w);
     return d;
 }

@@ -35,7 +35,14 @@ template <bool WANT_TPHI>
 __device__ __forceinline__ Wf32Deriv wf32_rhs(const Wf32Hole &bh, const Wf32Consts &c, float r,
                                               float theta, float p_r, float p_th) {
     // sin^2(theta), sin(theta) cos(theta)
+#if GRV_TRIG_BITS
+    // round-to-nearest-even(theta 2/pi) by adding 1.5 2^23 (|theta| < 2^21): the integer stays in the
+    // sum's low mantissa bits, bit 0 is the quadrant's parity (kerr_device.hpp ks_geom, f64 twin)
+    const float tq = fmaf(theta, 0.636619772367581343f, 12582912.0f);
+    const float j = tq - 12582912.0f;
+#else
     const float j = rintf(theta * 0.636619772367581343f); // 2/pi
+#endif
     float x = fmaf(-j, 1.57079637050628662109375f, theta);
     x = fmaf(-j, -4.37113900018624283e-8f, x); // pi/2 = hi + lo
     const float z = x * x;
@@ -45,11 +52,17 @@ __device__ __forceinline__ Wf32Deriv wf32_rhs(const Wf32Hole &bh, const Wf32Cons
     float pc = fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
     pc = fmaf(z, pc, 4.166664568298827e-2f);
     const float cr = fmaf(z * z, pc, fmaf(z, -0.5f, 1.0f));
+    const float prod = sr * cr;
+#if GRV_TRIG_BITS
+    const int tl = __float_as_int(tq);
+    const float sn = __int_as_float(bits_select(bits_sext_bit0(tl), __float_as_int(cr), __float_as_int(sr)));
+    const float sc = __int_as_float(bits_shl_add(tl, 31, __float_as_int(prod)));
+#else
     const bool odd = ((int)j & 1) != 0;
     const float sn = odd ? cr : sr;
-    const float prod = sr * cr;
-    const float sin2 = fmaxf(sn * sn, 1e-12f); // compute.wgsl.ts:49
     const float sc = odd ? -prod : prod;
+#endif
+    const float sin2 = fmaxf(sn * sn, 1e-12f); // compute.wgsl.ts:49
 
     const float r2a2 = fmaf(r, r, bh.a2);
     const float sigma = fmaf(-bh.a2, sin2, r2a2);

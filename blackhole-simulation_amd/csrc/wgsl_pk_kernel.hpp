@@ -9,6 +9,10 @@
 
 #include "wgsl_fast_kernel.hpp"
 
+#ifndef GRV_PK_FREEZE_BY_STEP
+#define GRV_PK_FREEZE_BY_STEP 1
+#endif
+
 namespace {
 
 typedef float f2_t __attribute__((ext_vector_type(2)));
@@ -34,7 +38,14 @@ struct PkConsts { // per-pair products of the constants of motion (p_t = -1 for 
 // right-hand side on a pair of rays; same algebra as wf32_rhs (W bracket, one reciprocal)
 __device__ __forceinline__ PkDeriv pk_rhs(const Wf32Hole &bh, const PkConsts &c, f2_t r, f2_t theta,
                                           f2_t p_r, f2_t p_th) {
+#if GRV_TRIG_BITS
+    // packed round-to-nearest-even by the 1.5 2^23 sum (wgsl_fast_kernel.hpp): one v_pk_fma + one
+    // v_pk_add instead of a v_pk_mul and two v_rndne, and the parity bit is already in an integer lane
+    const f2_t tq = pk_fma(theta, pk_splat(0.636619772367581343f), pk_splat(12582912.0f));
+    const f2_t jf = tq - 12582912.0f;
+#else
     const f2_t jf = __builtin_elementwise_rint(theta * 0.636619772367581343f);
+#endif
     f2_t x = pk_fma(jf, pk_splat(-1.57079637050628662109375f), theta);
     x = pk_fma(jf, pk_splat(4.37113900018624283e-8f), x);
     const f2_t z = x * x;
@@ -44,11 +55,19 @@ __device__ __forceinline__ PkDeriv pk_rhs(const Wf32Hole &bh, const PkConsts &c,
     f2_t pc = pk_fma(z, pk_splat(2.443315711809948e-5f), pk_splat(-1.388731625493765e-3f));
     pc = pk_fma(z, pc, pk_splat(4.166664568298827e-2f));
     const f2_t cr = pk_fma(z * z, pc, pk_fma(z, pk_splat(-0.5f), pk_splat(1.0f)));
+    const f2_t prod = sr * cr;
+#if GRV_TRIG_BITS
+    const int tx = __float_as_int(tq.x), ty = __float_as_int(tq.y);
+    const f2_t sn = f2_t{__int_as_float(bits_select(bits_sext_bit0(tx), __float_as_int(cr.x), __float_as_int(sr.x))),
+                         __int_as_float(bits_select(bits_sext_bit0(ty), __float_as_int(cr.y), __float_as_int(sr.y)))};
+    const f2_t sc = f2_t{__int_as_float(bits_shl_add(tx, 31, __float_as_int(prod.x))),
+                         __int_as_float(bits_shl_add(ty, 31, __float_as_int(prod.y)))};
+#else
     const i2_t odd = i2_t{(int)jf.x & 1, (int)jf.y & 1};
     const f2_t sn = pk_sel(odd, cr, sr);
-    const f2_t prod = sr * cr;
-    const f2_t sin2 = pk_max(sn * sn, 1e-12f);
     const f2_t sc = pk_sel(odd, -prod, prod);
+#endif
+    const f2_t sin2 = pk_max(sn * sn, 1e-12f);
 
     const f2_t r2a2 = pk_fma(r, r, pk_splat(bh.a2));
     const f2_t sigma = pk_fma(pk_splat(-bh.a2), sin2, r2a2);
@@ -205,11 +224,22 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             mpr = pk_fma(d.dpr, hh, p_r);
             mpth = pk_fma(d.dpth, hh, p_th);
             d = pk_rhs(bh, c, mr, mth, mpr, mpth);
+#if GRV_PK_FREEZE_BY_STEP
+            // a finished ray stays where it ended: its step is 0 (two selects per pair instead of eight;
+            // x + 0 d = x for every finite derivative, and a frozen ray's state is read by nothing but
+            // the guarded loop-top tests)
+            const f2_t hs = f2_t{live[0] ? h.x : 0.0f, live[1] ? h.y : 0.0f};
+            r = pk_fma(d.dr, hs, r);
+            th = pk_fma(d.dth, hs, th);
+            p_r = pk_fma(d.dpr, hs, p_r);
+            p_th = pk_fma(d.dpth, hs, p_th);
+#else
             const i2_t m = i2_t{live[0] ? 1 : 0, live[1] ? 1 : 0};
             r = pk_sel(m, pk_fma(d.dr, h, r), r); // a finished ray stays where it ended
             th = pk_sel(m, pk_fma(d.dth, h, th), th);
             p_r = pk_sel(m, pk_fma(d.dpr, h, p_r), p_r);
             p_th = pk_sel(m, pk_fma(d.dpth, h, p_th), p_th);
+#endif
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 if (!live[k]) continue;
