@@ -9,6 +9,9 @@
 
 #include "wgsl_fast_kernel.hpp"
 
+#ifndef GRV_PK_WAVES
+#define GRV_PK_WAVES 4 // waves per SIMD the packed march is compiled for (5 spills: measured slower)
+#endif
 #ifndef GRV_PK_FREEZE_BY_STEP
 #define GRV_PK_FREEZE_BY_STEP 1
 #endif
@@ -150,7 +153,7 @@ __device__ __forceinline__ void pk_shade(float rb, float M, float a, float isco,
     alpha += target_opacity * mri_sat;
 }
 
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void wgsl_symplectic_pk_kernel(FrameGeom G, WgslParams P,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GRV_PK_WAVES, GRV_PK_WAVES))) void wgsl_symplectic_pk_kernel(FrameGeom G, WgslParams P,
                                                                     float4 *__restrict__ out_rgba,
                                                                     uint32_t *__restrict__ out_steps,
                                                                     unsigned long long *total_steps,
