@@ -335,6 +335,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: wait for each frame's gather before integrating the next frame")
+    ap.add_argument("--two-streams", action="store_true",
+                    help="N = 1: even / odd frames on two streams as for N > 1 (the roofline block then comes from "
+                         "profiled frames after the timed loop)")
     ap.add_argument("--one-stream", action="store_true",
                     help="queue every frame on one stream (default: even / odd frames on two streams, "
                          "so one frame's tail runs under the next frame's head)")
@@ -443,7 +446,7 @@ def main():
     # launch -- too few waves left to fill 256 CUs -- runs under the head of the next frame
     # (N > 1 only: at N = 1 the tail is 1 % of a frame, and one stream keeps the in-loop HIP events
     # bracketing one kernel at a time, which is what the roofline block is defined on)
-    two = world > 1 and not args.one_stream and not args.no_overlap
+    two = (world > 1 or args.two_streams) and not args.one_stream and not args.no_overlap
     streams = [torch.cuda.Stream(), torch.cuda.Stream()] if two else [torch.cuda.current_stream()] * 2
     stream = streams[0].cuda_stream
     # all buffers live outside the frame loop: the padded send buffer doubles as the render
@@ -503,7 +506,7 @@ def main():
             del ev_pairs[:]
         return st, ms, n
 
-    in_loop_profile = world == 1  # no events in a multi-rank timed loop
+    in_loop_profile = world == 1 and not two  # no events in a multi-rank / two-stream timed loop
     if tg is not None:
         # communicator set-up (RCCL opens its xGMI peer connections on first use) belongs to
         # initialisation, not to a frame: one exchange of the still empty buffers, whatever --warmup is
