@@ -419,3 +419,33 @@ def test_random_renderer_sessions_are_bit_exact(engine_mod, oracle, seed):
             write = 1 - write
             want = oracle.bloom(resolved, 0.8, 0.5, 2, True) if bloom else oracle.bloom(resolved, 3e38, 0.0, 0, True)
             assert np.array_equal(screen.cpu().numpy(), want, equal_nan=True), (seed, f, w, h, bloom, moving)
+
+
+@pytest.mark.parametrize("seed", range(SEEDS))
+def test_random_paths_strict_is_bit_exact(engine_mod, oracle, seed):
+    """Trajectory.path (grv_integrate_paths) under the same hostile rays and random options: every
+    recorded point, the counts and the truncation at max_points are the checker's orc_integrate_path."""
+    bh = engine_mod
+    rng = np.random.default_rng(9000 + seed)
+    kinds = ((oracle.KERR_KS, bh.KERR_KS), (oracle.KERR_BL, bh.KERR_BL), (oracle.SCHWARZSCHILD, bh.SCHWARZSCHILD))
+    for _ in range(6):
+        okind, bkind = kinds[rng.integers(0, 3)]
+        mass = float(rng.choice([1.0, 0.37, 2.5]))
+        spin = 0.0 if okind == oracle.SCHWARZSCHILD else float(rng.choice([0.0, 0.9, 0.999, -0.7, 1.3]))
+        max_steps = int(rng.choice([0, 1, 7, 60, 150]))
+        kw = dict(method=int(rng.integers(0, 3)), tolerance=float(10.0 ** rng.uniform(-10, -5)),
+                  initial_step=float(rng.choice([0.01, 0.5, -0.01, 20.0])), max_steps=max_steps,
+                  escape_radius=float(rng.choice([1000.0, 80.0, 3.0])),
+                  renormalize_interval=int(rng.choice([1, 3, 10, 1000])), step_size=float(rng.choice([0.05, -0.05, 0.3])))
+        st = _rays(rng, 60, mass)
+        cap = int(rng.choice([max_steps + 1, 1, 5, 40]))
+        with bh.PhysicsEngine(mass, spin) as e:
+            got = e.integrate_paths(st, bh.engine.default_options(metric_kind=bkind, arith=bh.ARITH_STRICT, record_path=1, **kw),
+                                    max_points=cap)
+        m, oo = oracle.metric(okind, mass, spin), oracle.options(**kw)
+        for i in range(st.shape[0]):
+            t, path = oracle.integrate_path(st[i], m, oo, cap=max_steps + 1)
+            tag = (seed, kw, okind, spin, mass, i, cap)
+            assert int(got["counts"][i]) == path.shape[0] == int(t.steps_taken) + 1, tag
+            assert np.array_equal(got["paths"][i], path[:cap], equal_nan=True), tag
+            assert int(got["term"][i]) == int(t.termination) and int(got["steps"][i]) == int(t.steps_taken), tag
