@@ -11,6 +11,16 @@
 namespace grvhip {
 
 constexpr int kBlock = 256;
+// threads per block of the f32 march kernels (WGSL compute march in its three forms, GLSL fragment
+// shader): ONE wave.  A march wave's lanes run 35..1024 steps and its slot (registers, wave slot) goes
+// back to the dispatcher only when its whole block has ended; with four-wave blocks the packed march
+// measured 287 G ray-steps/s on the 8K config-4 frame, with one-wave blocks 308 G (A/B on one box,
+// profiles/r03_ab_march_block.jsonl).  The f64 segment kernel keeps kBlock: its waves live 40x longer
+// and neighbouring 8x8 blocks end together (one-wave blocks: +0.35 %, and slower on small shares).
+#ifndef GRV_MARCH_BLOCK
+#define GRV_MARCH_BLOCK 64
+#endif
+constexpr int kMarchBlock = GRV_MARCH_BLOCK;
 constexpr int kMaxCrossRec = 4;
 
 // flags word: bits 0-2 termination, bit 3 forced-min-step pending, bits 4-7 crossing

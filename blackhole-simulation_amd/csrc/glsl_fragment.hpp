@@ -691,13 +691,13 @@ __device__ uint32_t glsl_fragment(const GlslParams &U, uint32_t width, uint32_t 
 #define GRV_GLSL_FAST_WAVES 5
 #endif
 template <int ARITH>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ARITH == GRV_ARITH_FAST ? GRV_GLSL_FAST_WAVES : 1)))
+__global__ __launch_bounds__(kMarchBlock) __attribute__((amdgpu_waves_per_eu(ARITH == GRV_ARITH_FAST ? GRV_GLSL_FAST_WAVES : 1)))
 void glsl_fragment_kernel(FrameGeom G, GlslParams U,
                                                                float4 *__restrict__ out_rgba,
                                                                uint32_t *__restrict__ out_steps,
                                                                unsigned long long *total_steps,
                                                                uint32_t n_slots) {
-    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t slot = blockIdx.x * kMarchBlock + threadIdx.x;
     uint32_t X = 0, Y = 0, oi = 0;
     const bool valid = slot < n_slots && slot_to_pixel(G, slot, X, Y, oi);
     uint32_t steps = 0;

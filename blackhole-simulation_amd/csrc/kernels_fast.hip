@@ -63,7 +63,7 @@ hipError_t launch_wgsl_symplectic_fast(const FrameGeom &G, const WgslParams &P, 
                                        uint32_t *out_steps, unsigned long long *total_steps,
                                        uint32_t n_slots, hipStream_t s) {
     if (n_slots == 0) return hipSuccess;
-    hipLaunchKernelGGL(wgsl_symplectic_fast_kernel, dim3((n_slots + kBlock - 1) / kBlock), dim3(kBlock),
+    hipLaunchKernelGGL(wgsl_symplectic_fast_kernel, dim3((n_slots + kMarchBlock - 1) / kMarchBlock), dim3(kMarchBlock),
                        0, s, G, P, reinterpret_cast<float4 *>(out_rgba), out_steps, total_steps, n_slots);
     return hipGetLastError();
 }
@@ -72,8 +72,8 @@ hipError_t launch_glsl_fragment_fast(const FrameGeom &G, const GlslParams &P, fl
                                      uint32_t *out_steps, unsigned long long *total_steps,
                                      uint32_t n_slots, hipStream_t s) {
     if (n_slots == 0) return hipSuccess;
-    hipLaunchKernelGGL((glsl_fragment_kernel<GRV_ARITH_FAST>), dim3((n_slots + kBlock - 1) / kBlock),
-                       dim3(kBlock), 0, s, G, P, reinterpret_cast<float4 *>(out_rgba), out_steps,
+    hipLaunchKernelGGL((glsl_fragment_kernel<GRV_ARITH_FAST>), dim3((n_slots + kMarchBlock - 1) / kMarchBlock),
+                       dim3(kMarchBlock), 0, s, G, P, reinterpret_cast<float4 *>(out_rgba), out_steps,
                        total_steps, n_slots);
     return hipGetLastError();
 }
@@ -83,8 +83,13 @@ hipError_t launch_wgsl_symplectic_pk(const FrameGeom &G, const WgslParams &P, fl
                                      uint32_t n_slots, hipStream_t s) {
     if (n_slots == 0) return hipSuccess;
     const uint32_t pairs = (n_slots + 1u) / 2u;
-    hipLaunchKernelGGL(wgsl_symplectic_pk_kernel, dim3((pairs + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
-                       G, P, reinterpret_cast<float4 *>(out_rgba), out_steps, total_steps, n_slots);
+    // long marches: one-wave blocks; short ones: four-wave blocks (wgsl_pk_kernel.hpp)
+    if (P.max_steps > 512)
+        hipLaunchKernelGGL(wgsl_symplectic_pk_kernel, dim3((pairs + kMarchBlock - 1) / kMarchBlock), dim3(kMarchBlock), 0, s,
+                           G, P, reinterpret_cast<float4 *>(out_rgba), out_steps, total_steps, n_slots);
+    else
+        hipLaunchKernelGGL(wgsl_symplectic_pk_b256_kernel, dim3((pairs + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
+                           G, P, reinterpret_cast<float4 *>(out_rgba), out_steps, total_steps, n_slots);
     return hipGetLastError();
 }
 

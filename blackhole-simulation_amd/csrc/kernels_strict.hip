@@ -178,7 +178,7 @@ hipError_t launch_wgsl_symplectic(const FrameGeom &G, const WgslParams &P, float
                                   uint32_t *out_steps, unsigned long long *total_steps,
                                   uint32_t n_slots, hipStream_t s) {
     if (n_slots == 0) return hipSuccess;
-    hipLaunchKernelGGL(wgsl_symplectic_kernel, dim3((n_slots + kBlock - 1) / kBlock), dim3(kBlock), 0,
+    hipLaunchKernelGGL(wgsl_symplectic_kernel, dim3((n_slots + kMarchBlock - 1) / kMarchBlock), dim3(kMarchBlock), 0,
                        s, G, P, reinterpret_cast<float4 *>(out_rgba), out_steps, total_steps, n_slots);
     return hipGetLastError();
 }
@@ -187,7 +187,7 @@ hipError_t launch_glsl_fragment(const FrameGeom &G, const GlslParams &P, float *
                               uint32_t *out_steps, unsigned long long *total_steps,
                               uint32_t n_slots, hipStream_t s) {
     if (n_slots == 0) return hipSuccess;
-    hipLaunchKernelGGL((glsl_fragment_kernel<GRV_ARITH_STRICT>), dim3((n_slots + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
+    hipLaunchKernelGGL((glsl_fragment_kernel<GRV_ARITH_STRICT>), dim3((n_slots + kMarchBlock - 1) / kMarchBlock), dim3(kMarchBlock), 0, s,
                        G, P, reinterpret_cast<float4 *>(out_rgba), out_steps, total_steps, n_slots);
     return hipGetLastError();
 }

@@ -121,12 +121,12 @@ __device__ __forceinline__ void m4v4_f(const float *m, float x, float y, float z
 }
 
 // compute.wgsl.ts:147-258
-__global__ __launch_bounds__(kBlock) void wgsl_symplectic_kernel(FrameGeom G, WgslParams P,
+__global__ __launch_bounds__(kMarchBlock) void wgsl_symplectic_kernel(FrameGeom G, WgslParams P,
                                                                  float4 *__restrict__ out_rgba,
                                                                  uint32_t *__restrict__ out_steps,
                                                                  unsigned long long *total_steps,
                                                                  uint32_t n_slots) {
-    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t slot = blockIdx.x * kMarchBlock + threadIdx.x;
     uint32_t X = 0, Y = 0, oi = 0;
     const bool valid = slot < n_slots && slot_to_pixel(G, slot, X, Y, oi);
     uint32_t steps = 0;

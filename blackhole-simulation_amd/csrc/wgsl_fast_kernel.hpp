@@ -101,12 +101,12 @@ __device__ __forceinline__ void wf32_m4v4(const float *m, float x, float y, floa
     for (int r = 0; r < 4; ++r) o[r] = m[0 + r] * x + m[4 + r] * y + m[8 + r] * z + m[12 + r] * w;
 }
 
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void wgsl_symplectic_fast_kernel(FrameGeom G, WgslParams P,
+__global__ __launch_bounds__(kMarchBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void wgsl_symplectic_fast_kernel(FrameGeom G, WgslParams P,
                                                                       float4 *__restrict__ out_rgba,
                                                                       uint32_t *__restrict__ out_steps,
                                                                       unsigned long long *total_steps,
                                                                       uint32_t n_slots) {
-    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t slot = blockIdx.x * kMarchBlock + threadIdx.x;
     uint32_t X = 0, Y = 0, oi = 0;
     const bool valid = slot < n_slots && slot_to_pixel(G, slot, X, Y, oi);
     uint32_t steps = 0;
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
         if (out_steps) out_steps[oi] = steps;
     }
     // one atomic per block for the frame's step total
-    __shared__ unsigned long long s_w[kBlock / 64];
+    __shared__ unsigned long long s_w[kMarchBlock / 64];
     unsigned long long v = steps;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) 
     if (threadIdx.x == 0) {
         unsigned long long tot = 0;
 #pragma unroll
-        for (int w = 0; w < kBlock / 64; ++w) tot += s_w[w];
+        for (int w = 0; w < kMarchBlock / 64; ++w) tot += s_w[w];
         if (tot) atomicAdd(total_steps, tot);
     }
 }

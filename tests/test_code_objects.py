@@ -77,7 +77,8 @@ def test_headline_kernel_keeps_three_waves_per_simd(kernels):
 
 
 def test_no_hot_kernel_uses_scratch(kernels):
-    for part in ("integrate_segment_kernel", "integrate_refill_kernel", "wgsl_symplectic_pk_kernel", "init_from_pixels_kernel",
+    for part in ("integrate_segment_kernel", "integrate_refill_kernel", "wgsl_symplectic_pk_kernel", "wgsl_symplectic_pk_b256_kernel",
+                 "init_from_pixels_kernel",
                  "init_from_states_kernel", "finalize_frame_kernel", "finalize_batch_kernel", "taa_resolve_kernel",
                  "ataa_resolve_kernel", "bloom_", "blit_reinhard_kernel"):
         for kd in _find(kernels, part):
@@ -91,11 +92,21 @@ def test_f32_fast_marches_keep_their_occupancy(kernels):
     # the price of one spilled register outside the step loop; the GLSL march 2-3 % from 5 (<= 96, with
     # 72 B of spills in its disk / jet sampling branches) over the 4 (120 VGPRs) the compiler picks unaided
     # (profiles/r02_shader_kernels.jsonl)
-    for part, limit, scratch in (("wgsl_symplectic_pk_kernel", 128, 0), ("wgsl_symplectic_fast_kernel", 80, 16),
-                                 ("glsl_fragment_kernelILi1E", 96, 96)):
+    for part, limit, scratch in (("wgsl_symplectic_pk_kernel", 128, 0), ("wgsl_symplectic_pk_b256_kernel", 128, 0),
+                                 ("wgsl_symplectic_fast_kernel", 80, 16), ("glsl_fragment_kernelILi1E", 96, 96)):
         (kd,) = _find(kernels, part)
         assert kd[".vgpr_count"] + kd.get(".agpr_count", 0) <= limit, (part, kd[".vgpr_count"])
         assert kd[".private_segment_fixed_size"] <= scratch, (part, kd[".private_segment_fixed_size"])
+
+
+def test_march_kernels_launch_one_wave_blocks(kernels):
+    # one-wave blocks for the f32 marches (engine_types.hpp kMarchBlock; 8K x 1024 steps: +10 % measured),
+    # the four-wave form of the packed march for short step budgets
+    for part, size in (("wgsl_symplectic_pk_kernel", 64), ("wgsl_symplectic_pk_b256_kernel", 256),
+                       ("wgsl_symplectic_fast_kernel", 64), ("wgsl_symplectic_kernel", 64), ("glsl_fragment_kernelILi1E", 64),
+                       ("glsl_fragment_kernelILi0E", 64)):
+        (kd,) = _find(kernels, part)
+        assert kd[".max_flat_workgroup_size"] == size, (part, kd[".max_flat_workgroup_size"])
 
 
 def test_every_kernel_is_wave64_gfx950(kernels):
