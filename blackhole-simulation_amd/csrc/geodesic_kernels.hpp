@@ -479,12 +479,18 @@ __device__ __forceinline__ void ray_resume(const Hole<double> &bh, RayRegs &y,
 template <int KIND, int METHOD>
 constexpr int kSegmentWavesMin = (KIND == GRV_METRIC_KERR_KS && METHOD == GRV_METHOD_RKF45) ? 3 : 1;
 
+// threads per block of the segment kernel (A/B switch; see kMarchBlock in engine_types.hpp)
+#ifndef GRV_SEGMENT_BLOCK
+#define GRV_SEGMENT_BLOCK 256
+#endif
+constexpr int kSegBlock = GRV_SEGMENT_BLOCK;
+
 template <int KIND, int ARITH, int METHOD>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kSegmentWavesMin<KIND, METHOD>)))
+__global__ __launch_bounds__(kSegBlock) __attribute__((amdgpu_waves_per_eu(kSegmentWavesMin<KIND, METHOD>)))
 void integrate_segment_kernel(
     RayWorkspace ws, SegmentParams P, const uint32_t *__restrict__ live_in, uint32_t n_live,
     uint32_t *__restrict__ live_out, uint32_t *__restrict__ live_out_count) {
-    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t k = blockIdx.x * kSegBlock + threadIdx.x;
     const bool have = k < n_live;
     const uint32_t slot = have ? (live_in ? live_in[k] : k) : 0u;
 
@@ -512,7 +518,7 @@ void integrate_segment_kernel(
     // block-aggregated append of the survivors (ray compaction for the next launch):
     // per-wave ballot/popcount, one atomic per block, mbcnt-style prefix inside the wave.
     if (live_out) {
-        __shared__ uint32_t s_wave_cnt[kBlock / 64];
+        __shared__ uint32_t s_wave_cnt[kSegBlock / 64];
         __shared__ uint32_t s_base;
         const unsigned long long mask = __ballot(live);
         const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -521,7 +527,7 @@ void integrate_segment_kernel(
         if (threadIdx.x == 0) {
             uint32_t total = 0;
 #pragma unroll
-            for (int w = 0; w < kBlock / 64; ++w) total += s_wave_cnt[w];
+            for (int w = 0; w < kSegBlock / 64; ++w) total += s_wave_cnt[w];
             s_base = total ? atomicAdd(live_out_count, total) : 0u;
         }
         __syncthreads();
