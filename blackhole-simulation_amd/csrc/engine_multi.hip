@@ -293,13 +293,16 @@ int run_frame(grv_multi *m, uint32_t width, uint32_t height, float *d_rgba, hipS
         // one group: G-1 sends on the ranks' render streams (behind their kernels), G-1 receives
         // on rank 0's exchange stream -- concurrent point-to-point transfers, one xGMI link each
         GRVM_NCCL(m, g_rccl.GroupStart());
-        for (int r = (m->self_exchange ? 0 : 1); r < G; ++r) {
+        ncclResult_t gst = ncclSuccess; // a failed call must not leave the group open: always reach GroupEnd
+        for (int r = (m->self_exchange ? 0 : 1); r < G && gst == ncclSuccess; ++r) {
             if (n_px[r] == 0) continue;
-            GRVM_NCCL(m, g_rccl.Send(m->rank[r].send[b], n_px[r] * 4u, ncclFloat, 0, m->comm[r], m->rank[r].s[b]));
-            GRVM_NCCL(m, g_rccl.Recv(m->recv[b] + (size_t)r * m->slot_px * 4u, n_px[r] * 4u, ncclFloat, r,
-                                     m->comm[0], rs));
+            gst = g_rccl.Send(m->rank[r].send[b], n_px[r] * 4u, ncclFloat, 0, m->comm[r], m->rank[r].s[b]);
+            if (gst == ncclSuccess)
+                gst = g_rccl.Recv(m->recv[b] + (size_t)r * m->slot_px * 4u, n_px[r] * 4u, ncclFloat, r, m->comm[0], rs);
         }
-        GRVM_NCCL(m, g_rccl.GroupEnd());
+        const ncclResult_t gend = g_rccl.GroupEnd();
+        if (gst != ncclSuccess) return mfail(m, GRV_ERR_HIP, "ncclSend / ncclRecv failed: %s", g_rccl.GetErrorString(gst));
+        GRVM_NCCL(m, gend);
         if (!m->self_exchange) GRVM_HIP(m, hipStreamWaitEvent(rs, m->rank[0].arrived[b], 0));
     } else {
         for (int r = 0; r < G; ++r) GRVM_HIP(m, hipStreamWaitEvent(rs, m->rank[r].arrived[b], 0));
