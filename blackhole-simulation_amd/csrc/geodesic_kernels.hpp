@@ -479,6 +479,9 @@ __device__ __forceinline__ void ray_resume(const Hole<double> &bh, RayRegs &y,
 template <int KIND, int METHOD>
 constexpr int kSegmentWavesMin = (KIND == GRV_METRIC_KERR_KS && METHOD == GRV_METHOD_RKF45) ? 3 : 1;
 
+#ifndef GRV_WS_RELOAD
+#define GRV_WS_RELOAD 1
+#endif
 // threads per block of the segment kernel (A/B switch; see kMarchBlock in engine_types.hpp)
 #ifndef GRV_SEGMENT_BLOCK
 #define GRV_SEGMENT_BLOCK 256
@@ -513,7 +516,25 @@ void integrate_segment_kernel(
         y.flags = (y.flags & ~kFlagTermMask) | GRV_TERM_MAXSTEPS;
         live = false;
     }
+#if GRV_WS_RELOAD && defined(__HIP_DEVICE_COMPILE__)
+    // The epilogue takes the workspace pointers from the kernel-argument segment again (`ws` is the first
+    // argument: offset 0) through a pointer the optimiser cannot see through, instead of keeping a dozen
+    // SGPRs live across the try loop for ten stores at the very end: 10 of the 14 v_readlane spills of
+    // the FAST try loop go (+0.5-0.7 % measured A/B, profiles/r03_ab_ws_reload.jsonl).  Reloading the
+    // live-list pointers the same way gains nothing more and costs the STRICT form 20 B of scratch.
+    // (FAST forms only: the STRICT RKF45 forms answer the changed allocation with 20 B of scratch)
+    if constexpr (ARITH == GRV_ARITH_FAST) {
+        if (have) {
+            const RayWorkspace *w2 = reinterpret_cast<const RayWorkspace *>(__builtin_amdgcn_kernarg_segment_ptr());
+            asm volatile("" : "+s"(w2));
+            store_ray(*w2, slot, y);
+        }
+    } else {
+        if (have) store_ray(ws, slot, y);
+    }
+#else
     if (have) store_ray(ws, slot, y);
+#endif
 
     // block-aggregated append of the survivors (ray compaction for the next launch):
     // per-wave ballot/popcount, one atomic per block, mbcnt-style prefix inside the wave.
