@@ -1,6 +1,6 @@
 #!/bin/bash
 # ASan + UBSan pass over the PRODUCT's host code on the CPU box (GPU ASan is not available on this
-# pool): the host side of libgravitas_hip.so -- every engine*.hip entry point, control_plane.hip's
+# pool): the host side of libgravitas_hip.so -- every engine*.hip entry point (engine_multi.hip included), control_plane.hip's
 # host twins, grv_strict_math_host, the tile (un)pack helpers -- and napi/gravitas_napi.c.
 #   device code : compiled for gfx950 as shipped (-Xarch_host keeps the sanitizers off it)
 #   host code   : -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=undefined
@@ -32,15 +32,15 @@ restore() {
 }
 trap restore EXIT
 
-for tu in kernels_strict kernels_fast control_plane spacetime_viz engine engine_shaders engine_control; do
+for tu in kernels_strict kernels_fast control_plane spacetime_viz engine engine_shaders engine_control engine_multi; do
   fp="-ffp-contract=off"
   [ $tu = kernels_fast ] && fp="-ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt"
   (cd "$CS" && $HIPCC -O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $fp $XSAN \
-      -c $tu.hip -o $B/$tu.o) &
+      -I/opt/rocm/include -c $tu.hip -o $B/$tu.o) &
 done
 wait
 $HIPCC --offload-arch=gfx950 -shared -fPIC $SAN -shared-libsan -o "$LIB" $B/kernels_strict.o $B/kernels_fast.o \
-    $B/control_plane.o $B/spacetime_viz.o $B/engine.o $B/engine_shaders.o $B/engine_control.o
+    $B/control_plane.o $B/spacetime_viz.o $B/engine.o $B/engine_shaders.o $B/engine_control.o $B/engine_multi.o -ldl -lpthread
 # -asan-globals=0 on the addon only: its merged string literals land on odd addresses, which ASan's
 # global registration refuses under node; stack and heap checking (the argument buffers, the arena)
 # stay on
