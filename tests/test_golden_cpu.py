@@ -20,6 +20,7 @@ def test_golden_files_present():
     assert os.path.exists(os.path.join(GOLD, "rays_v1.npz"))
     assert os.path.exists(os.path.join(GOLD, "frame_v1.npz"))
     assert os.path.exists(os.path.join(GOLD, "make_golden.py"))
+    assert os.path.exists(os.path.join(GOLD, "paths_v1.npz")) and os.path.exists(os.path.join(GOLD, "make_golden_paths.py"))
 
 
 def test_oracle_reproduces_ray_golden(oracle):
@@ -60,3 +61,23 @@ def test_single_ray_ffi_matches_batch(oracle):
     out = oracle.integrate_ray_relativistic(1.0, 0.9, v, 2048, 1e-8, True)
     # the FFI fixes h0=0.01, escape=1000, renorm=10 (gravitas-wasm/src/lib.rs:444-452)
     np.testing.assert_array_equal(out, z[key + "_out"][0])
+
+
+def test_oracle_reproduces_path_golden(oracle):
+    """Trajectory.path fixtures (tests/golden/make_golden_paths.py): the oracle still returns every
+    recorded point bit for bit; point 0 is the input state (mod.rs:193-197), the last the end state."""
+    z = np.load(os.path.join(GOLD, "rays_v1.npz"))
+    pz = np.load(os.path.join(GOLD, "paths_v1.npz"))
+    for key in [str(c) for c in pz["cases"]]:
+        kind, spin, method, tol, max_steps, step, esc, renorm, h0 = z[key + "_meta"]
+        m = oracle.metric(int(kind), 1.0, float(spin))
+        o = oracle.options(method=int(method), tolerance=float(tol), initial_step=float(h0), max_steps=int(max_steps),
+                           escape_radius=float(esc), renormalize_interval=int(renorm), step_size=float(step))
+        for i in range(6):
+            t, p = oracle.integrate_path(z[key + "_in"][i], m, o, cap=int(max_steps) + 1)
+            n = int(pz[key + "_counts"][i])
+            assert p.shape[0] == n == int(z[key + "_steps"][i]) + 1
+            assert np.array_equal(p, pz[key + "_paths"][i, :n], equal_nan=True), (key, i)
+            assert np.array_equal(p[0], z[key + "_in"][i])
+            if n > 1:
+                assert np.array_equal(p[-1], z[key + "_out"][i], equal_nan=True)

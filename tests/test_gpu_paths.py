@@ -118,3 +118,21 @@ def test_paths_argument_errors(bh):
             e.integrate_paths(st, bh.engine.default_options(record_path=1, reserved=7))
         with pytest.raises(bh.GravitasError):
             e.integrate_paths(st, bh.engine.default_options(record_path=1, method=9))
+
+
+def test_golden_paths(bh):
+    """The committed Trajectory.path fixtures (tests/golden/paths_v1.npz), STRICT: bit for bit."""
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    z, pz = np.load(os.path.join(gold, "rays_v1.npz")), np.load(os.path.join(gold, "paths_v1.npz"))
+    for key in [str(c) for c in pz["cases"]]:
+        kind, spin, method, tol, max_steps, step, esc, renorm, h0 = z[key + "_meta"]
+        with bh.PhysicsEngine(1.0, float(spin)) as e:
+            o = bh.engine.default_options(method=int(method), metric_kind=int(kind), tolerance=float(tol),
+                                          initial_step=float(h0), max_steps=int(max_steps), escape_radius=float(esc),
+                                          renormalize_interval=int(renorm), step_size=float(step), record_path=1)
+            got = e.integrate_paths(z[key + "_in"][:6], o)
+        assert np.array_equal(got["counts"], pz[key + "_counts"]), key
+        for i in range(6):
+            n = int(pz[key + "_counts"][i])
+            assert np.array_equal(got["paths"][i], pz[key + "_paths"][i, :n], equal_nan=True), (key, i)
