@@ -59,11 +59,11 @@ int grv_generate_spectrum_lut(grv_engine *e, size_t width, size_t height, double
 
 int grv_strict_math(grv_engine *e, int op, size_t n, const double *x, const double *y, double *out) {
     if (!e) return GRV_ERR_INVALID;
-    if ((op & ~GRV_MATH_F32) < GRV_MATH_SINCOS_SIN || (op & ~GRV_MATH_F32) > GRV_MATH_DIV_SHARED ||
+    if ((op & ~GRV_MATH_F32) < GRV_MATH_SINCOS_SIN || (op & ~GRV_MATH_F32) > GRV_MATH_DIV_CONST ||
         ((op & GRV_MATH_F32) && (op & ~GRV_MATH_F32) > GRV_MATH_ATAN2))
         return fail(e, GRV_ERR_INVALID, "bad op %d", op);
     if (n == 0) return GRV_OK;
-    if (!x || !out || (((op & ~GRV_MATH_F32) == GRV_MATH_POW || (op & ~GRV_MATH_F32) >= GRV_MATH_ATAN2) && !y) || n > (1ull << 26))
+    if (!x || !out || (((op & ~GRV_MATH_F32) == GRV_MATH_POW || ((op & ~GRV_MATH_F32) >= GRV_MATH_ATAN2 && (op & ~GRV_MATH_F32) != GRV_MATH_RCP_R2)) && !y) || n > (1ull << 26))
         return fail(e, GRV_ERR_INVALID, "bad strict_math request");
     GRV_HIP(e, hipSetDevice(e->device));
     const size_t b = align_up(n * sizeof(double), 256);
@@ -82,10 +82,10 @@ int grv_strict_math(grv_engine *e, int op, size_t n, const double *x, const doub
 
 int grv_strict_math_host(int op, size_t n, const double *x, const double *y, double *out) {
     const int base = op & ~GRV_MATH_F32;
-    if (base < GRV_MATH_SINCOS_SIN || base > GRV_MATH_DIV_SHARED) return GRV_ERR_INVALID;
+    if (base < GRV_MATH_SINCOS_SIN || base > GRV_MATH_DIV_CONST) return GRV_ERR_INVALID;
     if ((op & GRV_MATH_F32) && base > GRV_MATH_ATAN2) return GRV_ERR_INVALID;
     if (n == 0) return GRV_OK;
-    if (!x || !out || ((base == GRV_MATH_POW || base >= GRV_MATH_ATAN2) && !y)) return GRV_ERR_INVALID;
+    if (!x || !out || ((base == GRV_MATH_POW || (base >= GRV_MATH_ATAN2 && base != GRV_MATH_RCP_R2)) && !y)) return GRV_ERR_INVALID;
     const bool f32 = (op & GRV_MATH_F32) != 0;
     for (size_t i = 0; i < n; ++i) {
         const double a = f32 ? (double)(float)x[i] : x[i];
@@ -102,7 +102,10 @@ int grv_strict_math_host(int op, size_t n, const double *x, const double *y, dou
         case GRV_MATH_LOG: r = strictm::sl_log(a); break;
         case GRV_MATH_ACOS: r = strictm::sl_acos(a); break;
         case GRV_MATH_DIV:
-        case GRV_MATH_DIV_SHARED: r = a / b; break; // the host's IEEE quotient: what both device forms must return
+        case GRV_MATH_DIV_SHARED:
+        case GRV_MATH_DIV_NOFIX:
+        case GRV_MATH_DIV_CONST: r = a / b; break; // the host's IEEE quotient: what every device form must return
+        case GRV_MATH_RCP_R2: r = 1.0 / a; break;  // correctly rounded; the device's refined seed equals it for most a
         default: r = strictm::sl_atan2(a, b); break;
         }
         out[i] = f32 ? (double)(float)r : r;

@@ -56,6 +56,7 @@ template <int KIND, int ARITH> constexpr bool kStage1Cache = kFastKsCache<KIND, 
 __device__ __forceinline__ Hole<double> make_hole(const SegmentParams &P) {
     Hole<double> bh{P.M, P.a, P.a2, 2.0 * P.M};
     bh.divs_ok = divs_ok_hole(P.M, P.a);
+    bh.divs_nf = divs_nf_hole(P.M, P.a);
     return bh;
 }
 
@@ -87,18 +88,34 @@ __device__ __forceinline__ double rkf45_try(const Hole<double> &bh, const RayReg
         s21 = h / 4.0;
         s31 = 3.0 * h / 32.0;
         s32 = 9.0 * h / 32.0;
-        s41 = 1932.0 * h / 2197.0;
-        s42 = -7200.0 * h / 2197.0;
-        s43 = 7296.0 * h / 2197.0;
-        s51 = 439.0 * h / 216.0;
         s52 = -8.0 * h;
-        s53 = 3680.0 * h / 513.0;
-        s54 = -845.0 * h / 4104.0;
-        s61 = -8.0 * h / 27.0;
         s62 = 2.0 * h;
-        s63 = -3544.0 * h / 2565.0;
-        s64 = 1859.0 * h / 4104.0;
-        s65 = -11.0 * h / 40.0;
+        // the ten quotients by a constant that is not a power of two: the same IEEE quotients through
+        // the literal-reciprocal form (ConstDen) when the whole wave's step sizes admit it -- always,
+        // after the first try: the controller keeps 1e-5 <= |h| <= 10
+        if (GRV_STRICT_CONSTDEN && __ballot(!const_div_ok(h)) == 0ull) {
+            s41 = ConstDen<2197>::div(1932.0 * h);
+            s42 = ConstDen<2197>::div(-7200.0 * h);
+            s43 = ConstDen<2197>::div(7296.0 * h);
+            s51 = ConstDen<216>::div(439.0 * h);
+            s53 = ConstDen<513>::div(3680.0 * h);
+            s54 = ConstDen<4104>::div(-845.0 * h);
+            s61 = ConstDen<27>::div(-8.0 * h);
+            s63 = ConstDen<2565>::div(-3544.0 * h);
+            s64 = ConstDen<4104>::div(1859.0 * h);
+            s65 = ConstDen<40>::div(-11.0 * h);
+        } else {
+            s41 = 1932.0 * h / 2197.0;
+            s42 = -7200.0 * h / 2197.0;
+            s43 = 7296.0 * h / 2197.0;
+            s51 = 439.0 * h / 216.0;
+            s53 = 3680.0 * h / 513.0;
+            s54 = -845.0 * h / 4104.0;
+            s61 = -8.0 * h / 27.0;
+            s63 = -3544.0 * h / 2565.0;
+            s64 = 1859.0 * h / 4104.0;
+            s65 = -11.0 * h / 40.0;
+        }
     } else {
         s21 = h * 0.25;
         s31 = h * (3.0 / 32.0);
@@ -297,6 +314,8 @@ __device__ __forceinline__ double post_step_ref(const Hole<double> &bh, RayRegs 
         return hv;
     };
     if constexpr (KIND == GRV_METRIC_KERR_KS) {
+        const bool nf = GRV_STRICT_NOFIXUP && bh.divs_nf && divs_nf_point(y.r, s, c);
+        if (GRV_STRICT_NOFIXUP && __ballot(!nf) == 0ull) return body(SharedDivNoFixup{});
         const bool ok = bh.divs_ok && divs_ok_point(y.r, s, c);
         if (__ballot(!ok) == 0ull) return body(SharedDiv{});
     }

@@ -230,6 +230,17 @@ __global__ __launch_bounds__(kBlock) void strict_math_kernel(int op, uint32_t n,
     case 8: out[i] = strictm::sl_acos(x[i]); break;
     case 10: out[i] = IeeeDiv::div(x[i], IeeeDiv::prep(y[i])); break;
     case 11: out[i] = SharedDiv::div(x[i], SharedDiv::prep(y[i])); break;
+    case 12: out[i] = SharedDivNoFixup::div(x[i], SharedDivNoFixup::prep(y[i])); break;
+    case 13: out[i] = SharedDiv::prep(x[i]).r; break;
+    case 14: {
+        const double n = x[i];
+        const int d = (int)y[i];
+        out[i] = d == 2197 ? ConstDen<2197>::div(n) : d == 216 ? ConstDen<216>::div(n)
+               : d == 513 ? ConstDen<513>::div(n) : d == 4104 ? ConstDen<4104>::div(n)
+               : d == 27 ? ConstDen<27>::div(n) : d == 2565 ? ConstDen<2565>::div(n)
+               : d == 40 ? ConstDen<40>::div(n) : __builtin_nan("");
+        break;
+    }
     default: out[i] = strictm::sl_atan2(x[i], y[i]); break;
     }
 }

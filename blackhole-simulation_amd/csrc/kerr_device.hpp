@@ -33,6 +33,7 @@ template <typename T> struct Hole {
     T a2; // a * a
     T two_m; // 2 M
     bool divs_ok = false; // M and a admit the shared-reciprocal division form (divs_ok_hole)
+    bool divs_nf = false; // ... and its form without v_div_fixup (divs_nf_hole)
 };
 
 template <typename T> struct Deriv {
@@ -103,6 +104,13 @@ __device__ __forceinline__ void fast_sincos(double x, double *sn, double *cs) {
     *cs = ((q + 1) & 2) ? -c0 : c0;
 }
 
+// A/B switches of the STRICT division forms (TU=strict tools/ab_build.sh builds the other forms)
+#ifndef GRV_STRICT_NOFIXUP
+#define GRV_STRICT_NOFIXUP 1 // SharedDivNoFixup ahead of SharedDiv
+#endif
+#ifndef GRV_STRICT_CONSTDEN
+#define GRV_STRICT_CONSTDEN 1 // ConstDen for the Fehlberg stage scales
+#endif
 // A/B switches of the FAST Kerr-Schild geometry (tools/ab_build.sh builds the other forms)
 #ifndef GRV_TRIG_BITS
 #define GRV_TRIG_BITS 1
@@ -177,13 +185,29 @@ __device__ __forceinline__ double fast_pow_m1_4(double x) {
 //   below admits a right-hand side to this form only then.  Inside that range the instruction
 //   sequence per quotient is the compiler's own, so the quotient has the same bits; outside it the
 //   wave takes the IeeeDiv form.  Which form ran is therefore invisible in the results.
+// SharedDivNoFixup (round 3): SharedDiv without the closing v_div_fixup either.  For finite non-zero
+//   operands of moderate magnitude v_div_fixup returns |q| with the sign of n/d, i.e. q itself; it only
+//   matters for zero, infinite or NaN operands.  `divs_nf` admits a right-hand side to this form when
+//   M, r are in [2^-20, 2^20] (positive), |a| in [2^-20, 2^20] and |sin|, |cos| >= 2^-70: then every
+//   operand is finite, every denominator positive, and the only zero a numerator can be is the +0 of an
+//   exact cancellation (delta, sigma - 2 r^2, the two-term numerators), for which the sequence
+//   gives q0 = +0, res = +0, q = +0 = (+0)/d.  A numerator of -0 would come out as +0, so the two
+//   numerators the reference negates AFTER a possible cancellation are divided before the negation
+//   (-(x)/d == -(x/d) bit for bit) and the one product whose zero can take either sign
+//   (delta * dSigma/dtheta) keeps the fixup (`div_signed`).  rhs_ref_at's NOFIX branches hold the
+//   case analysis next to each quotient.  Checked alone by GRV_MATH_DIV_NOFIX (tests/test_ref_libm.py).
+// kExactFma: the guarded forms may also contract a product that is exact by construction in their
+//   operand range (2 * x) into the neighbouring sum: fma(2, w, u) == u + 2 w when 2 w is exact.
 // ---------------------------------------------------------------------------
 struct IeeeDiv {
+    static constexpr bool kNoFixup = false;
     template <typename T> struct Den { T d; };
     template <typename T> static __device__ __forceinline__ Den<T> prep(T d) { return {d}; }
     template <typename T> static __device__ __forceinline__ T div(T n, const Den<T> &D) { return n / D.d; }
+    template <typename T> static __device__ __forceinline__ T div_signed(T n, const Den<T> &D) { return n / D.d; }
 };
 struct SharedDiv {
+    static constexpr bool kNoFixup = false;
     template <typename T> struct Den { T d, r; };
     static __device__ __forceinline__ Den<double> prep(double d) {
         // r2 of the f64 fdiv expansion: rcp seed + two Newton steps
@@ -198,7 +222,43 @@ struct SharedDiv {
         const double res = fma(-D.d, q0, n);
         return __builtin_amdgcn_div_fixup(fma(res, D.r, q0), D.d, n);
     }
+    static __device__ __forceinline__ double div_signed(double n, const Den<double> &D) { return div(n, D); }
 };
+struct SharedDivNoFixup {
+    static constexpr bool kNoFixup = true;
+    template <typename T> using Den = SharedDiv::Den<T>;
+    static __device__ __forceinline__ Den<double> prep(double d) { return SharedDiv::prep(d); }
+    // n finite and +0 or non-zero, d > 0, both moderate
+    static __device__ __forceinline__ double div(double n, const Den<double> &D) {
+        const double q0 = n * D.r;
+        const double res = fma(-D.d, q0, n);
+        return fma(res, D.r, q0);
+    }
+    // n may be -0
+    static __device__ __forceinline__ double div_signed(double n, const Den<double> &D) { return SharedDiv::div(n, D); }
+};
+
+// n / D for a compile-time D that is not a power of two (the Fehlberg tableau's 2197, 216, 513, 4104,
+// 27, 2565, 40): SharedDiv with the denominator's refined reciprocal as a literal.  kR2 must be the value
+// SharedDiv::prep(D).r takes on the device -- it is 1/D correctly rounded for each of the seven, which
+// GRV_MATH_RCP_R2 lets tests/test_ref_libm.py assert on the GPU -- so the instruction sequence per
+// quotient is again the compiler's own minus the two v_div_scale steps (the identity for a numerator
+// that is zero, non-finite or in [2^-100, 2^113]: const_div_ok).  v_div_fixup stays: the step size may
+// be a signed zero or NaN.
+template <int D> struct ConstDen {
+    static constexpr double kD = (double)D;
+    static constexpr double kR2 = 1.0 / (double)D;
+    static __device__ __forceinline__ double div(double n) {
+        const double q0 = n * kR2;
+        const double res = fma(-kD, q0, n);
+        return __builtin_amdgcn_div_fixup(fma(res, kR2, q0), kD, n);
+    }
+};
+// the step size h admits ConstDen for c * h (|c| <= 7296): zero, infinite, NaN or 2^-100 <= |h| <= 2^100
+__device__ __forceinline__ bool const_div_ok(double h) {
+    constexpr int kZeroInfNan = 0x001 | 0x002 | 0x004 | 0x200 | 0x020 | 0x040;
+    return __builtin_amdgcn_class(h, kZeroInfNan) || (fabs(h) >= 0x1p-100 && fabs(h) <= 0x1p100);
+}
 
 // x is zero or lo <= |x| <= hi  (false for NaN / infinities)
 __device__ __forceinline__ bool zero_or_within(double x, double lo, double hi) {
@@ -217,6 +277,16 @@ __device__ __forceinline__ bool divs_ok_hole(double M, double a) {
 __device__ __forceinline__ bool divs_ok_point(double r, double sin_theta, double cos_theta) {
     return zero_or_within(r, 0x1p-20, 0x1p20) && zero_or_within(sin_theta, 0x1p-70, 1.0) &&
            zero_or_within(cos_theta, 0x1p-70, 1.0);
+}
+
+// The stricter range of SharedDivNoFixup: no zeros, positive M and r (so that every denominator is
+// positive and no numerator is a signed zero other than the +0 of a cancellation).  Four compares
+// per point instead of the nine of divs_ok_point; NaN fails every one of them.
+__device__ __forceinline__ bool divs_nf_hole(double M, double a) {
+    return M >= 0x1p-20 && M <= 0x1p20 && fabs(a) >= 0x1p-20 && fabs(a) <= 0x1p20;
+}
+__device__ __forceinline__ bool divs_nf_point(double r, double sin_theta, double cos_theta) {
+    return r >= 0x1p-20 && r <= 0x1p20 && fabs(sin_theta) >= 0x1p-70 && fabs(cos_theta) >= 0x1p-70;
 }
 
 // ---------------------------------------------------------------------------
@@ -303,17 +373,37 @@ __device__ __forceinline__ Deriv<T> rhs_ref_at(const Hole<T> &bh, T r, T sin_the
         const auto by_sigma2 = DIV::prep(sigma2);
         const auto by_sigma2_sin2 = DIV::prep(sigma2 * sin2);
         const auto by_sigma2_sin4 = DIV::prep(sigma2 * sin2 * sin2);
-        const T dg_tt_dr = DIV::div(-(T(2) * m * (sigma - r * dsigma_dr)), by_sigma2);
+        T dg_tt_dr, dg_tr_dr, dg_phph_dtheta;
+        if constexpr (DIV::kNoFixup) {
+            // (SharedDivNoFixup; operand range of divs_nf: M, r > 0, a, sin, cos != 0, all moderate.)
+            // sigma - r (2r): r (2r) = 2 r^2 exactly in this range, so fma(-2, r^2, sigma) is the
+            // reference's difference; it is +0 or non-zero (sigma > 0), and so is 2M times it.  The
+            // reference negates BEFORE dividing, which would make a cancelled numerator -0: divide
+            // first (-(x)/d == -(x/d) bit for bit)
+            dg_tr_dr = DIV::div(T(2) * m * fma(T(-2), r2, sigma), by_sigma2);
+            dg_tt_dr = -dg_tr_dr;
+            // dsigma_dtheta sin^2 + ((2 sigma) sin) cos: the second term is 2 ((sigma sin) cos)
+            // exactly (no underflow: >= 2^-180), so fma(2, w, u) is the reference's sum; a sum of two
+            // non-zero terms is +0 or non-zero; negated after the division as above
+            dg_phph_dtheta = -DIV::div(fma(T(2), sigma * sin_theta * cos_theta, dsigma_dtheta * sin2), by_sigma2_sin4);
+        } else {
+            dg_tt_dr = DIV::div(-(T(2) * m * (sigma - r * dsigma_dr)), by_sigma2);
+            dg_tr_dr = -dg_tt_dr;
+            dg_phph_dtheta =
+                DIV::div(-(dsigma_dtheta * sin2 + sigma * T(2) * sin_theta * cos_theta), by_sigma2_sin4);
+        }
+        // 2 M r dsigma_dtheta, 2r, dsigma_dtheta, a 2r, a dsigma_dtheta: products of non-zero
+        // moderate factors under divs_nf -- never zero.  ddelta_dr sigma - delta 2r: a difference
+        // whose minuend cannot be -0 (2r - 2M cancels to +0): +0 or non-zero.
         const T dg_tt_dtheta = DIV::div(T(2) * m * r * dsigma_dtheta, by_sigma2);
-        const T dg_tr_dr = -dg_tt_dr;
         const T dg_tr_dtheta = -dg_tt_dtheta;
         const T dg_rr_dr = DIV::div(ddelta_dr * sigma - delta * dsigma_dr, by_sigma2);
-        const T dg_rr_dtheta = DIV::div(-(delta * dsigma_dtheta), by_sigma2);
+        // delta = +0 on a horizon radius and dsigma_dtheta of either sign: the one numerator that can be
+        // -0 either side of the negation -- keeps the fixup
+        const T dg_rr_dtheta = DIV::div_signed(-(delta * dsigma_dtheta), by_sigma2);
         const T dg_thth_dr = DIV::div(-dsigma_dr, by_sigma2);
         const T dg_thth_dtheta = DIV::div(-dsigma_dtheta, by_sigma2);
         const T dg_phph_dr = DIV::div(-dsigma_dr, by_sigma2_sin2);
-        const T dg_phph_dtheta =
-            DIV::div(-(dsigma_dtheta * sin2 + sigma * T(2) * sin_theta * cos_theta), by_sigma2_sin4);
         const T dg_rph_dr = DIV::div(-(a * dsigma_dr), by_sigma2);
         const T dg_rph_dtheta = DIV::div(-(a * dsigma_dtheta), by_sigma2);
 
@@ -422,6 +512,11 @@ __device__ __forceinline__ Deriv<T> rhs_ref(const Hole<T> &bh, T r, T theta, T p
     sincos_t(theta, &sin_theta, &cos_theta);
     if constexpr (KIND == GRV_METRIC_KERR_KS && sizeof(T) == 8) {
         // wave-uniform choice of the division form (see SharedDiv): same bits either way
+        const bool nf = GRV_STRICT_NOFIXUP && bh.divs_nf && divs_nf_point(r, sin_theta, cos_theta);
+        if (GRV_STRICT_NOFIXUP && __ballot(!nf) == 0ull) {
+            const GInv<T> g = contravariant_ref<KIND, T, SharedDivNoFixup>(bh, r, sin_theta, cos_theta);
+            return rhs_ref_at<KIND, T, SharedDivNoFixup>(bh, r, sin_theta, cos_theta, g, p_t, p_r, p_th, p_ph);
+        }
         const bool ok = bh.divs_ok && divs_ok_point(r, sin_theta, cos_theta);
         if (__ballot(!ok) == 0ull) {
             const GInv<T> g = contravariant_ref<KIND, T, SharedDiv>(bh, r, sin_theta, cos_theta);

@@ -31,6 +31,10 @@
 #include <cstdint>
 
 #define GRV_HD __host__ __device__
+// A/B switch: products that are exact by construction contracted into the neighbouring sum (same bits)
+#ifndef GRV_STRICT_EXACT_FMA
+#define GRV_STRICT_EXACT_FMA 1
+#endif
 
 namespace strictm {
 
@@ -65,16 +69,29 @@ GRV_HD inline double k_sin(double x, double y, int iy) {
     const double r = S2 + z * (S3 + z * S4) + z * w * (S5 + z * S6);
     const double v = z * x;
     if (iy == 0) return x + v * (S1 + z * r);
+    /* 0.5 * y is exact, so the fused form rounds 0.5 y - v r once, exactly as the separate product and
+     * difference do: same bits, one instruction less */
+#if GRV_STRICT_EXACT_FMA
+    return x - ((z * __builtin_fma(0.5, y, -(v * r)) - y) - v * S1);
+#else
     return x - ((z * (0.5 * y - v * r) - y) - v * S1);
+#endif
 }
 
 GRV_HD inline double k_cos(double x, double y) {
     const double z = x * x;
     double w = z * z;
     const double r = z * (C1 + z * (C2 + z * C3)) + (w * w) * (C4 + z * (C5 + z * C6));
+    /* hz = 0.5 z is exact: w = 1 - hz and (1 - w) - hz through fma(-0.5, z, .) are the same
+     * differences without forming hz (same bits, one instruction less) */
+#if GRV_STRICT_EXACT_FMA
+    w = __builtin_fma(-0.5, z, 1.0);
+    return w + (__builtin_fma(-0.5, z, 1.0 - w) + (z * r - x * y));
+#else
     const double hz = 0.5 * z;
     w = 1.0 - hz;
     return w + (((1.0 - w) - hz) + (z * r - x * y));
+#endif
 }
 
 /* ---- x = n pi/2 + (y0 + y1), |y0 + y1| <= pi/4: Cody-Waite with 33+33+33+53 bits of pi/2 ---- */
@@ -107,7 +124,11 @@ GRV_HD inline int rem_pio2_medium(double x, double *y0, double *y1) {
     *y0 = y;
     *y1 = (r - y) - w;
     /* quadrant = fn mod 4, exact for any integer-valued fn */
+#if GRV_STRICT_EXACT_FMA
+    return (int)__builtin_fma(-4.0, ::floor(fn * 0.25), fn); /* 4 floor(.) is exact: the same difference */
+#else
     return (int)(fn - 4.0 * ::floor(fn * 0.25));
+#endif
 }
 
 GRV_HD inline double sl_sin(double x) {

@@ -21,7 +21,7 @@ ARITH_STRICT, ARITH_FAST, ARITH_FAST_PACKED = 0, 1, 2
 DISK_PROFILE_SHORTCUT, DISK_PROFILE_PAGE_THORNE = 0, 1
 MATH_SINCOS_SIN, MATH_SINCOS_COS, MATH_SIN, MATH_COS, MATH_POW, MATH_EXP, MATH_ATAN = 0, 1, 2, 3, 4, 5, 6
 MATH_LOG, MATH_ACOS, MATH_ATAN2, MATH_F32 = 7, 8, 9, 16
-MATH_DIV, MATH_DIV_SHARED = 10, 11
+MATH_DIV, MATH_DIV_SHARED, MATH_DIV_NOFIX, MATH_RCP_R2, MATH_DIV_CONST = 10, 11, 12, 13, 14
 TERM_NONE, TERM_HORIZON, TERM_ESCAPE, TERM_MAXSTEPS, TERM_DISK_CROSSING = 0, 1, 2, 3, 4
 _STATUS = {0: "GRV_OK", 1: "GRV_ERR_INVALID", 2: "GRV_ERR_NO_DEVICE", 3: "GRV_ERR_HIP",
            4: "GRV_ERR_OOM"}

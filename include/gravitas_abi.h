@@ -454,6 +454,12 @@ enum { GRV_MATH_SINCOS_SIN = 0, GRV_MATH_SINCOS_COS = 1, GRV_MATH_SIN = 2, GRV_M
                                    (csrc/kerr_device.hpp SharedDiv): the same bits as GRV_MATH_DIV whenever
                                    both operands are zero or moderate in magnitude, which is the only case in
                                    which the kernels use it */,
+       GRV_MATH_DIV_NOFIX = 12 /* the same without the closing v_div_fixup (SharedDivNoFixup): the IEEE quotient
+                                  for y[i] > 0 and x[i] = +0 or non-zero, both finite and moderate */,
+       GRV_MATH_RCP_R2 = 13 /* the refined reciprocal SharedDiv::prep(x[i]) holds (rcp seed + two Newton steps):
+                               lets a test assert that the literal reciprocals of ConstDen are the device's */,
+       GRV_MATH_DIV_CONST = 14 /* x[i] / y[i] through ConstDen for y[i] in {2197, 216, 513, 4104, 27, 2565, 40}
+                                  (the Fehlberg tableau's denominators); any other y[i] yields NaN */,
        GRV_MATH_F32 = 16 /* or-ed in: the f32 form (float)op((double)(float)x) of the shader-order kernels */ };
 int grv_strict_math(grv_engine *e, int op, size_t n, const double *x, const double *y, double *out);
 /* the same routines compiled for the host (they also serve the engine's host-side closed forms):

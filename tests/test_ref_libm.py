@@ -302,3 +302,51 @@ def test_shared_reciprocal_quotient_is_the_ieee_quotient_inside_its_range(engine
     with bh.PhysicsEngine(1.0, 0.9) as e:
         a, b = e.strict_math(E.MATH_DIV, sp_n, sp_d), e.strict_math(E.MATH_DIV_SHARED, sp_n, sp_d)
     assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
+
+
+@pytest.mark.gpu
+def test_no_fixup_quotient_and_literal_reciprocal_forms(engine_mod):
+    """Round 3 forms of the STRICT divisions (csrc/kerr_device.hpp).
+    SharedDivNoFixup: SharedDiv without v_div_fixup, admitted by divs_nf only for positive moderate
+    denominators and numerators that are +0 or non-zero moderate -- there it must return the IEEE
+    quotient.  ConstDen: the Fehlberg stage scales c h / D with D's refined reciprocal as a literal; the
+    literal must be the value the device's own refinement yields (RCP_R2), and the quotient the IEEE one
+    for every numerator const_div_ok admits (zero, non-finite, 2^-100 <= |h| <= 2^100 times |c| <= 7296)."""
+    bh = engine_mod
+    E = bh.engine
+    rng = np.random.default_rng(20261001)
+    n = 4_000_000
+
+    def moderate(k, lo, hi):
+        mant = 1.0 + rng.random(k)
+        mant[rng.random(k) < 0.02] = 1.0
+        mant[rng.random(k) < 0.02] = np.nextafter(2.0, 1.0)
+        return np.ldexp(mant, rng.integers(lo, hi, k))
+    num = moderate(n, -290, 83) * rng.choice([-1.0, 1.0], n)
+    num[rng.random(n) < 0.03] = 0.0  # +0 only: the kernels never hand this form a -0
+    den = moderate(n, -266, 82)
+    dens = np.array([2197.0, 216.0, 513.0, 4104.0, 27.0, 2565.0, 40.0])
+    coef = np.array([1932.0, -7200.0, 7296.0, 439.0, 3680.0, -845.0, -8.0, -3544.0, 1859.0, -11.0])
+    h = moderate(n, -100, 100) * rng.choice([-1.0, 1.0], n)
+    h[:8] = [0.0, -0.0, np.inf, -np.inf, np.nan, 2.0 ** -100, 2.0 ** 100, -2.0 ** 100]
+    h[8:2008] = rng.uniform(1e-5, 10.0, 2000)  # the controller's range
+    cn = coef[rng.integers(0, coef.size, n)] * h
+    cd = dens[rng.integers(0, dens.size, n)]
+    with bh.PhysicsEngine(1.0, 0.9) as e:
+        nofix = e.strict_math(E.MATH_DIV_NOFIX, num, den)
+        r2 = e.strict_math(E.MATH_RCP_R2, dens)
+        cq = e.strict_math(E.MATH_DIV_CONST, cn, cd)
+        unknown = e.strict_math(E.MATH_DIV_CONST, np.ones(2), np.array([7.0, 2196.0]))
+    want = num / den
+    bad = np.flatnonzero(nofix.view(np.uint64) != want.view(np.uint64))
+    assert bad.size == 0, (bad.size, num[bad[:4]], den[bad[:4]], nofix[bad[:4]], want[bad[:4]])
+    assert np.array_equal(r2.view(np.uint64), (1.0 / dens).view(np.uint64)), (r2, 1.0 / dens)
+    with np.errstate(invalid="ignore"):
+        cwant = cn / cd
+    ok = ~np.isnan(cwant)
+    assert np.array_equal(np.isnan(cq), np.isnan(cwant))
+    bad = np.flatnonzero(cq.view(np.uint64)[ok] != cwant.view(np.uint64)[ok])
+    assert bad.size == 0, (bad.size, cn[ok][bad[:4]], cd[ok][bad[:4]])
+    assert np.isnan(unknown).all()
+    assert np.array_equal(E.strict_math_host(E.MATH_DIV_CONST, cn[ok], cd[ok]).view(np.uint64),
+                          cwant.view(np.uint64)[ok])

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box: every ab_libs/lib_*.so takes the in-tree library's place in turn, REPS rounds
 # interleaved (A B C A B C ...), bench.py c3 (and c4 with AB_C4=1) each time; one line per run in
-# gpurun_out/$1/ab.jsonl: {"lib", "config", "value", "ms_per_step", "avg_launch_ms"}.
+# (AB_ARGS="--arith strict" AB_STEPS=8 for the STRICT contract) gpurun_out/$1/ab.jsonl: {"lib", "config", "value", "ms_per_step", "avg_launch_ms"}.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 T=${1:-ab}
@@ -17,7 +17,7 @@ for rep in $(seq 1 $REPS); do
     cp $so $LIB
     for cfg in c3 ${AB_C4:+c4}; do
       extra=""; [ $cfg = c4 ] && extra="--config c4 --steps 10 --warmup 2"
-      [ $cfg = c3 ] && extra="--steps 20 --warmup 3"
+      [ $cfg = c3 ] && extra="--steps ${AB_STEPS:-20} --warmup 3 ${AB_ARGS:-}"
       python bench.py $extra --no-cpu-baseline 2> $O/err_${name}_$cfg.txt | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])

@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B builds of the FAST translation unit: tools/ab_build.sh NAME "-DSWITCH=0 ..." compiles
 # kernels_fast.hip with the extra flags and links ab_libs/lib_NAME.so from it and the other
-# (unchanged) objects of csrc/build.  ab_libs/ is git-ignored but travels to the GPU box, where
+# (unchanged) objects of csrc/build.  TU=strict does the same with kernels_strict.hip (-ffp-contract=off).  ab_libs/ is git-ignored but travels to the GPU box, where
 # tools/ab_bench.sh swaps each library in under bench.py in turn on ONE box (box-to-box spread of the
 # f64 headline is +-4 %: never compare numbers of two boxes).
 set -eu
@@ -11,9 +11,18 @@ NAME=$1; shift
 EXTRA="${1:-}"
 mkdir -p $R/ab_libs
 make -C $C -s
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=fast \
-  -fno-hip-fp32-correctly-rounded-divide-sqrt $EXTRA -c $C/kernels_fast.hip -o $C/build/kernels_fast_$NAME.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/ab_libs/lib_$NAME.so $C/build/kernels_strict.o \
-  $C/build/kernels_fast_$NAME.o $C/build/control_plane.o $C/build/spacetime_viz.o $C/build/engine.o \
+FAST_O=$C/build/kernels_fast.o
+STRICT_O=$C/build/kernels_strict.o
+if [ "${TU:-fast}" = strict ]; then
+  STRICT_O=$C/build/kernels_strict_$NAME.o
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=off \
+    $EXTRA -c $C/kernels_strict.hip -o $STRICT_O
+else
+  FAST_O=$C/build/kernels_fast_$NAME.o
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=fast \
+    -fno-hip-fp32-correctly-rounded-divide-sqrt $EXTRA -c $C/kernels_fast.hip -o $FAST_O
+fi
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/ab_libs/lib_$NAME.so $STRICT_O \
+  $FAST_O $C/build/control_plane.o $C/build/spacetime_viz.o $C/build/engine.o \
   $C/build/engine_shaders.o $C/build/engine_control.o $C/build/engine_multi.o -ldl -lpthread
 echo "ab_libs/lib_$NAME.so  ($EXTRA)"
