@@ -98,8 +98,44 @@ __global__ __launch_bounds__(256) void taa_resolve_fast_kernel(uint32_t w, uint3
     }
 }
 
-// ataa.wgsl.ts:29-86 (ataa_resolve_kernel of post_kernels.hpp), FAST contract
-__global__ __launch_bounds__(256) void ataa_resolve_fast_kernel(uint32_t w, uint32_t h, AtaaCamera cam,
+// ataa.wgsl.ts:29-86 (ataa_resolve_kernel of post_kernels.hpp), FAST contract.
+// The reprojection chain of the shader -- ndc -> inv_proj -> perspective divide -> normalise ->
+// inv_view -> position + 12 dir -> prev_view_proj -> perspective divide -> uv -> texel coordinates --
+// is three 4x4 products, two divisions and a square root per pixel (about 75 VALU instructions, more
+// than the resolve itself).  Everything in it except the normalisation is linear in the pixel
+// coordinates, so the launcher folds the matrices once, in f64 (ataa_reproj_fold):
+//   vt      = inv_proj (ndc.x, -ndc.y, 1, 1)                          = Vx px + Vy py + V0
+//   clip    = K + s (B (ndc.x, -ndc.y, 1, 1)),  s = 12 sign(vt.w) / |vt.xyz|
+//             K = prev_view_proj (position, 1),  B = prev_view_proj[:, :3] inv_view[:3, :3] inv_proj[:3, :]
+//   texel x = (0.5 w clip.x + (0.5 w - 0.5) clip.w) / clip.w   (row combination folded into K and B)
+// which leaves seven fma per pixel row, a dot product, one v_rsq_f32, one v_rcp_f32 and five more
+// multiply-adds (19 instructions).  The tap position agrees with the shader-order chain to the
+// latter's own f32 rounding (the fold is exact to f64): tests/test_post_chain.py holds it to the same
+// tap-position bound as before.
+struct AtaaReproj {
+    // per quantity q in (vt.x, vt.y, vt.z, vt.w, clipx', clipy', clipw): q = c[q][0] px + c[q][1] py + c[q][2]
+    // (clip rows: the part multiplied by s), k = the constant part of the three clip rows
+    float c[7][3];
+    float k[3];
+};
+
+// bilinear LINEAR + CLAMP_TO_EDGE tap at texel coordinates (x, y) = (u w - 0.5, v h - 0.5)
+__device__ __forceinline__ float4 fast_sample_xy(const float4 *__restrict__ tex, uint32_t w, uint32_t h, float x,
+                                                 float y) {
+    const float fx = floorf(x), fy = floorf(y);
+    const float a = x - fx, b = y - fy;
+    const int i0 = post_clampi((int)fx, 0, (int)w - 1), i1 = post_clampi((int)fx + 1, 0, (int)w - 1);
+    const int j0 = post_clampi((int)fy, 0, (int)h - 1), j1 = post_clampi((int)fy + 1, 0, (int)h - 1);
+    const float4 t00 = tex[(size_t)j0 * w + i0], t10 = tex[(size_t)j0 * w + i1];
+    const float4 t01 = tex[(size_t)j1 * w + i0], t11 = tex[(size_t)j1 * w + i1];
+    const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    return make_float4(w00 * t00.x + w10 * t10.x + w01 * t01.x + w11 * t11.x,
+                       w00 * t00.y + w10 * t10.y + w01 * t01.y + w11 * t11.y,
+                       w00 * t00.z + w10 * t10.z + w01 * t01.z + w11 * t11.z,
+                       w00 * t00.w + w10 * t10.w + w01 * t01.w + w11 * t11.w);
+}
+
+__global__ __launch_bounds__(256) void ataa_resolve_fast_kernel(uint32_t w, uint32_t h, AtaaReproj rp,
                                                                 const float4 *__restrict__ current,
                                                                 const float4 *__restrict__ history,
                                                                 int half_storage, float4 *__restrict__ out) {
@@ -109,29 +145,19 @@ __global__ __launch_bounds__(256) void ataa_resolve_fast_kernel(uint32_t w, uint
     if (px >= w) return;
     FastNeighbourhood N;
     fast_neighbourhood(tile, N);
-    const float u = ((float)px + 0.5f) / (float)w;
-    const float ndcx = u * 2.0f - 1.0f;
+    float col[7]; // the part of each quantity that depends on the column only
+#pragma unroll
+    for (int q = 0; q < 7; ++q) col[q] = fmaf((float)px, rp.c[q][0], rp.c[q][2]);
 #pragma unroll
     for (int i = 0; i < kFtRows; ++i) {
         const uint32_t py = blockIdx.y * kFtH + threadIdx.y * kFtRows + (uint32_t)i;
         if (py >= h) break;
-        const float v = ((float)py + 0.5f) / (float)h;
-        const float ndcy = v * 2.0f - 1.0f;
-        float vt[4], wd[4], pc[4];
-        post_m4v4(cam.inv_proj, ndcx, -ndcy, 1.0f, 1.0f, vt);
-        const float iw = 1.0f / vt[3];
-        float vx = vt[0] * iw, vy = vt[1] * iw, vz = vt[2] * iw;
-        const float il = 1.0f / sqrtf(vx * vx + vy * vy + vz * vz);
-        vx *= il;
-        vy *= il;
-        vz *= il;
-        post_m4v4(cam.inv_view, vx, vy, vz, 0.0f, wd);
-        const float depth = 12.0f; // reprojectDepth, ataa.wgsl.ts:68
-        post_m4v4(cam.prev_view_proj, cam.position[0] + wd[0] * depth, cam.position[1] + wd[1] * depth,
-                  cam.position[2] + wd[2] * depth, 1.0f, pc);
-        const float ipw = 1.0f / pc[3];
-        const float pu = (pc[0] * ipw) * 0.5f + 0.5f, pv = (pc[1] * ipw) * -0.5f + 0.5f;
-        const float4 h4 = post_sample(history, w, h, pu, pv);
+        float q[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) q[k] = fmaf((float)py, rp.c[k][1], col[k]);
+        const float s = copysignf(12.0f * __builtin_amdgcn_rsqf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]), q[3]);
+        const float ipw = __builtin_amdgcn_rcpf(fmaf(s, q[6], rp.k[2]));
+        const float4 h4 = fast_sample_xy(history, w, h, fmaf(s, q[4], rp.k[0]) * ipw, fmaf(s, q[5], rp.k[1]) * ipw);
         YCC hy = to_ycocg(h4.x, h4.y, h4.z);
         hy.y = post_clamp(hy.y, N.mean[i][0] - 2.0f * N.sd[i][0], N.mean[i][0] + 2.0f * N.sd[i][0]);
         hy.co = post_clamp(hy.co, N.mean[i][1] - 2.0f * N.sd[i][1], N.mean[i][1] + 2.0f * N.sd[i][1]);

@@ -130,7 +130,10 @@ def _close(got, ref, fast=False, tap_noise=0.0):
         # O(1) HDR values; the binary16 store then adds at most one half-ulp (2^-11 relative).
         ad = np.abs(got - ref)
         ok = ad <= 1e-4 + tap_noise + 1e-3 * np.abs(ref)
-        assert ok.mean() >= 0.999 and np.median(ad) <= 1e-5, (ok.mean(), np.median(ad))
+        # (a reprojected tap -- tap_noise > 0 -- also moves the median: the checker's own f32 chain sits a
+        # median 6e-5 texel from the exactly evaluated position on the 960-wide case, the folded FAST form
+        # 4e-5; 1/32 of the worst-case bound covers the two)
+        assert ok.mean() >= 0.999 and np.median(ad) <= 1e-5 + tap_noise / 32.0, (ok.mean(), np.median(ad))
     else:   # shader order, IEEE divide / sqrt, specified powf: the checker's bits
         assert np.array_equal(got, ref, equal_nan=True), (rel <= 1e-6).mean()
 
@@ -159,9 +162,12 @@ def test_fast_post_chain_matches_oracle(engine_mod, oracle, half, size):
             ap.position[k] = cam.position[k]
         e.post_ataa_resolve(ap, dc, dh, out)
         torch.cuda.synchronize()
-        # the reprojected history tap goes through three approximate reciprocals: its coordinate is off by
-        # a few f32 ulps, i.e. by ~4 * 2^-23 * max(w, h) texels, times the texel-to-texel step of this
-        # noise image (up to its full range, 4) -- a bound that grows with the image, unlike the others
+        # the reprojected history tap: the FAST kernel evaluates the chain with its matrices folded (in
+        # f64, by the launcher) and one rsq + one rcp, the checker in the shader's f32 order with three
+        # 4x4 products, two divides and a square root -- the two coordinates differ by the CHECKER's own
+        # rounding, a few f32 ulps of uv, i.e. ~4 * 2^-23 * max(w, h) texels (the folded form is the one
+        # closer to the exactly evaluated position), times the texel-to-texel step of this noise image
+        # (up to its full range, 4) -- a bound that grows with the image, unlike the others
         _close(out.cpu().numpy(), oracle.ataa_resolve(cam, cur, hist, half), fast=True,
                tap_noise=4.0 * 2.0 ** -23 * max(w, h) * 4.0)
         scene = _image(h, w, hdr=6.0)
