@@ -37,6 +37,7 @@ struct RayRegs {
     double drift;
     uint32_t steps, tries, flags;
     uint32_t phase; // steps % renorm_interval, carried incrementally (no division in the loop)
+    bool nf_ok; // STRICT Kerr-Schild: M, a, p_t, p_phi admit the NOFIX forms (ray_resume)
     Deriv<double> k1; // FAST Kerr-Schild only: right-hand side at the current state, formed by
                       // the post-step bookkeeping and reused as stage 1 of the next try
 };
@@ -80,7 +81,7 @@ __device__ __forceinline__ double rkf45_try(const Hole<double> &bh, const RayReg
         if constexpr (kFastKsCache<KIND, ARITH>)
             return rhs_ks_geom(bh, ks_geom(bh, r_, th_), r_, rc, pr_, pth_);
         else
-            return rhs<KIND, ARITH>(bh, r_, th_, y.pt, pr_, pth_, y.pph);
+            return rhs<KIND, ARITH>(bh, r_, th_, y.pt, pr_, pth_, y.pph, y.nf_ok);
     };
     // stage scale factors, same expressions as integrator.rs:119-160
     double s21, s31, s32, s41, s42, s43, s51, s52, s53, s54, s61, s62, s63, s64, s65;
@@ -142,7 +143,7 @@ __device__ __forceinline__ double rkf45_try(const Hole<double> &bh, const RayReg
     if constexpr (kStage1Cache<KIND, ARITH>)
         k1 = y.k1;
     else
-        k1 = rhs<KIND, ARITH>(bh, y.r, y.th, y.pt, y.pr, y.pth, y.pph);
+        k1 = rhs<KIND, ARITH>(bh, y.r, y.th, y.pt, y.pr, y.pth, y.pph, y.nf_ok);
     // t and phi never feed back into the right-hand side: keep only their running
     // 5th-order and error sums (same left-to-right order as the reference).
     double a5_t = c1 * k1.dt, a5_ph = c1 * k1.dph;
@@ -227,13 +228,13 @@ __device__ __forceinline__ void rk4_step(const Hole<double> &bh, RayRegs &y, dou
     if constexpr (kStage1Cache<KIND, ARITH>)
         k1 = y.k1; // the right-hand side at the current state (post-step bookkeeping)
     else
-        k1 = rhs<KIND, ARITH>(bh, y.r, y.th, y.pt, y.pr, y.pth, y.pph);
+        k1 = rhs<KIND, ARITH>(bh, y.r, y.th, y.pt, y.pr, y.pth, y.pph, y.nf_ok);
     const Deriv<double> k2 = rhs<KIND, ARITH>(bh, y.r + k1.dr * hh, y.th + k1.dth * hh, y.pt,
-                                              y.pr + k1.dpr * hh, y.pth + k1.dpth * hh, y.pph);
+                                              y.pr + k1.dpr * hh, y.pth + k1.dpth * hh, y.pph, y.nf_ok);
     const Deriv<double> k3 = rhs<KIND, ARITH>(bh, y.r + k2.dr * hh, y.th + k2.dth * hh, y.pt,
-                                              y.pr + k2.dpr * hh, y.pth + k2.dpth * hh, y.pph);
+                                              y.pr + k2.dpr * hh, y.pth + k2.dpth * hh, y.pph, y.nf_ok);
     const Deriv<double> k4 = rhs<KIND, ARITH>(bh, y.r + k3.dr * h, y.th + k3.dth * h, y.pt,
-                                              y.pr + k3.dpr * h, y.pth + k3.dpth * h, y.pph);
+                                              y.pr + k3.dpr * h, y.pth + k3.dpth * h, y.pph, y.nf_ok);
     const double h6 = h / 6.0;
     y.t += h6 * (k1.dt + 2.0 * k2.dt + 2.0 * k3.dt + k4.dt);
     y.r += h6 * (k1.dr + 2.0 * k2.dr + 2.0 * k3.dr + k4.dr);
@@ -254,16 +255,16 @@ __device__ __forceinline__ void symplectic_step(const Hole<double> &bh, RayRegs 
         if constexpr (kStage1Cache<KIND, ARITH>) {
             // the first sweep evaluates the right-hand side at the current state: cached
             if (it == 0) d = y.k1;
-            else d = rhs<KIND, ARITH>(bh, mr, mth, y.pt, mpr, mpth, y.pph);
+            else d = rhs<KIND, ARITH>(bh, mr, mth, y.pt, mpr, mpth, y.pph, y.nf_ok);
         } else {
-            d = rhs<KIND, ARITH>(bh, mr, mth, y.pt, mpr, mpth, y.pph);
+            d = rhs<KIND, ARITH>(bh, mr, mth, y.pt, mpr, mpth, y.pph, y.nf_ok);
         }
         mr = 0.5 * (y.r + (y.r + d.dr * h));
         mth = 0.5 * (y.th + (y.th + d.dth * h));
         mpr = 0.5 * (y.pr + (y.pr + d.dpr * h));
         mpth = 0.5 * (y.pth + (y.pth + d.dpth * h));
     }
-    const Deriv<double> f = rhs<KIND, ARITH>(bh, mr, mth, y.pt, mpr, mpth, y.pph);
+    const Deriv<double> f = rhs<KIND, ARITH>(bh, mr, mth, y.pt, mpr, mpth, y.pph, y.nf_ok);
     y.t += f.dt * h;
     y.r += f.dr * h;
     y.th += f.dth * h;
@@ -308,13 +309,13 @@ __device__ __forceinline__ double post_step_ref(const Hole<double> &bh, RayRegs 
     auto body = [&](auto div) {
         using DIV = decltype(div);
         const GInv<double> g = contravariant_ref<KIND, double, DIV>(bh, y.r, s, c);
-        if (renorm) y.pr = renormalized_pr<KIND, GRV_ARITH_STRICT, double>(g, y.pt, y.pr, y.pth, y.pph);
-        const double hv = hamiltonian_of<KIND, double>(g, y.pt, y.pr, y.pth, y.pph);
+        if (renorm) y.pr = renormalized_pr<KIND, GRV_ARITH_STRICT, double, DIV::kNoFixup>(g, y.pt, y.pr, y.pth, y.pph);
+        const double hv = hamiltonian_of<KIND, double, DIV::kNoFixup>(g, y.pt, y.pr, y.pth, y.pph);
         y.k1 = rhs_ref_at<KIND, double, DIV>(bh, y.r, s, c, g, y.pt, y.pr, y.pth, y.pph);
         return hv;
     };
     if constexpr (KIND == GRV_METRIC_KERR_KS) {
-        const bool nf = GRV_STRICT_NOFIXUP && bh.divs_nf && divs_nf_point(y.r, s, c);
+        const bool nf = GRV_STRICT_NOFIXUP && y.nf_ok && divs_nf_point(y.r, s, c);
         if (GRV_STRICT_NOFIXUP && __ballot(!nf) == 0ull) return body(SharedDivNoFixup{});
         const bool ok = bh.divs_ok && divs_ok_point(y.r, s, c);
         if (__ballot(!ok) == 0ull) return body(SharedDiv{});
@@ -482,11 +483,12 @@ __device__ __forceinline__ void ray_resume(const Hole<double> &bh, RayRegs &y,
                                            const SegmentParams &P, bool live, KsRayConsts &rc) {
     y.phase = P.renorm_interval ? y.steps % P.renorm_interval : 1u;
     rc = ks_ray_consts(bh, y.pt, y.pph); // p_t, p_phi never change
+    y.nf_ok = bh.divs_nf && divs_nf_consts(y.pt, y.pph);
     if constexpr (kFastKsCache<KIND, ARITH>) {
         // rebuild the stage-1 cache
         if (live) y.k1 = rhs_ks_geom(bh, ks_geom(bh, y.r, y.th), y.r, rc, y.pr, y.pth);
     } else if constexpr (kStrictCache<KIND, ARITH>) {
-        if (live) y.k1 = rhs<KIND, ARITH>(bh, y.r, y.th, y.pt, y.pr, y.pth, y.pph);
+        if (live) y.k1 = rhs<KIND, ARITH>(bh, y.r, y.th, y.pt, y.pr, y.pth, y.pph, y.nf_ok);
     }
 }
 
@@ -518,6 +520,7 @@ void integrate_segment_kernel(
 
     RayRegs y;
     y.flags = 0;
+    y.nf_ok = false;
     y.pt = y.pph = 0.0;
     if (have) load_ray(ws, slot, y);
     const Hole<double> bh = make_hole(P);
@@ -597,6 +600,7 @@ __global__ __launch_bounds__(kBlock) void integrate_path_kernel(
     const bool have = slot < ws.n;
     RayRegs y;
     y.flags = 0;
+    y.nf_ok = false;
     y.pt = y.pph = 0.0;
     if (have) load_ray(ws, slot, y);
     const Hole<double> bh = make_hole(P);
@@ -656,6 +660,7 @@ void integrate_refill_kernel(RayWorkspace ws, SegmentParams P,
     const Hole<double> bh = make_hole(P);
     RayRegs y;
     y.flags = 0;
+    y.nf_ok = false;
     y.pt = y.pph = 0.0;
     KsRayConsts rc = ks_ray_consts(bh, 0.0, 0.0);
     uint32_t slot = 0;

@@ -33,7 +33,7 @@ template <typename T> struct Hole {
     T a2; // a * a
     T two_m; // 2 M
     bool divs_ok = false; // M and a admit the shared-reciprocal division form (divs_ok_hole)
-    bool divs_nf = false; // ... and its form without v_div_fixup (divs_nf_hole)
+    bool divs_nf = false; // ... and its form without v_div_fixup (divs_nf_hole; per ray: RayRegs::nf_ok)
 };
 
 template <typename T> struct Deriv {
@@ -285,6 +285,12 @@ __device__ __forceinline__ bool divs_ok_point(double r, double sin_theta, double
 __device__ __forceinline__ bool divs_nf_hole(double M, double a) {
     return M >= 0x1p-20 && M <= 0x1p20 && fabs(a) >= 0x1p-20 && fabs(a) <= 0x1p20;
 }
+// per-ray part of the admission: p_t and p_phi (constants of the motion) non-zero and moderate.  Then
+// g^tt p_t (g^tt <= -1) and g^phph p_phi are non-zero normal numbers, which is what lets the NOFIX
+// forms drop the products with the structurally zero g^{t phi} (see rhs_ref_at)
+__device__ __forceinline__ bool divs_nf_consts(double p_t, double p_ph) {
+    return fabs(p_t) >= 0x1p-500 && fabs(p_t) <= 0x1p500 && fabs(p_ph) >= 0x1p-500 && fabs(p_ph) <= 0x1p500;
+}
 __device__ __forceinline__ bool divs_nf_point(double r, double sin_theta, double cos_theta) {
     return r >= 0x1p-20 && r <= 0x1p20 && fabs(sin_theta) >= 0x1p-70 && fabs(cos_theta) >= 0x1p-70;
 }
@@ -354,10 +360,20 @@ __device__ __forceinline__ Deriv<T> rhs_ref_at(const Hole<T> &bh, T r, T sin_the
         // the contraction of get_state_derivative keeps the structurally zero entries of the
         // metric (hamiltonian.rs:19-28): 0 * p is not 0 for a non-finite momentum, and x + 0 loses
         // the sign of x = -0
-        d.dt = g.tt * p_t + g.tr * p_r + g.tph * p_ph;
+        if constexpr (DIV::kNoFixup) {
+            // ... unless neither can happen (divs_nf_consts: p_t, p_phi non-zero and moderate).
+            // dt: x = g^tt p_t + g^tr p_r has a non-zero first term, so it is non-zero or the +0 of a
+            // cancellation, never -0, and x + (+-0) == x.  dphi: (+-0 + y) + w with w = g^phph p_phi
+            // non-zero: +-0 + y == y for y != 0, and for y == +-0 the sum is a zero of some sign that
+            // w absorbs.  Same bits, four instructions fewer
+            d.dt = g.tt * p_t + g.tr * p_r;
+            d.dph = g.rph * p_r + g.phph * p_ph;
+        } else {
+            d.dt = g.tt * p_t + g.tr * p_r + g.tph * p_ph;
+            d.dph = g.tph * p_t + g.rph * p_r + g.phph * p_ph;
+        }
         d.dr = g.tr * p_t + g.rr * p_r + g.rph * p_ph;
         d.dth = g.thth * p_th;
-        d.dph = g.tph * p_t + g.rph * p_r + g.phph * p_ph;
 
         const T r2 = r * r;
         const T sin2 = fmax_t(sin_theta * sin_theta, T(1e-12));
@@ -505,14 +521,15 @@ __device__ __forceinline__ Deriv<T> rhs_ref_at(const Hole<T> &bh, T r, T sin_the
     return d;
 }
 
+// nf_ok: this ray's constants admit the NOFIX forms (bh.divs_nf && divs_nf_consts, formed once per ray)
 template <int KIND, typename T>
 __device__ __forceinline__ Deriv<T> rhs_ref(const Hole<T> &bh, T r, T theta, T p_t, T p_r,
-                                            T p_th, T p_ph) {
+                                            T p_th, T p_ph, bool nf_ok = false) {
     T sin_theta, cos_theta;
     sincos_t(theta, &sin_theta, &cos_theta);
     if constexpr (KIND == GRV_METRIC_KERR_KS && sizeof(T) == 8) {
         // wave-uniform choice of the division form (see SharedDiv): same bits either way
-        const bool nf = GRV_STRICT_NOFIXUP && bh.divs_nf && divs_nf_point(r, sin_theta, cos_theta);
+        const bool nf = GRV_STRICT_NOFIXUP && nf_ok && divs_nf_point(r, sin_theta, cos_theta);
         if (GRV_STRICT_NOFIXUP && __ballot(!nf) == 0ull) {
             const GInv<T> g = contravariant_ref<KIND, T, SharedDivNoFixup>(bh, r, sin_theta, cos_theta);
             return rhs_ref_at<KIND, T, SharedDivNoFixup>(bh, r, sin_theta, cos_theta, g, p_t, p_r, p_th, p_ph);
@@ -693,11 +710,11 @@ __device__ __forceinline__ GInv<double> ginv_from_geom(const Hole<double> &bh, c
 
 template <int KIND, int ARITH, typename T>
 __device__ __forceinline__ Deriv<T> rhs(const Hole<T> &bh, T r, T theta, T p_t, T p_r, T p_th,
-                                        T p_ph) {
+                                        T p_ph, bool nf_ok = false) {
     if constexpr (ARITH == GRV_ARITH_FAST && KIND == GRV_METRIC_KERR_KS)
         return rhs_ks_fast<T>(bh, r, theta, p_t, p_r, p_th, p_ph);
     else
-        return rhs_ref<KIND, T>(bh, r, theta, p_t, p_r, p_th, p_ph);
+        return rhs_ref<KIND, T>(bh, r, theta, p_t, p_r, p_th, p_ph, nf_ok);
 }
 
 // ---------------------------------------------------------------------------
@@ -706,21 +723,28 @@ __device__ __forceinline__ Deriv<T> rhs(const Hole<T> &bh, T r, T theta, T p_t, 
 // `do_renorm` first projects p_r, then H is evaluated on the projected state,
 // exactly as geodesic/mod.rs:229-237 does with two contravariant() calls.
 // ---------------------------------------------------------------------------
-template <int KIND, typename T>
+// SKIP_TPH (Kerr-Schild under divs_nf_consts only): the partial sum ahead of the g^{t phi} term starts
+// with the non-zero g^tt p_t^2, so it is never -0 and adding the term's +-0 leaves it as it is
+template <int KIND, typename T, bool SKIP_TPH = false>
 __device__ __forceinline__ T hamiltonian_of(const GInv<T> &g, T p_t, T p_r, T p_th, T p_ph) {
     // invariants/mod.rs:25-37, zero entries of the metric included (see rhs_ref)
-    return T(0.5) * (g.tt * p_t * p_t + g.rr * p_r * p_r + g.thth * p_th * p_th + g.phph * p_ph * p_ph +
-                     T(2) * g.tph * p_t * p_ph + T(2) * g.tr * p_t * p_r + T(2) * g.rph * p_r * p_ph);
+    if constexpr (SKIP_TPH && KIND == GRV_METRIC_KERR_KS)
+        return T(0.5) * (g.tt * p_t * p_t + g.rr * p_r * p_r + g.thth * p_th * p_th + g.phph * p_ph * p_ph +
+                         T(2) * g.tr * p_t * p_r + T(2) * g.rph * p_r * p_ph);
+    else
+        return T(0.5) * (g.tt * p_t * p_t + g.rr * p_r * p_r + g.thth * p_th * p_th + g.phph * p_ph * p_ph +
+                         T(2) * g.tph * p_t * p_ph + T(2) * g.tr * p_t * p_r + T(2) * g.rph * p_r * p_ph);
 }
 
-template <int KIND, int ARITH, typename T>
+template <int KIND, int ARITH, typename T, bool SKIP_TPH = false>
 __device__ __forceinline__ T renormalized_pr(const GInv<T> &g, T p_t, T p_r, T p_th, T p_ph) {
     const T a_quad = g.rr;
     // renormalization.rs:21-27.  STRICT keeps the zero entries of the metric (see rhs_ref); the
     // FAST contract, defined on finite states only, drops the Kerr-Schild g^{t phi} = 0 term
     const T b_quad = T(2) * (g.tr * p_t + g.rph * p_ph);
     T c_quad = g.tt * p_t * p_t + g.thth * p_th * p_th + g.phph * p_ph * p_ph;
-    if constexpr (!(ARITH == GRV_ARITH_FAST && KIND == GRV_METRIC_KERR_KS)) c_quad = c_quad + T(2) * g.tph * p_t * p_ph;
+    if constexpr (!(ARITH == GRV_ARITH_FAST && KIND == GRV_METRIC_KERR_KS) && !(SKIP_TPH && KIND == GRV_METRIC_KERR_KS))
+        c_quad = c_quad + T(2) * g.tph * p_t * p_ph;
     T out = p_r;
     if (fabs_t(a_quad) > T(1e-12)) {
         const T disc = b_quad * b_quad - T(4) * a_quad * c_quad;
