@@ -80,6 +80,24 @@ int grv_strict_math(grv_engine *e, int op, size_t n, const double *x, const doub
     return GRV_OK;
 }
 
+int grv_strict_rhs_probe(grv_engine *e, int form, size_t n, const double *states, double *out) {
+    if (!e) return GRV_ERR_INVALID;
+    if (form < GRV_RHS_FORM_IEEE || form > GRV_RHS_FORM_NOFIXUP) return fail(e, GRV_ERR_INVALID, "bad form %d", form);
+    if (n == 0) return GRV_OK;
+    if (!states || !out || n > (1ull << 24)) return fail(e, GRV_ERR_INVALID, "bad rhs_probe request");
+    GRV_HIP(e, hipSetDevice(e->device));
+    const size_t b_in = align_up(n * 8 * sizeof(double), 256), b_out = align_up(n * 7 * sizeof(double), 256);
+    int rc = ensure_stage(e, b_in + b_out);
+    if (rc != GRV_OK) return rc;
+    char *base = static_cast<char *>(e->stage_mem);
+    double *din = reinterpret_cast<double *>(base), *dout = reinterpret_cast<double *>(base + b_in);
+    GRV_HIP(e, hipMemcpy(din, states, n * 8 * sizeof(double), hipMemcpyHostToDevice));
+    GRV_HIP(e, launch_strict_rhs_probe(form, (uint32_t)n, e->mass, e->spin_c * e->mass, din, dout, nullptr));
+    GRV_HIP(e, hipDeviceSynchronize());
+    GRV_HIP(e, hipMemcpy(out, dout, n * 7 * sizeof(double), hipMemcpyDeviceToHost));
+    return GRV_OK;
+}
+
 int grv_strict_math_host(int op, size_t n, const double *x, const double *y, double *out) {
     const int base = op & ~GRV_MATH_F32;
     if (base < GRV_MATH_SINCOS_SIN || base > GRV_MATH_DIV_CONST) return GRV_ERR_INVALID;

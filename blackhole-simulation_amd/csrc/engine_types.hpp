@@ -165,6 +165,8 @@ hipError_t launch_wgsl_symplectic(const FrameGeom &G, const WgslParams &P, float
 hipError_t launch_glsl_fragment(const FrameGeom &G, const GlslParams &P, float *out_rgba,
                               uint32_t *out_steps, unsigned long long *total_steps,
                               uint32_t n_slots, hipStream_t s);
+hipError_t launch_strict_rhs_probe(int form, uint32_t n, double M, double a, const double *states, double *out,
+                                   hipStream_t s);
 hipError_t launch_strict_math(int op, uint32_t n, const double *x, const double *y, double *out,
                               hipStream_t s);
 hipError_t launch_spectrum_lut(float *out, uint32_t width, uint32_t height, double max_temp,

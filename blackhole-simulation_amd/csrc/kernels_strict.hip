@@ -246,6 +246,58 @@ __global__ __launch_bounds__(kBlock) void strict_math_kernel(int op, uint32_t n,
 }
 } // namespace
 
+namespace {
+// the STRICT Kerr-Schild right-hand side at given states, through a chosen division form
+// (grv_strict_rhs_probe: the forms must agree bit for bit wherever the guards admit them)
+__global__ __launch_bounds__(kBlock) void strict_rhs_probe_kernel(int form, uint32_t n, double M, double a,
+                                                                 const double *__restrict__ st,
+                                                                 double *__restrict__ out) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    Hole<double> bh{M, a, a * a, 2.0 * M};
+    bh.divs_ok = divs_ok_hole(M, a);
+    bh.divs_nf = divs_nf_hole(M, a);
+    const double r = st[8 * i + 1], th = st[8 * i + 2], pt = st[8 * i + 4], pr = st[8 * i + 5],
+                 pth = st[8 * i + 6], pph = st[8 * i + 7];
+    double sn, cs;
+    sincos_t<double>(th, &sn, &cs);
+    // per lane here (no ballot): the probe reports which form it was allowed to take
+    const bool nf = bh.divs_nf && divs_nf_consts(pt, pph) && divs_nf_point(r, sn, cs);
+    const bool ok = bh.divs_ok && divs_ok_point(r, sn, cs);
+    Deriv<double> d;
+    double used;
+    if (form == GRV_RHS_FORM_NOFIXUP && nf) {
+        const GInv<double> g = contravariant_ref<GRV_METRIC_KERR_KS, double, SharedDivNoFixup>(bh, r, sn, cs);
+        d = rhs_ref_at<GRV_METRIC_KERR_KS, double, SharedDivNoFixup>(bh, r, sn, cs, g, pt, pr, pth, pph);
+        used = GRV_RHS_FORM_NOFIXUP;
+    } else if (form >= GRV_RHS_FORM_SHARED && ok) {
+        const GInv<double> g = contravariant_ref<GRV_METRIC_KERR_KS, double, SharedDiv>(bh, r, sn, cs);
+        d = rhs_ref_at<GRV_METRIC_KERR_KS, double, SharedDiv>(bh, r, sn, cs, g, pt, pr, pth, pph);
+        used = GRV_RHS_FORM_SHARED;
+    } else {
+        const GInv<double> g = contravariant_ref<GRV_METRIC_KERR_KS, double>(bh, r, sn, cs);
+        d = rhs_ref_at<GRV_METRIC_KERR_KS, double>(bh, r, sn, cs, g, pt, pr, pth, pph);
+        used = GRV_RHS_FORM_IEEE;
+    }
+    double *o = out + 7 * (size_t)i;
+    o[0] = d.dt;
+    o[1] = d.dr;
+    o[2] = d.dth;
+    o[3] = d.dph;
+    o[4] = d.dpr;
+    o[5] = d.dpth;
+    o[6] = used;
+}
+} // namespace
+
+hipError_t launch_strict_rhs_probe(int form, uint32_t n, double M, double a, const double *states, double *out,
+                                   hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(strict_rhs_probe_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, form, n, M, a,
+                       states, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_strict_math(int op, uint32_t n, const double *x, const double *y, double *out,
                               hipStream_t s) {
     if (n == 0) return hipSuccess;

@@ -22,6 +22,7 @@ DISK_PROFILE_SHORTCUT, DISK_PROFILE_PAGE_THORNE = 0, 1
 MATH_SINCOS_SIN, MATH_SINCOS_COS, MATH_SIN, MATH_COS, MATH_POW, MATH_EXP, MATH_ATAN = 0, 1, 2, 3, 4, 5, 6
 MATH_LOG, MATH_ACOS, MATH_ATAN2, MATH_F32 = 7, 8, 9, 16
 MATH_DIV, MATH_DIV_SHARED, MATH_DIV_NOFIX, MATH_RCP_R2, MATH_DIV_CONST = 10, 11, 12, 13, 14
+RHS_FORM_IEEE, RHS_FORM_SHARED, RHS_FORM_NOFIXUP = 0, 1, 2
 TERM_NONE, TERM_HORIZON, TERM_ESCAPE, TERM_MAXSTEPS, TERM_DISK_CROSSING = 0, 1, 2, 3, 4
 _STATUS = {0: "GRV_OK", 1: "GRV_ERR_INVALID", 2: "GRV_ERR_NO_DEVICE", 3: "GRV_ERR_HIP",
            4: "GRV_ERR_OOM"}
@@ -209,6 +210,8 @@ def load_library():
     L.grv_strict_math_host.argtypes = [i, sz, p, p, p]
     L.grv_strict_math.restype = i
     L.grv_strict_math.argtypes = [p, i, sz, p, p, p]
+    L.grv_strict_rhs_probe.restype = i
+    L.grv_strict_rhs_probe.argtypes = [p, i, sz, p, p]
     L.grv_generate_spectrum_lut_device.restype = i
     L.grv_generate_spectrum_lut_device.argtypes = [p, sz, sz, d, p, p]
     L.grv_wgsl_params_default.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(Camera), d, d,
@@ -650,6 +653,15 @@ class PhysicsEngine:
         out = np.zeros_like(x)
         self._check(self._lib.grv_strict_math(self._h, int(op), x.size, _np_ptr(x), _np_ptr(y),
                                               _np_ptr(out)), "strict_math")
+        return out
+
+    def strict_rhs_probe(self, form, states):
+        """The STRICT Kerr-Schild right-hand side of [n, 8] states through division form RHS_FORM_*:
+        [n, 7] = (dt, dr, dtheta, dphi, dp_r, dp_theta, form that ran)."""
+        st = np.ascontiguousarray(states, np.float64).reshape(-1, 8)
+        out = np.zeros((st.shape[0], 7))
+        self._check(self._lib.grv_strict_rhs_probe(self._h, int(form), st.shape[0], _np_ptr(st), _np_ptr(out)),
+                    "strict_rhs_probe")
         return out
 
     # ---- lib.rs:107-110, 161-205 ----

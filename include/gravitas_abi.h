@@ -462,6 +462,15 @@ enum { GRV_MATH_SINCOS_SIN = 0, GRV_MATH_SINCOS_COS = 1, GRV_MATH_SIN = 2, GRV_M
                                   (the Fehlberg tableau's denominators); any other y[i] yields NaN */,
        GRV_MATH_F32 = 16 /* or-ed in: the f32 form (float)op((double)(float)x) of the shader-order kernels */ };
 int grv_strict_math(grv_engine *e, int op, size_t n, const double *x, const double *y, double *out);
+/* The STRICT Kerr-Schild right-hand side (get_state_derivative, geodesic/hamiltonian.rs:13-35 over
+ * kerr.rs:412-499) of n states [t, r, theta, phi, p_t, p_r, p_theta, p_phi] through one of the three
+ * division forms the STRICT kernels choose between per wave (csrc/kerr_device.hpp): verification hook,
+ * host buffers.  out[7 i ..] = dt, dr, dtheta, dphi, dp_r, dp_theta, and the form that ran -- the one
+ * asked for where its operand guard admits the state, else the next more general one.  Every form must
+ * return the same bits. */
+enum { GRV_RHS_FORM_IEEE = 0 /* the compiler's `/` */, GRV_RHS_FORM_SHARED = 1 /* SharedDiv */,
+       GRV_RHS_FORM_NOFIXUP = 2 /* SharedDivNoFixup */ };
+int grv_strict_rhs_probe(grv_engine *e, int form, size_t n, const double *states, double *out);
 /* the same routines compiled for the host (they also serve the engine's host-side closed forms):
  * no device needed.  op as above; GRV_MATH_SINCOS_* evaluate sin / cos. */
 int grv_strict_math_host(int op, size_t n, const double *x, const double *y, double *out);
