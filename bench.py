@@ -8,6 +8,10 @@
   7680x4320, the f32 compute march (compute.wgsl.ts) at a fixed 1024-step budget: every
   ray marches until it terminates or has done 1024 steps.
 
+--config c5 (BASELINE.json configs[4], the numerical-parity run):
+  the c3 frame at RKF45 tol 1e-9 under the reference-order STRICT contract (the arithmetic whose
+  end states, step counts and pixels equal the CPU oracle's bit for bit).
+
 A "step" is one frame: pixel->state init, integrate, shade (all on the GPU, outputs resident
 in HBM), and for N > 1 the single gather of finished tiles to rank 0 (RCCL over xGMI).
 
@@ -90,20 +94,20 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline_c3(width, height, eye, target_seconds=15.0):
+def cpu_baseline_c3(width, height, eye, target_seconds=15.0, tolerance=1e-8):
     """The oracle (C restatement of gravitas-core) timed on the host cores on a bounded,
     pixel-strided sample of the same workload.  Checker/baseline only."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
     cores = usable_cores()
     cam = po.camera_look_at(eye, aspect=width / height)
-    fp = po.frame_params(width, height, spin=0.999)
+    fp = po.frame_params(width, height, spin=0.999, opt=po.options(max_steps=2048, tolerance=tolerance))
     lut = po.blackbody_lut(fp.lut_width, fp.lut_height, fp.lut_max_temp)
     t = time.time()
     probe = po.render_frame(cam, fp, lut, stride=(16, 16), nthreads=cores, want_states=False)
     dt = max(time.time() - t, 1e-3)
     rate = probe["stats"].accepted_steps / dt
-    total = 183.0 * width * height  # ~steps in the full frame
+    total = probe["stats"].accepted_steps * 256.0  # ~steps in the full frame (the probe is a 1/256 sample)
     # the finest pixel stride whose estimated time stays inside the 10-30 s the sample is meant to take
     sx, sy = 32, 32
     for cand in ((1, 1), (2, 1), (2, 2), (3, 2), (3, 3), (4, 3), (4, 4), (6, 4), (6, 6), (8, 8), (12, 12),
@@ -201,11 +205,15 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+TOL = 1e-8                # RKF45 tolerance of the f64 frame (--config c5 / --tolerance change it)
+BASELINE_LABEL = {"c3": "configs[2]", "c4": "configs[3]", "c5": "configs[4]"}
+
+
 def workload_text(cfg, W, H, split):
     if cfg == "c3":
-        return ("%dx%d frame%s, a=0.999 Kerr-Schild, adaptive RKF45 tol=1e-8 h0=0.01 escape=1000 "
+        return ("%dx%d frame%s, a=0.999 Kerr-Schild, adaptive RKF45 tol=%g h0=0.01 escape=1000 "
                 "renorm=10 max_steps=2048, Planck LUT 512x64 Tmax=1e5 redshift shading, camera "
-                "r0=60M theta=97deg fov=60deg" % (W, H, split))
+                "r0=60M theta=97deg fov=60deg" % (W, H, split, TOL))
     return ("%dx%d frame%s, a=0.999, f32 compute march (Kerr-Schild implicit-midpoint, "
             "compute.wgsl.ts) at a fixed 1024-step budget, disk g-factor shading + star field "
             "(packed / fast arithmetic: the star hash takes a FAST-contract sin, so individual stars "
@@ -245,9 +253,10 @@ def main_native(args, cfg, base_w, base_h):
     eye = (60.0 * np.sin(th), 60.0 * np.cos(th), 0.0)
     arith = {"fast": bh.ARITH_FAST, "strict": bh.ARITH_STRICT, "packed": bh.ARITH_FAST_PACKED}[args.arith]
     cam = bh.camera_look_at(eye, aspect=W / H)
-    params = bh.render_params(W, H, arith=arith if cfg == "c3" else bh.ARITH_FAST, segment_tries=args.segment_tries)
+    params = bh.render_params(W, H, arith=arith if cfg == "c3" else bh.ARITH_FAST, segment_tries=args.segment_tries,
+                              tolerance=TOL)
     prof = bh.render_params(W, H, arith=arith if cfg == "c3" else bh.ARITH_FAST, segment_tries=args.segment_tries,
-                            profile=1)
+                            profile=1, tolerance=TOL)
     wp = bh.wgsl_params(W, H, cam, 1.0, 0.999, max_steps=1024, arith=arith) if cfg == "c4" else None
     images = [torch.empty((H, W, 4), dtype=torch.float32, device="cuda:0") for _ in range(2)]
     m.stats_accumulate(True)
@@ -298,7 +307,7 @@ def main_native(args, cfg, base_w, base_h):
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f64" if cfg == "c3" else "f32", "data": "synthetic",
         "config": {"workload": workload_text(cfg, W, H, "" if G == 1 else " split over %d GPUs" % G),
-                   "baseline_config": "configs[2]" if cfg == "c3" else "configs[3]", "arith": args.arith,
+                   "baseline_config": args.baseline_label, "arith": args.arith,
                    "segment_tries": args.segment_tries or "one launch",
                    "host": "one process through the C ABI (grv_engine_create_multi): a host thread and two "
                            "streams per device",
@@ -324,7 +333,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", choices=["c3", "c4"], default="c3")
+    ap.add_argument("--config", choices=["c3", "c4", "c5"], default="c3",
+                    help="c3 = BASELINE configs[2] (the headline), c4 = configs[3] (8K f32 march), c5 = configs[4]: "
+                         "the c3 frame at tol = 1e-9 under the reference-order STRICT contract (the parity run)")
+    ap.add_argument("--tolerance", type=float, default=None, help="RKF45 tolerance of the f64 frame (default 1e-8; c5: 1e-9)")
     ap.add_argument("--arith", choices=["fast", "strict", "packed"], default=None,
                     help="arithmetic contract (default: fast for c3; packed = the FAST contract with two rays per "
                          "lane on the packed-f32 ops for c4)")
@@ -351,6 +363,19 @@ def main():
                     help="--native: exchange transport (auto: RCCL between real devices)")
     args = ap.parse_args()
     cfg = args.config
+    global TOL
+    label = BASELINE_LABEL[cfg]
+    if cfg == "c5":  # the c3 code path with the parity run's tolerance and arithmetic
+        cfg = "c3"
+        if args.arith is None:
+            args.arith = "strict"
+        if args.tolerance is None:
+            args.tolerance = 1e-9
+    if args.tolerance is not None:
+        if cfg != "c3":
+            raise SystemExit("--tolerance applies to the f64 frame (--config c3 / c5)")
+        TOL = args.tolerance
+    args.baseline_label = label
     if args.arith is None:
         args.arith = "fast" if cfg == "c3" else "packed"
     if cfg == "c3" and args.arith == "packed":
@@ -432,7 +457,7 @@ def main():
     eng = bh.PhysicsEngine(1.0, 0.999, device=local_rank)
     cam = bh.camera_look_at(eye, aspect=W / H)
     params = bh.render_params(W, H, arith=arith if cfg == "c3" else bh.ARITH_FAST,
-                              segment_tries=args.segment_tries, profile=0)
+                              segment_tries=args.segment_tries, profile=0, tolerance=TOL)
     rp = D.rank_params(params, world, rank)
     prof_rp = D.rank_params(params, world, rank)
     prof_rp.profile = 1
@@ -561,7 +586,7 @@ def main():
         achieved = (per_frame_bytes / launches_per_frame) / (avg_launch_ms * 1e-3) / 1e9
         kernel_pretty = KERNEL_OF[(cfg, args.arith)]
         pmc, pmc_src = committed_pmc(kernel_pretty, bh.library_path())
-        usable_pmc = pmc if (pmc and world == 1 and not args.segment_tries and
+        usable_pmc = pmc if (pmc and world == 1 and not args.segment_tries and (cfg != "c3" or TOL == 1e-8) and
                              (W, H) == tuple(pmc.get("frame", (W, H)))) else None
         peak_tf = FP64_PEAK_TFLOPS if cfg == "c3" else FP32_PEAK_TFLOPS
         nominal_frac = achieved / HBM_PEAK_GBS
@@ -607,7 +632,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64" if cfg == "c3" else "f32", "data": "synthetic",
-            "config": {"workload": workload, "baseline_config": "configs[2]" if cfg == "c3" else "configs[3]",
+            "config": {"workload": workload, "baseline_config": args.baseline_label,
                        "arith": args.arith, "segment_tries": args.segment_tries or "one launch",
                        "partition": ("64x64 tiles round-robin, one RCCL gather to rank 0 per frame%s"
                                      % (", overlapped with the next frame" if overlap else ""))
@@ -621,7 +646,7 @@ def main():
         if cfg == "c3":
             line["config"]["max_hamiltonian_drift_rank0"] = max_drift
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = (cpu_baseline_c3(base_w, base_h, eye) if cfg == "c3"
+            line["cpu_baseline"] = (cpu_baseline_c3(base_w, base_h, eye, tolerance=TOL) if cfg == "c3"
                                     else cpu_baseline_c4(wp, base_w, base_h))
         sys.stdout.flush()
         os.dup2(stdout_fd, 1)
