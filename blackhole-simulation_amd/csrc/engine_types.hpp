@@ -21,6 +21,40 @@ constexpr int kBlock = 256;
 #define GRV_MARCH_BLOCK 64
 #endif
 constexpr int kMarchBlock = GRV_MARCH_BLOCK;
+// Dispatch order of a frame's blocks.  Workgroups start in blockIdx order, and a frame's long rays
+// (photon ring, disk) sit in the middle rows of the image, i.e. in the middle of a rank's block list:
+// centre-out order starts them first, so the last blocks to start hold the short rays of the image's
+// edge rows and the launch's tail is as short as it can be.  Storage is untouched: a block only
+// changes WHICH slots it works on, not where they live.  Measured A/B on one box
+// (profiles/r03_ab_centre_out.jsonl): the packed f32 march of config 4, whose 0.013 % of rays at the
+// 1024-step budget run seven times as long as the rest, gains 2.1 % on the whole 8K frame (311.0 ->
+// 317.4 G ray-steps/s) and 1 % on an eighth of it with two frames in flight; the f64 RKF45 frame
+// (longest wave 3x the median) loses 0.5 % at N = 1 and gains 1.4 % on an eighth -- so the f32 marches
+// take it and the f64 segment kernel keeps the natural order (GRV_CENTRE_OUT_F64 = 0).
+#ifndef GRV_CENTRE_OUT
+#define GRV_CENTRE_OUT 1
+#endif
+#ifndef GRV_CENTRE_OUT_F64
+#define GRV_CENTRE_OUT_F64 0
+#endif
+__device__ __forceinline__ uint32_t centre_out_block(uint32_t b, uint32_t nb) {
+    const uint32_t half = nb >> 1;
+    return (b & 1u) ? (half - 1u - (b >> 1)) : (half + (b >> 1)); // bijection of [0, nb)
+}
+__device__ __forceinline__ uint32_t dispatch_block(uint32_t b, uint32_t nb) {
+#if GRV_CENTRE_OUT
+    return centre_out_block(b, nb);
+#else
+    return b;
+#endif
+}
+__device__ __forceinline__ uint32_t dispatch_block_f64(uint32_t b, uint32_t nb) {
+#if GRV_CENTRE_OUT_F64
+    return centre_out_block(b, nb);
+#else
+    return b;
+#endif
+}
 constexpr int kMaxCrossRec = 4;
 
 // flags word: bits 0-2 termination, bit 3 forced-min-step pending, bits 4-7 crossing

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(kMarchBlock) __attribute__((amdgpu_waves_per_eu(6, 
                                                                       uint32_t *__restrict__ out_steps,
                                                                       unsigned long long *total_steps,
                                                                       uint32_t n_slots) {
-    const uint32_t slot = blockIdx.x * kMarchBlock + threadIdx.x;
+    const uint32_t slot = dispatch_block(blockIdx.x, gridDim.x) * kMarchBlock + threadIdx.x;
     uint32_t X = 0, Y = 0, oi = 0;
     const bool valid = slot < n_slots && slot_to_pixel(G, slot, X, Y, oi);
     uint32_t steps = 0;
