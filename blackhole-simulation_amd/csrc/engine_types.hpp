@@ -30,7 +30,9 @@ constexpr int kMarchBlock = GRV_MARCH_BLOCK;
 // 1024-step budget run seven times as long as the rest, gains 2.1 % on the whole 8K frame (311.0 ->
 // 317.4 G ray-steps/s) and 1 % on an eighth of it with two frames in flight; the f64 RKF45 frame
 // (longest wave 3x the median) loses 0.5 % at N = 1 and gains 1.4 % on an eighth -- so the f32 marches
-// take it and the f64 segment kernel keeps the natural order (GRV_CENTRE_OUT_F64 = 0).
+// take it and the f64 segment kernel keeps the natural order (GRV_CENTRE_OUT_F64 = 0).  The GLSL
+// fragment march was measured too and loses 2-12 % (its long rays are the disk-slab samplers, which
+// contend when they all start together): natural order there.
 #ifndef GRV_CENTRE_OUT
 #define GRV_CENTRE_OUT 1
 #endif
