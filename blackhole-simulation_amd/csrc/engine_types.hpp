@@ -32,7 +32,10 @@ constexpr int kMarchBlock = GRV_MARCH_BLOCK;
 // (longest wave 3x the median) loses 0.5 % at N = 1 and gains 1.4 % on an eighth -- so the f32 marches
 // take it and the f64 segment kernel keeps the natural order (GRV_CENTRE_OUT_F64 = 0).  The GLSL
 // fragment march was measured too and loses 2-12 % (its long rays are the disk-slab samplers, which
-// contend when they all start together): natural order there.
+// contend when they all start together): natural order there.  A prime stride through the block list
+// (consecutive starts a quarter of the image apart) was measured as well and loses everywhere: f64
+// -1.5 %, packed march -2 % against centre-out, GLSL up to -20 % (neighbouring tiles share the noise /
+// star texels' cache lines) -- lib_f2 / lib_p2 / lib_g2 in the same file.
 #ifndef GRV_CENTRE_OUT
 #define GRV_CENTRE_OUT 1
 #endif
