@@ -195,6 +195,7 @@ SegmentParams make_segment_params(const grv_engine *e, const GrvOptions &o) {
     P.disk_inner = 0.0;
     P.disk_outer = 0.0;
     P.max_crossings = 0xFFFFFFFFu;
+    P.block_order = 0;
     return P;
 }
 
@@ -877,6 +878,7 @@ int grv_render_frame_device(grv_engine *e, const GrvCamera *cam, const GrvRender
     if (rc != GRV_OK) return rc;
 
     SegmentParams P = make_segment_params(e, p->opt);
+    P.block_order = p->tile_world > 1 ? 1u : 0u; // a rank's share: long middle rows first (engine_types.hpp)
     const double spin = (p->opt.metric_kind == GRV_METRIC_SCHWARZSCHILD) ? 0.0 : e->spin_c;
     const double disk_inner = p->disk_inner > 0.0 ? p->disk_inner : isco_prograde(e->mass, e->spin_c);
     if (p->shading) {

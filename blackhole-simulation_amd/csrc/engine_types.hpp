@@ -30,7 +30,10 @@ constexpr int kMarchBlock = GRV_MARCH_BLOCK;
 // 1024-step budget run seven times as long as the rest, gains 2.1 % on the whole 8K frame (311.0 ->
 // 317.4 G ray-steps/s) and 1 % on an eighth of it with two frames in flight; the f64 RKF45 frame
 // (longest wave 3x the median) loses 0.5 % at N = 1 and gains 1.4 % on an eighth -- so the f32 marches
-// take it and the f64 segment kernel keeps the natural order (GRV_CENTRE_OUT_F64 = 0).  The GLSL
+// take it, and the f64 segment kernel takes it for a rank's share of a split frame only
+// (SegmentParams::block_order, set by grv_render_frame_device when tile_world > 1; measured on the
+// shares of the strong 4K split with two frames in flight: N = 2 14.10 -> 13.84 ms, N = 4 7.07 -> 7.02,
+// N = 8 3.64 -> 3.59) and keeps the natural order for a whole frame.  The GLSL
 // fragment march was measured too and loses 2-12 % (its long rays are the disk-slab samplers, which
 // contend when they all start together): natural order there.  A prime stride through the block list
 // (consecutive starts a quarter of the image apart) was measured as well and loses everywhere: f64
@@ -53,11 +56,11 @@ __device__ __forceinline__ uint32_t dispatch_block(uint32_t b, uint32_t nb) {
     return b;
 #endif
 }
-__device__ __forceinline__ uint32_t dispatch_block_f64(uint32_t b, uint32_t nb) {
+__device__ __forceinline__ uint32_t dispatch_block_f64(uint32_t b, uint32_t nb, uint32_t order) {
 #if GRV_CENTRE_OUT_F64
     return centre_out_block(b, nb);
 #else
-    return b;
+    return order ? centre_out_block(b, nb) : b;
 #endif
 }
 constexpr int kMaxCrossRec = 4;
@@ -97,6 +100,7 @@ struct SegmentParams {
     int32_t shading;
     double disk_inner, disk_outer;
     uint32_t max_crossings;
+    uint32_t block_order; // segment kernel: 0 = blocks in slot order, 1 = centre-out (a rank's share of a split frame)
 };
 
 struct FrameGeom {

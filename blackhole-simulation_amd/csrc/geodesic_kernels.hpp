@@ -514,7 +514,7 @@ __global__ __launch_bounds__(kSegBlock) __attribute__((amdgpu_waves_per_eu(kSegm
 void integrate_segment_kernel(
     RayWorkspace ws, SegmentParams P, const uint32_t *__restrict__ live_in, uint32_t n_live,
     uint32_t *__restrict__ live_out, uint32_t *__restrict__ live_out_count) {
-    const uint32_t k = dispatch_block_f64(blockIdx.x, gridDim.x) * kSegBlock + threadIdx.x;
+    const uint32_t k = dispatch_block_f64(blockIdx.x, gridDim.x, P.block_order) * kSegBlock + threadIdx.x;
     const bool have = k < n_live;
     const uint32_t slot = have ? (live_in ? live_in[k] : k) : 0u;
 
