@@ -38,7 +38,9 @@ constexpr int kMarchBlock = GRV_MARCH_BLOCK;
 // contend when they all start together): natural order there.  A prime stride through the block list
 // (consecutive starts a quarter of the image apart) was measured as well and loses everywhere: f64
 // -1.5 %, packed march -2 % against centre-out, GLSL up to -20 % (neighbouring tiles share the noise /
-// star texels' cache lines) -- lib_f2 / lib_p2 / lib_g2 in the same file.
+// star texels' cache lines) -- lib_f2 / lib_p2 / lib_g2 in the same file.  An XCD-contiguous deal (each
+// XCD takes a contiguous eighth of the block list) loses 30 % on the GLSL march: the eighths differ in
+// work and the XCDs finish at different times.
 #ifndef GRV_CENTRE_OUT
 #define GRV_CENTRE_OUT 1
 #endif
