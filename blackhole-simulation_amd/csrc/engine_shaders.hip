@@ -194,6 +194,20 @@ int grv_post_ataa_resolve(grv_engine *e, const GrvAtaaParams *p, const float *d_
     return GRV_OK;
 }
 
+int grv_ataa_reproj_fold(const GrvAtaaParams *p, float out24[24]) {
+    if (!p || !out24 || p->width == 0 || p->height == 0) return GRV_ERR_INVALID;
+    AtaaCameraHost cam;
+    std::memcpy(cam.inv_view, p->inv_view, sizeof cam.inv_view);
+    std::memcpy(cam.inv_proj, p->inv_proj, sizeof cam.inv_proj);
+    std::memcpy(cam.prev_view_proj, p->prev_view_proj, sizeof cam.prev_view_proj);
+    std::memcpy(cam.position, p->position, sizeof cam.position);
+    AtaaReprojHost rp;
+    ataa_reproj_fold(cam, p->width, p->height, rp);
+    std::memcpy(out24, &rp, sizeof rp);
+    static_assert(sizeof(AtaaReprojHost) == 24 * sizeof(float), "24 coefficients");
+    return GRV_OK;
+}
+
 void grv_bloom_params_default(uint32_t width, uint32_t height, GrvBloomParams *p) {
     if (!p) return;
     p->width = width;

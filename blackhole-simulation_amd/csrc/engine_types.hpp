@@ -223,6 +223,51 @@ struct AtaaCameraHost {
 hipError_t launch_taa_resolve(uint32_t w, uint32_t h, const float *current, const float *history,
                               float blend_factor, int camera_moving, int half_storage, float *out,
                               hipStream_t s);
+// The FAST ATAA resolve's reprojection chain folded once per launch (post_fast_kernels.hpp, AtaaReproj):
+// c[q] = (per px, per py, constant) of vt.x, vt.y, vt.z, vt.w and the texel-x / texel-y / w combinations
+// of the clip rows (the part multiplied by s = 12 sign(vt.w) / |vt.xyz|), k = their constant parts.
+// Plain host arithmetic in f64 (matrices column-major: m[col * 4 + row]); grv_ataa_reproj_fold exposes
+// it to the CPU tests.
+struct AtaaReprojHost {
+    float c[7][3];
+    float k[3];
+};
+inline void ataa_reproj_fold(const AtaaCameraHost &cam, uint32_t w, uint32_t h, AtaaReprojHost &rp) {
+    auto at = [](const float *m, int r, int col) { return (double)m[col * 4 + r]; };
+    double A[4][3], B[4][4], K[4];
+    for (int r = 0; r < 4; ++r) {
+        for (int j = 0; j < 3; ++j) {
+            A[r][j] = 0.0;
+            for (int t = 0; t < 3; ++t) A[r][j] += at(cam.prev_view_proj, r, t) * at(cam.inv_view, t, j);
+        }
+        for (int j = 0; j < 4; ++j) {
+            B[r][j] = 0.0;
+            for (int t = 0; t < 3; ++t) B[r][j] += A[r][t] * at(cam.inv_proj, t, j);
+        }
+        K[r] = at(cam.prev_view_proj, r, 3);
+        for (int t = 0; t < 3; ++t) K[r] += at(cam.prev_view_proj, r, t) * (double)cam.position[t];
+    }
+    // rows: vt (inv_proj rows 0..3), then the texel-x, texel-y and w combinations of the clip rows:
+    // x = (0.5 w clip.x + (0.5 w - 0.5) clip.w) / clip.w,  y = (-0.5 h clip.y + (0.5 h - 0.5) clip.w) / clip.w
+    const double hw = 0.5 * (double)w, hh = 0.5 * (double)h;
+    double M[7][4], Kc[3];
+    for (int j = 0; j < 4; ++j) {
+        for (int r = 0; r < 4; ++r) M[r][j] = at(cam.inv_proj, r, j);
+        M[4][j] = hw * B[0][j] + (hw - 0.5) * B[3][j];
+        M[5][j] = -hh * B[1][j] + (hh - 0.5) * B[3][j];
+        M[6][j] = B[3][j];
+    }
+    Kc[0] = hw * K[0] + (hw - 0.5) * K[3];
+    Kc[1] = -hh * K[1] + (hh - 0.5) * K[3];
+    Kc[2] = K[3];
+    // M (ndc.x, -ndc.y, 1, 1) with ndc.x = (2 px + 1) / w - 1, ndc.y = (2 py + 1) / h - 1
+    for (int q = 0; q < 7; ++q) {
+        rp.c[q][0] = (float)(M[q][0] * 2.0 / (double)w);
+        rp.c[q][1] = (float)(-M[q][1] * 2.0 / (double)h);
+        rp.c[q][2] = (float)(M[q][0] * (1.0 / (double)w - 1.0) - M[q][1] * (1.0 / (double)h - 1.0) + M[q][2] + M[q][3]);
+    }
+    for (int q = 0; q < 3; ++q) rp.k[q] = (float)Kc[q];
+}
 hipError_t launch_ataa_resolve(uint32_t w, uint32_t h, const AtaaCameraHost &cam, const float *current,
                                const float *history, int half_storage, float *out, hipStream_t s);
 // scratch: (w/2*h/2 + 2*(w/4*h/4)) float4

@@ -385,6 +385,14 @@ typedef struct { /* src/shaders/postprocess/ataa.wgsl.ts:29-86 (CameraUniforms, 
 int grv_post_ataa_resolve(grv_engine *e, const GrvAtaaParams *p, const float *d_current,
                           const float *d_history, float *d_out, void *stream);
 
+/* Verification hook (no device): the 24 coefficients the FAST ATAA resolve evaluates its reprojected
+ * history tap from -- the shader's chain ndc -> inv_proj -> divide -> normalise -> inv_view ->
+ * position + 12 dir -> prev_view_proj -> divide -> uv -> texel (ataa.wgsl.ts:60-75) folded in f64 into
+ * seven linear forms of the pixel coordinates: out[3 q + {0, 1, 2}] = (per px, per py, constant) of
+ * q = vt.x, vt.y, vt.z, vt.w, X, Y, W, then out[21..23] = kx, ky, kw; with s = 12 sign(vt.w) / |vt.xyz|
+ * the tap sits at texel ((kx + s X) / (kw + s W), (ky + s Y) / (kw + s W)). */
+int grv_ataa_reproj_fold(const GrvAtaaParams *p, float out24[24]);
+
 typedef struct { /* src/rendering/bloom.ts:23-39 BloomConfig */
     uint32_t width, height;
     float intensity;      /* 0.5 */

@@ -118,6 +118,63 @@ def test_bloom_properties(oracle):
     assert tiny.shape == (3, 5, 4) and np.all(np.isfinite(tiny))
 
 
+def test_ataa_reprojection_fold_is_the_shader_chain(engine_mod, oracle):
+    """CPU: the 24 coefficients the FAST ATAA resolve evaluates its history tap from
+    (grv_ataa_reproj_fold: the launcher's f64 fold of ataa.wgsl.ts:60-75) against the chain itself
+    evaluated in f64 -- they must describe the same tap to f32 rounding of the coefficients, and the fold
+    must sit at least as close to that position as the shader-order f32 chain does."""
+    import ctypes as C
+    bh = engine_mod
+    L = bh.load_library()
+    f = np.float32
+    for (h, w), eye, prev in (((540, 960), (59.55, -7.31, 0.0), (59.0, -7.31, 4.0)),
+                              ((2160, 3840), (20.0, 3.0, -35.0), (20.5, 3.2, -34.0)),
+                              ((37, 53), (0.0, 1.0, 60.0), (0.0, 1.0, 60.0))):  # last: static camera
+        cam = _cam(oracle, bh, eye, prev, w / h)
+        ap = bh.AtaaParams()
+        ap.width, ap.height = w, h
+        for name in ("inv_view", "inv_proj", "prev_view_proj"):
+            for k in range(16):
+                getattr(ap, name)[k] = getattr(cam, name)[k]
+        for k in range(3):
+            ap.position[k] = cam.position[k]
+        out = (C.c_float * 24)()
+        assert L.grv_ataa_reproj_fold(C.byref(ap), out) == 0
+        co = np.array(out[:21], np.float64).reshape(7, 3)
+        kk = np.array(out[21:], np.float64)
+        IV = np.array(ap.inv_view[:], np.float64).reshape(4, 4).T
+        IP = np.array(ap.inv_proj[:], np.float64).reshape(4, 4).T
+        PVP = np.array(ap.prev_view_proj[:], np.float64).reshape(4, 4).T
+        pos = np.array(ap.position[:], np.float64)
+        step = max(1, w // 480)  # every pixel of the small frames, a 1/64 lattice of the 4K one
+        px, py = np.meshgrid(np.arange(0, w, step, dtype=np.float64), np.arange(0, h, step, dtype=np.float64))
+
+        def chain(dt):
+            n = np.stack([((px + 0.5) / w * 2 - 1).astype(dt), (-((py + 0.5) / h * 2 - 1)).astype(dt),
+                          np.ones_like(px, dt), np.ones_like(px, dt)], -1)
+            vt = n @ IP.astype(dt).T
+            v = vt[..., :3] / vt[..., 3:4]
+            v = v / np.sqrt((v * v).sum(-1, keepdims=True)).astype(dt)
+            world = pos.astype(dt) + (v @ IV.astype(dt)[:3, :3].T) * dt(12)
+            pc = np.concatenate([world, np.ones_like(world[..., :1])], -1) @ PVP.astype(dt).T
+            pu = (pc[..., 0] / pc[..., 3]) * dt(.5) + dt(.5)
+            pv = (pc[..., 1] / pc[..., 3]) * dt(-.5) + dt(.5)
+            return (pu * dt(w) - dt(.5)).astype(np.float64), (pv * dt(h) - dt(.5)).astype(np.float64)
+        xe, ye = chain(np.float64)
+        x32, y32 = chain(f)
+        q = [co[i, 0] * px + co[i, 1] * py + co[i, 2] for i in range(7)]
+        s = 12.0 / np.sqrt(q[0] ** 2 + q[1] ** 2 + q[2] ** 2) * np.sign(q[3])
+        ipw = 1.0 / (kk[2] + s * q[6])
+        xf, yf = (kk[0] + s * q[4]) * ipw, (kk[1] + s * q[5]) * ipw
+        d_fold = np.hypot(xf - xe, yf - ye)
+        d_f32 = np.hypot(x32 - xe, y32 - ye)
+        # the fold's only error is the f32 rounding of its 24 coefficients: a few ulps of the texel
+        # coordinate, and no worse than the shader-order chain's own rounding
+        assert d_fold.max() <= 8 * 2.0 ** -23 * max(w, h), (d_fold.max(), w, h)
+        assert np.median(d_fold) <= 1.5 * np.median(d_f32) + 1e-7, (np.median(d_fold), np.median(d_f32))
+    assert L.grv_ataa_reproj_fold(None, out) != 0
+
+
 # ---- HIP kernels vs oracle (GPU box) ----------------------------------------------------------
 def _close(got, ref, fast=False, tap_noise=0.0):
     d = np.abs(got - ref) / np.maximum(1.0, np.abs(ref))
