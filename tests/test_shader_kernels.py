@@ -154,17 +154,22 @@ def _compare(got_rgba, got_steps, ref_rgba, ref_steps, exact=False, bars=FAST_BA
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("arith", [1, 2])
+@pytest.mark.parametrize("arith", [0, 1, 2])
 def test_config4_bench_form_against_the_oracle(engine_mod, oracle, arith):
     """BASELINE configs[3] exactly as `bench.py --config c4` runs it -- 7680x4320, fixed 1024-step
     budget, FAST contract (arith 2 = two rays per lane on the packed-f32 ops, the bench default) --
     against the shader-order oracle on every 16th pixel in x and y (129 600 rays), stars off (one ulp
     of the hash's sin lights a different star: the bench line's sky differs star by star from the
-    shader-order sky, and config.workload says so).  The FAST checks otherwise stop at 480x270."""
+    shader-order sky, and config.workload says so).  The FAST checks otherwise stop at 480x270.
+    arith 0 = the shader-order kernel: the checker's bits, stars on.  GRV_C4_STRIDE=1 compares EVERY
+    pixel of the 33.2 M (the C oracle marches the 4.9 G steps of the frame in about a minute on 16
+    cores); GRV_C4_JSON=<path> appends the measured figures (profiles/r03_full_frame_parity_c4.jsonl)."""
+    import json
+    import os
     import torch
-    W, H, stride = 7680, 4320, 16
+    W, H, stride = 7680, 4320, int(os.environ.get("GRV_C4_STRIDE", "16"))
     cam = engine_mod.camera_look_at(EYE, aspect=W / H)
-    gp = engine_mod.wgsl_params(W, H, cam, 1.0, 0.999, max_steps=1024, arith=arith, stars=0)
+    gp = engine_mod.wgsl_params(W, H, cam, 1.0, 0.999, max_steps=1024, arith=arith, stars=1 if arith == 0 else 0)
     with engine_mod.PhysicsEngine(1.0, 0.999) as e:
         rgba = torch.zeros(W * H, 4, dtype=torch.float32, device="cuda:0")
         steps = torch.zeros(W * H, dtype=torch.int32, device="cuda:0")
@@ -173,13 +178,27 @@ def test_config4_bench_form_against_the_oracle(engine_mod, oracle, arith):
         g = rgba.view(H, W, 4)[::stride, ::stride].cpu().numpy()
         s = steps.view(H, W)[::stride, ::stride].cpu().numpy()
     ref_rgba, ref_steps = oracle.wgsl_frame(oracle.wgsl_params_from(gp), stride=(stride, stride), nthreads=16)
-    assert ref_steps.shape == s.shape == (270, 480)
-    m = _compare(g, s, ref_rgba, ref_steps)
-    assert m["colour_max"] <= 5e-2
-    # rays still marching when the budget runs out orbit next to the critical curve, where one ulp
-    # decides between another turn and falling in: a handful of the 129 600 on either side (measured
-    # 13 here against 3 in the oracle)
-    assert int((s == 1024).sum()) <= 40 and int((ref_steps == 1024).sum()) <= 40
+    assert ref_steps.shape == s.shape == ((H + stride - 1) // stride, (W + stride - 1) // stride)
+    m = _compare(g, s, ref_rgba, ref_steps, exact=(arith == 0))
+    if arith != 0:
+        # on the 129 600-pixel lattice nothing differs by more than 5e-2 of the peak; on all 33.2 M
+        # pixels 348 do (1.05e-5 of them, up to 0.37 of the peak): near-critical rays whose step count
+        # differs, where the one decides for the disk and the other for the hole -- bounded by
+        # FAST_BARS["beyond_5e2"] = 1e-4 inside _compare
+        assert stride < 16 or m["colour_max"] <= 5e-2
+        # rays still marching when the budget runs out orbit next to the critical curve, where one ulp
+        # decides between another turn and falling in: a handful of the 129 600 on either side (measured
+        # 13 here against 3 in the oracle); in proportion on a finer lattice
+        cap = 40 * max(1, (16 // stride) ** 2)
+        assert int((s == 1024).sum()) <= cap and int((ref_steps == 1024).sum()) <= cap
+    path = os.environ.get("GRV_C4_JSON")
+    if path:
+        rec = {"frame": "7680x4320 f32 compute march, 1024-step budget, a=0.999", "arith": ["shader order", "FAST", "FAST packed"][arith],
+               "stride": stride, "pixels_compared": int(s.size), "oracle_steps": int(ref_steps.sum()),
+               "at_budget_engine": int((s == 1024).sum()), "at_budget_oracle": int((ref_steps == 1024).sum())}
+        rec.update(m if m else {"bit_identical": True})
+        with open(path, "a") as f:
+            f.write(json.dumps(rec) + "\n")
 
 
 @pytest.mark.gpu
