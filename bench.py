@@ -4,6 +4,11 @@
 --config c3 (default; BASELINE.json configs[2], the one the metric is quoted on):
   3840x2160, a = 0.999 Kerr-Schild, adaptive RKF45 tol 1e-8, <= 2048 steps, f64,
   + Planck (T x g) LUT redshift shading; camera r0 = 60 M, theta = 97 deg, fov 60 deg.
+--config c2 (BASELINE.json configs[1]): 1920x1080, a = 0.999, 512 max steps, one GPU, f32:
+  --kernel glsl (default): the Cartesian Velocity-Verlet march of the WebGL fragment shader
+  (fragment.glsl.ts:129-221 + chunks/metric.ts:96-149, the reference's production loop; the shader
+  itself clamps the budget to 500), default "high-quality" preset; --kernel wgsl: the Kerr-Schild
+  implicit-midpoint compute march (compute.wgsl.ts) at 512 steps.
 --config c4 (BASELINE.json configs[3]):
   7680x4320, the f32 compute march (compute.wgsl.ts) at a fixed 1024-step budget: every
   ray marches until it terminates or has done 1024 steps.
@@ -19,6 +24,15 @@ N > 1 (default --scaling strong, the split BASELINE's metric names: "at 3840x216
 GPU"): the ONE frame is cut in 64x64 tiles dealt round-robin to the N ranks, so total work is
 fixed and each rank integrates 1/N of the rays.  --scaling weak grows the image plane to
 (W*gx) x (H*gy), gx*gy = N, instead (every GPU integrates one full frame's worth of rays).
+
+Two hosts drive N > 1, both through the same C ABI and the same 64x64 round-robin tile deal:
+  bare `python bench.py --gpus N`  (--launcher native, the default without a launcher): ONE process,
+      the C ABI's multi-GPU handle (grv_engine_create_multi: a host thread and two streams per device,
+      one RCCL send/recv group per frame) -- the host BASELINE's north_star names;
+  under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (WORLD_SIZE set; or
+      bare with --launcher torchrun): one process per GPU, one grv_engine each, the gather through
+      torch.distributed's nccl backend (= RCCL).
+Either line carries transport, rccl_version, rank_devices and the per-rank integrate times.
 
 The frame loop holds no host wait: frames are queued back to back, the per-frame counters
 accumulate on the device (grv_stats_accumulate) and are read once after the timed region.
@@ -44,8 +58,8 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_PEAK_TFLOPS = 78.6  # same guide: vector FP64
 FP32_PEAK_TFLOPS = 157.3  # same guide: vector FP32
 # algorithmic bytes and flops per unit: SURVEY.md 8(d) / DESIGN.md section 4
-B_STEP = {"c3": 144, "c4": 72}
-B_RAY = {"c3": 96, "c4": 56}
+B_STEP = {"c3": 144, "c4": 72, "c2": 72}
+B_RAY = {"c3": 96, "c4": 56, "c2": 56}
 # flops are no longer estimated: they are the hardware's own count of the profiled launch
 # (SQ_INSTS_VALU_FLOPS_* x 64 lanes, profiles/traffic.json -> valu.flops_counted_per_launch), quoted
 # only when the library on disk holds the very kernel the counters were read on
@@ -53,7 +67,9 @@ KERNEL_OF = {("c3", "fast"): "integrate_segment_kernel<1,1,0>",
              ("c3", "strict"): "integrate_segment_kernel<1,0,0>",
              ("c4", "fast"): "wgsl_symplectic_fast_kernel",
              ("c4", "packed"): "wgsl_symplectic_pk_kernel",
-             ("c4", "strict"): "wgsl_symplectic_kernel"}
+             ("c4", "strict"): "wgsl_symplectic_kernel",
+             ("c2", "fast"): "glsl_fragment_kernel<1>",
+             ("c2", "strict"): "glsl_fragment_kernel<0>"}
 
 
 def usable_cores():
@@ -158,7 +174,34 @@ def cpu_baseline_c4(wp, width, height, target_seconds=12.0):
                       "rays, %d steps in %.1f s" % (sx * sy, width, height, osteps.size, steps, dt)}
 
 
-def committed_pmc(kernel_pretty, lib_path):
+def cpu_baseline_c2_glsl(gp, width, height, target_seconds=12.0):
+    """The shader oracle's GLSL fragment march (C restatement of fragment.glsl.ts + chunks) on the
+    host cores, pixel-strided sample of the same 1080p / 512-step frame."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    cores = usable_cores()
+    op = po.glsl_params_from(gp)
+    t = time.time()
+    _, psteps = po.glsl_frame(op, stride=(32, 32), nthreads=cores)
+    rate = float(np.sum(psteps)) / max(time.time() - t, 1e-3)
+    total = float(np.mean(psteps)) * width * height
+    sx = sy = 32
+    for cand in ((1, 1), (2, 1), (2, 2), (3, 2), (3, 3), (4, 4), (6, 6), (8, 8), (12, 12), (16, 16), (32, 32)):
+        if total / (cand[0] * cand[1]) / rate <= 1.6 * target_seconds:
+            sx, sy = cand
+            break
+    t = time.time()
+    _, osteps = po.glsl_frame(op, stride=(sx, sy), nthreads=cores)
+    dt = time.time() - t
+    steps = int(np.sum(osteps))
+    return {"value": round(steps / dt / 1e6, 4), "unit": "Mray-steps/s", "cores": cores,
+            "cpu_model": cpu_model(), "kind": "port",
+            "sample": "C restatement of the f32 fragment-shader march (fragment.glsl.ts + chunks; no "
+                      "GLSL runtime here), OpenMP over pixels, 1/%d pixel-strided subset of the %dx%d "
+                      "frame: %d rays, %d steps in %.1f s" % (sx * sy, width, height, osteps.size, steps, dt)}
+
+
+def committed_pmc(kernel_pretty, lib_path, frame=None):
     """HBM bytes and VALU issue fraction per launch of the dominant kernel from the committed
     rocprofv3 PMC passes (profiles/traffic.json) -- valid only for the code object they were
     measured on: the file carries the kernel's code hash, and a library whose kernel hashes
@@ -172,7 +215,9 @@ def committed_pmc(kernel_pretty, lib_path):
         now = kr.kernel_code_hash(lib_path, kernel_pretty)
     except Exception as exc:  # no file / unreadable library: no committed figures
         return None, "unavailable (%s)" % type(exc).__name__
-    ent = (t.get("kernels") or {}).get(kernel_pretty)
+    ks = t.get("kernels") or {}
+    # a kernel measured at a second frame size is filed under "<kernel>@<W>x<H>"
+    ent = (ks.get("%s@%dx%d" % (kernel_pretty, frame[0], frame[1])) if frame else None) or ks.get(kernel_pretty)
     if not ent:
         return None, "no committed PMC pass for %s" % kernel_pretty
     if ent.get("code_hash") != now:
@@ -206,10 +251,20 @@ def spawn_ranks(n):
 
 
 TOL = 1e-8                # RKF45 tolerance of the f64 frame (--config c5 / --tolerance change it)
-BASELINE_LABEL = {"c3": "configs[2]", "c4": "configs[3]", "c5": "configs[4]"}
+BASELINE_LABEL = {"c2": "configs[1]", "c3": "configs[2]", "c4": "configs[3]", "c5": "configs[4]"}
+KERNEL = "glsl"           # --kernel of --config c2
 
 
 def workload_text(cfg, W, H, split):
+    if cfg == "c2" and KERNEL == "glsl":
+        return ("%dx%d frame%s, a=0.999, f32 Cartesian Velocity-Verlet march of the WebGL fragment shader "
+                "(fragment.glsl.ts:129-221, chunks/metric.ts:96-149) at u_maxRaySteps=512 (the shader clamps "
+                "to 500), default high-quality preset (lensing, volumetric disk + Doppler, jets, stars, photon "
+                "glow, blue-noise dither; seeded noise textures), mouse camera zoom=60 theta=97deg" % (W, H, split))
+    if cfg == "c2":
+        return ("%dx%d frame%s, a=0.999, f32 compute march (Kerr-Schild implicit-midpoint, compute.wgsl.ts) "
+                "at a 512-step budget, disk g-factor shading + star field, camera r0=60M theta=97deg "
+                "fov=60deg" % (W, H, split))
     if cfg == "c3":
         return ("%dx%d frame%s, a=0.999 Kerr-Schild, adaptive RKF45 tol=%g h0=0.01 escape=1000 "
                 "renorm=10 max_steps=2048, Planck LUT 512x64 Tmax=1e5 redshift shading, camera "
@@ -234,17 +289,24 @@ def main_native(args, cfg, base_w, base_h):
     import torch
 
     import blackhole_simulation_amd as bh
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
-    if not os.path.exists(bh.library_path()):
-        bh.build_library()
     G = args.gpus
     one_device = os.environ.get("GRV_BENCH_ONE_DEVICE") == "1"
-    if not one_device and torch.cuda.device_count() < G:
-        raise SystemExit("--gpus %d but only %d HIP device(s) visible" % (G, torch.cuda.device_count()))
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < (1 if one_device else G):
+        sys.stderr.write("bench.py: --gpus %d but only %d HIP device(s) visible (the engine has no CPU path)\n"
+                         % (G, have))
+        raise SystemExit(2)
+    if not os.path.exists(bh.library_path()):
+        bh.build_library()
     transport = {"auto": bh.TRANSPORT_AUTO, "rccl": bh.TRANSPORT_RCCL, "peer": bh.TRANSPORT_PEER_COPY}[args.transport]
-    m = (bh.MultiEngine(1.0, 0.999, virtual_ranks=G) if one_device
-         else bh.MultiEngine(1.0, 0.999, devices=list(range(G)), transport=transport))
+    try:
+        m = (bh.MultiEngine(1.0, 0.999, virtual_ranks=G) if one_device
+             else bh.MultiEngine(1.0, 0.999, devices=list(range(G)), transport=transport))
+    except bh.GravitasError as exc:
+        # RCCL missing / ncclCommInitAll failing: the reason goes to stderr, no JSON line is printed
+        # and nothing falls back to another transport
+        sys.stderr.write("bench.py: %s\n" % exc)
+        raise SystemExit(3)
     if m.ranks != G:
         raise SystemExit("--gpus %d but the handle has %d ranks" % (G, m.ranks))
     torch.cuda.set_device(0)
@@ -282,6 +344,7 @@ def main_native(args, cfg, base_w, base_h):
     # the dominant kernel of one rank's share, from profiled frames after the timed loop (c3: HIP
     # events recorded by the library on each rank's launch stream; the slowest rank counts)
     roofline = None
+    rank_ms = None
     if cfg == "c3":
         k = max(args.profile_frames, 1)
         m.frame_stats_reset()
@@ -289,6 +352,8 @@ def main_native(args, cfg, base_w, base_h):
             frame(i, prof)
             m.synchronize()  # one frame at a time: the events then bracket one launch per rank
         pst = m.frame_stats()
+        per_rank = [m.rank_frame_stats(r) for r in range(G)]
+        rank_ms = [round(p.integrate_ms / k, 4) for p in per_rank]
         launches_per_rank = max(pst.launches / G, 1.0)
         avg_launch_ms = pst.integrate_ms / max(launches_per_rank, 1.0)
         share_bytes = (pst.accepted_steps / k * B_STEP[cfg] + W * H * B_RAY[cfg]) / G / max(launches_per_rank / k, 1.0)
@@ -303,7 +368,15 @@ def main_native(args, cfg, base_w, base_h):
                     "bound_actual": "fp64_valu_issue"}
     line = {
         "metric": "Mray-steps/s", "value": round(total_steps / elapsed / 1e6, 2), "unit": "Mray-steps/s",
-        "n_gpus": G, "ranks": m.ranks, "rank_devices": m.rank_devices(), "steps": args.steps,
+        "n_gpus": G, "ranks": m.ranks, "rank_devices": m.rank_devices(),
+        "launcher": "native (one process, grv_engine_create_multi)",
+        "transport": {bh.TRANSPORT_RCCL: "rccl", bh.TRANSPORT_PEER_COPY: "peer_copy"}.get(m.transport, m.transport),
+        "rccl_version": bh.rccl_probe()[0] if m.transport == bh.TRANSPORT_RCCL else None,
+        "rank_integrate_ms": ({"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms,
+                               "source": "HIP events around each rank's integrate launch, mean of %d profiled "
+                                         "frames after the timed loop" % max(args.profile_frames, 1)}
+                              if rank_ms else None),
+        "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f64" if cfg == "c3" else "f32", "data": "synthetic",
         "config": {"workload": workload_text(cfg, W, H, "" if G == 1 else " split over %d GPUs" % G),
@@ -333,9 +406,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", choices=["c3", "c4", "c5"], default="c3",
-                    help="c3 = BASELINE configs[2] (the headline), c4 = configs[3] (8K f32 march), c5 = configs[4]: "
+    ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c3",
+                    help="c2 = BASELINE configs[1] (1080p f32 march, 512 steps, one GPU), "
+                         "c3 = BASELINE configs[2] (the headline), c4 = configs[3] (8K f32 march), c5 = configs[4]: "
                          "the c3 frame at tol = 1e-9 under the reference-order STRICT contract (the parity run)")
+    ap.add_argument("--kernel", choices=["glsl", "wgsl"], default="glsl",
+                    help="--config c2: the WebGL fragment shader's Verlet march (default, the reference's "
+                         "production loop) or the WGSL compute march")
+    ap.add_argument("--launcher", choices=["auto", "native", "torchrun"], default="auto",
+                    help="N > 1 host: native = ONE process through the C ABI's multi-GPU handle; torchrun = one "
+                         "process per GPU under torch.distributed.run.  auto: torchrun when started by a launcher "
+                         "(WORLD_SIZE set), native for a bare command")
     ap.add_argument("--tolerance", type=float, default=None, help="RKF45 tolerance of the f64 frame (default 1e-8; c5: 1e-9)")
     ap.add_argument("--arith", choices=["fast", "strict", "packed"], default=None,
                     help="arithmetic contract (default: fast for c3; packed = the FAST contract with two rays per "
@@ -363,7 +444,8 @@ def main():
                     help="--native: exchange transport (auto: RCCL between real devices)")
     args = ap.parse_args()
     cfg = args.config
-    global TOL
+    global TOL, KERNEL
+    KERNEL = args.kernel
     label = BASELINE_LABEL[cfg]
     if cfg == "c5":  # the c3 code path with the parity run's tolerance and arithmetic
         cfg = "c3"
@@ -376,18 +458,26 @@ def main():
             raise SystemExit("--tolerance applies to the f64 frame (--config c3 / c5)")
         TOL = args.tolerance
     args.baseline_label = label
+    glsl = cfg == "c2" and KERNEL == "glsl"
     if args.arith is None:
-        args.arith = "fast" if cfg == "c3" else "packed"
-    if cfg == "c3" and args.arith == "packed":
-        raise SystemExit("--arith packed is the two-rays-per-lane form of the f32 march (--config c4)")
-    base_w = args.width or (3840 if cfg == "c3" else 7680)
-    base_h = args.height or (2160 if cfg == "c3" else 4320)
+        args.arith = "fast" if (cfg == "c3" or glsl) else "packed"
+    if (cfg == "c3" or glsl) and args.arith == "packed":
+        raise SystemExit("--arith packed is the two-rays-per-lane form of the WGSL compute march")
+    base_w = args.width or {"c2": 1920, "c3": 3840, "c4": 7680}[cfg]
+    base_h = args.height or {"c2": 1080, "c3": 2160, "c4": 4320}[cfg]
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
-    if args.native:
+    if cfg == "c2" and args.gpus > 1:
+        raise SystemExit("--config c2 is BASELINE configs[1]: one GPU")
+    launched = int(os.environ.get("WORLD_SIZE", "0") or 0) >= 1 and "RANK" in os.environ
+    if args.launcher == "auto":
+        args.launcher = "torchrun" if launched else "native"
+    if args.native or (args.gpus > 1 and args.launcher == "native"):
+        if launched and int(os.environ["WORLD_SIZE"]) > 1:
+            raise SystemExit("--launcher native is one process: do not start it under torch.distributed.run")
         return main_native(args, cfg, base_w, base_h)
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # a bare `python bench.py --gpus N`: launch the N ranks ourselves (one process per GPU)
+    if args.gpus > 1 and not launched:
+        # `python bench.py --gpus N --launcher torchrun`: start the N ranks ourselves (one process per GPU)
         raise SystemExit(spawn_ranks(args.gpus))
 
     # stdout carries exactly one line, the JSON result: libraries that print banners on load
@@ -462,10 +552,15 @@ def main():
     prof_rp = D.rank_params(params, world, rank)
     prof_rp.profile = 1
     n_local = eng.frame_ray_count(rp)
-    wp = None
-    if cfg == "c4":
-        wp = bh.wgsl_params(W, H, cam, 1.0, 0.999, max_steps=1024, arith=arith,
+    wp = gp = None
+    glsl = cfg == "c2" and KERNEL == "glsl"
+    if cfg == "c4" or (cfg == "c2" and not glsl):
+        wp = bh.wgsl_params(W, H, cam, 1.0, 0.999, max_steps=1024 if cfg == "c4" else 512, arith=arith,
                             tile_world=world, tile_rank=rank)
+    if glsl:
+        # the uniforms WebGLRenderer uploads at the default preset (grv_glsl_params_default), with the
+        # config's step budget; linear output (the post chain owns tone mapping upstream)
+        gp = bh.glsl_params(W, H, 1.0, 0.999, max_ray_steps=512, arith=arith, tile_world=world, tile_rank=rank)
     # two frames in flight: even and odd frames go to two streams (the engine alternates two ray
     # workspaces and orders each behind its previous user), so the tail of one frame's integrate
     # launch -- too few waves left to fill 256 CUs -- runs under the head of the next frame
@@ -500,7 +595,10 @@ def main():
             if profiled:
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
-            eng.render_frame_wgsl(wp, target, stream=s, want_total=False)
+            if glsl:
+                eng.render_frame_glsl(gp, target, stream=s, want_total=False)
+            else:
+                eng.render_frame_wgsl(wp, target, stream=s, want_total=False)
             if profiled:
                 b.record()
                 ev_pairs.append((a, b))
@@ -525,7 +623,7 @@ def main():
         st = eng.frame_stats(stream)
         ms = st.integrate_ms
         n = st.launches
-        if cfg == "c4":
+        if cfg != "c3":
             ms = sum(a.elapsed_time(b) for a, b in ev_pairs)
             n = len(ev_pairs)
             del ev_pairs[:]
@@ -566,6 +664,12 @@ def main():
     else:
         prof_steps_per_frame = steps_local / max(args.steps, 1)
 
+    # per-rank mean integrate-launch time (every rank's own HIP events), gathered for the JSON line
+    my_ms = integ_ms / max(launches, 1)
+    rank_ms = [my_ms]
+    if use_dist:
+        rank_ms = [None] * world
+        dist.all_gather_object(rank_ms, my_ms)
     agg = torch.tensor([elapsed, float(steps_local), float(rays_local)], dtype=torch.float64, device="cuda")
     if use_dist:
         tmax = agg[:1].clone()
@@ -584,8 +688,8 @@ def main():
         launches_per_frame = max(launches / frames_prof, 1.0)
         avg_launch_ms = integ_ms / max(launches, 1)
         achieved = (per_frame_bytes / launches_per_frame) / (avg_launch_ms * 1e-3) / 1e9
-        kernel_pretty = KERNEL_OF[(cfg, args.arith)]
-        pmc, pmc_src = committed_pmc(kernel_pretty, bh.library_path())
+        kernel_pretty = KERNEL_OF[("c4" if wp is not None else cfg, args.arith)]
+        pmc, pmc_src = committed_pmc(kernel_pretty, bh.library_path(), (W, H))
         usable_pmc = pmc if (pmc and world == 1 and not args.segment_tries and (cfg != "c3" or TOL == 1e-8) and
                              (W, H) == tuple(pmc.get("frame", (W, H)))) else None
         peak_tf = FP64_PEAK_TFLOPS if cfg == "c3" else FP32_PEAK_TFLOPS
@@ -628,7 +732,15 @@ def main():
         line = {
             "metric": "Mray-steps/s", "value": round(value, 2), "unit": "Mray-steps/s",
             "n_gpus": world, "ranks": dist.get_world_size() if use_dist else 1,
-            "rank_devices": rank_devices, "steps": args.steps, "warmup": args.warmup,
+            "rank_devices": rank_devices,
+            "launcher": ("torchrun (one process per GPU, torch.distributed)" if use_dist else "single process"),
+            "transport": (("rccl" if backend == "nccl" else backend) if use_dist else None),
+            "rccl_version": (".".join(str(x) for x in torch.cuda.nccl.version())
+                             if use_dist and backend == "nccl" else None),
+            "rank_integrate_ms": {"min": round(min(rank_ms), 4), "max": round(max(rank_ms), 4),
+                                  "per_rank": [round(x, 4) for x in rank_ms],
+                                  "source": "mean HIP-event time of a rank's march / integrate launch (%s)" % prof_note},
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64" if cfg == "c3" else "f32", "data": "synthetic",
@@ -645,8 +757,11 @@ def main():
         }
         if cfg == "c3":
             line["config"]["max_hamiltonian_drift_rank0"] = max_drift
+        if cfg == "c2":
+            line["config"]["kernel"] = KERNEL
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = (cpu_baseline_c3(base_w, base_h, eye, tolerance=TOL) if cfg == "c3"
+                                    else cpu_baseline_c2_glsl(gp, base_w, base_h) if glsl
                                     else cpu_baseline_c4(wp, base_w, base_h))
         sys.stdout.flush()
         os.dup2(stdout_fd, 1)

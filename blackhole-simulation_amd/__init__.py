@@ -13,5 +13,5 @@ from .engine import (  # noqa: F401
     load_library, render_params, seeded_noise_rgba8, unpack_tiles, wgsl_params,
     GLSL_LENSING, GLSL_DISK, GLSL_DOPPLER, GLSL_STARS, GLSL_PHOTON_GLOW, GLSL_JETS, GLSL_REDSHIFT,
     GLSL_DITHER, GLSL_FEATURES_DEFAULT, AtaaParams, BloomParams, TaaParams,
-    MultiEngine, TRANSPORT_AUTO, TRANSPORT_PEER_COPY, TRANSPORT_RCCL,
+    MultiEngine, TRANSPORT_AUTO, TRANSPORT_PEER_COPY, TRANSPORT_RCCL, rccl_probe,
 )

@@ -144,7 +144,9 @@ int ensure_workspace(grv_engine *e, size_t slots, hipStream_t s) {
         W.slots = cap;
         W.ws = w;
     }
-    if (W.used && W.last_stream != s) GRV_HIP(e, hipStreamWaitEvent(s, W.done, 0));
+    // always ordered behind the set's previous user, same stream or not: a stream handle can be
+    // re-issued by the runtime after its owner destroyed it, and a wait on the own stream is free
+    if (W.used) GRV_HIP(e, hipStreamWaitEvent(s, W.done, 0));
     W.last_stream = s;
     W.ws.n = (uint32_t)slots;
     e->ws = W.ws;
@@ -245,12 +247,10 @@ constexpr uint32_t kRefillPeriod = 8;
 // unconditionally -- at most ln(1e6) / ln(1 / 0.9) = 132 rejects, one forced try.  steps <= max_steps,
 // so 160 max_steps + 64 is never reached by a correct kernel; a ray still live there (a NaN the
 // argument missed, a future stepper) is ended as TERM_MAXSTEPS instead of hanging the GPU.
-uint32_t try_bound(uint64_t max_steps) {
-    // test hook: a tiny bound makes the "never a hang" exit reachable (tests/test_gpu_async.py)
-    if (const char *dbg = std::getenv("GRV_DEBUG_TRY_BOUND")) {
-        const long v = std::strtol(dbg, nullptr, 10);
-        if (v > 0) return (uint32_t)v;
-    }
+uint32_t try_bound(const grv_engine *e, uint64_t max_steps) {
+    // verification hook (grv_test_set_try_bound, an explicit call on this handle -- nothing in the
+    // process environment reaches the result): a tiny bound makes the "never a hang" exit reachable
+    if (e && e->try_bound_override) return e->try_bound_override;
     const uint64_t b = (max_steps > (0xFFFFFFFFull - 64u) / 160u) ? 0xFFFFFFFFull : 160u * max_steps + 64u;
     return (uint32_t)b;
 }
@@ -264,7 +264,7 @@ uint32_t try_bound(uint64_t max_steps) {
 //     the next launch.  Results are bitwise those of the single launch.
 int run_segments(grv_engine *e, const GrvOptions &o, SegmentParams P, uint32_t seg_tries,
                  hipStream_t s, bool profile) {
-    const uint32_t bound = try_bound(o.max_steps);
+    const uint32_t bound = try_bound(e, o.max_steps);
     if (seg_tries == 0) {
         P.max_tries = bound;
         P.final_launch = 1;
@@ -536,6 +536,7 @@ void grv_engine_destroy(grv_engine *e) {
         if (W.done) (void)hipEventDestroy(W.done);
     }
     if (e->stage_mem) (void)hipFree(e->stage_mem);
+    if (e->path_stage) (void)hipHostFree(e->path_stage);
     if (e->d_lut) (void)hipFree(e->d_lut);
     if (e->d_disk_lut) (void)hipFree(e->d_disk_lut);
     if (e->d_noise) (void)hipFree(e->d_noise);
@@ -619,7 +620,7 @@ int grv_integrate_batch_device(grv_engine *e, size_t n, const double *d_states,
         if (rc != GRV_OK) return rc;
     } else {
         P.max_tries = opt->segment_tries < 0 ? (uint32_t)(-(int64_t)opt->segment_tries) : kRefillPeriod;
-        P.try_cap = try_bound(opt->max_steps);
+        P.try_cap = try_bound(e, opt->max_steps);
         GRV_HIP(e, launch_refill(opt->arith, opt->metric_kind, opt->method, e->ws, P,
                                  e->d_counters + 2, e->n_cu, s));
         e->last_launches += 1;
@@ -686,7 +687,7 @@ int grv_integrate_paths_device(grv_engine *e, size_t n, const double *d_states, 
     if (rc != GRV_OK) return rc;
     GRV_HIP(e, launch_init_states(opt->metric_kind, e->ws, P, d_states, opt->initial_step,
                                   opt->method == GRV_METHOD_RKF45, s));
-    P.max_tries = try_bound(opt->max_steps);
+    P.max_tries = try_bound(e, opt->max_steps);
     P.final_launch = 1;
     GRV_HIP(e, launch_path(opt->arith, opt->metric_kind, opt->method, e->ws, P, d_states, d_paths, d_counts,
                            (uint32_t)max_points, s));
@@ -727,14 +728,39 @@ int grv_integrate_paths(grv_engine *e, size_t n, const double *states, const Grv
     GRV_HIP(e, hipMemcpy(out_counts, d_counts, n * 4, hipMemcpyDeviceToHost));
     if (rec && max_points) {
         // a ray's row holds min(count, max_points) points; the rest of the caller's row stays untouched
+        size_t kmax = 0;
         bool full = true;
-        for (size_t i = 0; i < n; ++i) full = full && out_counts[i] >= max_points;
+        for (size_t i = 0; i < n; ++i) {
+            const size_t k = out_counts[i] < max_points ? out_counts[i] : max_points;
+            kmax = k > kmax ? k : kmax;
+            full = full && k == max_points;
+        }
         if (full) {
             GRV_HIP(e, hipMemcpy(out_paths, d_paths, n * max_points * 64, hipMemcpyDeviceToHost));
-        } else {
-            for (size_t i = 0; i < n; ++i) {
-                const size_t k = out_counts[i] < max_points ? out_counts[i] : max_points;
-                if (k) GRV_HIP(e, hipMemcpy(out_paths + i * max_points * 8, d_paths + i * max_points * 8, k * 64, hipMemcpyDeviceToHost));
+        } else if (kmax) {
+            // ragged rows: the first kmax points of a block of rays leave the device in ONE strided
+            // transfer into pinned staging (<= 64 MiB a block), the rows are cut to length on the host
+            // -- not one blocking copy per ray (thousands of rays from integrate_batch({recordPath}))
+            const size_t row = kmax * 64;
+            size_t rays_per_block = ((size_t)64 << 20) / row;
+            rays_per_block = rays_per_block ? rays_per_block : 1;
+            rays_per_block = rays_per_block < n ? rays_per_block : n;
+            if (e->path_stage_bytes < rays_per_block * row) {
+                if (e->path_stage) (void)hipHostFree(e->path_stage);
+                e->path_stage = nullptr;
+                e->path_stage_bytes = 0;
+                GRV_HIP(e, hipHostMalloc(&e->path_stage, rays_per_block * row, hipHostMallocDefault));
+                e->path_stage_bytes = rays_per_block * row;
+            }
+            const char *stage = static_cast<const char *>(e->path_stage);
+            for (size_t i0 = 0; i0 < n; i0 += rays_per_block) {
+                const size_t m = n - i0 < rays_per_block ? n - i0 : rays_per_block;
+                GRV_HIP(e, hipMemcpy2D(e->path_stage, row, d_paths + i0 * max_points * 8, max_points * 64, row, m,
+                                       hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < m; ++i) {
+                    const size_t k = out_counts[i0 + i] < max_points ? out_counts[i0 + i] : max_points;
+                    if (k) std::memcpy(out_paths + (i0 + i) * max_points * 8, stage + i * row, k * 64);
+                }
             }
         }
     }
@@ -783,7 +809,7 @@ size_t grv_integrate_ray_relativistic_ex(grv_engine *e, const double *initial_st
     hipError_t st = hipSetDevice(e->device);
     if (st != hipSuccess) return nan_out("hipSetDevice", st);
     SegmentParams P = make_segment_params(e, o);
-    P.try_cap = try_bound(o.max_steps);
+    P.try_cap = try_bound(e, o.max_steps);
     SingleRayIn in;
     std::memcpy(in.v, initial_state, sizeof in.v);
     const uint32_t seq = ++e->ray_seq ? e->ray_seq : ++e->ray_seq; // never 0 (the block starts zeroed)
@@ -1022,6 +1048,12 @@ void *grv_host_alloc(size_t bytes) {
 
 void grv_host_free(void *p) {
     if (p) (void)hipHostFree(p);
+}
+
+int grv_test_set_try_bound(grv_engine *e, uint32_t tries) {
+    if (!e) return GRV_ERR_INVALID;
+    e->try_bound_override = tries;
+    return GRV_OK;
 }
 
 int grv_stats_accumulate(grv_engine *e, int enable) {

@@ -29,6 +29,7 @@ struct grv_engine {
     double spin = 0.0;   // as given (lib.rs:44-45)
     double spin_c = 0.0; // clamped copy held by the metrics (kerr.rs:48-63)
     int n_cu = 256;
+    uint32_t try_bound_override = 0; // grv_test_set_try_bound (verification hook), 0 = the derived bound
     std::string err;
 
     // ray workspaces (device).  Up to two sets, so a caller that alternates two streams keeps two
@@ -78,6 +79,8 @@ struct grv_engine {
     // staging buffers for host-pointer entry points
     void *stage_mem = nullptr;
     size_t stage_bytes = 0;
+    void *path_stage = nullptr; // pinned: ragged Trajectory.path rows on their way out (grv_integrate_paths)
+    size_t path_stage_bytes = 0;
 
     // cached spectrum LUT (device)
     float *d_lut = nullptr;
@@ -170,7 +173,7 @@ struct CallScope {
     }
 };
 // hard bound on the integrator tries of one ray (see run_segments)
-uint32_t try_bound(uint64_t max_steps);
+uint32_t try_bound(const grv_engine *e, uint64_t max_steps);
 int resolve_frame_events(grv_engine *e);
 uint32_t tile_pitch(uint32_t width, uint32_t world);
 void frame_geometry(const GrvRenderParams &p, FrameGeom &G);

@@ -41,34 +41,77 @@ struct RcclApi {
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
     std::string err;
+    bool ready = false;
+    // Binds librccl once.  A failed attempt leaves the object exactly as it was (no half-bound
+    // library: a later load() must not report success over null entry points).
     bool load() {
-        if (lib) return true;
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-            if (lib) break;
+        if (ready) return true;
+        void *h = nullptr;
+        std::string why;
+        // GRV_RCCL_LIBRARY names the library of a non-standard install; when set it is the only
+        // candidate (a wrong path fails loudly instead of binding some other copy)
+        const char *forced = std::getenv("GRV_RCCL_LIBRARY");
+        std::vector<const char *> names;
+        if (forced && *forced) names = {forced};
+        else names = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *name : names) {
+            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+            const char *m = dlerror(); // returns the message ONCE and resets it: read it into a variable
+            if (why.empty()) why = m ? m : "not found";
         }
-        if (!lib) {
-            err = std::string("dlopen(librccl.so.1): ") + (dlerror() ? dlerror() : "not found");
+        if (!h) {
+            err = std::string("dlopen(") + names[0] + "): " + why;
             return false;
         }
-        auto sym = [&](const char *n) { return dlsym(lib, n); };
-        CommInitAll = reinterpret_cast<decltype(CommInitAll)>(sym("ncclCommInitAll"));
-        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
-        GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
-        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
-        Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
-        Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
-        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
-        if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Send || !Recv || !GetErrorString) {
-            err = "librccl is missing a symbol";
+        const char *missing = nullptr;
+        auto sym = [&](const char *n) {
+            void *p = dlsym(h, n);
+            if (!p && !missing) missing = n;
+            return p;
+        };
+        auto init_all = reinterpret_cast<decltype(CommInitAll)>(sym("ncclCommInitAll"));
+        auto destroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+        auto gstart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
+        auto gend = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
+        auto send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
+        auto recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
+        auto estr = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+        auto ver = reinterpret_cast<decltype(GetVersion)>(sym("ncclGetVersion"));
+        if (missing) {
+            err = std::string("librccl lacks ") + missing;
+            dlclose(h);
             return false;
         }
+        lib = h;
+        CommInitAll = init_all;
+        CommDestroy = destroy;
+        GroupStart = gstart;
+        GroupEnd = gend;
+        Send = send;
+        Recv = recv;
+        GetErrorString = estr;
+        GetVersion = ver;
+        ready = true;
         return true;
     }
 };
 RcclApi g_rccl;
 std::mutex g_rccl_mu;
+// why the last grv_engine_create_multi* of this thread failed (no handle exists to carry it)
+thread_local std::string g_create_err;
+int cfail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_create_err = buf;
+    std::fprintf(stderr, "gravitas: %s\n", buf);
+    return code;
+}
 
 // One worker thread per rank.  run(job) hands `job(rank)` to every worker and returns when all of
 // them have finished QUEUEING (the device work stays asynchronous); the first non-zero status wins.
@@ -333,22 +376,28 @@ int create_common(double mass, double spin, const std::vector<int> &devs, bool v
                   grv_multi **out) {
     if (!out) return GRV_ERR_INVALID;
     *out = nullptr;
+    g_create_err.clear();
     const int G = (int)devs.size();
-    if (G < 1 || G > 64) return GRV_ERR_INVALID;
+    if (G < 1 || G > 64) return cfail(GRV_ERR_INVALID, "multi-GPU handle: %d ranks (1..64)", G);
     int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return GRV_ERR_NO_DEVICE;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        return cfail(GRV_ERR_NO_DEVICE, "multi-GPU handle: no HIP device");
+    }
     for (int d : devs)
-        if (d < 0 || d >= count) return GRV_ERR_NO_DEVICE;
+        if (d < 0 || d >= count)
+            return cfail(GRV_ERR_NO_DEVICE, "multi-GPU handle: device %d asked for, %d visible", d, count);
     if (transport == GRV_TRANSPORT_AUTO) transport = (virt || G == 1) ? GRV_TRANSPORT_PEER_COPY : GRV_TRANSPORT_RCCL;
-    if (transport != GRV_TRANSPORT_RCCL && transport != GRV_TRANSPORT_PEER_COPY) return GRV_ERR_INVALID;
-    if (transport == GRV_TRANSPORT_RCCL && virt && G > 1) return GRV_ERR_INVALID; // RCCL: one rank per device
+    if (transport != GRV_TRANSPORT_RCCL && transport != GRV_TRANSPORT_PEER_COPY)
+        return cfail(GRV_ERR_INVALID, "multi-GPU handle: unknown transport %d", transport);
+    if (transport == GRV_TRANSPORT_RCCL && virt && G > 1) // RCCL: one rank per device
+        return cfail(GRV_ERR_INVALID, "multi-GPU handle: RCCL takes one rank per device");
     grv_multi *m = new (std::nothrow) grv_multi();
     if (!m) return GRV_ERR_OOM;
     m->G = G;
     m->dev = devs;
     m->virtual_ranks = virt;
     m->transport = transport;
-    m->self_exchange = std::getenv("GRV_MULTI_SELF_EXCHANGE") != nullptr;
     m->eng.assign(G, nullptr);
     m->rank.resize(G);
     auto bail = [&](int code) {
@@ -381,16 +430,15 @@ int create_common(double mass, double spin, const std::vector<int> &devs, bool v
     if (hipEventCreateWithFlags(&m->caller_ready, hipEventDisableTiming) != hipSuccess) return bail(GRV_ERR_HIP);
     if (transport == GRV_TRANSPORT_RCCL) {
         std::lock_guard<std::mutex> lk(g_rccl_mu);
-        if (!g_rccl.load()) {
-            std::fprintf(stderr, "gravitas: RCCL transport unavailable: %s\n", g_rccl.err.c_str());
-            return bail(GRV_ERR_NO_DEVICE);
-        }
+        // never a silent fall back to peer copies: a handle that asked for RCCL (AUTO between real
+        // devices included) and cannot have it is refused, with the reason
+        if (!g_rccl.load())
+            return bail(cfail(GRV_ERR_NO_DEVICE, "RCCL transport unavailable: %s", g_rccl.err.c_str()));
         m->comm.assign(G, nullptr);
         const ncclResult_t st = g_rccl.CommInitAll(m->comm.data(), G, devs.data());
         if (st != ncclSuccess) {
-            std::fprintf(stderr, "gravitas: ncclCommInitAll failed: %s\n", g_rccl.GetErrorString(st));
             m->comm.clear();
-            return bail(GRV_ERR_HIP);
+            return bail(cfail(GRV_ERR_HIP, "ncclCommInitAll over %d devices failed: %s", G, g_rccl.GetErrorString(st)));
         }
     }
     m->threads = new (std::nothrow) RankThreads(G);
@@ -453,6 +501,58 @@ int grv_multi_rank_device(const grv_multi *m, int rank) {
     return (m && rank >= 0 && rank < m->G) ? m->dev[rank] : -1;
 }
 int grv_multi_transport(const grv_multi *m) { return m ? m->transport : -1; }
+
+const char *grv_multi_create_error(void) { return g_create_err.c_str(); }
+
+int grv_rccl_probe(int *version, char *msg, size_t msg_len) {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (version) *version = 0;
+    if (msg && msg_len) msg[0] = 0;
+    if (!g_rccl.load()) {
+        if (msg && msg_len) std::snprintf(msg, msg_len, "%s", g_rccl.err.c_str());
+        return GRV_ERR_NO_DEVICE;
+    }
+    int v = 0;
+    const ncclResult_t st = g_rccl.GetVersion(&v);
+    if (st != ncclSuccess) {
+        if (msg && msg_len) std::snprintf(msg, msg_len, "ncclGetVersion: %s", g_rccl.GetErrorString(st));
+        return GRV_ERR_HIP;
+    }
+    if (version) *version = v;
+    return GRV_OK;
+}
+
+int grv_multi_test_self_exchange(grv_multi *m, int enable) {
+    if (!m) return GRV_ERR_INVALID;
+    const int rc = grv_multi_synchronize(m);
+    if (rc != GRV_OK) return rc;
+    // the buffers are laid out for the other mode: drop them, the next frame allocates afresh
+    for (int r = 0; r < m->G; ++r) {
+        GRVM_HIP(m, hipSetDevice(m->dev[r]));
+        for (int b = 0; b < 2; ++b) {
+            if (m->rank[r].send[b]) (void)hipFree(m->rank[r].send[b]);
+            m->rank[r].send[b] = nullptr;
+        }
+    }
+    GRVM_HIP(m, hipSetDevice(m->dev[0]));
+    for (int b = 0; b < 2; ++b) {
+        if (m->recv[b]) (void)hipFree(m->recv[b]);
+        m->recv[b] = nullptr;
+        m->unpacked_rec[b] = false;
+    }
+    m->slot_px = 0;
+    m->self_exchange = enable != 0;
+    return GRV_OK;
+}
+
+int grv_multi_rank_frame_stats(grv_multi *m, int rank, GrvFrameStats *out) {
+    if (!m || !out || rank < 0 || rank >= m->G) return GRV_ERR_INVALID;
+    int rc = grv_multi_synchronize(m);
+    if (rc != GRV_OK) return rc;
+    rc = grv_frame_stats(m->eng[rank], m->rank[rank].s[0], out);
+    if (rc != GRV_OK) return mfail(m, rc, "rank %d: %s", rank, grv_last_error(m->eng[rank]));
+    return GRV_OK;
+}
 grv_engine *grv_multi_engine(grv_multi *m, int rank) {
     return (m && rank >= 0 && rank < m->G) ? m->eng[rank] : nullptr;
 }

@@ -294,6 +294,16 @@ def load_library():
     L.grv_multi_stats_accumulate.argtypes = [p, i]
     L.grv_multi_frame_stats.restype = i
     L.grv_multi_frame_stats.argtypes = [p, C.POINTER(FrameStats)]
+    L.grv_multi_create_error.restype = C.c_char_p
+    L.grv_multi_create_error.argtypes = []
+    L.grv_rccl_probe.restype = i
+    L.grv_rccl_probe.argtypes = [C.POINTER(C.c_int), C.c_char_p, sz]
+    L.grv_multi_rank_frame_stats.restype = i
+    L.grv_multi_rank_frame_stats.argtypes = [p, i, C.POINTER(FrameStats)]
+    L.grv_test_set_try_bound.restype = i
+    L.grv_test_set_try_bound.argtypes = [p, C.c_uint32]
+    L.grv_multi_test_self_exchange.restype = i
+    L.grv_multi_test_self_exchange.argtypes = [p, i]
     L.grv_attach_sab.restype = i
     L.grv_attach_sab.argtypes = [p, p]
     L.grv_set_camera_state.argtypes = [p, d, d, d]
@@ -317,6 +327,14 @@ def _dev_ptr(t):
     if isinstance(t, int):
         return C.c_void_p(t)
     return C.c_void_p(t.data_ptr())
+
+
+def rccl_probe():
+    """(version code, "") when librccl binds, (0, reason) when it does not.  No device needed."""
+    v = C.c_int(0)
+    msg = C.create_string_buffer(512)
+    rc = load_library().grv_rccl_probe(C.byref(v), msg, len(msg))
+    return (v.value, "") if rc == 0 else (0, msg.value.decode())
 
 
 def strict_math_host(op, x, y=None):
@@ -785,7 +803,9 @@ class MultiEngine:
                 mask |= 1 << int(dv)
             rc = self._lib.grv_engine_create_multi(float(mass), float(spin), mask, int(transport), C.byref(h))
         if rc != 0:
-            raise GravitasError("grv_engine_create_multi: %s (no CPU fallback exists)" % _STATUS.get(rc, rc))
+            why = self._lib.grv_multi_create_error()
+            raise GravitasError("grv_engine_create_multi: %s: %s (no CPU fallback, and no silent change of "
+                                "transport, exists)" % (_STATUS.get(rc, rc), why.decode() if why else ""))
         self._h = h
 
     def close(self):
@@ -850,3 +870,12 @@ class MultiEngine:
         st = FrameStats()
         self._check(self._lib.grv_multi_frame_stats(self._h, C.byref(st)), "multi_frame_stats")
         return st
+
+    def rank_frame_stats(self, rank):
+        st = FrameStats()
+        self._check(self._lib.grv_multi_rank_frame_stats(self._h, int(rank), C.byref(st)), "multi_rank_frame_stats")
+        return st
+
+    def test_self_exchange(self, enable=True):
+        """Verification hook: rank 0's own share goes through the transport too."""
+        self._check(self._lib.grv_multi_test_self_exchange(self._h, 1 if enable else 0), "multi_test_self_exchange")

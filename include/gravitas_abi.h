@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GRV_ABI_VERSION 4
+#define GRV_ABI_VERSION 5
 
 typedef struct grv_engine grv_engine;
 
@@ -268,6 +268,18 @@ const char *grv_multi_last_error(const grv_multi *m);
 int grv_multi_rank_count(const grv_multi *m);
 int grv_multi_rank_device(const grv_multi *m, int rank);
 int grv_multi_transport(const grv_multi *m);
+/* why the calling thread's last grv_engine_create_multi* failed ("" after a success): the RCCL /
+ * HIP error text, also written to stderr.  A handle that asks for RCCL and cannot have it (library
+ * absent, ncclCommInitAll failing) is REFUSED -- the transport never degrades silently. */
+const char *grv_multi_create_error(void);
+/* binds librccl (dlopen; the environment variable GRV_RCCL_LIBRARY names a non-standard copy and is
+ * then the only candidate) and reports ncclGetVersion's code (e.g. 22703).  No device needed.
+ * GRV_ERR_NO_DEVICE with the loader's message in `msg` when the library or one of its entry points
+ * is missing; the attempt leaves nothing half-bound. */
+int grv_rccl_probe(int *version, char *msg, size_t msg_len);
+/* one rank's counters and event times (grv_multi_frame_stats sums / maxes them): lets a scaling
+ * point be audited rank by rank */
+int grv_multi_rank_frame_stats(grv_multi *m, int rank, GrvFrameStats *stats);
 grv_engine *grv_multi_engine(grv_multi *m, int rank); /* rank's engine: closed forms, LUT entry points ... */
 int grv_multi_update_params(grv_multi *m, double mass, double spin);
 /* p->tile_world must be 0 or 1 (the handle deals the tiles).  d_rgba: W x H x 4 f32 on rank 0's device */
@@ -281,6 +293,16 @@ int grv_multi_stats_accumulate(grv_multi *m, int enable);
 int grv_multi_frame_stats_reset(grv_multi *m);
 /* waits for every rank, then sums the ranks' counters (max for max_drift and the event times) */
 int grv_multi_frame_stats(grv_multi *m, GrvFrameStats *stats);
+
+/* ---- verification hooks: explicit calls on a handle (nothing is read from the environment) ----
+ * grv_test_set_try_bound: hard bound on the integrator tries of one ray (0 restores the derived
+ * 160 max_steps + 64, which a correct kernel never reaches); a tiny value makes the "a ray can
+ * never hang the device" exit reachable: such rays end as GRV_TERM_MAXSTEPS.
+ * grv_multi_test_self_exchange: rank 0's own share travels through the transport as well (send
+ * buffer -> exchange -> receive slot) instead of being rendered into its slot, so that every
+ * transport call runs on a one-device box.  Waits for the handle's queued frames. */
+int grv_test_set_try_bound(grv_engine *e, uint32_t tries);
+int grv_multi_test_self_exchange(grv_multi *m, int enable);
 
 /* ---- f32 march loops of the reference's GPU shaders ----
  * Uniform blocks as the shaders receive them.  Outputs are device pointers: RGBA f32

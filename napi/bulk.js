@@ -77,6 +77,29 @@ const now = () => { const t = process.hrtime(); return t[0] * 1e3 + t[1] / 1e6; 
   const pp = engine.integrate_batch(init.slice(0, 128), { maxSteps: 2000, tolerance: 1e-8, recordPath: true, maxPoints: 64 });
   res.paths = { init: Array.from(init.slice(0, 128)), counts: Array.from(pp.counts), maxPoints: pp.maxPoints,
                 rows: Array.from(pp.paths), steps: Array.from(pp.steps) };
+  // memory JS can reach while a work is queued: the async forms work on their own copies
+  {
+    const { MessageChannel } = require("worker_threads");
+    const o = { width: 96, height: 54, eye: [59.55, -7.31, 0.0] };
+    engine.update_params(1.0, 0.9);
+    const want = engine.renderFrame(o).rgba;
+    const keepOut = new Float32Array(96 * 54 * 4), goneOut = new Float32Array(96 * 54 * 4);
+    const pk = engine.renderFrameAsync({ ...o, out: keepOut });
+    const pg = engine.renderFrameAsync({ ...o, out: goneOut });
+    const ch = new MessageChannel();
+    ch.port1.postMessage(goneOut.buffer, [goneOut.buffer]);   // detached while the frame is queued
+    const st2 = init.slice(0, 512);
+    const pb = engine.integrateBatchAsync(st2, opts);
+    st2.fill(NaN);                                            // overwritten while the batch is queued
+    let detachedRejected = null;
+    try { await pg; } catch (e) { detachedRejected = String(e.message); }
+    const fk = await pk, bb = await pb;
+    ch.port1.close(); ch.port2.close();
+    const ref = engine.integrate_batch(init.slice(0, 512), opts);
+    res.async_memory = { out_filled: same(want, keepOut) && fk.rgba === keepOut, detached_rejected: detachedRejected,
+                         input_copy: bb.states.every((v, i) => Object.is(v, ref.states[i])) };
+    engine.update_params(1.0, 0.5);
+  }
   // free() with a work still queued: the promise still settles
   const e2 = new wasm.PhysicsEngine(1.0, 0.7);
   const late = e2.integrateBatchAsync(init.slice(0, 800), opts);

@@ -68,7 +68,8 @@ static int slot_acquire(void) {
 static void slot_release(engine_box *box) {
     if (box->slot >= 0) {
         g_slot_used[box->slot] = 0;
-        if (g_arena) memset(g_arena + box->sab_off, 0, SLOT_BYTES); /* the next owner starts from zeros */
+        /* the slot's own region (sab_off may have been re-pointed by attach_sab): the next owner starts from zeros */
+        if (g_arena) memset(g_arena + (size_t)box->slot * SLOT_BYTES, 0, SLOT_BYTES);
         box->slot = -1;
     }
 }
@@ -370,6 +371,30 @@ static napi_value m_get_sab_ptr(napi_env env, napi_callback_info info) { /* lib.
     return v;
 }
 
+/* attach_sab(ptr) lib.rs:74: the reference stores a raw `*mut f32` into the module's linear memory and
+ * tick_sab writes through it from then on.  Here `memory.buffer` is the arena, so a pointer is a byte
+ * offset into it: an offset that is 4-byte aligned and leaves room for the 2048-float block becomes the
+ * block tick_sab reads its controls from and publishes into (lib.rs:309-313; get_sab_ptr still names the
+ * engine's own block, lib.rs:116-118); anything else -- a raw pointer has no other meaning in JS --
+ * throws a RangeError instead of being dereferenced. */
+static napi_value m_attach_sab(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    engine_box *b = unwrap(env, info, &argc, argv);
+    if (!b) return NULL;
+    const double ptr = argc > 0 ? arg_f64(env, argv[0]) : -1.0;
+    if (!g_arena || !(ptr >= 0.0) || ptr != (double)(uint32_t)ptr || ((uint32_t)ptr & 3u) ||
+        (uint32_t)ptr > ARENA_BYTES - SAB_BYTES) {
+        napi_throw_range_error(env, NULL, "attach_sab: not a 4-byte aligned offset into memory.buffer with room for 2048 floats");
+        return NULL;
+    }
+    if (grv_attach_sab(b->h, (float *)(g_arena + (uint32_t)ptr)) != GRV_OK) {
+        napi_throw_error(env, NULL, "attach_sab failed");
+        return NULL;
+    }
+    return NULL; /* get_sab_ptr keeps naming the engine's own block, as lib.rs:116-118 does */
+}
+
 static napi_value m_get_sab_layout(napi_env env, napi_callback_info info) { /* lib.rs:411 */
     (void)info;
     size_t off[5];
@@ -585,7 +610,16 @@ typedef struct {
     GrvCamera cam;
     GrvRenderParams p;
     int devices, virtual_ranks;
-    float *rgba;    /* W*H*4, memory of the result's ArrayBuffer */
+    int transport;  /* GRV_TRANSPORT_* the frame's tiles travelled through; 0 = one device, no exchange */
+    float *rgba;    /* W*H*4: memory of the result's ArrayBuffer, or own_rgba */
+    /* The *Async forms run on a pool thread while JS keeps running: memory JS can reach in the
+     * meantime (the caller's input array, a caller-supplied `out`) may be written, transferred or
+     * detached under the work.  So the async forms never hold pointers into it: the input is copied
+     * into the work item, and a caller's `out` is filled on the JS thread when the work completes,
+     * after checking that its buffer is still attached. */
+    float *own_rgba;   /* pinned staging of an async frame with a caller-supplied `out` */
+    size_t rgba_elems;
+    void *own_in;      /* copy of an async batch's input states */
     GrvFrameStats st;
     /* batch */
     size_t n;
@@ -618,8 +652,8 @@ static int multi_for(grv_multi **slot, int *cur_ranks, int *cur_virtual, int ran
                       : grv_engine_create_multi(mass, spin, ranks >= 64 ? ~0ull : ((1ull << ranks) - 1ull),
                                                 GRV_TRANSPORT_AUTO, slot);
         if (rc != GRV_OK) {
-            snprintf(err, cap, "renderFrame: cannot open %d %s (status %d)", ranks,
-                     virt ? "virtual ranks" : "HIP devices", rc);
+            snprintf(err, cap, "renderFrame: cannot open %d %s (status %d): %s", ranks,
+                     virt ? "virtual ranks" : "HIP devices", rc, grv_multi_create_error());
             return rc;
         }
         *cur_ranks = ranks;
@@ -653,6 +687,7 @@ static void bulk_execute(bulk_work *w) {
         if (ranks > 1 || w->virtual_ranks > 0) {
             w->rc = multi_for(mslot, mr, mv, ranks, w->virtual_ranks > 0, w->mass, w->spin, w->err, sizeof w->err);
             if (w->rc == GRV_OK) {
+                w->transport = grv_multi_transport(*mslot);
                 w->rc = grv_render_frame_multi(*mslot, &w->cam, &w->p, w->rgba, &w->st);
                 if (w->rc != GRV_OK) snprintf(w->err, sizeof w->err, "%s", grv_multi_last_error(*mslot));
             }
@@ -685,6 +720,9 @@ static napi_value bulk_result(napi_env env, bulk_work *w) {
         napi_set_named_property(env, out, "launches", mk_f64(env, (double)w->st.launches));
         napi_set_named_property(env, out, "devices",
                                 mk_f64(env, w->virtual_ranks > 0 ? w->virtual_ranks : (w->devices > 1 ? w->devices : 1)));
+        napi_value tr;
+        const char *tn = w->transport == GRV_TRANSPORT_RCCL ? "rccl" : w->transport == GRV_TRANSPORT_PEER_COPY ? "peer_copy" : "none";
+        if (napi_create_string_utf8(env, tn, NAPI_AUTO_LENGTH, &tr) == napi_ok) napi_set_named_property(env, out, "transport", tr);
     } else {
         napi_set_named_property(env, out, "states", v[0]);
         napi_set_named_property(env, out, "steps", v[1]);
@@ -700,6 +738,8 @@ static napi_value bulk_result(napi_env env, bulk_work *w) {
 }
 
 static void bulk_release(napi_env env, bulk_work *w) {
+    if (w->own_rgba) grv_host_free(w->own_rgba);
+    free(w->own_in);
     for (int k = 0; k < w->n_keep; k++) napi_delete_reference(env, w->keep[k]);
     if (w->self_ref) napi_delete_reference(env, w->self_ref);
     free(w);
@@ -714,6 +754,21 @@ static void bulk_async_complete(napi_env env, napi_status status, void *data) {
     bulk_work *w = (bulk_work *)data;
     engine_box *b = w->box;
     napi_value res = NULL;
+    if (status == napi_ok && w->rc == GRV_OK && w->own_rgba) {
+        /* caller-supplied `out`: look at it again NOW -- a buffer transferred or detached while the work
+         * was queued reports no data / a shorter length, and the promise rejects instead of writing freed memory */
+        napi_value ta;
+        napi_typedarray_type ty;
+        size_t len = 0;
+        void *data = NULL;
+        if (napi_get_reference_value(env, w->keep[0], &ta) == napi_ok && ta &&
+            napi_get_typedarray_info(env, ta, &ty, &len, &data, NULL, NULL) == napi_ok && data && len >= w->rgba_elems) {
+            memcpy(data, w->own_rgba, w->rgba_elems * sizeof(float));
+        } else {
+            w->rc = GRV_ERR_INVALID;
+            snprintf(w->err, sizeof w->err, "renderFrameAsync: `out` was detached or transferred while the frame was queued");
+        }
+    }
     if (status == napi_ok && w->rc == GRV_OK) res = bulk_result(env, w);
     if (res) {
         napi_resolve_deferred(env, w->deferred, res);
@@ -843,6 +898,16 @@ static napi_value render_frame_common(napi_env env, napi_callback_info info, int
             return NULL;
         }
         wk->rgba = (float *)data;
+        if (is_async) { /* see bulk_work.own_rgba: the pool thread renders into staging, not into JS-reachable memory */
+            wk->own_rgba = (float *)grv_host_alloc(n * sizeof(float));
+            if (!wk->own_rgba) {
+                free(wk);
+                napi_throw_error(env, NULL, "renderFrameAsync: cannot allocate the staging image");
+                return NULL;
+            }
+            wk->rgba = wk->own_rgba;
+            wk->rgba_elems = n;
+        }
     } else {
         napi_value ab;
         void *dst;
@@ -855,6 +920,7 @@ static napi_value render_frame_common(napi_env env, napi_callback_info info, int
         wk->rgba = (float *)dst;
     }
     if (!keep_ref(env, wk, rgba)) {
+        if (wk->own_rgba) grv_host_free(wk->own_rgba);
         free(wk);
         napi_throw_error(env, NULL, "renderFrame: reference failed");
         return NULL;
@@ -903,6 +969,16 @@ static napi_value integrate_batch_common(napi_env env, napi_callback_info info, 
     wk->spin = b->spin;
     wk->n = len / 8;
     wk->in = (double *)data;
+    if (is_async && len) { /* the caller may overwrite or transfer `states` while the work is queued: take a copy */
+        wk->own_in = malloc(len * sizeof(double));
+        if (!wk->own_in) {
+            free(wk);
+            napi_throw_error(env, NULL, "out of memory");
+            return NULL;
+        }
+        memcpy(wk->own_in, data, len * sizeof(double));
+        wk->in = (double *)wk->own_in;
+    }
     GrvOptions *o = &wk->opt;
     grv_options_default(o);
     napi_valuetype t;
@@ -929,6 +1005,7 @@ static napi_value integrate_batch_common(napi_env env, napi_callback_info info, 
     }
     const size_t n = wk->n;
     if (o->record_path && wk->max_points && n > ((size_t)1 << 33) / 64 / wk->max_points) { /* 8 GiB of rows */
+        free(wk->own_in);
         free(wk);
         napi_throw_range_error(env, NULL, "integrate_batch: n x maxPoints is too large; pass a smaller maxPoints");
         return NULL;
@@ -948,7 +1025,7 @@ static napi_value integrate_batch_common(napi_env env, napi_callback_info info, 
             return NULL;
         }
     }
-    if (!keep_ref(env, wk, argv[0])) { /* the input stays alive (and should stay unmodified) while queued */
+    if (!keep_ref(env, wk, argv[0])) { /* the input stays alive while queued (the async form works on its own copy) */
         bulk_release(env, wk);
         napi_throw_error(env, NULL, "integrate_batch: reference failed");
         return NULL;
@@ -1151,6 +1228,7 @@ static napi_value module_init(napi_env env, napi_value exports) {
         METHOD("set_auto_spin", m_set_auto_spin),
         METHOD("tick_sab", m_tick_sab),
         METHOD("get_sab_ptr", m_get_sab_ptr),
+        METHOD("attach_sab", m_attach_sab),
         METHOD("get_sab_layout", m_get_sab_layout),
         METHOD("compute_shadow_shift", m_compute_shadow_shift),
         METHOD("get_disk_lut_ptr", m_get_disk_lut_ptr),

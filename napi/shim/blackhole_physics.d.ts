@@ -80,6 +80,9 @@ export interface RenderFrameResult {
   acceptedSteps: number;
   launches: number;
   devices: number;
+  /** how the finished tiles reached device 0: "rccl" (one send/recv group over xGMI), "peer_copy", or
+   * "none" for a one-device frame.  A multi-device request whose RCCL cannot be opened throws. */
+  transport: "rccl" | "peer_copy" | "none";
 }
 
 export interface WebGLFrameOptions {
@@ -123,6 +126,10 @@ export class PhysicsEngine {
   generate_spectrum_lut(width: number, height: number, max_temp: number): Float32Array;
 
   get_sab_ptr(): number;
+  /** lib.rs:74.  `ptr` is a byte offset into `memory.buffer` (4-byte aligned, room for 2048 floats):
+   *  tick_sab then reads its controls from and publishes into that block.  Anything else throws a
+   *  RangeError (a raw pointer has no other meaning in JS). */
+  attach_sab(ptr: number): void;
   get_sab_layout(): number[];
   set_camera_state(px: number, py: number, pz: number, lx: number, ly: number, lz: number): void;
   set_auto_spin(enabled: boolean): void;

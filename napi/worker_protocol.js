@@ -41,6 +41,23 @@ const OFFSETS = { CONTROL: 0, CAMERA: 64, PHYSICS: 128, TELEMETRY: 256, LUTS: 20
     ticks.push({ seq: seq1, finite: cam.slice(0, 3).every(Number.isFinite), camera: cam, physics: phys,
                  inputs_consumed: wasmF32[startIdx + 1] === 0 && wasmF32[startIdx + 3] === 0 });
   }
-  console.log(JSON.stringify({ ticks: ticks, torn: torn }));
+  // attach_sab (lib.rs:74): tick_sab moves to another block of memory.buffer; get_sab_ptr does not
+  const own = engine.get_sab_ptr(), other = 512 * 1024;
+  engine.attach_sab(other);
+  wasmF32.fill(0, other / 4, other / 4 + 2048);
+  wasmF32[other / 4 + OFFSETS.CONTROL + 3] = -0.1;
+  const before = Array.from(wasmF32.subarray(own / 4 + OFFSETS.CAMERA, own / 4 + OFFSETS.CAMERA + 3));
+  engine.tick_sab(0.016);
+  const attach = { ptr_unchanged: engine.get_sab_ptr() === own,
+                   published_there: wasmF32[other / 4 + OFFSETS.PHYSICS + 2] === 1.0 &&
+                                    Number.isFinite(wasmF32[other / 4 + OFFSETS.CAMERA]),
+                   control_consumed_there: wasmF32[other / 4 + OFFSETS.CONTROL + 3] === 0,
+                   own_block_untouched: before.every((v, i) => v === wasmF32[own / 4 + OFFSETS.CAMERA + i]),
+                   errors: [] };
+  for (const bad of [-4, 2, 1 << 20, (1 << 20) - 4096, NaN, 1e12]) {
+    try { engine.attach_sab(bad); attach.errors.push(null); } catch (e) { attach.errors.push(e instanceof RangeError); }
+  }
+  engine.attach_sab(own);
+  console.log(JSON.stringify({ ticks: ticks, torn: torn, attach: attach }));
   engine.free();
 })().catch((e) => { console.error("FAILED", e); process.exit(1); });

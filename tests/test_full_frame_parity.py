@@ -37,51 +37,64 @@ def test_every_ray_of_the_bench_frame(engine_mod, oracle):
     out = {"frame": "%dx%d a=0.999 RKF45 tol=%g max_steps=2048" % (W, H, TOL), "rays": n,
            "oracle_seconds": round(time.time() - t, 1), "oracle_threads": _threads(),
            "oracle_accepted_steps": int(ref["steps"].sum())}
-    peak = float(ref["rgba"][..., :3].max())
-    with bh.PhysicsEngine(1.0, 0.999) as e:
-        cam = bh.camera_look_at(EYE, aspect=W / H)
-        for name, arith in (("strict", bh.ARITH_STRICT), ("fast", bh.ARITH_FAST)):
-            p = bh.render_params(W, H, arith=arith, tolerance=TOL)
-            rgba = torch.zeros(n, 4, dtype=torch.float32, device="cuda:0")
-            fs = torch.zeros(n, 8, dtype=torch.float64, device="cuda:0")
-            steps = torch.zeros(n, dtype=torch.int32, device="cuda:0")
-            term = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
-            drift = torch.zeros(n, dtype=torch.float64, device="cuda:0")
-            e.render_frame_device(cam, p, rgba, fs, steps, term, drift)
-            torch.cuda.synchronize()
-            a, b = fs.cpu().numpy(), ref["states"]
-            err = (np.abs(a - b) / np.maximum(1.0, np.abs(b))).max(axis=1)
-            st = steps.cpu().numpy().astype(np.int64)
-            ds = np.abs(st - ref["steps"].astype(np.int64))
-            cls = term.cpu().numpy() != ref["term"]
-            dpx = float(np.abs(rgba.cpu().numpy() - ref["rgba"].reshape(-1, 4)).max())
-            out[name] = {
-                "accepted_steps": int(st.sum()),
-                "termination_class_mismatches": int(cls.sum()),
-                "step_count_mismatches": int((ds > 0).sum()), "max_step_count_difference": int(ds.max()),
-                "endpoint_rel_err": {"p50": float(np.median(err)), "p99": float(np.percentile(err, 99)),
-                                     "p99.99": float(np.percentile(err, 99.99)), "max": float(err.max())},
-                "rays_above_1e-6": int((err > 1e-6).sum()),
-                "pixel_max_abs_diff_over_peak": dpx / peak,
-                "rays_with_any_bit_different": int(((a != b) & ~(np.isnan(a) & np.isnan(b))).any(axis=1).sum()),
-                "drift_values_different": int((drift.cpu().numpy() != ref["drift"]).sum()),
-                "pixels_with_any_bit_different": int((rgba.cpu().numpy() != ref["rgba"].reshape(-1, 4)).any(axis=1).sum()),
-            }
-            same = ds == 0
-            if arith == bh.ARITH_STRICT:
-                # reference operation order + the specified sin/cos/pow: the same bits as the
-                # checker for every end state, step count, class, drift and pixel of the frame
-                assert cls.sum() == 0 and ds.max() == 0
-                assert out[name]["rays_with_any_bit_different"] == 0
-                assert out[name]["drift_values_different"] == 0
-                assert out[name]["pixels_with_any_bit_different"] == 0
-            else:   # FAST: rounding may flip an accept / reject decision of the controller on a few
-                    # rays (one more step, or the same count through a different h history)
-                assert cls.sum() <= 2 and (~same).sum() <= 1e-5 * n and (err > 1e-5).sum() <= 1e-6 * n
-            # (FAST's median sits at 1.9e-10 at tol 1e-8 and 1.3e-9 at tol 1e-9 -- a third more steps per
-            # ray and smaller ones, so the rounding of the step-size controller weighs more; STRICT: 0)
-            assert np.median(err) <= (1e-9 if TOL >= 1e-8 else 1e-8) and dpx <= 1e-5 * peak
-    path = os.environ.get("GRV_PARITY_JSON")
-    if path:
-        with open(path, "w") as f:
-            json.dump(out, f, indent=1)
+    try:
+        peak = float(ref["rgba"][..., :3].max())
+        with bh.PhysicsEngine(1.0, 0.999) as e:
+            cam = bh.camera_look_at(EYE, aspect=W / H)
+            for name, arith in (("strict", bh.ARITH_STRICT), ("fast", bh.ARITH_FAST)):
+                p = bh.render_params(W, H, arith=arith, tolerance=TOL)
+                rgba = torch.zeros(n, 4, dtype=torch.float32, device="cuda:0")
+                fs = torch.zeros(n, 8, dtype=torch.float64, device="cuda:0")
+                steps = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+                term = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
+                drift = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+                e.render_frame_device(cam, p, rgba, fs, steps, term, drift)
+                torch.cuda.synchronize()
+                a, b = fs.cpu().numpy(), ref["states"]
+                err = (np.abs(a - b) / np.maximum(1.0, np.abs(b))).max(axis=1)
+                st = steps.cpu().numpy().astype(np.int64)
+                ds = np.abs(st - ref["steps"].astype(np.int64))
+                cls = term.cpu().numpy() != ref["term"]
+                dpx = float(np.abs(rgba.cpu().numpy() - ref["rgba"].reshape(-1, 4)).max())
+                out[name] = {
+                    "accepted_steps": int(st.sum()),
+                    "termination_class_mismatches": int(cls.sum()),
+                    "step_count_mismatches": int((ds > 0).sum()), "max_step_count_difference": int(ds.max()),
+                    "endpoint_rel_err": {"p50": float(np.median(err)), "p99": float(np.percentile(err, 99)),
+                                         "p99.99": float(np.percentile(err, 99.99)), "max": float(err.max())},
+                    "rays_above_1e-6": int((err > 1e-6).sum()),
+                    "pixel_max_abs_diff_over_peak": dpx / peak,
+                    "rays_with_any_bit_different": int(((a != b) & ~(np.isnan(a) & np.isnan(b))).any(axis=1).sum()),
+                    "drift_values_different": int((drift.cpu().numpy() != ref["drift"]).sum()),
+                    "pixels_with_any_bit_different": int((rgba.cpu().numpy() != ref["rgba"].reshape(-1, 4)).any(axis=1).sum()),
+                }
+                same = ds == 0
+                big = np.flatnonzero(err > 1e-5)
+                out[name]["rays_above_1e-5"] = [
+                    {"ray": int(i), "pixel": [int(i % W), int(i // W)], "rel_err": float(err[i]), "steps_oracle": int(ref["steps"][i]),
+                     "step_count_difference": int(st[i] - int(ref["steps"][i])), "class_mismatch": bool(cls[i])}
+                    for i in big[:64]]
+                if arith == bh.ARITH_STRICT:
+                    # reference operation order + the specified sin/cos/pow: the same bits as the
+                    # checker for every end state, step count, class, drift and pixel of the frame
+                    assert cls.sum() == 0 and ds.max() == 0
+                    assert out[name]["rays_with_any_bit_different"] == 0
+                    assert out[name]["drift_values_different"] == 0
+                    assert out[name]["pixels_with_any_bit_different"] == 0
+                else:   # FAST: rounding may flip an accept / reject decision of the controller on a few
+                        # rays (one more step, or the same count through a different h history)
+                    assert cls.sum() <= 2 and (~same).sum() <= 1e-5 * n and big.size <= 1e-6 * n
+                    # ... and the few rays beyond 1e-5 are NAMED and BOUNDED: each is a ray whose accept / reject
+                    # history departed from the oracle's (its step count differs, or its class), and it ends
+                    # within one RKF45 step of the oracle's end point (|h| <= 10 far out, where a step moves
+                    # r ~ 1000 by <= 1 %: 5e-2 relative) -- not merely "few"
+                    assert float(err[big].max(initial=0.0)) <= 5e-2
+                    assert all((ds[i] > 0) or cls[i] for i in big), out[name]["rays_above_1e-5"]
+                # (FAST's median sits at 1.9e-10 at tol 1e-8 and 1.3e-9 at tol 1e-9 -- a third more steps per
+                # ray and smaller ones, so the rounding of the step-size controller weighs more; STRICT: 0)
+                assert np.median(err) <= (1e-9 if TOL >= 1e-8 else 1e-8) and dpx <= 1e-5 * peak
+    finally:  # the record is written even when a bar above fails: the failing rays are in it
+        path = os.environ.get("GRV_PARITY_JSON")
+        if path:
+            with open(path, "w") as f:
+                json.dump(out, f, indent=1)

@@ -364,10 +364,14 @@ def test_try_bound_ends_rays_instead_of_hanging(bh, torch_mod, monkeypatch):
     """The one-launch schedule, the refill kernel and the single-ray kernel carry a hard bound on a
     ray's tries (160 max_steps + 64, never reached by a correct kernel).  With the bound forced down
     to 40 tries every ray that would need more comes back as TERM_MAXSTEPS with fewer than max_steps
-    accepted steps -- and the call returns."""
+    accepted steps -- and the call returns.  The bound is set by an explicit call on the handle
+    (grv_test_set_try_bound); the process environment does not reach it."""
     torch = torch_mod
-    monkeypatch.setenv("GRV_DEBUG_TRY_BOUND", "40")
+    monkeypatch.setenv("GRV_DEBUG_TRY_BOUND", "40")  # the retired environment hook: must be inert
     with bh.PhysicsEngine(1.0, 0.999) as e:
+        o = _frame(bh, torch, e, 128, 72, arith=1)
+        assert (o["term"].cpu().numpy() == 3).sum() == 0
+        assert e._lib.grv_test_set_try_bound(e._h, 40) == 0
         o = _frame(bh, torch, e, 128, 72, arith=1)
         torch.cuda.synchronize()
         term, steps = o["term"].cpu().numpy(), o["steps"].cpu().numpy()
@@ -382,7 +386,6 @@ def test_try_bound_ends_rays_instead_of_hanging(bh, torch_mod, monkeypatch):
                                                  out.ctypes.data_as(C.c_void_p), C.byref(ex[0]), C.byref(ex[1]),
                                                  C.byref(ex[2]))
         assert ex[1].value == 3 and ex[0].value <= 40 and np.isfinite(out).all()
-    monkeypatch.delenv("GRV_DEBUG_TRY_BOUND")
-    with bh.PhysicsEngine(1.0, 0.999) as e:  # and without the hook nothing is cut short
+        assert e._lib.grv_test_set_try_bound(e._h, 0) == 0  # back to the derived bound: nothing is cut short
         o = _frame(bh, torch, e, 128, 72, arith=1)
         assert (o["term"].cpu().numpy() == 3).sum() == 0

@@ -106,8 +106,10 @@ def test_ranks_sharing_one_gpu_assemble_the_whole_frame_bitwise(tmp_path, engine
 
 
 def _bench(world, *args, launcher=False):
-    """bench.py as the driver invokes it.  Default: the BARE command `python bench.py --gpus N ...`
-    (bench.py launches its own N ranks); launcher=True: under `python -m torch.distributed.run`."""
+    """bench.py's one-process-per-GPU host.  Default: `python bench.py --gpus N --launcher torchrun`
+    (bench.py starts its own N ranks); launcher=True: under `python -m torch.distributed.run`, as
+    the round-end driver starts N > 1.  (A bare `python bench.py --gpus N` goes through the C ABI's
+    multi-GPU handle instead: tests/test_gpu_multi_native.py.)"""
     env = dict(os.environ, GRV_BENCH_BACKEND="gloo", GRV_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
@@ -115,7 +117,7 @@ def _bench(world, *args, launcher=False):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")]
     else:
-        cmd = [sys.executable, os.path.join(ROOT, "bench.py")]
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--launcher", "torchrun"]
     cmd += ["--gpus", str(world)] + list(args)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -124,14 +126,19 @@ def _bench(world, *args, launcher=False):
     return json.loads(lines[0])
 
 
-def test_bare_bench_command_launches_its_own_ranks():
-    """`python bench.py --gpus 2 --steps 5 --warmup 2` with no launcher around it must run two ranks
-    and say so; the same command line under torch.distributed.run must give the same workload."""
+def test_self_launched_ranks_and_launcher_started_ranks_agree():
+    """`python bench.py --gpus 2 --launcher torchrun` with no launcher around it must start two ranks
+    and say so; the same command line under torch.distributed.run must give the same workload, and
+    both lines carry the audit fields of a scaling point."""
     bare = _bench(2, "--width", "640", "--height", "360", "--steps", "5", "--warmup", "2")
     assert bare["n_gpus"] == 2 and bare["ranks"] == 2 and bare["rank_devices"] == [0, 0]
     under = _bench(2, "--width", "640", "--height", "360", "--steps", "5", "--warmup", "2", launcher=True)
     assert under["n_gpus"] == 2 and under["ranks"] == 2
     assert bare["config"]["accepted_steps_per_frame"] == under["config"]["accepted_steps_per_frame"]
+    for ln in (bare, under):
+        assert "torchrun" in ln["launcher"] and ln["transport"] == "gloo" and ln["rccl_version"] is None
+        rk = ln["rank_integrate_ms"]
+        assert len(rk["per_rank"]) == 2 and 0 < rk["min"] <= rk["max"]
 
 
 def test_bench_refuses_more_ranks_than_devices():

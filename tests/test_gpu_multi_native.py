@@ -165,6 +165,7 @@ with bh.PhysicsEngine(1.0, 0.999) as e:
     torch.cuda.synchronize()
 with bh.MultiEngine(1.0, 0.999, devices=[0], transport=bh.TRANSPORT_RCCL) as m:
     assert m.transport == bh.TRANSPORT_RCCL
+    m.test_self_exchange(True)
     for k in range(3):
         got = torch.zeros(h, w, 4, dtype=torch.float32, device="cuda:0")
         m.render_frame_device(cam, p, got)
@@ -175,21 +176,21 @@ print("RCCL_WALK_OK")
 
 
 def test_rccl_transport_walk_on_one_device():
-    """ncclCommInitAll on one device and, with GRV_MULTI_SELF_EXCHANGE, rank 0's share travelling
+    """ncclCommInitAll on one device and, with grv_multi_test_self_exchange, rank 0's share travelling
     through one ncclSend / ncclRecv group per frame before the unpack: every RCCL call of the
     transport runs, on the one device this pool has."""
-    env = dict(os.environ, GRV_MULTI_SELF_EXCHANGE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", _RCCL_WALK % {"root": ROOT}], capture_output=True, text=True,
                        timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0 and "RCCL_WALK_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
-def _bench_native(*args):
+def _bench_native(*args, flag=("--native",)):
     import json
     env = dict(os.environ, GRV_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--native"] + list(args),
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(flag) + list(args),
                        capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -201,8 +202,13 @@ def test_bench_native_drives_the_c_abi_multi_handle():
     """bench.py --native: one process, grv_engine_create_multi (here: virtual ranks on the one GPU),
     same frame and the same accepted steps per frame as the one-rank run."""
     one = _bench_native("--gpus", "1", "--width", "640", "--height", "360", "--steps", "4", "--warmup", "1")
-    four = _bench_native("--gpus", "4", "--width", "640", "--height", "360", "--steps", "4", "--warmup", "1")
+    # a BARE `python bench.py --gpus 4` (no launcher around it, no flag) is this host: one process,
+    # the C ABI's multi-GPU handle
+    four = _bench_native("--gpus", "4", "--width", "640", "--height", "360", "--steps", "4", "--warmup", "1", flag=())
     assert one["n_gpus"] == 1 and four["n_gpus"] == 4 and four["ranks"] == 4 and four["rank_devices"] == [0] * 4
+    assert "native" in four["launcher"] and four["transport"] == "peer_copy" and four["rccl_version"] is None
+    rk = four["rank_integrate_ms"]
+    assert len(rk["per_rank"]) == 4 and 0 < rk["min"] <= rk["max"]
     assert four["config"]["accepted_steps_per_frame"] == one["config"]["accepted_steps_per_frame"]
     assert four["config"]["virtual_ranks_on_one_device"] and four["config"]["frames_in_flight"] == 2
     assert four["roofline"]["avg_launch_ms"] > 0 and four["value"] > 0

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(engine_mod):
     assert len(names) >= 25
     for n in names:
         assert hasattr(lib, n), "libgravitas_hip.so does not export %s" % n
-    assert lib.grv_abi_version() == 4
+    assert lib.grv_abi_version() == 5
 
 
 def test_no_device_fails_loudly(engine_mod):
@@ -32,6 +32,47 @@ def test_no_device_fails_loudly(engine_mod):
         pytest.skip("GPU present")
     with pytest.raises(engine_mod.GravitasError):
         engine_mod.PhysicsEngine(1.0, 0.9)
+
+
+_RCCL_PROBE = r"""
+import sys
+sys.path.insert(0, %(root)r)
+import ctypes as C
+import blackhole_simulation_amd as bh
+L = bh.load_library()
+for attempt in range(3):   # a failed bind must stay a clean failure: never "already loaded" over null entry points
+    v, why = bh.rccl_probe()
+    print("PROBE", v, why)
+h = C.c_void_p()
+rc = L.grv_engine_create_multi(1.0, 0.5, 0b11, bh.TRANSPORT_RCCL, C.byref(h))
+print("CREATE", rc, bool(h.value), L.grv_multi_create_error().decode())
+"""
+
+
+@pytest.mark.parametrize("lib,expect", [("/nonexistent/librccl.so.1", "dlopen(/nonexistent/librccl.so.1)"),
+                                        ("libm.so.6", "librccl lacks ncclCommInitAll")])
+def test_rccl_transport_without_a_usable_librccl_is_a_clean_error(engine_mod, lib, expect):
+    """A host whose librccl is absent (or is not RCCL) gets status codes and the loader's text, not a
+    crash: dlerror() is read once, and a library that lacks an entry point is closed again instead of
+    staying half-bound (csrc/engine_multi.hip RcclApi::load)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, GRV_RCCL_LIBRARY=lib)
+    r = subprocess.run([sys.executable, "-c", _RCCL_PROBE % {"root": ROOT}], capture_output=True, text=True,
+                       timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+    probes = [ln for ln in r.stdout.splitlines() if ln.startswith("PROBE")]
+    assert len(probes) == 3 and all(ln.startswith("PROBE 0 ") and expect in ln for ln in probes), r.stdout
+    create = [ln for ln in r.stdout.splitlines() if ln.startswith("CREATE")][0].split(" ", 3)
+    # no GPU here: refused for the missing device before RCCL is looked at; on a GPU box: for RCCL
+    assert create[1] == "2" and create[2] == "False" and create[3], r.stdout
+
+
+def test_rccl_probe_reports_the_bound_version(engine_mod):
+    v, why = engine_mod.rccl_probe()
+    if v == 0:
+        pytest.skip("no librccl on this host: %s" % why)
+    assert v >= 20000 and why == ""  # ncclGetVersion's code: major * 10000 + minor * 100 + patch
 
 
 def test_package_has_no_oracle_dependency():

@@ -17,9 +17,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ADDON = os.path.join(ROOT, "napi", "blackhole_physics.node")
 NODE = shutil.which("node")
 
-# every `pub fn` of `#[wasm_bindgen] impl PhysicsEngine` (lib.rs:56-465) except attach_sab,
-# whose raw-pointer argument has no JS meaning (the addon attaches its arena block itself)
+# every `pub fn` of `#[wasm_bindgen] impl PhysicsEngine` (lib.rs:56-465); attach_sab's raw pointer is
+# a byte offset into `memory.buffer` (the arena), anything else throws
 WASM_METHODS = [
+    "attach_sab",
     "update_params", "compute_horizon", "compute_isco", "compute_photon_sphere", "compute_dilation",
     "generate_disk_lut", "get_disk_lut_ptr", "get_sab_ptr", "set_camera_state", "set_auto_spin",
     "generate_spectrum_lut", "generate_embedding_mesh", "generate_ergosphere_mesh",
@@ -88,7 +89,7 @@ def test_method_list_is_the_reference_ffi(oracle):
     if not os.path.exists(src):
         pytest.skip("reference not mounted")
     names = re.findall(r"pub fn (\w+)\(", open(src).read())
-    want = set(names) - {"init_hooks", "new", "attach_sab"}
+    want = set(names) - {"init_hooks", "new"}
     assert want <= set(WASM_METHODS), want - set(WASM_METHODS)
 
 
@@ -156,6 +157,9 @@ def test_worker_and_bridge_sab_protocol(oracle):
     assert r.returncode == 0, r.stderr + r.stdout
     res = json.loads(r.stdout.strip().splitlines()[-1])
     assert res["torn"] == 0 and [t["seq"] for t in res["ticks"]] == [2, 4, 6, 8]
+    at = res["attach"]  # attach_sab (lib.rs:74): tick_sab moves, get_sab_ptr does not; bad offsets throw RangeError
+    assert at["ptr_unchanged"] and at["published_there"] and at["control_consumed_there"] and at["own_block_untouched"]
+    assert at["errors"] == [True] * 6
     o = oracle.sab_engine(1.0, 0.9)
     o.camera.auto_spin = 1
     o.camera.position[0], o.camera.position[1], o.camera.position[2] = 3.0, 4.0, 12.0
@@ -207,6 +211,8 @@ def test_bulk_js_batch_async_and_multi_device_entries(oracle, tmp_path):
     f = res["frames"]
     assert f["ranks_equal"] and f["async_ranks_equal"] and f["pinned_equal"] and f["pinned_is_out"]
     assert f["steps1"] == f["steps4"] and f["devices4"] == 4 and f["update_reaches_ranks"]
+    am = res["async_memory"]  # the async forms never hold pointers into memory JS can reach meanwhile
+    assert am["out_filled"] and am["input_copy"] and am["detached_rejected"] and "detached" in am["detached_rejected"]
     e = res["errors"]
     assert all(e["sync"]) and "8 n" in e["sync"][0] and "out of range" in e["sync"][1] and "out must be" in e["sync"][2]
     assert e["async_rejected"] and res["empty"] == 0 and res["free_while_pending"] == 100

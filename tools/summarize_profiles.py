@@ -53,8 +53,11 @@ def pmc_summary(dbpath):
 
 out = {}
 TRACE_CMD = {"trace": "--steps 10 --warmup 2", "trace_k16": "--steps 10 --warmup 2 --segment-tries 16",
-             "trace_strict": "--steps 5 --warmup 1 --arith strict", "trace_c4": "--steps 5 --warmup 1 --config c4"}
-for label in ("trace", "trace_k16", "trace_strict", "trace_c4"):
+             "trace_strict": "--steps 5 --warmup 1 --arith strict", "trace_c4": "--steps 5 --warmup 1 --config c4",
+             "trace_c4fast": "--steps 5 --warmup 1 --config c4 --arith fast",
+             "trace_c2": "--steps 5 --warmup 1 --config c2", "trace_c2wgsl": "--steps 5 --warmup 1 --config c2 --kernel wgsl",
+             "trace_c5": "--steps 5 --warmup 1 --config c5"}
+for label in TRACE_CMD:
     p = os.path.join(SRC, label, "bench_results.db")
     if os.path.exists(p):
         txt, rows = trace_summary(p, "python bench.py %s --no-cpu-baseline" % TRACE_CMD[label])
@@ -65,10 +68,10 @@ for label in ("trace", "trace_k16", "trace_strict", "trace_c4"):
         print(txt)
 
 pm = {}
-for label in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_fetch_k16", "pmc_write_k16", "pmc_fetch_strict", "pmc_write_strict",
-              "pmc_sq_strict", "pmc_fetch_c4", "pmc_write_c4", "pmc_sq_c4", "pmc_fetch_c4fast", "pmc_write_c4fast",
-              "pmc_sq_c4fast", "pmc_cls32", "pmc_cls64", "pmc_occ", "pmc_cls32_strict", "pmc_cls64_strict", "pmc_occ_strict",
-              "pmc_cls32_c4", "pmc_cls64_c4", "pmc_occ_c4", "pmc_cls32_c4fast", "pmc_cls64_c4fast", "pmc_occ_c4fast"):
+PMC_LABELS = ["pmc_fetch_k16", "pmc_write_k16"] + [
+    "pmc_%s%s" % (kind, sfx) for sfx in ("", "_strict", "_c4", "_c4fast", "_c2", "_c2wgsl")
+    for kind in ("fetch", "write", "sq", "cls32", "cls64", "occ", "mem")]
+for label in PMC_LABELS:
     p = os.path.join(SRC, label, "bench_results.db")
     if os.path.exists(p):
         for k, c, n, avg, tot in pmc_summary(p):
@@ -76,7 +79,7 @@ for label in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_fetch_k16", "pmc_write_k1
 open(os.path.join(DST, "%s_pmc_counters.json" % TAG), "w").write(json.dumps(pm, indent=1))
 for label, items in pm.items():
     for it in items:
-        if "integrate" in it["kernel"] or "finalize" in it["kernel"] or "init_from" in it["kernel"] or "wgsl" in it["kernel"]:
+        if any(w in it["kernel"] for w in ("integrate", "finalize", "init_from", "wgsl", "glsl")):
             print(label, it)
 
 # HBM traffic of the dominant kernels per launch (bench.py reads profiles/traffic.json).  Every
@@ -105,7 +108,11 @@ if os.path.exists(tpath):
 CASES = [("integrate_segment_kernel<1,1,0>", "integrate_segment_kernel<1, 1, 0>", "", [3840, 2160], 8355840 * (92 + 76)),
          ("integrate_segment_kernel<1,0,0>", "integrate_segment_kernel<1, 0, 0>", "_strict", [3840, 2160], 8355840 * (92 + 76)),
          ("wgsl_symplectic_pk_kernel", "wgsl_symplectic_pk_kernel", "_c4", [7680, 4320], None),
-         ("wgsl_symplectic_fast_kernel", "wgsl_symplectic_fast_kernel", "_c4fast", [7680, 4320], None)]
+         ("wgsl_symplectic_fast_kernel", "wgsl_symplectic_fast_kernel", "_c4fast", [7680, 4320], None),
+         # BASELINE configs[1]: the 1080p / 512-step marches (a kernel measured at a second frame size is filed
+         # under "<kernel>@<W>x<H>"; bench.py looks that key up first)
+         ("glsl_fragment_kernel<1>", "glsl_fragment_kernel<1>", "_c2", [1920, 1080], None),
+         ("wgsl_symplectic_pk_kernel@1920x1080", "wgsl_symplectic_pk_kernel", "_c2wgsl", [1920, 1080], None)]
 for pretty, needle, sfx, frame, layout in CASES:
     f, w = _avg("pmc_fetch" + sfx, "FETCH_SIZE", needle), _avg("pmc_write" + sfx, "WRITE_SIZE", needle)
     if f is None or w is None:
@@ -114,9 +121,10 @@ for pretty, needle, sfx, frame, layout in CASES:
     # (/opt/skills/guides/MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 64 B per 128-B request
     # on coalesced streaming reads -> x2.  Cross-check for the f64 frame: 8 355 840 slots x 92 B
     # read = 0.769 GB, x 76 B written = 0.635 GB.
-    ent = {"name": needle, "code_hash": hashes.get(pretty), "frame": frame,
+    ent = {"name": needle, "code_hash": hashes.get(pretty.split("@")[0]), "frame": frame,
            "command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline" +
-                      {"": "", "_strict": " --arith strict", "_c4": " --config c4", "_c4fast": " --config c4 --arith fast"}[sfx],
+                      {"": "", "_strict": " --arith strict", "_c4": " --config c4", "_c4fast": " --config c4 --arith fast",
+                       "_c2": " --config c2", "_c2wgsl": " --config c2 --kernel wgsl"}[sfx],
            "fetch_size_kib_raw_avg_per_launch": f, "write_size_kib_avg_per_launch": w,
            "fetch_correction": 2.0, "hbm_bytes_per_launch": int((2.0 * f + w) * 1024)}
     if layout:
@@ -158,6 +166,11 @@ for pretty, needle, sfx, frame, layout in CASES:
                            "issue_frac": round((act - act2) * 4.0 / 1024.0 / (gui / 8.0), 4),
                            "note": "(SQ_ACTIVE_INST_VALU - SQ_ACTIVE_INST_VALU2) x 4 cycles / 1024 SIMDs / elapsed cycles "
                                    "(the two counters from two runs)"}
+    mem = {c: _avg("pmc_mem" + sfx, c, needle) for c in ("SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_FLAT",
+                                                        "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_SMEM",
+                                                        "SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES")}
+    if any(v is not None for v in mem.values()):
+        ent["memory_side_instructions_per_launch"] = mem
     traffic["kernels"][pretty] = ent
 open(tpath, "w").write(json.dumps(traffic, indent=1))
 print(json.dumps(traffic, indent=1))
