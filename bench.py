@@ -689,6 +689,8 @@ def main():
         avg_launch_ms = integ_ms / max(launches, 1)
         achieved = (per_frame_bytes / launches_per_frame) / (avg_launch_ms * 1e-3) / 1e9
         kernel_pretty = KERNEL_OF[("c4" if wp is not None else cfg, args.arith)]
+        if cfg == "c2" and args.arith == "packed":
+            kernel_pretty = "wgsl_symplectic_pk_b256_kernel"  # budgets <= 512: the four-wave-block form (kernels_fast.hip)
         pmc, pmc_src = committed_pmc(kernel_pretty, bh.library_path(), (W, H))
         usable_pmc = pmc if (pmc and world == 1 and not args.segment_tries and (cfg != "c3" or TOL == 1e-8) and
                              (W, H) == tuple(pmc.get("frame", (W, H)))) else None

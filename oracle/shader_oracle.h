@@ -18,6 +18,7 @@
 #ifndef SHADER_ORACLE_H
 #define SHADER_ORACLE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -40,6 +41,12 @@ typedef struct {
 uint32_t orc_wgsl_pixel(const orc_wgsl_params *p, uint32_t ix, uint32_t iy, float rgba[4]);
 void orc_wgsl_frame(const orc_wgsl_params *p, uint32_t stride_x, uint32_t stride_y, float *rgba,
                     uint32_t *steps, int nthreads);
+/* wgsl_f64_twin.c: the same march evaluated in double (analysis instrument for disagreements between
+ * two f32 forms of it).  exit class: 0 horizon, 1 escape, 2 step budget, 3 opaque */
+uint32_t orc_wgsl_pixel_f64(const orc_wgsl_params *p, uint32_t ix, uint32_t iy, double rgb[3],
+                            int32_t *exit_class, double *min_r);
+void orc_wgsl_pixels_f64(const orc_wgsl_params *p, size_t n, const uint32_t *xy, double *rgb, uint32_t *steps,
+                         int32_t *cls, double *min_r, int nthreads);
 
 /* ShaderManager #defines (src/shaders/manager.ts:61-82) as bits */
 #define ORC_GLSL_LENSING 1u

@@ -548,3 +548,35 @@ def test_bloom_blur_kernel_on_an_impulse(oracle):
     mask[7:10] = False            # the lit block and its bilinear neighbours: scene + bloom saturates ACES
     assert np.allclose(row_q[mask], want[mask], rtol=5e-4, atol=1e-4), (row_q, want)
     assert row_q[:3].max() == 0.0 and row_q[14:].max() == 0.0      # 9 taps: nothing beyond +-4 texels (+1 bilinear)
+
+
+# --------------------------------------------------------------------------------------------
+# the f64 twin of the compute march (oracle/wgsl_f64_twin.c), the instrument behind
+# tests/measure_c4_budget_rays.py: it must be the SAME discrete march as the f32 oracle
+# --------------------------------------------------------------------------------------------
+def test_f64_twin_of_the_compute_march_is_the_same_algorithm(oracle):
+    """Every 24th pixel of the 1080p / 512-step frame at a = 0.999 (stars off): the double-precision
+    twin takes the same number of steps as the f32 shader-order oracle on > 99.9 % of the pixels
+    (the rest: rays on the unstable photon orbit, where f32 rounding decides the step count -- the
+    question the twin exists to answer), never more than the budget, and its colours sit within
+    2e-3 of peak of the f32 ones at the 99.9th percentile."""
+    W, H = 1920, 1080
+    th = np.deg2rad(97.0)
+    cam = oracle.camera_look_at((60.0 * np.sin(th), 60.0 * np.cos(th), 0.0), aspect=W / H)
+    op = oracle.WgslParams()
+    for k in range(16):
+        op.inv_view[k], op.inv_proj[k] = cam.inv_view[k], cam.inv_proj[k]
+    for k in range(3):
+        op.position[k] = cam.position[k]
+    op.mass, op.spin, op.width, op.height, op.max_steps, op.stars = 1.0, 0.999, W, H, 512, 0
+    rgba, steps = oracle.wgsl_frame(op, stride=(24, 24), nthreads=8)
+    ys, xs = np.mgrid[0:H:24, 0:W:24]
+    d = oracle.wgsl_pixels_f64(op, np.stack([xs.ravel(), ys.ravel()], 1), nthreads=8)
+    ds = np.abs(d["steps"].astype(np.int64) - steps.ravel().astype(np.int64))
+    assert (ds == 0).mean() > 0.999 and d["steps"].max() <= 512
+    assert set(np.unique(d["cls"])) <= {0, 1, 2, 3} and (d["cls"] == 1).mean() > 0.5
+    peak = rgba[..., :3].max()
+    dc = np.abs(d["rgb"] - rgba.reshape(-1, 4)[:, :3]).max(1) / peak
+    assert np.percentile(dc, 99.9) <= 2e-3
+    # exit classes are consistent with the step counts
+    assert ((d["cls"] == 2) == (d["steps"] == 512)).all()
