@@ -1050,6 +1050,14 @@ void grv_host_free(void *p) {
     if (p) (void)hipHostFree(p);
 }
 
+int grv_last_ray_clocks(const grv_engine *e, uint64_t out3[3]) {
+    if (!e || !out3 || !e->ray_out) return GRV_ERR_INVALID;
+    out3[0] = e->ray_out->loop_cycles;
+    out3[1] = e->ray_out->loop_ticks;
+    out3[2] = e->ray_out->tries;
+    return GRV_OK;
+}
+
 int grv_test_set_try_bound(grv_engine *e, uint32_t tries) {
     if (!e) return GRV_ERR_INVALID;
     e->try_bound_override = tries;

@@ -70,9 +70,10 @@ int grv_set_glsl_noise(grv_engine *e, const uint8_t *noise_rgba, const uint8_t *
     if (!e) return GRV_ERR_INVALID;
     GRV_HIP(e, hipSetDevice(e->device));
     constexpr size_t kPlane = 256 * 256;
+    // [2][kPlane] bytes (noise, blue noise), then the noise plane once more as f32 texel values
     if (!e->d_noise) {
-        GRV_HIP(e, hipMalloc(reinterpret_cast<void **>(&e->d_noise), 2 * kPlane));
-        GRV_HIP(e, hipMemset(e->d_noise, 0, 2 * kPlane));
+        GRV_HIP(e, hipMalloc(reinterpret_cast<void **>(&e->d_noise), 2 * kPlane + kPlane * sizeof(float)));
+        GRV_HIP(e, hipMemset(e->d_noise, 0, 2 * kPlane + kPlane * sizeof(float)));
     }
     std::vector<uint8_t> plane(kPlane);
     const uint8_t *src[2] = {noise_rgba, blue_rgba};
@@ -80,6 +81,11 @@ int grv_set_glsl_noise(grv_engine *e, const uint8_t *noise_rgba, const uint8_t *
         if (!src[t]) continue;
         for (size_t i = 0; i < kPlane; ++i) plane[i] = src[t][4 * i]; // .r
         GRV_HIP(e, hipMemcpy(e->d_noise + t * kPlane, plane.data(), kPlane, hipMemcpyHostToDevice));
+        if (t == 0) { // UNORM8 -> float as the sampler does it: byte / 255.0f, the IEEE quotient
+            std::vector<float> tex(kPlane);
+            for (size_t i = 0; i < kPlane; ++i) tex[i] = (float)plane[i] / 255.0f;
+            GRV_HIP(e, hipMemcpy(e->d_noise + 2 * kPlane, tex.data(), kPlane * sizeof(float), hipMemcpyHostToDevice));
+        }
     }
     return GRV_OK;
 }
@@ -151,6 +157,7 @@ int grv_render_frame_glsl(grv_engine *e, const GrvGlslParams *p, float *d_rgba, 
     }
     P.noise_r = e->d_noise;
     P.blue_r = e->d_noise + 256 * 256;
+    P.noise_f = reinterpret_cast<const float *>(e->d_noise + 2 * 256 * 256);
     hipStream_t s = static_cast<hipStream_t>(stream);
     return run_shader_frame(e, p->width, p->height, p->tile_world, p->tile_rank, total_steps, s,
                             [&](const FrameGeom &G, uint32_t n, unsigned long long *tot) {

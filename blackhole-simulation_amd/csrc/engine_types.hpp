@@ -159,6 +159,7 @@ struct GlslParams {
     float shadow_curve[64][2];
     const uint8_t *noise_r; // 256x256 R channel of u_noiseTex (device)
     const uint8_t *blue_r;  // 256x256 R channel of u_blueNoiseTex (device)
+    const float *noise_f;   // the same noise plane as f32 texel values (byte / 255.0f), FAST lattice noise
 };
 
 // single-ray entry (grv_integrate_ray_relativistic): arguments by value, result in pinned host memory
@@ -170,6 +171,9 @@ struct SingleRayOut {
     double drift;
     uint32_t steps, tries, term;
     uint32_t seq; // written last (system scope): the call's sequence number
+    // the try loop on the device's own clocks (s_memtime: shader cycles; s_memrealtime: the constant
+    // 100 MHz counter): what one accepted step costs without the launch and the PCIe round trip
+    unsigned long long loop_cycles, loop_ticks;
 };
 
 struct FrameStatsDev {

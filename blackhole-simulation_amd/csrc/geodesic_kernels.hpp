@@ -735,7 +735,10 @@ __global__ __launch_bounds__(64) void single_ray_kernel(SegmentParams P, SingleR
     KsRayConsts rc;
     ray_resume<KIND, ARITH>(bh, y, P, live, rc);
     RayWorkspace ws{}; // only the crossing recorder writes to it, and P.shading == 0 here
+    const unsigned long long c0 = clock64(), w0 = wall_clock64();
     while (live && y.tries < P.try_cap) live = advance_one<KIND, ARITH, GRV_METHOD_RKF45>(bh, y, P, ws, 0u, rc);
+    out->loop_cycles = clock64() - c0;
+    out->loop_ticks = wall_clock64() - w0;
     if (live) y.flags = (y.flags & ~kFlagTermMask) | GRV_TERM_MAXSTEPS; // hard bound reached: never a hang
     out->state[0] = y.t;
     out->state[1] = y.r;

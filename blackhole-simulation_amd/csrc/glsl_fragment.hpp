@@ -33,6 +33,25 @@ template <int ARITH> __device__ __forceinline__ F3 normalize_t(F3 a) {
     if constexpr (ARITH == GRV_ARITH_FAST) return scale_f3(a, __builtin_amdgcn_rsqf(dot_f3(a, a)));
     else return normalize_f3(a);
 }
+// divide / sqrt of the sampling branches: FAST = x * v_rcp_f32(y), v_sqrt_f32, v_rsq_f32 (1 ulp each, no
+// denormal rescue -- every operand here is a radius, a temperature or a density of moderate size); the
+// compiler's own FAST-mode `/` and sqrtf() wrap the same instructions in frexp / ldexp scaling, 6-7
+// instructions per quotient, and the disk block has twenty of them
+#ifndef GRV_GLSL_RAW_DIV
+#define GRV_GLSL_RAW_DIV 1
+#endif
+template <int ARITH> __device__ __forceinline__ float div_t(float a, float b) {
+    if constexpr (ARITH == GRV_ARITH_FAST && GRV_GLSL_RAW_DIV) return a * __builtin_amdgcn_rcpf(b);
+    else return a / b;
+}
+template <int ARITH> __device__ __forceinline__ float sqrt_t(float a) {
+    if constexpr (ARITH == GRV_ARITH_FAST && GRV_GLSL_RAW_DIV) return __builtin_amdgcn_sqrtf(a);
+    else return sqrtf(a);
+}
+template <int ARITH> __device__ __forceinline__ float rsqrt_t(float a) { // 1 / sqrt(a)
+    if constexpr (ARITH == GRV_ARITH_FAST && GRV_GLSL_RAW_DIV) return __builtin_amdgcn_rsqf(a);
+    else return 1.0f / sqrtf(a);
+}
 template <int ARITH> __device__ __forceinline__ float smoothstep_t(float e0, float e1, float x) {
     if constexpr (ARITH == GRV_ARITH_FAST) {
         // (1 / (e1 - e0) folds at compile time for the literal edges of the march; v_rcp_f32 otherwise)
@@ -193,7 +212,7 @@ __device__ __forceinline__ void glsl_rot(float ang, float &x, float &y) {
 // chunks/blackbody.ts:9-34
 template <int ARITH>
 __device__ __forceinline__ void glsl_blackbody(float temp, float rgb[3]) {
-    const float t = fmaxf(temp, 1.0f) / 100.0f;
+    const float t = (ARITH == GRV_ARITH_FAST && GRV_GLSL_RAW_DIV) ? fmaxf(temp, 1.0f) * 0.01f : fmaxf(temp, 1.0f) / 100.0f;
     float r, g, b;
     if (t <= 66.0f) {
         r = 255.0f;
@@ -204,9 +223,16 @@ __device__ __forceinline__ void glsl_blackbody(float temp, float rgb[3]) {
         g = 288.1221695283f * pow_d<ARITH>(t - 60.0f, -0.0755148492f);
         b = 255.0f;
     }
-    rgb[0] = pow_d<ARITH>(fmaxf(r / 255.0f, 0.0f), 2.2f);
-    rgb[1] = pow_d<ARITH>(fmaxf(g / 255.0f, 0.0f), 2.2f);
-    rgb[2] = pow_d<ARITH>(fmaxf(b / 255.0f, 0.0f), 2.2f);
+    constexpr float k255 = (ARITH == GRV_ARITH_FAST && GRV_GLSL_RAW_DIV) ? 1.0f / 255.0f : 0.0f;
+    if constexpr (ARITH == GRV_ARITH_FAST && GRV_GLSL_RAW_DIV) {
+        rgb[0] = pow_d<ARITH>(fmaxf(r * k255, 0.0f), 2.2f);
+        rgb[1] = pow_d<ARITH>(fmaxf(g * k255, 0.0f), 2.2f);
+        rgb[2] = pow_d<ARITH>(fmaxf(b * k255, 0.0f), 2.2f);
+    } else {
+        rgb[0] = pow_d<ARITH>(fmaxf(r / 255.0f, 0.0f), 2.2f);
+        rgb[1] = pow_d<ARITH>(fmaxf(g / 255.0f, 0.0f), 2.2f);
+        rgb[2] = pow_d<ARITH>(fmaxf(b / 255.0f, 0.0f), 2.2f);
+    }
 }
 
 // ---- chunks/noise.ts: the 256x256 R channels live in HBM/L2 (64 KiB each) ----
@@ -237,9 +263,12 @@ __device__ __forceinline__ float glsl_hash_uv(const uint8_t *__restrict__ T, flo
 __device__ __forceinline__ float glsl_hash(const uint8_t *__restrict__ T, F3 p) { // noise.ts:3-9
     return glsl_hash_uv(T, p.x + p.z * 37.0f, p.y + p.z * 37.0f);
 }
+#ifndef GRV_GLSL_NOISE_INLINE
+#define GRV_GLSL_NOISE_INLINE
+#endif
 __device__ __forceinline__ float mix_d(float a, float b, float t) { return a * (1.0f - t) + b * t; }
 __device__ __forceinline__ float fract_d(float x) { return x - floorf(x); }
-__device__ float glsl_noise(const uint8_t *__restrict__ T, F3 p) { // noise.ts:11-21
+__device__ GRV_GLSL_NOISE_INLINE float glsl_noise(const uint8_t *__restrict__ T, F3 p) { // noise.ts:11-21
     const F3 i{floorf(p.x), floorf(p.y), floorf(p.z)};
     F3 f{fract_d(p.x), fract_d(p.y), fract_d(p.z)};
     f.x = f.x * f.x * (3.0f - 2.0f * f.x);
@@ -249,10 +278,46 @@ __device__ float glsl_noise(const uint8_t *__restrict__ T, F3 p) { // noise.ts:1
     return mix_d(mix_d(mix_d(H(0, 0, 0), H(1, 0, 0), f.x), mix_d(H(0, 1, 0), H(1, 1, 0), f.x), f.y),
                  mix_d(mix_d(H(0, 0, 1), H(1, 0, 1), f.x), mix_d(H(0, 1, 1), H(1, 1, 1), f.x), f.y), f.z);
 }
-__device__ __forceinline__ float glsl_fbm(const uint8_t *__restrict__ T, F3 p) { // noise.ts:23-33
+// FAST contract: noise() on the integer lattice.  Every corner noise() hashes is an integer point, so
+// hash()'s texture coordinate (p.xy + p.z * 37 + 0.5) / 256 is a texel centre: LINEAR filtering
+// returns that one texel (weights 1, 0, 0, 0 -- glsl_hash_uv's a == b == 0 case), and with REPEAT
+// wrapping the texel index is ((x + 37 z) mod 256, (y + 37 z) mod 256) of the corner.  That is
+// integer arithmetic on the cell's base corner reduced mod 256 (i - 256 floor(i / 256): exact for every
+// float): one add / mask per corner instead of the float round trip through uv space (~30
+// instructions per corner), and the texel comes from an f32 copy of the plane (byte / 255.0f, the IEEE
+// quotient, formed once on the host) instead of load + convert + divide.  For |coordinates| < 2^17
+// every f32 operation of the shader's hash() is exact too, so the value equals the shader-order
+// noise() bit for bit; beyond that the shader's own sums round (p.z * 37 leaves the 24-bit mantissa)
+// and this form keeps the exact index.
+#ifndef GRV_GLSL_LATTICE_NOISE
+#define GRV_GLSL_LATTICE_NOISE 1
+#endif
+__device__ __forceinline__ float glsl_noise_lattice(const GlslParams &U, F3 p) {
+    const F3 i{floorf(p.x), floorf(p.y), floorf(p.z)};
+    F3 f{p.x - i.x, p.y - i.y, p.z - i.z};
+    f.x = f.x * f.x * (3.0f - 2.0f * f.x);
+    f.y = f.y * f.y * (3.0f - 2.0f * f.y);
+    f.z = f.z * f.z * (3.0f - 2.0f * f.z);
+    const int rx = (int)fmaf(-256.0f, floorf(i.x * 0.00390625f), i.x);
+    const int ry = (int)fmaf(-256.0f, floorf(i.y * 0.00390625f), i.y);
+    const int rz = (int)fmaf(-256.0f, floorf(i.z * 0.00390625f), i.z);
+    const int ux = rx + 37 * rz, uy = ry + 37 * rz;
+    const float *__restrict__ Tf = U.noise_f;
+    auto H = [&](int dx, int dy, int dz) {
+        return Tf[(((uint32_t)(uy + dy + 37 * dz) & 255u) << 8) | ((uint32_t)(ux + dx + 37 * dz) & 255u)];
+    };
+    return mix_d(mix_d(mix_d(H(0, 0, 0), H(1, 0, 0), f.x), mix_d(H(0, 1, 0), H(1, 1, 0), f.x), f.y),
+                 mix_d(mix_d(H(0, 0, 1), H(1, 0, 1), f.x), mix_d(H(0, 1, 1), H(1, 1, 1), f.x), f.y), f.z);
+}
+template <int ARITH> __device__ __forceinline__ float glsl_noise_t(const GlslParams &U, F3 p) {
+    if constexpr (ARITH == GRV_ARITH_FAST && GRV_GLSL_LATTICE_NOISE) return glsl_noise_lattice(U, p);
+    else return glsl_noise(U.noise_r, p);
+}
+template <int ARITH>
+__device__ __forceinline__ float glsl_fbm(const GlslParams &U, F3 p) { // noise.ts:23-33
     float f = 0.0f, amp = 0.5f;
     for (int i = 0; i < 4; ++i) {
-        f += amp * glsl_noise(T, p);
+        f += amp * glsl_noise_t<ARITH>(U, p);
         p = scale_f3(p, 2.0f);
         amp *= 0.5f;
     }
@@ -301,7 +366,7 @@ __device__ void glsl_starfield(const GlslParams &U, F3 dir, float stars[3]) {
         for (int c = 0; c < 3; ++c) stars[c] += sc[c] * brightness;
     }
     const float tt = U.time * 0.01f;
-    const float nebula = glsl_fbm(T, F3{dir.x * 2.0f + tt, dir.y * 2.0f + tt, dir.z * 2.0f + tt}) * 0.03f;
+    const float nebula = glsl_fbm<ARITH>(U, F3{dir.x * 2.0f + tt, dir.y * 2.0f + tt, dir.z * 2.0f + tt}) * 0.03f;
     const float ln = fabsf(nebula);
     stars[0] += nebula * 0.2f + 0.05f * ln;
     stars[1] += nebula * 0.3f + 0.02f * ln;
@@ -320,7 +385,7 @@ __device__ __forceinline__ void glsl_sample_disk(const GlslParams &U, F3 p, F3 p
     F3 sp = p;
     float sampleR = r_p;
     if (crossed) {
-        const float t = fabsf(p_prev.y) / fmaxf(0.0001f, fabsf(p_prev.y) + fabsf(p.y));
+        const float t = div_t<ARITH>(fabsf(p_prev.y), fmaxf(0.0001f, fabsf(p_prev.y) + fabsf(p.y)));
         sp.x = p_prev.x * (1.0f - t) + p.x * t;
         sp.y = p_prev.y * (1.0f - t) + p.y * t;
         sp.z = p_prev.z * (1.0f - t) + p.z * t;
@@ -334,9 +399,9 @@ __device__ __forceinline__ void glsl_sample_disk(const GlslParams &U, F3 p, F3 p
     if (!((fabsf(sp.y) < diskHeight || crossed) && sampleR > diskInner && sampleR < diskOuter)) return;
     float turbulence = U.turbulence;
     if (turbulence < 0.0f) { // disk.ts:43-55: Keplerian phase rotation of the noise field
-        const float sqrt_Mp = sqrtf(M);
+        const float sqrt_Mp = sqrt_t<ARITH>(M);
         const float signSpinPhase = sign_d(U.spin + 1e-8f);
-        const float OmegaPhase = (signSpinPhase * sqrt_Mp) / (sampleR * sqrtf(sampleR) + a * sqrt_Mp);
+        const float OmegaPhase = div_t<ARITH>(signSpinPhase * sqrt_Mp, sampleR * sqrt_t<ARITH>(sampleR) + a * sqrt_Mp);
         const float rotAngle = OmegaPhase * U.time * 0.12f * 10.0f;
         float cs, sn;
         if constexpr (ARITH == GRV_ARITH_FAST) {
@@ -347,27 +412,42 @@ __device__ __forceinline__ void glsl_sample_disk(const GlslParams &U, F3 p, F3 p
         }
         F3 np{sp.x * cs + sp.z * (-sn), sp.y, sp.x * sn + sp.z * cs};
         np = scale_f3(np, 0.75f);
-        turbulence = glsl_noise(U.noise_r, np) * 0.5f + glsl_noise(U.noise_r, scale_f3(np, 2.5f)) * 0.25f;
+        turbulence = glsl_noise_t<ARITH>(U, np) * 0.5f + glsl_noise_t<ARITH>(U, scale_f3(np, 2.5f)) * 0.25f;
     }
-    const float heightFalloff = exp_d<ARITH>(-fabsf(sp.y) / fmaxf(0.001f, (sampleR * effH) * 0.25f));
-    const float radialFalloff = smoothstep_d(diskOuter, diskInner, sampleR);
+    const float heightFalloff = exp_d<ARITH>(div_t<ARITH>(-fabsf(sp.y), fmaxf(0.001f, (sampleR * effH) * 0.25f)));
+    float radialFalloff;
+    if constexpr (ARITH == GRV_ARITH_FAST && GRV_GLSL_RAW_DIV) {
+        const float ts = clampf_d((sampleR - diskOuter) * __builtin_amdgcn_rcpf(diskInner - diskOuter), 0.0f, 1.0f);
+        radialFalloff = ts * ts * (3.0f - 2.0f * ts);
+    } else {
+        radialFalloff = smoothstep_d(diskOuter, diskInner, sampleR);
+    }
     const float baseDensity = turbulence * heightFalloff * radialFalloff;
     if (!(baseDensity > 0.001f)) return;
 
     const float r2 = sampleR * sampleR;
-    const float sqrt_M = sqrtf(M);
+    const float sqrt_M = sqrt_t<ARITH>(M);
     const float signSpin = sign_d(U.spin + 1e-8f);
-    const float Omega = (signSpin * sqrt_M) / (sampleR * sqrtf(sampleR) + a * sqrt_M);
-    const float g_tt = -(1.0f - 2.0f * M / sampleR);
-    const float g_tphi = -2.0f * M * a / sampleR;
-    const float g_phiphi = r2 + a * a + 2.0f * M * a * a / sampleR;
+    const float Omega = div_t<ARITH>(signSpin * sqrt_M, sampleR * sqrt_t<ARITH>(sampleR) + a * sqrt_M);
+    float g_tt, g_tphi, g_phiphi, isco_r;
+    if constexpr (ARITH == GRV_ARITH_FAST && GRV_GLSL_RAW_DIV) { // the four quotients by sampleR share one v_rcp_f32
+        const float inv_r = __builtin_amdgcn_rcpf(sampleR);
+        g_tt = -(1.0f - 2.0f * M * inv_r);
+        g_tphi = -2.0f * M * a * inv_r;
+        g_phiphi = r2 + a * a + 2.0f * M * a * a * inv_r;
+        isco_r = clampf_d(isco * inv_r, 0.0f, 1.0f);
+    } else {
+        g_tt = -(1.0f - 2.0f * M / sampleR);
+        g_tphi = -2.0f * M * a / sampleR;
+        g_phiphi = r2 + a * a + 2.0f * M * a * a / sampleR;
+        isco_r = clampf_d(isco / sampleR, 0.0f, 1.0f);
+    }
     const float u_t_sq = -(g_tt + 2.0f * Omega * g_tphi + Omega * Omega * g_phiphi);
-    const float u_t = 1.0f / sqrtf(fmaxf(1e-6f, u_t_sq));
+    const float u_t = rsqrt_t<ARITH>(fmaxf(1e-6f, u_t_sq));
     const float L_photon = p.z * v.x - p.x * v.z;
-    const float delta = 1.0f / fmaxf(0.01f, u_t * (1.0f - Omega * L_photon));
+    const float delta = div_t<ARITH>(1.0f, fmaxf(0.01f, u_t * (1.0f - Omega * L_photon)));
     const float beaming = (U.features & GRV_GLSL_DOPPLER) ? fmaxf(0.01f, pow_d<ARITH>(delta, 3.5f)) : 1.0f;
-    const float isco_r = clampf_d(isco / sampleR, 0.0f, 1.0f);
-    const float nt_factor = fmaxf(0.0f, 1.0f - sqrtf(isco_r));
+    const float nt_factor = fmaxf(0.0f, 1.0f - sqrt_t<ARITH>(isco_r));
     const float grad = pow_d<ARITH>(isco_r, 0.75f) * pow_d<ARITH>(nt_factor, 0.25f);
     const float temperature = U.disk_temp * grad * delta;
     float bb[3];
@@ -384,23 +464,23 @@ __device__ __forceinline__ void glsl_sample_jets(const GlslParams &U, F3 p, F3 v
                                                  float col[3], float &alpha) {
     const float jetVerticalPos = fabsf(p.y);
     if (!(jetVerticalPos > rh * 1.8f && jetVerticalPos < 10000.0f * 0.8f)) return;
-    const float jetRadialDist = sqrtf(p.x * p.x + p.z * p.z);
+    const float jetRadialDist = sqrt_t<ARITH>(p.x * p.x + p.z * p.z);
     const float jetWidth = 1.0f + jetVerticalPos * 0.15f;
     if (!(jetRadialDist < jetWidth * 2.0f)) return;
-    const float radialFalloff = exp_d<ARITH>(-(jetRadialDist * jetRadialDist) / (jetWidth * 0.5f));
+    const float radialFalloff = exp_d<ARITH>(div_t<ARITH>(-(jetRadialDist * jetRadialDist), jetWidth * 0.5f));
     const float lengthFalloff = exp_d<ARITH>(-jetVerticalPos * 0.05f);
     const float flow = p.y * 2.0f - U.time * 8.0f;
     const F3 uvJet{p.x, flow, p.z};
-    const float noiseVal = glsl_noise(U.noise_r, scale_f3(uvJet, 0.5f)) * 0.6f +
-                           glsl_noise(U.noise_r, scale_f3(uvJet, 1.5f)) * 0.4f;
+    const float noiseVal = glsl_noise_t<ARITH>(U, scale_f3(uvJet, 0.5f)) * 0.6f +
+                           glsl_noise_t<ARITH>(U, scale_f3(uvJet, 1.5f)) * 0.4f;
     const float jetDensity = radialFalloff * lengthFalloff * fmaxf(0.0f, noiseVal - 0.2f);
     if (!(jetDensity > 0.001f)) return;
     const float jetVel = 0.92f * sign_d(p.y);
     const F3 nv = normalize_f3(F3{0.0f, jetVel, 0.0f});
     const float cosThetaJet = dot_f3(nv, F3{-v.x, -v.y, -v.z});
     const float betaJet = fabsf(jetVel);
-    const float gammaJet = 1.0f / sqrtf(1.0f - betaJet * betaJet);
-    const float deltaJet = 1.0f / (gammaJet * (1.0f - betaJet * cosThetaJet));
+    const float gammaJet = rsqrt_t<ARITH>(1.0f - betaJet * betaJet);
+    const float deltaJet = div_t<ARITH>(1.0f, gammaJet * (1.0f - betaJet * cosThetaJet));
     const float beamingJet = pow_d<ARITH>(deltaJet, 3.5f);
     const float base[3] = {0.4f, 0.7f, 1.0f};
 #pragma unroll

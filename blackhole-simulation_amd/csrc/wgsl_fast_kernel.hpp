@@ -18,6 +18,17 @@
 
 #include "geodesic_kernels.hpp"
 
+// the horizon exit of the FAST f32 marches: !(r >= r_stop), so that a non-finite state leaves as well
+// (wgsl_pk_body.inc); GRV_F32_NAN_EXIT=0 compiles the shader's literal r < r_stop for A/B runs
+#ifndef GRV_F32_NAN_EXIT
+#define GRV_F32_NAN_EXIT 1
+#endif
+#if GRV_F32_NAN_EXIT
+#define GRV_F32_BELOW(r, lim) (!((r) >= (lim)))
+#else
+#define GRV_F32_BELOW(r, lim) ((r) < (lim))
+#endif
+
 namespace {
 
 struct Wf32Hole {
@@ -156,7 +167,7 @@ __global__ __launch_bounds__(kMarchBlock) __attribute__((amdgpu_waves_per_eu(6, 
         float col[3] = {0.0f, 0.0f, 0.0f};
         float alpha = 0.0f;
         for (int i = 0; i < P.max_steps; ++i) {
-            if (r < r_stop) break;
+            if (GRV_F32_BELOW(r, r_stop)) break; // NaN leaves here too: see wgsl_pk_body.inc
             if (r > 100.0f) { // star hash of the escape branch, compute.wgsl.ts:199-206
                 if (P.stars) {
                     const float sx = p_r, sy = p_th / r, sz = p_ph / (r * fmaxf(st, 1e-4f));

@@ -300,6 +300,8 @@ def load_library():
     L.grv_rccl_probe.argtypes = [C.POINTER(C.c_int), C.c_char_p, sz]
     L.grv_multi_rank_frame_stats.restype = i
     L.grv_multi_rank_frame_stats.argtypes = [p, i, C.POINTER(FrameStats)]
+    L.grv_last_ray_clocks.restype = i
+    L.grv_last_ray_clocks.argtypes = [p, C.POINTER(C.c_uint64 * 3)]
     L.grv_test_set_try_bound.restype = i
     L.grv_test_set_try_bound.argtypes = [p, C.c_uint32]
     L.grv_multi_test_self_exchange.restype = i

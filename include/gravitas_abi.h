@@ -182,6 +182,11 @@ size_t grv_integrate_ray_relativistic_ex(grv_engine *e, const double *initial_st
                                          double *out, uint32_t *steps_taken, uint8_t *termination,
                                          double *max_drift);
 
+/* the device's own clocks around the try loop of the LAST grv_integrate_ray_relativistic* call:
+ * out3 = {shader cycles (s_memtime), ticks of the constant 100 MHz counter (s_memrealtime), integrator
+ * tries}.  What one step of the serial chain costs without the launch and the PCIe round trip. */
+int grv_last_ray_clocks(const grv_engine *e, uint64_t out3[3]);
+
 /* ---- batch extension: n independent integrate() calls (geodesic/mod.rs:180-253).
  * Host pointers; states AoS [n][8].  steps/termination/drift may be NULL. */
 int grv_integrate_batch(grv_engine *e, size_t n, const double *states, const GrvOptions *opt,

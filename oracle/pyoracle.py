@@ -536,17 +536,19 @@ def wgsl_frame(params, stride=(1, 1), nthreads=1):
 
 def wgsl_pixels_f64(params, xy, nthreads=1):
     """The compute march in double (wgsl_f64_twin.c) at the pixels xy[n, 2] -> dict of rgb[n, 3],
-    steps[n], cls[n] (0 horizon, 1 escape, 2 budget, 3 opaque), min_r[n]."""
+    steps[n], cls[n] (0 horizon, 1 escape, 2 budget, 3 opaque), min_r[n], axis_margin[n] (min over the
+    visited states of min(theta, pi - theta): closest approach to the polar axis, negative = crossed)."""
     xy = np.ascontiguousarray(xy, np.uint32).reshape(-1, 2)
     n = xy.shape[0]
     rgb, steps = np.zeros((n, 3)), np.zeros(n, np.uint32)
-    cls, min_r = np.zeros(n, np.int32), np.zeros(n)
+    cls, min_r, min_sin = np.zeros(n, np.int32), np.zeros(n), np.zeros(n)
     L = lib()
     L.orc_wgsl_pixels_f64.argtypes = [C.POINTER(WgslParams), C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
-                                      C.c_void_p, C.c_void_p, C.c_int]
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.orc_wgsl_pixels_f64.restype = None
-    L.orc_wgsl_pixels_f64(C.byref(params), n, _ptr(xy), _ptr(rgb), _ptr(steps), _ptr(cls), _ptr(min_r), nthreads)
-    return {"rgb": rgb, "steps": steps, "cls": cls, "min_r": min_r}
+    L.orc_wgsl_pixels_f64(C.byref(params), n, _ptr(xy), _ptr(rgb), _ptr(steps), _ptr(cls), _ptr(min_r), _ptr(min_sin),
+                          nthreads)
+    return {"rgb": rgb, "steps": steps, "cls": cls, "min_r": min_r, "axis_margin": min_sin}
 
 
 def glsl_frame(params, stride=(1, 1), nthreads=1):

@@ -46,7 +46,7 @@ void orc_wgsl_frame(const orc_wgsl_params *p, uint32_t stride_x, uint32_t stride
 uint32_t orc_wgsl_pixel_f64(const orc_wgsl_params *p, uint32_t ix, uint32_t iy, double rgb[3],
                             int32_t *exit_class, double *min_r);
 void orc_wgsl_pixels_f64(const orc_wgsl_params *p, size_t n, const uint32_t *xy, double *rgb, uint32_t *steps,
-                         int32_t *cls, double *min_r, int nthreads);
+                         int32_t *cls, double *min_r, double *axis_margin, int nthreads);
 
 /* ShaderManager #defines (src/shaders/manager.ts:61-82) as bits */
 #define ORC_GLSL_LENSING 1u

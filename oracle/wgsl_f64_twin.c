@@ -99,8 +99,16 @@ static void norm3d(double v[3]) {
 
 /* compute.wgsl.ts:147-258 (stars are not drawn: the comparisons this serves run with stars off).
  * out: rgb[3]; exit_class; min_r: the smallest r the ray reached; returns the steps taken. */
+static uint32_t pixel_f64(const orc_wgsl_params *P, uint32_t ix, uint32_t iy, double rgb[3],
+                          int32_t *exit_class, double *min_r, double *axis_margin);
 uint32_t orc_wgsl_pixel_f64(const orc_wgsl_params *P, uint32_t ix, uint32_t iy, double rgb[3],
                             int32_t *exit_class, double *min_r) {
+    return pixel_f64(P, ix, iy, rgb, exit_class, min_r, NULL);
+}
+/* axis_margin: min over the visited states of min(theta, pi - theta): how close the ray came to the
+ * polar axis, where the shader's spherical coordinates break down; negative = it stepped across */
+static uint32_t pixel_f64(const orc_wgsl_params *P, uint32_t ix, uint32_t iy, double rgb[3],
+                          int32_t *exit_class, double *min_r, double *axis_margin) {
     const double PI = (double)3.14159265f; /* the shader's literal, as f32 holds it */
     double fw = (double)P->width, fh = (double)P->height;
     double jx = (double)P->jitter[0] / fw, jy = (double)P->jitter[1] / fh;
@@ -139,10 +147,11 @@ uint32_t orc_wgsl_pixel_f64(const orc_wgsl_params *P, uint32_t ix, uint32_t iy, 
     double color[3] = {0.0, 0.0, 0.0}, alpha = 0.0;
     uint32_t steps = 0;
     int32_t cls = 2;
-    double rmin = r0;
+    double rmin = r0, smin = 4.0;
     for (int i = 0; i < P->max_steps; i++) {
         double r = s.x[1];
         if (r < rmin) rmin = r;
+        { double mg = fmin(s.x[2], 3.14159265358979323846 - s.x[2]); if (mg < smin) smin = mg; }
         if (r < rh * (double)1.001f) { cls = 0; break; }
         if (r > 100.0) { cls = 1; break; }
         double prev_theta = s.x[2];
@@ -175,14 +184,16 @@ uint32_t orc_wgsl_pixel_f64(const orc_wgsl_params *P, uint32_t ix, uint32_t iy, 
     memcpy(rgb, color, sizeof color);
     if (exit_class) *exit_class = cls;
     if (min_r) *min_r = rmin;
+    if (axis_margin) *axis_margin = smin;
     return steps;
 }
 
-/* n pixels (xy[2 k], xy[2 k + 1]) -> rgb[3 k ..], steps[k], cls[k], min_r[k] */
+/* n pixels (xy[2 k], xy[2 k + 1]) -> rgb[3 k ..], steps[k], cls[k], min_r[k], axis_margin[k] (may be NULL) */
 void orc_wgsl_pixels_f64(const orc_wgsl_params *p, size_t n, const uint32_t *xy, double *rgb, uint32_t *steps,
-                         int32_t *cls, double *min_r, int nthreads) {
+                         int32_t *cls, double *min_r, double *axis_margin, int nthreads) {
     if (nthreads < 1) nthreads = 1;
 #pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads) if (nthreads > 1)
     for (long long k = 0; k < (long long)n; k++)
-        steps[k] = orc_wgsl_pixel_f64(p, xy[2 * k], xy[2 * k + 1], rgb + 3 * k, cls + k, min_r + k);
+        steps[k] = pixel_f64(p, xy[2 * k], xy[2 * k + 1], rgb + 3 * k, cls + k, min_r + k,
+                             axis_margin ? axis_margin + k : NULL);
 }

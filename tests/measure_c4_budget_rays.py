@@ -59,6 +59,9 @@ def main():
     A = {"pixels": int(xy.shape[0]), "f64_at_budget": int(f64_budget.sum()),
          "f64_exit_classes": {k: int((d["cls"] == v).sum()) for k, v in (("horizon", 0), ("escape", 1), ("budget", 2), ("opaque", 3))},
          "f64_min_r_percentiles": dict(zip(("1", "50", "99"), [float(v) for v in np.percentile(d["min_r"], [1, 50, 99])])),
+         # how close these rays come to the polar axis: min(theta, pi - theta) along the double march
+         "f64_rays_that_step_across_the_polar_axis": int((d["axis_margin"] < 0.0).sum()),
+         "f64_ended_rays_that_step_across_the_polar_axis": int(((d["axis_margin"] < 0.0) & ~f64_budget).sum()),
          "forms": {}}
     for n, _ in FORMS:
         st = frames[n][1][ys, xs].astype(np.int64)
@@ -91,6 +94,10 @@ def main():
         lit_f = frames[n][0][ys2, xs2].sum(-1) > 0
         lit_s = frames["shader_order"][0][ys2, xs2].sum(-1) > 0
         B[n] = {"pixels": int(xy2.shape[0]), "max_colour_difference_over_peak": float(dc.max()),
+                "rays_that_step_across_the_polar_axis": int((d2["axis_margin"] < 0.0).sum()),
+                "rays_within_0.05_rad_of_the_polar_axis": int((d2["axis_margin"] < 0.05).sum()),
+                "rays_at_budget_in_f64": int((d2["cls"] == 2).sum()),
+                "axis_margin_rad_percentiles": dict(zip(("10", "50", "90"), [float(v) for v in np.percentile(d2["axis_margin"], [10, 50, 90])])),
                 "form_closer_to_f64": int((e_form < e_so).sum()), "shader_order_closer_to_f64": int((e_so < e_form).sum()),
                 "tie": int((e_so == e_form).sum()),
                 "lit_dark_agrees_with_f64": {"form": int((lit_f == lit64).sum()), "shader_order": int((lit_s == lit64).sum())},

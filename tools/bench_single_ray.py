@@ -3,6 +3,7 @@ call: a serial chain on one GPU lane.  Reports the per-call wall time for the do
 (~220 accepted steps), for 0-step and 1-step calls (fixed overhead of the fused launch: one kernel
 launch + the PCIe write of the result the host polls) and the per-ray time of the same rays in
 batches.  Run on the GPU box: python tools/bench_single_ray.py"""
+import ctypes as C
 import json
 import os
 import sys
@@ -25,6 +26,13 @@ if __name__ == "__main__":
                 e.integrate_ray_relativistic(v, steps, 1e-8, True)
             dt = (time.perf_counter() - t) / n
             res[steps] = dt
+            clk = (C.c_uint64 * 3)()
+            e._lib.grv_last_ray_clocks(e._h, C.byref(clk))
+            if clk[2]:
+                print(json.dumps({"call": "integrate_ray_relativistic", "case": label + ": the try loop on the device clocks",
+                                  "tries": int(clk[2]), "shader_cycles": int(clk[0]), "us_100MHz_counter": clk[1] / 100.0,
+                                  "shader_MHz": round(clk[0] / max(clk[1] / 100.0, 1e-9), 1),
+                                  "cycles_per_try": round(clk[0] / clk[2], 1)}), flush=True)
             print(json.dumps({"call": "integrate_ray_relativistic", "case": label, "us_per_call": round(dt * 1e6, 1)}), flush=True)
         print(json.dumps({"call": "integrate_ray_relativistic", "case": "per accepted step (224 steps, overhead removed)",
                           "us_per_step": round((res[10000] - res[0]) / 224 * 1e6, 3)}), flush=True)
