@@ -430,7 +430,7 @@ def main():
                     help="N > 1: wait for each frame's gather before integrating the next frame")
     ap.add_argument("--two-streams", action="store_true",
                     help="N = 1: even / odd frames on two streams as for N > 1 (the roofline block then comes from "
-                         "profiled frames after the timed loop)")
+                         "profiled frames after the timed loop); the default of --config c2")
     ap.add_argument("--one-stream", action="store_true",
                     help="queue every frame on one stream (default: even / odd frames on two streams, "
                          "so one frame's tail runs under the next frame's head)")
@@ -497,12 +497,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:  # never an N = 1 line for a --gpus 8 command (or the reverse)
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     one_device = os.environ.get("GRV_BENCH_ONE_DEVICE") == "1"
-    n_dev = torch.cuda.device_count()
-    if not one_device and n_dev < world:
-        raise SystemExit("--gpus %d but only %d HIP device(s) visible" % (world, n_dev))
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n_dev < (1 if one_device else world):
+        sys.stderr.write("bench.py: --gpus %d but only %d HIP device(s) visible (the engine has no CPU path)\n"
+                         % (world, n_dev))
+        raise SystemExit(2)
     if not os.path.exists(bh.library_path()):
         if local_rank == 0:
             bh.build_library()  # checkout without the built artefact: compile it (hipcc)
@@ -566,7 +566,9 @@ def main():
     # launch -- too few waves left to fill 256 CUs -- runs under the head of the next frame
     # (N > 1 only: at N = 1 the tail is 1 % of a frame, and one stream keeps the in-loop HIP events
     # bracketing one kernel at a time, which is what the roofline block is defined on)
-    two = (world > 1 or args.two_streams) and not args.one_stream and not args.no_overlap
+    # (c2: a 1080p march is 1-4 ms, a 16 000-32 000-wave grid whose ramp and tail are 6-19 % of the launch:
+    # two frames in flight by default there too, as a renderer's frame loop keeps them)
+    two = (world > 1 or args.two_streams or cfg == "c2") and not args.one_stream and not args.no_overlap
     streams = [torch.cuda.Stream(), torch.cuda.Stream()] if two else [torch.cuda.current_stream()] * 2
     stream = streams[0].cuda_stream
     # all buffers live outside the frame loop: the padded send buffer doubles as the render

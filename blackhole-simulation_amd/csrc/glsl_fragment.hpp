@@ -604,6 +604,75 @@ __device__ uint32_t glsl_fragment(const GlslParams &U, uint32_t width, uint32_t 
         }
     }
 
+    // FAST: the same march with ONE loop exit.  The shader's loop leaves from three places (horizon and
+    // far tests at the top, the opaque disk in the middle); compiled as written, every exit keeps its own
+    // copies of the loop-carried state alive and the loop head spends ~25 moves and ~30 exec-mask
+    // operations per iteration on merging them.  Here the three conditions are evaluated where the shader
+    // evaluates them and tested together at the top of the next iteration; nothing else runs in between
+    // (the jets of an iteration whose disk sample went opaque are skipped, as the shader's break skips them).
+#ifndef GRV_GLSL_SINGLE_EXIT
+#define GRV_GLSL_SINGLE_EXIT 1
+#endif
+    if constexpr (ARITH == GRV_ARITH_FAST && GRV_GLSL_CARRY_GEOM && GRV_GLSL_SINGLE_EXIT) {
+        int i = 0;
+        bool opaque = false, hz = false;
+        for (;;) {
+            const float r = r_cur;
+            hz = r < rh * 1.15f;
+            if (!(i < maxSteps) || opaque || hz || r > 10000.0f) break;
+            p_prev = p;
+            const float distFactor = 1.0f + r * 0.05f;
+            float dt = clampf_d((r - rh) * 0.1f * distFactor, 0.01f, 1.2f * distFactor);
+            if (r > 30.0f) {
+                const float farBoost = (r - 30.0f) * 0.08f;
+                dt = fmaxf(dt, 0.01f + farBoost);
+                dt = fminf(dt, 1.2f * 2.5f);
+            }
+            const float sphereProx = fabsf(r - rph);
+            dt = fminf(dt, 0.01f + sphereProx * 0.15f);
+            const float hRefinement = smoothstep_t<ARITH>(0.2f, 0.0f, fabsf(p.y));
+            const float cdt = dt * (1.0f - hRefinement * 0.7f);
+            F3 accel{0.0f, 0.0f, 0.0f};
+            if (lensing) {
+                accel = glsl_accel_from_geom(geom, p, v, a);
+                glsl_rot<ARITH>(geom.drag * cdt, v.x, v.z);
+            }
+            const float k2 = 0.5f * cdt * cdt * U.lensing_strength;
+            p = F3{fmaf(accel.x, k2, fmaf(v.x, cdt, p.x)), fmaf(accel.y, k2, fmaf(v.y, cdt, p.y)),
+                   fmaf(accel.z, k2, fmaf(v.z, cdt, p.z))};
+            float r_new;
+            if (lensing) {
+                geom = glsl_geom_fast(p, M, a);
+                r_new = __builtin_amdgcn_sqrtf(geom.rho2);
+            } else {
+                r_new = length_t<ARITH>(p);
+            }
+            r_cur = r_new;
+            if (lensing && alpha < 0.95f) {
+                const F3 accel_new = glsl_accel_from_geom(geom, p, v, a);
+                const float kv = 0.5f * cdt * U.lensing_strength;
+                v = F3{fmaf(accel.x + accel_new.x, kv, v.x), fmaf(accel.y + accel_new.y, kv, v.y),
+                       fmaf(accel.z + accel_new.z, kv, v.z)};
+            }
+            v = normalize_t<ARITH>(v);
+            ++i;
+            if (p_prev.y * p.y < 0.0f && r_new < rph * 2.0f && r_new > rh)
+                photonCrossings = photonCrossings + 1 < 3 ? photonCrossings + 1 : 3;
+            if (U.show_redshift > 0.5f) {
+                const float potential = sqrtf(fmaxf(0.0f, 1.0f - rs / r_new));
+                maxRedshift = redshiftInit ? fminf(maxRedshift, potential) : potential;
+                redshiftInit = true;
+            }
+            if (disk) {
+                glsl_sample_disk<ARITH>(U, p, p_prev, v, isco, M, a, cdt, col, alpha, r_new);
+                opaque = alpha > 0.99f;
+            }
+            if (jets && !opaque) glsl_sample_jets<ARITH>(U, p, v, rh, dt, col, alpha); // un-refined dt (fragment.glsl.ts:219)
+        }
+        steps = (uint32_t)i;
+        hitHorizon = hitHorizon || (hz && !opaque && i < maxSteps);
+        (void)prevY;
+    } else
     for (int i = 0; i < maxSteps; ++i) {
         p_prev = p;
         float r;

@@ -258,3 +258,24 @@ def test_bench_gpus_n_is_never_silently_one_gpu():
     assert r.returncode != 0
     assert "HIP device(s) visible" in r.stderr
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_refuses_what_it_cannot_run_before_touching_a_device():
+    """`python bench.py --gpus N` on a host with fewer devices exits 2 with the device count on stderr
+    and no JSON line (never a line for fewer GPUs than asked); --config c2 is a one-GPU configuration."""
+    import subprocess
+    import sys
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "GRV_BENCH_ONE_DEVICE")}
+    bench = os.path.join(ROOT, "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", str(have + 1)], capture_output=True, text=True, timeout=300,
+                       env=env, cwd=ROOT)
+    assert r.returncode == 2 and "only %d HIP device" % have in r.stderr, (r.returncode, r.stderr[-500:])
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    r = subprocess.run([sys.executable, bench, "--config", "c2", "--gpus", "2"], capture_output=True, text=True,
+                       timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0 and "one GPU" in r.stderr
+    r = subprocess.run([sys.executable, bench, "--config", "c3", "--arith", "packed"], capture_output=True, text=True,
+                       timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0 and "packed" in r.stderr

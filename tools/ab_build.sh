@@ -15,12 +15,12 @@ FAST_O=$C/build/kernels_fast.o
 STRICT_O=$C/build/kernels_strict.o
 if [ "${TU:-fast}" = strict ]; then
   STRICT_O=$C/build/kernels_strict_$NAME.o
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=off \
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=off -fno-slp-vectorize \
     $EXTRA -c $C/kernels_strict.hip -o $STRICT_O
 else
   FAST_O=$C/build/kernels_fast_$NAME.o
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=fast \
-    -fno-hip-fp32-correctly-rounded-divide-sqrt $EXTRA -c $C/kernels_fast.hip -o $FAST_O
+    -fno-hip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize $EXTRA -c $C/kernels_fast.hip -o $FAST_O
 fi
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/ab_libs/lib_$NAME.so $STRICT_O \
   $FAST_O $C/build/control_plane.o $C/build/spacetime_viz.o $C/build/engine.o \
