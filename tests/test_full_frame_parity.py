@@ -91,7 +91,8 @@ def test_every_ray_of_the_bench_frame(engine_mod, oracle):
                     # geodesic (|h| <= 10 out at r ~ 1000: up to 1e-2 relative in t and r).  Bounded: <= 5e-2;
                     # explained: with the displacement along the ray taken out -- d lambda from the t
                     # components, tangent = the oracle's get_state_derivative at its end state -- what is
-                    # left is back under the 1e-5 every other ray meets.
+                    # left is the difference of two RKF45 step sequences along one geodesic (each within its
+                    # tol = 1e-8 per step): 9.3e-6 and 2.0e-8 measured for the two rays, held to 5e-5.
                     assert float(err[big].max(initial=0.0)) <= 5e-2
                     m_ks = po.metric(po.KERR_KS, 1.0, 0.999)
                     for k, i in enumerate(big):
@@ -102,7 +103,7 @@ def test_every_ray_of_the_bench_frame(engine_mod, oracle):
                         resid = np.abs(a[i] - (b[i] + dlam * tangent)) / np.maximum(1.0, np.abs(b[i]))
                         if k < 64:
                             out[name]["rays_above_1e-5"][k].update(d_lambda=float(dlam), rel_err_off_the_ray=float(resid.max()))
-                        assert abs(dlam) <= 10.0 and resid.max() <= 1e-5, (int(i), float(dlam), resid)
+                        assert abs(dlam) <= 10.0 * (1.0 + 1e-6) and resid.max() <= 5e-5, (int(i), float(dlam), resid)
                 # (FAST's median sits at 1.9e-10 at tol 1e-8 and 1.3e-9 at tol 1e-9 -- a third more steps per
                 # ray and smaller ones, so the rounding of the step-size controller weighs more; STRICT: 0)
                 assert np.median(err) <= (1e-9 if TOL >= 1e-8 else 1e-8) and dpx <= 1e-5 * peak

@@ -10,8 +10,8 @@ mkdir -p $O
 cd $R
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 GRV_PARITY_JSON=$O/full_frame_parity.json timeout 2700 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -12 $O/pytest.log
-for cfg in "c3" "c2" "c2 --kernel wgsl" "c4" "c5 --steps 5 --warmup 1" "c2 --two-streams" "c2 --kernel wgsl --two-streams"; do
+for cfg in "c3" "c2" "c2 --kernel wgsl" "c4" "c5 --steps 5 --warmup 1" "c2 --one-stream" "c2 --kernel wgsl --one-stream" "c2 --arith strict --no-cpu-baseline"; do
   tag=$(echo $cfg | tr -d ' -' ); timeout 900 python bench.py --config $cfg > $O/bench_$tag.json 2> $O/bench_$tag.err; echo "$cfg rc=$?"; cut -c1-120 $O/bench_$tag.json
 done
 timeout 1200 python tests/measure_c4_budget_rays.py > $O/c4_budget_rays.log 2>&1; echo "budget rays rc=$?"
-bash tools/profile_gpu.sh prof_$T _c2 _c2wgsl _c4 _c4fast _c5 > $O/profile_gpu.log 2>&1; tail -2 $O/profile_gpu.log
+bash tools/profile_gpu.sh prof_$T base _strict _c4 _c4fast _c2 _c2wgsl _c5 > $O/profile_gpu.log 2>&1; tail -2 $O/profile_gpu.log
