@@ -18,6 +18,20 @@ import torch  # noqa: E402
 import blackhole_simulation_amd as bh  # noqa: E402
 W, H = 1920, 1080
 out = {}
+if os.environ.get("AB_KERNEL") == "wgsl":  # the one-ray FAST compute march, stars on (the escape branch runs)
+    import numpy as _np
+    EYE = (60.0 * _np.sin(_np.deg2rad(97.0)), 60.0 * _np.cos(_np.deg2rad(97.0)), 0.0)
+    with bh.PhysicsEngine(1.0, 0.999) as e:
+        for name, spin, ms in (("a999", 0.999, 512), ("a5", 0.5, 150)):
+            cam = bh.camera_look_at(EYE, aspect=W / H)
+            gp = bh.wgsl_params(W, H, cam, 1.0, spin, max_steps=ms, arith=1, stars=1)
+            e.update_params(1.0, spin)
+            rgba = torch.zeros(W * H, 4, dtype=torch.float32, device="cuda:0")
+            steps = torch.zeros(W * H, dtype=torch.int32, device="cuda:0")
+            e.render_frame_wgsl(gp, rgba, steps)
+            out[name] = (rgba.cpu().numpy(), steps.cpu().numpy())
+    np.savez(sys.argv[1], rgba=np.stack([v[0] for v in out.values()]), steps=np.stack([v[1] for v in out.values()]))
+    sys.exit(0)
 with bh.PhysicsEngine(1.0, 0.999) as e:
     for name, kw in (("default", {}), ("time", {"time": 12.5}), ("march_disk", {"features": 7, "turbulence": 0.75})):
         gp = bh.glsl_params(W, H, 1.0, 0.999, max_ray_steps=512, arith=1, **kw)
