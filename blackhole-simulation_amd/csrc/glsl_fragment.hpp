@@ -69,9 +69,6 @@ template <int ARITH> __device__ __forceinline__ float smoothstep_t(float e0, flo
 // at the same position with the new direction: the march forms the position part once per position
 // and carries it across the iteration boundary (with |p| for the step-size logic), which removes
 // five of the six quarter-rate instructions and about half of the second evaluation.
-#ifndef GRV_GLSL_CARRY_GEOM
-#define GRV_GLSL_CARRY_GEOM 1
-#endif
 struct GlslGeomFast {
     float rho2;   // |p|^2
     float r2_inv; // 1 / r_k^2
@@ -595,7 +592,7 @@ __device__ uint32_t glsl_fragment(const GlslParams &U, uint32_t width, uint32_t 
     // previous iteration's second evaluation (see GlslGeomFast)
     GlslGeomFast geom{};
     float r_cur = 0.0f;
-    if constexpr (ARITH == GRV_ARITH_FAST && GRV_GLSL_CARRY_GEOM) {
+    if constexpr (ARITH == GRV_ARITH_FAST) {
         if (lensing) {
             geom = glsl_geom_fast(p, M, a);
             r_cur = __builtin_amdgcn_sqrtf(geom.rho2);
@@ -610,10 +607,7 @@ __device__ uint32_t glsl_fragment(const GlslParams &U, uint32_t width, uint32_t 
     // operations per iteration on merging them.  Here the three conditions are evaluated where the shader
     // evaluates them and tested together at the top of the next iteration; nothing else runs in between
     // (the jets of an iteration whose disk sample went opaque are skipped, as the shader's break skips them).
-#ifndef GRV_GLSL_SINGLE_EXIT
-#define GRV_GLSL_SINGLE_EXIT 1
-#endif
-    if constexpr (ARITH == GRV_ARITH_FAST && GRV_GLSL_CARRY_GEOM && GRV_GLSL_SINGLE_EXIT) {
+    if constexpr (ARITH == GRV_ARITH_FAST) {
         int i = 0;
         bool opaque = false, hz = false;
         for (;;) {
@@ -672,92 +666,59 @@ __device__ uint32_t glsl_fragment(const GlslParams &U, uint32_t width, uint32_t 
         steps = (uint32_t)i;
         hitHorizon = hitHorizon || (hz && !opaque && i < maxSteps);
         (void)prevY;
-    } else
-    for (int i = 0; i < maxSteps; ++i) {
-        p_prev = p;
-        float r;
-        if constexpr (ARITH == GRV_ARITH_FAST && GRV_GLSL_CARRY_GEOM) r = r_cur;
-        else r = length_t<ARITH>(p);
-        if (r < rh * 1.15f) {
-            hitHorizon = true;
-            break;
-        }
-        if (r > 10000.0f) break;
-        const float distFactor = 1.0f + r * 0.05f;
-        float dt = clampf_d((r - rh) * 0.1f * distFactor, 0.01f, 1.2f * distFactor);
-        if (r > 30.0f) {
-            const float farBoost = (r - 30.0f) * 0.08f;
-            dt = fmaxf(dt, 0.01f + farBoost);
-            dt = fminf(dt, 1.2f * 2.5f);
-        }
-        const float sphereProx = fabsf(r - rph);
-        dt = fminf(dt, 0.01f + sphereProx * 0.15f);
-        const float hRefinement = smoothstep_t<ARITH>(0.2f, 0.0f, fabsf(p.y));
-        const float cdt = dt * (1.0f - hRefinement * 0.7f);
+    } else {
+        // shader order: the operations of fragment.glsl.ts:129-221 in their order, in the same one-exit
+        // loop form (control flow only: every arithmetic result is the shader's, bit for bit)
+        int i = 0;
+        bool opaque = false, hz = false;
+        for (;;) {
+            const float r = length_t<ARITH>(p);
+            hz = r < rh * 1.15f;
+            if (!(i < maxSteps) || opaque || hz || r > 10000.0f) break;
+            p_prev = p;
+            const float distFactor = 1.0f + r * 0.05f;
+            float dt = clampf_d((r - rh) * 0.1f * distFactor, 0.01f, 1.2f * distFactor);
+            if (r > 30.0f) {
+                const float farBoost = (r - 30.0f) * 0.08f;
+                dt = fmaxf(dt, 0.01f + farBoost);
+                dt = fminf(dt, 1.2f * 2.5f);
+            }
+            const float sphereProx = fabsf(r - rph);
+            dt = fminf(dt, 0.01f + sphereProx * 0.15f);
+            const float hRefinement = smoothstep_t<ARITH>(0.2f, 0.0f, fabsf(p.y));
+            const float cdt = dt * (1.0f - hRefinement * 0.7f);
 
-        F3 accel{0.0f, 0.0f, 0.0f};
-        if (lensing) {
-            float omega;
-            if constexpr (ARITH == GRV_ARITH_FAST && GRV_GLSL_CARRY_GEOM) {
-                accel = glsl_accel_from_geom(geom, p, v, a); // unscaled: u_lensing_strength rides in k2 / kv below
-                omega = geom.drag;
-            } else {
-                accel = scale_f3(glsl_accel<ARITH>(p, v, M, a, omega), U.lensing_strength);
-            }
-            glsl_rot<ARITH>(omega * cdt, v.x, v.z);
-        }
-        if constexpr (ARITH == GRV_ARITH_FAST && GRV_GLSL_CARRY_GEOM) {
-            // p + v dt + (a / 2) dt^2 with the three scalings of a folded into one factor
-            const float k2 = 0.5f * cdt * cdt * U.lensing_strength;
-            p = F3{fmaf(accel.x, k2, fmaf(v.x, cdt, p.x)), fmaf(accel.y, k2, fmaf(v.y, cdt, p.y)),
-                   fmaf(accel.z, k2, fmaf(v.z, cdt, p.z))};
-        } else {
-            p = add_f3(p, add_f3(scale_f3(v, cdt), scale_f3(scale_f3(scale_f3(accel, 0.5f), cdt), cdt)));
-        }
-        float r_new;
-        if constexpr (ARITH == GRV_ARITH_FAST && GRV_GLSL_CARRY_GEOM) {
+            F3 accel{0.0f, 0.0f, 0.0f};
             if (lensing) {
-                geom = glsl_geom_fast(p, M, a);
-                r_new = __builtin_amdgcn_sqrtf(geom.rho2);
-            } else {
-                r_new = length_t<ARITH>(p);
+                float omega;
+                accel = scale_f3(glsl_accel<ARITH>(p, v, M, a, omega), U.lensing_strength);
+                glsl_rot<ARITH>(omega * cdt, v.x, v.z);
             }
-            r_cur = r_new;
-        } else {
-            r_new = length_t<ARITH>(p);
-        }
-        if (lensing && alpha < 0.95f) {
-            if constexpr (ARITH == GRV_ARITH_FAST && GRV_GLSL_CARRY_GEOM) {
-                const F3 accel_new = glsl_accel_from_geom(geom, p, v, a);
-                const float kv = 0.5f * cdt * U.lensing_strength;
-                v = F3{fmaf(accel.x + accel_new.x, kv, v.x), fmaf(accel.y + accel_new.y, kv, v.y),
-                       fmaf(accel.z + accel_new.z, kv, v.z)};
-            } else {
+            p = add_f3(p, add_f3(scale_f3(v, cdt), scale_f3(scale_f3(scale_f3(accel, 0.5f), cdt), cdt)));
+            const float r_new = length_t<ARITH>(p);
+            if (lensing && alpha < 0.95f) {
                 float om2;
                 const F3 accel_new = scale_f3(glsl_accel<ARITH>(p, v, M, a, om2), U.lensing_strength);
                 v = add_f3(v, scale_f3(scale_f3(add_f3(accel, accel_new), 0.5f), cdt));
             }
-        }
-        v = normalize_t<ARITH>(v);
-        ++steps;
-
-        if (prevY * p.y < 0.0f && r_new < rph * 2.0f && r_new > rh)
-            photonCrossings = photonCrossings + 1 < 3 ? photonCrossings + 1 : 3;
-        if (U.show_redshift > 0.5f) {
-            const float potential = sqrtf(fmaxf(0.0f, 1.0f - rs / r_new));
-            if (!redshiftInit) {
-                maxRedshift = potential;
+            v = normalize_t<ARITH>(v);
+            ++i;
+            if (p_prev.y * p.y < 0.0f && r_new < rph * 2.0f && r_new > rh)
+                photonCrossings = photonCrossings + 1 < 3 ? photonCrossings + 1 : 3;
+            if (U.show_redshift > 0.5f) {
+                const float potential = sqrtf(fmaxf(0.0f, 1.0f - rs / r_new));
+                maxRedshift = redshiftInit ? fminf(maxRedshift, potential) : potential;
                 redshiftInit = true;
-            } else {
-                maxRedshift = fminf(maxRedshift, potential);
             }
+            if (disk) {
+                glsl_sample_disk<ARITH>(U, p, p_prev, v, isco, M, a, cdt, col, alpha, r_new);
+                opaque = alpha > 0.99f;
+            }
+            if (jets && !opaque) glsl_sample_jets<ARITH>(U, p, v, rh, dt, col, alpha); // un-refined dt (fragment.glsl.ts:219)
         }
-        prevY = p.y;
-        if (disk) {
-            glsl_sample_disk<ARITH>(U, p, p_prev, v, isco, M, a, cdt, col, alpha, r_new);
-            if (alpha > 0.99f) break;
-        }
-        if (jets) glsl_sample_jets<ARITH>(U, p, v, rh, dt, col, alpha); // un-refined dt (fragment.glsl.ts:219)
+        steps = (uint32_t)i;
+        hitHorizon = hitHorizon || (hz && !opaque && i < maxSteps);
+        (void)prevY;
     }
 
     if ((F & GRV_GLSL_REDSHIFT) && U.show_redshift > 0.5f) { // fragment.glsl.ts:224-237

@@ -177,22 +177,21 @@ __global__ __launch_bounds__(kMarchBlock) void wgsl_symplectic_kernel(FrameGeom 
 
         float col[3] = {0.0f, 0.0f, 0.0f};
         float alpha = 0.0f;
-        for (int i = 0; i < P.max_steps; ++i) {
+        // the shader's operations in their order, in a loop with ONE exit (control flow only: the three
+        // places the shader leaves from -- horizon and far tests at the top, the opaque test at the
+        // bottom -- are tested together at the top of the next iteration; the escape branch's star hash
+        // runs after the loop on the rays that left through r > 100)
+        int i = 0;
+        bool opaque = false, below = false, far = false;
+        for (;;) {
             const float r = s.r;
-            if (r < rh * 1.001f) break;
-            if (r > 100.0f) { // compute.wgsl.ts:199-206
-                if (P.stars) {
-                    const F3 vdir = normalize_f3(F3{s.pr, s.pth / r, s.pph / (r * safe_st)});
-                    const float sn = sh_sinf(vdir.x * 12.9898f + vdir.y * 78.233f + vdir.z * 45.164f) * 43758.5453f;
-                    if (sn - floorf(sn) > 0.999f)
-                        for (int c = 0; c < 3; ++c) col[c] += 1.0f * (1.0f - alpha);
-                }
-                break;
-            }
+            below = r < rh * 1.001f;
+            far = r > 100.0f;
+            if (!(i < P.max_steps) || opaque || below || far) break;
             const float prev_theta = s.th;
             const float h = clampf_d((r - rh) * 0.15f, 0.05f, 1.0f);
             s = wgsl_symplectic(s, h, M, P.spin);
-            ++steps;
+            ++i;
             const float curr_theta = s.th;
             if ((prev_theta - PI * 0.5f) * (curr_theta - PI * 0.5f) <= 0.0f && r > isco && r < 30.0f) {
                 const float Omega = 1.0f / (sh_powf(r, 1.5f) + a);
@@ -218,7 +217,15 @@ __global__ __launch_bounds__(kMarchBlock) void wgsl_symplectic_kernel(FrameGeom 
                 }
                 alpha += target_opacity * mri_sat;
             }
-            if (alpha > 0.99f) break;
+            opaque = alpha > 0.99f;
+        }
+        steps = (uint32_t)i;
+        if (P.stars && far && !below && !opaque && i < P.max_steps) { // compute.wgsl.ts:199-206
+            const float r = s.r;
+            const F3 vdir = normalize_f3(F3{s.pr, s.pth / r, s.pph / (r * safe_st)});
+            const float sn = sh_sinf(vdir.x * 12.9898f + vdir.y * 78.233f + vdir.z * 45.164f) * 43758.5453f;
+            if (sn - floorf(sn) > 0.999f)
+                for (int c = 0; c < 3; ++c) col[c] += 1.0f * (1.0f - alpha);
         }
         if (out_rgba) out_rgba[oi] = make_float4(col[0], col[1], col[2], 1.0f);
         if (out_steps) out_steps[oi] = steps;

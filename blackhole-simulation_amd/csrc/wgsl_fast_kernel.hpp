@@ -170,10 +170,6 @@ __global__ __launch_bounds__(kMarchBlock) __attribute__((amdgpu_waves_per_eu(6, 
         // and far tests at the top, the opaque disk at the bottom; tested together at the top of the next
         // iteration the loop-carried state is merged once instead of once per exit.  The star hash of
         // the escape branch runs after the loop, on the rays that left through r > 100.
-#ifndef GRV_WGSL_SINGLE_EXIT
-#define GRV_WGSL_SINGLE_EXIT 1
-#endif
-#if GRV_WGSL_SINGLE_EXIT
         int i = 0;
         bool opaque = false, below = false, far = false;
         for (;;) {
@@ -235,65 +231,6 @@ __global__ __launch_bounds__(kMarchBlock) __attribute__((amdgpu_waves_per_eu(6, 
             if (sn - floorf(sn) > 0.999f)
                 for (int k = 0; k < 3; ++k) col[k] += 1.0f * (1.0f - alpha);
         }
-#else
-        for (int i = 0; i < P.max_steps; ++i) {
-            if (GRV_F32_BELOW(r, r_stop)) break; // NaN leaves here too: see wgsl_pk_body.inc
-            if (r > 100.0f) { // star hash of the escape branch, compute.wgsl.ts:199-206
-                if (P.stars) {
-                    const float sx = p_r, sy = p_th / r, sz = p_ph / (r * fmaxf(st, 1e-4f));
-                    const float inv = __builtin_amdgcn_rsqf(sx * sx + sy * sy + sz * sz);
-                    const float sn = sinf((sx * 12.9898f + sy * 78.233f + sz * 45.164f) * inv) * 43758.5453f;
-                    if (sn - floorf(sn) > 0.999f)
-                        for (int k = 0; k < 3; ++k) col[k] += 1.0f * (1.0f - alpha);
-                }
-                break;
-            }
-            const float r_before = r, th_before = th;
-            const float h = fminf(fmaxf((r - rh) * 0.15f, 0.05f), 1.0f);
-            const float hh = 0.5f * h;
-            // implicit midpoint, two fixed-point sweeps then the update (compute.wgsl.ts:122-133)
-            Wf32Deriv d = wf32_rhs<false>(bh, c, r, th, p_r, p_th);
-            float mr = fmaf(d.dr, hh, r), mth = fmaf(d.dth, hh, th);
-            float mpr = fmaf(d.dpr, hh, p_r), mpth = fmaf(d.dpth, hh, p_th);
-            d = wf32_rhs<false>(bh, c, mr, mth, mpr, mpth);
-            mr = fmaf(d.dr, hh, r);
-            mth = fmaf(d.dth, hh, th);
-            mpr = fmaf(d.dpr, hh, p_r);
-            mpth = fmaf(d.dpth, hh, p_th);
-            d = wf32_rhs<true>(bh, c, mr, mth, mpr, mpth);
-            t = fmaf(d.dt, h, t);
-            r = fmaf(d.dr, h, r);
-            th = fmaf(d.dth, h, th);
-            ph = fmaf(d.dph, h, ph);
-            p_r = fmaf(d.dpr, h, p_r);
-            p_th = fmaf(d.dpth, h, p_th);
-            ++steps;
-            // thin-disk plane crossing, shaded with the pre-step radius (compute.wgsl.ts:216-246)
-            const float rb = r_before;
-            if ((th_before - PI * 0.5f) * (th - PI * 0.5f) <= 0.0f && rb > isco && rb < 30.0f) {
-                const float Omega = 1.0f / (powf(rb, 1.5f) + a);
-                const float u_t =
-                    1.0f / sqrtf(fmaxf(1.0f - 2.0f * M / rb - Omega * Omega * (rb * rb + a * a), 1e-4f));
-                const float u_phi = Omega * u_t;
-                const float g_factor = -p_t / fmaxf(-(u_t * p_t + u_phi * p_ph), 1e-4f);
-                const float artistic_T = (1.0f / powf(fmaxf(rb / isco, 1.0f), 0.75f)) * g_factor;
-                const float base[3] = {1.0f, 0.5f, 0.1f}, blue[3] = {0.5f, 0.7f, 1.0f},
-                            red[3] = {1.0f, 0.2f, 0.0f};
-                const float bs = fmaxf(g_factor - 1.0f, 0.0f), rs = fmaxf(1.0f - g_factor, 0.0f) * 0.5f;
-                const float target_opacity = 0.6f * artistic_T;
-                const float g4 = powf(g_factor, 4.0f);
-                const float mri_sat = 1.0f + 0.0001f * sinf(rb * 100.0f * powf(rb, -1.5f));
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const float target = (base[k] + blue[k] * bs - red[k] * rs) * artistic_T * 4.0f;
-                    const float I_em = target * target_opacity / fmaxf(g4, 1e-5f);
-                    col[k] += g4 * (I_em * mri_sat) * (1.0f - alpha);
-                }
-                alpha += target_opacity * mri_sat;
-            }
-            if (alpha > 0.99f) break;
-        }
-#endif
         (void)t;
         (void)ph;
         if (out_rgba) out_rgba[oi] = make_float4(col[0], col[1], col[2], 1.0f);
