@@ -309,6 +309,43 @@ def test_glsl_kernel_matches_oracle(engine_mod, oracle, spin, tone, kw, arith):
              exact=(arith == 0))
 
 
+_ORACLE_FRAMES = {}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arith", [0, 1])
+def test_config2_bench_form_against_the_oracle(engine_mod, oracle, arith):
+    """BASELINE configs[1] exactly as `bench.py --config c2` runs it -- 1920x1080, u_maxRaySteps = 512
+    (the shader clamps to 500), the reference's default preset with its noise textures, jets, stars and
+    glows -- EVERY pixel against the shader oracle (the C oracle marches the frame's 786 M steps in a
+    few seconds on 16 cores).  arith 0 = shader order: the checker's step counts and colours bit for
+    bit on all 2 073 600 pixels; arith 1 = the FAST form the bench line runs: FAST_BARS, plus the
+    measured figures to GRV_C2_JSON=<path> (profiles/r04_full_frame_parity_c2.jsonl)."""
+    import json
+    import os
+    import torch
+    W, H = 1920, 1080
+    gp = engine_mod.glsl_params(W, H, 1.0, 0.999, max_ray_steps=512, arith=arith)
+    with engine_mod.PhysicsEngine(1.0, 0.999) as e:
+        rgba = torch.zeros(W * H, 4, dtype=torch.float32, device="cuda:0")
+        steps = torch.zeros(W * H, dtype=torch.int32, device="cuda:0")
+        tot = e.render_frame_glsl(gp, rgba, steps)
+        assert tot == int(steps.sum(dtype=torch.int64).item())
+        g, s = rgba.view(H, W, 4).cpu().numpy(), steps.view(H, W).cpu().numpy()
+    if "c2" not in _ORACLE_FRAMES:  # one oracle frame serves both contracts (the uniforms are the same)
+        _ORACLE_FRAMES["c2"] = oracle.glsl_frame(oracle.glsl_params_from(gp), nthreads=16)
+    ref_rgba, ref_steps = _ORACLE_FRAMES["c2"]
+    m = _compare(g, s, ref_rgba, ref_steps, exact=(arith == 0))
+    path = os.environ.get("GRV_C2_JSON")
+    if path:
+        rec = {"frame": "1920x1080 GLSL fragment march, default preset, u_maxRaySteps=512, a=0.999",
+               "arith": ["shader order", "FAST"][arith], "pixels_compared": int(s.size), "oracle_steps": int(ref_steps.sum()),
+               "engine_steps": int(tot)}
+        rec.update(m if m else {"bit_identical": True})
+        with open(path, "a") as f:
+            f.write(json.dumps(rec) + "\n")
+
+
 @pytest.mark.gpu
 def test_glsl_kernel_shadow_guide_and_custom_textures(engine_mod, oracle):
     import torch
