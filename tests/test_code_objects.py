@@ -89,11 +89,12 @@ def test_no_hot_kernel_uses_scratch(kernels):
 def test_f32_fast_marches_keep_their_occupancy(kernels):
     # measured on MI355X (profiles/r01_shader_kernels.jsonl): the packed WGSL march gains 4-7 % from
     # 4 waves/SIMD (<= 128 VGPRs) over 3, the one-ray-per-lane march 3-4 % from 6 (<= 80) over 5 at
-    # the price of one spilled register outside the step loop; the GLSL march 2-3 % from 5 (<= 96, with
-    # 72 B of spills in its disk / jet sampling branches) over the 4 (120 VGPRs) the compiler picks unaided
-    # (profiles/r02_shader_kernels.jsonl)
+    # the price of one spilled register outside the step loop; the GLSL march runs at 5 (<= 96).  Since
+    # round 4 (lattice noise, raw rcp / sqrt, one loop exit, no SLP vectoriser: profiles/EXPERIMENTS.md G)
+    # none of the four spills anything: the GLSL march's 72 B of scratch showed as 80 MB of HBM writes per
+    # 1080p frame in the counters
     for part, limit, scratch in (("wgsl_symplectic_pk_kernel", 128, 0), ("wgsl_symplectic_pk_b256_kernel", 128, 0),
-                                 ("wgsl_symplectic_fast_kernel", 80, 16), ("glsl_fragment_kernelILi1E", 96, 96)):
+                                 ("wgsl_symplectic_fast_kernel", 80, 0), ("glsl_fragment_kernelILi1E", 96, 0)):
         (kd,) = _find(kernels, part)
         assert kd[".vgpr_count"] + kd.get(".agpr_count", 0) <= limit, (part, kd[".vgpr_count"])
         assert kd[".private_segment_fixed_size"] <= scratch, (part, kd[".private_segment_fixed_size"])
