@@ -580,3 +580,42 @@ def test_f64_twin_of_the_compute_march_is_the_same_algorithm(oracle):
     assert np.percentile(dc, 99.9) <= 2e-3
     # exit classes are consistent with the step counts
     assert ((d["cls"] == 2) == (d["steps"] == 512)).all()
+
+
+def test_lattice_form_of_the_noise_hash_is_the_shaders_arithmetic():
+    """csrc/glsl_fragment.hpp glsl_noise_lattice (FAST) indexes the noise texel of a cell corner by
+    integer arithmetic: ((x + 37 z) mod 256, (y + 37 z) mod 256).  The shader's hash() (noise.ts:3-9)
+    reaches its texel through f32: uv = p.xy + p.z * 37, texture coordinate (uv + 0.5) / 256, LINEAR
+    filtering at s * 256 - 0.5.  For integer corners with |coordinates| < 2^17 every one of those f32
+    operations is exact: the filter position is the integer uv itself (fractional weights exactly 0 --
+    one texel) and its REPEAT-wrapped index is the integer formula.  Checked here in numpy f32, with the
+    products formed both ways a compiler may form them (separate multiply and add, or one fma)."""
+    rng = np.random.default_rng(4)
+    n = 200000
+    lim = 2 ** 17 - 1
+    pts = rng.integers(-lim, lim + 1, size=(n, 3))
+    pts[:64] = rng.choice([-lim, lim, 0, -1, 1, 255, 256, -256, -255], size=(64, 3))
+    x, y, z = (pts[:, k].astype(np.float32) for k in range(3))
+    for fused in (False, True):
+        if fused:   # fma(z, 37, x): one rounding of the exact value -- exact integers below 2^24 either way
+            uvx = (pts[:, 0].astype(np.float64) + pts[:, 2].astype(np.float64) * 37.0).astype(np.float32)
+            uvy = (pts[:, 1].astype(np.float64) + pts[:, 2].astype(np.float64) * 37.0).astype(np.float32)
+        else:
+            uvx = x + z * np.float32(37.0)
+            uvy = y + z * np.float32(37.0)
+        s = (uvx + np.float32(0.5)) / np.float32(256.0)
+        t = (uvy + np.float32(0.5)) / np.float32(256.0)
+        u = s * np.float32(256.0) - np.float32(0.5)
+        v = t * np.float32(256.0) - np.float32(0.5)
+        fu, fv = np.floor(u), np.floor(v)
+        assert np.all(u - fu == 0) and np.all(v - fv == 0)            # a texel centre: weights (1, 0, 0, 0)
+        ix = fu.astype(np.int64) & 255
+        iy = fv.astype(np.int64) & 255
+        assert np.array_equal(ix, (pts[:, 0] + 37 * pts[:, 2]) & 255)
+        assert np.array_equal(iy, (pts[:, 1] + 37 * pts[:, 2]) & 255)
+    # the kernel reduces each coordinate mod 256 first (i - 256 floor(i / 256), exact in f32 for any float):
+    # the index is unchanged
+    r = (x - np.float32(256.0) * np.floor(x * np.float32(0.00390625))).astype(np.int64)
+    rz = (z - np.float32(256.0) * np.floor(z * np.float32(0.00390625))).astype(np.int64)
+    assert np.all((r >= 0) & (r < 256))
+    assert np.array_equal((r + 37 * rz) & 255, (pts[:, 0] + 37 * pts[:, 2]) & 255)
