@@ -83,7 +83,9 @@ __device__ __forceinline__ GlslGeomFast glsl_geom_fast(F3 p, float M, float a) {
     const float diff = g.rho2 - a2;
     const float py2 = p.y * p.y;
     const float disc = fmaf(diff, diff, 4.0f * a2 * py2);
-    const float r2 = 0.5f * (diff + __builtin_amdgcn_sqrtf(fmaxf(0.0f, disc)));
+    // (disc = diff^2 + 4 a^2 y^2 and L2_eff below are sums of squares closed by an fma: never negative,
+    // so the shader's max(0, .) on them is the identity and is not issued)
+    const float r2 = 0.5f * (diff + __builtin_amdgcn_sqrtf(disc));
     const float r2c = fmaxf(1e-8f, r2);
     const float inv_rk = __builtin_amdgcn_rsqf(r2c); // 1 / r_k
     const float r_k = r2c * inv_rk;
@@ -100,7 +102,7 @@ __device__ __forceinline__ F3 glsl_accel_from_geom(const GlslGeomFast &g, F3 p, 
     const float Ly_eff = L.y - a;
     const float L2_eff = fmaf(Ly_eff, Ly_eff, fmaf(L.x, L.x, L.z * L.z));
     // M r^-2 S + 3 M max(0, L^2) r^-4 S, along -normalize(p)
-    const float s = -(g.k_pull * fmaf(3.0f * fmaxf(0.0f, L2_eff), g.r2_inv, 1.0f)) * g.rs;
+    const float s = -(g.k_pull * fmaf(3.0f * L2_eff, g.r2_inv, 1.0f)) * g.rs;
     // cross((0,1,0), v) = (v.z, 0, -v.x)
     return F3{fmaf(p.x, s, v.z * g.drag), p.y * s, fmaf(p.z, s, -v.x * g.drag)};
 }
@@ -147,6 +149,15 @@ __device__ __forceinline__ F3 glsl_accel(F3 p, F3 v, float M, float a, float &om
 // sin / cos of the FAST contract: two-term Cody-Waite reduction by pi/2 + cephes minimax
 // polynomials on [-pi/4, pi/4] (~1 ulp f32 for the O(1) angles of the march)
 __device__ __forceinline__ void glsl_fast_sincos(float ang, float &s, float &c) {
+    if (__ballot(!(fabsf(ang) <= 0.0625f)) == 0ull) {
+        // the whole wave twists by less than 1/16 rad (every march step beyond r ~ 3 M does): the next
+        // terms of both series, x^7 / 5040 and x^6 / 720, stay below 2^-36 and 2^-33 -- far under half an
+        // ulp of the results -- so two fma fewer give the same roundings as the full polynomials
+        const float z = ang * ang;
+        s = fmaf(ang * z, fmaf(z, 8.3333333333e-3f, -1.6666666667e-1f), ang);
+        c = fmaf(z * z, 4.1666666667e-2f, fmaf(z, -0.5f, 1.0f));
+        return;
+    }
     if (__ballot(!(fabsf(ang) <= 0.78539816f)) == 0ull) {
         // the whole wave is inside [-pi/4, pi/4] (the ZAMO twist omega * dt of a march step always is):
         // j = 0, the reduction returns the argument and the quadrant logic is the identity -- same bits
@@ -461,10 +472,19 @@ __device__ __forceinline__ void glsl_sample_jets(const GlslParams &U, F3 p, F3 v
                                                  float col[3], float &alpha) {
     const float jetVerticalPos = fabsf(p.y);
     if (!(jetVerticalPos > rh * 1.8f && jetVerticalPos < 10000.0f * 0.8f)) return;
-    const float jetRadialDist = sqrt_t<ARITH>(p.x * p.x + p.z * p.z);
     const float jetWidth = 1.0f + jetVerticalPos * 0.15f;
-    if (!(jetRadialDist < jetWidth * 2.0f)) return;
-    const float radialFalloff = exp_d<ARITH>(div_t<ARITH>(-(jetRadialDist * jetRadialDist), jetWidth * 0.5f));
+    float radialFalloff;
+    if constexpr (ARITH == GRV_ARITH_FAST) {
+        // the shader only ever uses the axial distance squared: compared against the squared width and
+        // fed to the falloff as it is, no root (most steps outside the slab reach this test and fail it)
+        const float rad2 = fmaf(p.x, p.x, p.z * p.z), w2 = jetWidth * 2.0f;
+        if (!(rad2 < w2 * w2)) return;
+        radialFalloff = exp_d<ARITH>(div_t<ARITH>(-rad2, jetWidth * 0.5f));
+    } else {
+        const float jetRadialDist = sqrt_t<ARITH>(p.x * p.x + p.z * p.z);
+        if (!(jetRadialDist < jetWidth * 2.0f)) return;
+        radialFalloff = exp_d<ARITH>(div_t<ARITH>(-(jetRadialDist * jetRadialDist), jetWidth * 0.5f));
+    }
     const float lengthFalloff = exp_d<ARITH>(-jetVerticalPos * 0.05f);
     const float flow = p.y * 2.0f - U.time * 8.0f;
     const F3 uvJet{p.x, flow, p.z};
@@ -595,7 +615,7 @@ __device__ uint32_t glsl_fragment(const GlslParams &U, uint32_t width, uint32_t 
     if constexpr (ARITH == GRV_ARITH_FAST) {
         if (lensing) {
             geom = glsl_geom_fast(p, M, a);
-            r_cur = __builtin_amdgcn_sqrtf(geom.rho2);
+            r_cur = geom.rho2 * geom.rs; // |p| from the reciprocal root the pull needs anyway
         } else {
             r_cur = length_t<ARITH>(p);
         }
@@ -610,20 +630,40 @@ __device__ uint32_t glsl_fragment(const GlslParams &U, uint32_t width, uint32_t 
     if constexpr (ARITH == GRV_ARITH_FAST) {
         int i = 0;
         bool opaque = false, hz = false;
+        const float slabH = fminf(U.disk_scale_height, 0.45f); // sample_disk's effH
+        const bool far_is_min3 = rh < 17.9f;                    // wave-uniform (r_h of the launch's hole)
+        float neg_inf = -INFINITY; // in an SGPR and opaque, or the optimiser turns the med3 back into fminf
+        asm volatile("" : "+s"(neg_inf));
         for (;;) {
             const float r = r_cur;
             hz = r < rh * 1.15f;
             if (!(i < maxSteps) || opaque || hz || r > 10000.0f) break;
             p_prev = p;
             const float distFactor = 1.0f + r * 0.05f;
-            float dt = clampf_d((r - rh) * 0.1f * distFactor, 0.01f, 1.2f * distFactor);
-            if (r > 30.0f) {
-                const float farBoost = (r - 30.0f) * 0.08f;
-                dt = fmaxf(dt, 0.01f + farBoost);
-                dt = fminf(dt, 1.2f * 2.5f);
-            }
+            // (v_med3_f32 is the clamp for lo <= hi -- 1.2 distFactor >= 1.2 -- and, with -inf as the third
+            // operand, the minimum of two finite values: unlike fminf it needs no quieting v_max x, x of an
+            // operand that reaches it through the merge of the two far-field forms below)
+            float dt = __builtin_amdgcn_fmed3f((r - rh) * 0.1f * distFactor, 0.01f, 1.2f * distFactor);
+            // The shader's far-field block (fragment.glsl.ts:152-156) IS `dt = min(dt, 3.0f)` whenever
+            // r_h < 17.9.  r > 30: (r - r_h) 0.1f > 1.2f, so the clamp above returned its upper edge
+            // 1.2f distFactor, and distFactor = fma(r, 0.05f, 1) >= 2.5f makes that >= 3.0f (1.2f x 2.5f is the
+            // exact tie between 3.0f and its successor: round-to-even gives 3.0f); the max with the far boost
+            // keeps it >= 3.0f and the shader's min(., 1.2 * 2.5) returns 3.0f.  r <= 30: distFactor <= 2.5f,
+            // the upper edge is <= 3.0f and a min with 3.0f changes nothing -- as the shader, which skips the
+            // block.  And for ANY hole dt <= 3.0f after the block, so the 3.0f can join the photon-sphere
+            // limit, min(min(dt, 3), lim) = min(dt, min(lim, 3)): one v_min_f32 on the limit replaces a
+            // compare, four operations and a select; larger holes run the block as written.
             const float sphereProx = fabsf(r - rph);
-            dt = fminf(dt, 0.01f + sphereProx * 0.15f);
+            const float lim = fminf(0.01f + sphereProx * 0.15f, 3.0f);
+            if (!far_is_min3) {
+                asm volatile(""); // keeps this a (wave-uniform) branch instead of six selects-worth of work
+                if (r > 30.0f) {
+                    const float farBoost = (r - 30.0f) * 0.08f;
+                    dt = fmaxf(dt, 0.01f + farBoost);
+                    dt = fminf(dt, 1.2f * 2.5f);
+                }
+            }
+            dt = __builtin_amdgcn_fmed3f(dt, lim, neg_inf);
             const float hRefinement = smoothstep_t<ARITH>(0.2f, 0.0f, fabsf(p.y));
             const float cdt = dt * (1.0f - hRefinement * 0.7f);
             F3 accel{0.0f, 0.0f, 0.0f};
@@ -637,7 +677,7 @@ __device__ uint32_t glsl_fragment(const GlslParams &U, uint32_t width, uint32_t 
             float r_new;
             if (lensing) {
                 geom = glsl_geom_fast(p, M, a);
-                r_new = __builtin_amdgcn_sqrtf(geom.rho2);
+                r_new = geom.rho2 * geom.rs;
             } else {
                 r_new = length_t<ARITH>(p);
             }
@@ -650,17 +690,25 @@ __device__ uint32_t glsl_fragment(const GlslParams &U, uint32_t width, uint32_t 
             }
             v = normalize_t<ARITH>(v);
             ++i;
-            if (p_prev.y * p.y < 0.0f && r_new < rph * 2.0f && r_new > rh)
-                photonCrossings = photonCrossings + 1 < 3 ? photonCrossings + 1 : 3;
             if (U.show_redshift > 0.5f) {
                 const float potential = sqrtf(fmaxf(0.0f, 1.0f - rs / r_new));
                 maxRedshift = redshiftInit ? fminf(maxRedshift, potential) : potential;
                 redshiftInit = true;
             }
-            if (disk) {
-                glsl_sample_disk<ARITH>(U, p, p_prev, v, isco, M, a, cdt, col, alpha, r_new);
-                opaque = alpha > 0.99f;
+            // the plane-crossing counter and the disk sample only matter on the few steps that cross the
+            // equatorial plane or land inside the slab |y| < r effH (sample_disk returns at once otherwise:
+            // without a crossing its sample point is p and its radius r_new): two products and two compares
+            // decide that, and everything else sits behind ONE branch (the empty asm keeps the optimiser
+            // from turning the block back into selects issued on every step)
+            const bool crossed = p_prev.y * p.y < 0.0f;
+            const bool in_slab = fabsf(p.y) < r_new * slabH;
+            if (crossed || (disk && in_slab)) {
+                asm volatile("" ::: "memory");
+                if (crossed && r_new < rph * 2.0f && r_new > rh)
+                    photonCrossings = photonCrossings + 1 < 3 ? photonCrossings + 1 : 3;
+                if (disk) glsl_sample_disk<ARITH>(U, p, p_prev, v, isco, M, a, cdt, col, alpha, r_new);
             }
+            if (disk) opaque = alpha > 0.99f;
             if (jets && !opaque) glsl_sample_jets<ARITH>(U, p, v, rh, dt, col, alpha); // un-refined dt (fragment.glsl.ts:219)
         }
         steps = (uint32_t)i;
@@ -794,11 +842,13 @@ __device__ uint32_t glsl_fragment(const GlslParams &U, uint32_t width, uint32_t 
 }
 
 // one thread per pixel of this rank's tile set; a wave is one 8x8 pixel block
-// FAST form compiled for five waves per SIMD (96 VGPRs; 72 B of scratch, all in the disk / jet sampling
-// branches): +2-3 % over the 120 registers / four waves the compiler takes on its own, measured A/B;
-// six waves (80 VGPRs, 132 B of scratch) loses on the default preset
+// FAST form compiled for eight waves per SIMD (64 VGPRs; ~50 B of scratch, all inside the disk / jet
+// sampling branches, none on the far-field step).  A gfx950 SIMD issues two plain 32-bit VALU operations
+// of two different waves in one quad-cycle (tools/valu_microbench.hip), and how often it finds a partner
+// grows with the waves it can pick from: 5 -> 6 -> 7 -> 8 waves measured +2.3 / +5.3 / +6.3 % on the
+// 1080p default preset (profiles/r04_ab_glsl_waves.jsonl)
 #ifndef GRV_GLSL_FAST_WAVES
-#define GRV_GLSL_FAST_WAVES 5
+#define GRV_GLSL_FAST_WAVES 8
 #endif
 template <int ARITH>
 __global__ __launch_bounds__(kMarchBlock) __attribute__((amdgpu_waves_per_eu(ARITH == GRV_ARITH_FAST ? GRV_GLSL_FAST_WAVES : 1)))

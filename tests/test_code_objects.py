@@ -89,15 +89,52 @@ def test_no_hot_kernel_uses_scratch(kernels):
 def test_f32_fast_marches_keep_their_occupancy(kernels):
     # measured on MI355X (profiles/r01_shader_kernels.jsonl): the packed WGSL march gains 4-7 % from
     # 4 waves/SIMD (<= 128 VGPRs) over 3, the one-ray-per-lane march 3-4 % from 6 (<= 80) over 5 at
-    # the price of one spilled register outside the step loop; the GLSL march runs at 5 (<= 96).  Since
-    # round 4 (lattice noise, raw rcp / sqrt, one loop exit, no SLP vectoriser: profiles/EXPERIMENTS.md G)
-    # none of the four spills anything: the GLSL march's 72 B of scratch showed as 80 MB of HBM writes per
-    # 1080p frame in the counters
+    # the price of one spilled register outside the step loop.  The GLSL march runs at 8 waves (<= 64
+    # VGPRs) since the second half of round 4: a SIMD pairs plain 32-bit VALU operations of two different
+    # waves in one quad-cycle and finds a partner more often the more waves it holds (5 -> 6 -> 7 -> 8
+    # waves: +2.3 / +5.3 / +6.3 % on the 1080p default preset, profiles/r04_ab_glsl_waves.jsonl); its
+    # ~50 B of scratch sit inside the disk / jet sampling branches, none on the far-field step
     for part, limit, scratch in (("wgsl_symplectic_pk_kernel", 128, 0), ("wgsl_symplectic_pk_b256_kernel", 128, 0),
-                                 ("wgsl_symplectic_fast_kernel", 80, 0), ("glsl_fragment_kernelILi1E", 96, 0)):
+                                 ("wgsl_symplectic_fast_kernel", 80, 0), ("glsl_fragment_kernelILi1E", 64, 64)):
         (kd,) = _find(kernels, part)
         assert kd[".vgpr_count"] + kd.get(".agpr_count", 0) <= limit, (part, kd[".vgpr_count"])
         assert kd[".private_segment_fixed_size"] <= scratch, (part, kd[".private_segment_fixed_size"])
+
+
+def test_glsl_fast_march_spills_nothing_on_the_far_field_step(engine_mod):
+    # the scratch of the eight-wave GLSL march must stay inside the sampling branches: between the loop
+    # head (the step-count compare) and the reciprocal root that normalises the direction at the end of
+    # the Verlet step there is no scratch_load / scratch_store
+    import subprocess
+    import sys
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not found")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import kernel_resources as kr
+    text = None
+    key = "glsl_fragment_kernelILi1E"
+    for elf in kr.code_objects(engine_mod.library_path()):
+        path = os.path.join("/tmp", "grv_co_%d.elf" % os.getpid())
+        with open(path, "wb") as f:
+            f.write(elf)
+        out = subprocess.run([objdump, "-d", "--no-show-raw-insn", path], capture_output=True, text=True).stdout
+        os.unlink(path)
+        at = out.find(key + "EEvN")
+        if at >= 0:
+            body = out[at:]
+            text = body[:body.index("s_endpgm")]
+            break
+    assert text is not None
+    lines = [ln.split("//")[0].strip() for ln in text.splitlines()]
+    head = next(i for i, ln in enumerate(lines) if ln.startswith("v_cmp_ge_i32"))   # i >= maxSteps
+    # 1 / r_k, 1 / |p| and 1 / |v| are the step's three v_rsq_f32; the third ends it
+    rsq = [i for i, ln in enumerate(lines) if i > head and ln.startswith("v_rsq_f32")]
+    assert len(rsq) >= 3
+    step = lines[head:rsq[2] + 1]
+    n_valu = sum(ln.startswith("v_") for ln in step)
+    assert 100 < n_valu < 260, n_valu
+    assert not [ln for ln in step if ln.startswith("scratch_")]
 
 
 def test_march_kernels_launch_one_wave_blocks(kernels):
