@@ -112,7 +112,13 @@ __device__ __forceinline__ void wf32_m4v4(const float *m, float x, float y, floa
     for (int r = 0; r < 4; ++r) o[r] = m[0 + r] * x + m[4 + r] * y + m[8 + r] * z + m[12 + r] * w;
 }
 
-__global__ __launch_bounds__(kMarchBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void wgsl_symplectic_fast_kernel(FrameGeom G, WgslParams P,
+// seven waves per SIMD (72 VGPRs, no scratch): +2.6-3.3 % over six on the 4K and 1080p marches (cross-wave
+// pairing of plain f32 ops, as for the GLSL march); eight spills 20 B into the loop and loses 2 %
+// (profiles/r04_ab_wgsl_one_ray_waves.txt)
+#ifndef GRV_WF32_WAVES
+#define GRV_WF32_WAVES 7
+#endif
+__global__ __launch_bounds__(kMarchBlock) __attribute__((amdgpu_waves_per_eu(GRV_WF32_WAVES, GRV_WF32_WAVES))) void wgsl_symplectic_fast_kernel(FrameGeom G, WgslParams P,
                                                                       float4 *__restrict__ out_rgba,
                                                                       uint32_t *__restrict__ out_steps,
                                                                       unsigned long long *total_steps,

@@ -88,14 +88,14 @@ def test_no_hot_kernel_uses_scratch(kernels):
 
 def test_f32_fast_marches_keep_their_occupancy(kernels):
     # measured on MI355X (profiles/r01_shader_kernels.jsonl): the packed WGSL march gains 4-7 % from
-    # 4 waves/SIMD (<= 128 VGPRs) over 3, the one-ray-per-lane march 3-4 % from 6 (<= 80) over 5 at
-    # the price of one spilled register outside the step loop.  The GLSL march runs at 8 waves (<= 64
+    # 4 waves/SIMD (<= 128 VGPRs) over 3, the one-ray-per-lane march 3-4 % from 6 (<= 80) over 5 and
+    # another 3 % from 7 (<= 72, profiles/r04_ab_wgsl_one_ray_waves.txt).  The GLSL march runs at 8 waves (<= 64
     # VGPRs) since the second half of round 4: a SIMD pairs plain 32-bit VALU operations of two different
     # waves in one quad-cycle and finds a partner more often the more waves it holds (5 -> 6 -> 7 -> 8
     # waves: +2.3 / +5.3 / +6.3 % on the 1080p default preset, profiles/r04_ab_glsl_waves.jsonl); its
     # ~50 B of scratch sit inside the disk / jet sampling branches, none on the far-field step
     for part, limit, scratch in (("wgsl_symplectic_pk_kernel", 128, 0), ("wgsl_symplectic_pk_b256_kernel", 128, 0),
-                                 ("wgsl_symplectic_fast_kernel", 80, 0), ("glsl_fragment_kernelILi1E", 64, 64)):
+                                 ("wgsl_symplectic_fast_kernel", 72, 0), ("glsl_fragment_kernelILi1E", 64, 64)):
         (kd,) = _find(kernels, part)
         assert kd[".vgpr_count"] + kd.get(".agpr_count", 0) <= limit, (part, kd[".vgpr_count"])
         assert kd[".private_segment_fixed_size"] <= scratch, (part, kd[".private_segment_fixed_size"])

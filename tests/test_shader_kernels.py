@@ -309,6 +309,28 @@ def test_glsl_kernel_matches_oracle(engine_mod, oracle, spin, tone, kw, arith):
              exact=(arith == 0))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mass", [12.4, 12.6, 14.0])   # r_h = 17.80 / 18.09 / 20.10 at a = 0.9 M
+@pytest.mark.parametrize("arith", [0, 1])
+def test_glsl_far_field_step_of_a_large_hole(engine_mod, oracle, mass, arith):
+    """The FAST march replaces the shader's r > 30 block (fragment.glsl.ts:152-156) by a min on the
+    photon-sphere limit when r_h < 17.9 (glsl_fragment.hpp: the block then always returns 3.0f) and runs
+    it as written for larger holes.  Both sides of the guard, and a hole well past it, against the
+    oracle: shader order bit for bit, FAST to the same bars and -- the identity is exact -- with the step
+    counts of the small-hole cases' quality."""
+    import torch
+    W, H = 320, 180
+    gp = engine_mod.glsl_params(W, H, mass, 0.9, max_ray_steps=512, arith=arith, zoom=90.0)
+    with engine_mod.PhysicsEngine(mass, 0.9) as e:
+        rgba = torch.zeros(W * H, 4, dtype=torch.float32, device="cuda:0")
+        steps = torch.zeros(W * H, dtype=torch.int32, device="cuda:0")
+        tot = e.render_frame_glsl(gp, rgba, steps)
+    ref_rgba, ref_steps = oracle.glsl_frame(oracle.glsl_params_from(gp), nthreads=8)
+    assert tot == int(steps.sum().item()) and tot > 20 * W * H   # the rays do march from r = 90 > 30
+    _compare(rgba.cpu().numpy().reshape(H, W, 4), steps.cpu().numpy().reshape(H, W), ref_rgba, ref_steps,
+             exact=(arith == 0))
+
+
 _ORACLE_FRAMES = {}
 
 

@@ -9,7 +9,7 @@ O=$R/gpurun_out/$T
 mkdir -p $O
 cd $R
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
-GRV_PARITY_JSON=$O/full_frame_parity.json timeout 2700 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -12 $O/pytest.log
+GRV_C2_JSON=$O/full_frame_parity_c2.jsonl GRV_PARITY_JSON=$O/full_frame_parity.json timeout 2700 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -12 $O/pytest.log
 for cfg in "c3" "c2" "c2 --kernel wgsl" "c4" "c5 --steps 5 --warmup 1" "c2 --one-stream" "c2 --kernel wgsl --one-stream" "c2 --arith strict --no-cpu-baseline"; do
   tag=$(echo $cfg | tr -d ' -' ); timeout 900 python bench.py --config $cfg > $O/bench_$tag.json 2> $O/bench_$tag.err; echo "$cfg rc=$?"; cut -c1-120 $O/bench_$tag.json
 done
