@@ -631,39 +631,28 @@ __device__ uint32_t glsl_fragment(const GlslParams &U, uint32_t width, uint32_t 
         int i = 0;
         bool opaque = false, hz = false;
         const float slabH = fminf(U.disk_scale_height, 0.45f); // sample_disk's effH
-        const bool far_is_min3 = rh < 17.9f;                    // wave-uniform (r_h of the launch's hole)
-        float neg_inf = -INFINITY; // in an SGPR and opaque, or the optimiser turns the med3 back into fminf
-        asm volatile("" : "+s"(neg_inf));
         for (;;) {
             const float r = r_cur;
             hz = r < rh * 1.15f;
             if (!(i < maxSteps) || opaque || hz || r > 10000.0f) break;
             p_prev = p;
             const float distFactor = 1.0f + r * 0.05f;
-            // (v_med3_f32 is the clamp for lo <= hi -- 1.2 distFactor >= 1.2 -- and, with -inf as the third
-            // operand, the minimum of two finite values: unlike fminf it needs no quieting v_max x, x of an
-            // operand that reaches it through the merge of the two far-field forms below)
+            // (v_med3_f32 is the clamp for lo <= hi: 1.2 distFactor >= 1.2)
             float dt = __builtin_amdgcn_fmed3f((r - rh) * 0.1f * distFactor, 0.01f, 1.2f * distFactor);
-            // The shader's far-field block (fragment.glsl.ts:152-156) IS `dt = min(dt, 3.0f)` whenever
-            // r_h < 17.9.  r > 30: (r - r_h) 0.1f > 1.2f, so the clamp above returned its upper edge
-            // 1.2f distFactor, and distFactor = fma(r, 0.05f, 1) >= 2.5f makes that >= 3.0f (1.2f x 2.5f is the
-            // exact tie between 3.0f and its successor: round-to-even gives 3.0f); the max with the far boost
-            // keeps it >= 3.0f and the shader's min(., 1.2 * 2.5) returns 3.0f.  r <= 30: distFactor <= 2.5f,
-            // the upper edge is <= 3.0f and a min with 3.0f changes nothing -- as the shader, which skips the
-            // block.  And for ANY hole dt <= 3.0f after the block, so the 3.0f can join the photon-sphere
-            // limit, min(min(dt, 3), lim) = min(dt, min(lim, 3)): one v_min_f32 on the limit replaces a
-            // compare, four operations and a select; larger holes run the block as written.
+            // The shader's far-field block (fragment.glsl.ts:152-156) IS `dt = min(dt, 3.0f)` on every radius
+            // the march can hold (1.15 r_h <= r: the horizon test above leaves first).  r > 30: the un-clamped
+            // step 0.1 (r - r_h)(1 + 0.05 r) exceeds the far boost 0.01 + 0.08 (r - 30) by >= 0.67 there (a
+            // quadratic in r without real roots), so max(dt, boost) = dt unless dt sits at its upper clamp
+            // 1.2f distFactor -- and distFactor = fma(r, 0.05f, 1) >= 2.5f makes that >= 3.0f (1.2f x 2.5f is the
+            // exact tie between 3.0f and its successor: round-to-even gives 3.0f), where the shader's
+            // min(., 1.2 * 2.5) returns 3.0f either way.  r <= 30: distFactor <= 2.5f, dt <= 3.0f, a min
+            // changes nothing -- as the shader, which skips the block.  The 3.0f joins the photon-sphere
+            // limit, min(min(dt, 3), lim) = min(dt, min(lim, 3)): one v_min_f32 for a compare, four
+            // operations and a select.  Every f32 radius, for holes from r_h = 1 to 2000:
+            // tests/test_glsl_fast_identities.py.
             const float sphereProx = fabsf(r - rph);
             const float lim = fminf(0.01f + sphereProx * 0.15f, 3.0f);
-            if (!far_is_min3) {
-                asm volatile(""); // keeps this a (wave-uniform) branch instead of six selects-worth of work
-                if (r > 30.0f) {
-                    const float farBoost = (r - 30.0f) * 0.08f;
-                    dt = fmaxf(dt, 0.01f + farBoost);
-                    dt = fminf(dt, 1.2f * 2.5f);
-                }
-            }
-            dt = __builtin_amdgcn_fmed3f(dt, lim, neg_inf);
+            dt = fminf(dt, lim);
             const float hRefinement = smoothstep_t<ARITH>(0.2f, 0.0f, fabsf(p.y));
             const float cdt = dt * (1.0f - hRefinement * 0.7f);
             F3 accel{0.0f, 0.0f, 0.0f};

@@ -313,11 +313,10 @@ def test_glsl_kernel_matches_oracle(engine_mod, oracle, spin, tone, kw, arith):
 @pytest.mark.parametrize("mass", [12.4, 12.6, 14.0])   # r_h = 17.80 / 18.09 / 20.10 at a = 0.9 M
 @pytest.mark.parametrize("arith", [0, 1])
 def test_glsl_far_field_step_of_a_large_hole(engine_mod, oracle, mass, arith):
-    """The FAST march replaces the shader's r > 30 block (fragment.glsl.ts:152-156) by a min on the
-    photon-sphere limit when r_h < 17.9 (glsl_fragment.hpp: the block then always returns 3.0f) and runs
-    it as written for larger holes.  Both sides of the guard, and a hole well past it, against the
-    oracle: shader order bit for bit, FAST to the same bars and -- the identity is exact -- with the step
-    counts of the small-hole cases' quality."""
+    """The FAST march replaces the shader's r > 30 block (fragment.glsl.ts:152-156) by a min with 3.0 on
+    the photon-sphere limit (glsl_fragment.hpp; the identity over every f32 radius:
+    tests/test_glsl_fast_identities.py).  Holes large enough that the block's compare, boost and clamp all
+    see radii near r = 30, against the oracle: shader order bit for bit, FAST to the usual bars."""
     import torch
     W, H = 320, 180
     gp = engine_mod.glsl_params(W, H, mass, 0.9, max_ray_steps=512, arith=arith, zoom=300.0)
