@@ -149,6 +149,14 @@ __device__ __forceinline__ F3 glsl_accel(F3 p, F3 v, float M, float a, float &om
 // sin / cos of the FAST contract: two-term Cody-Waite reduction by pi/2 + cephes minimax
 // polynomials on [-pi/4, pi/4] (~1 ulp f32 for the O(1) angles of the march)
 __device__ __forceinline__ void glsl_fast_sincos(float ang, float &s, float &c) {
+    if (__ballot(!(fabsf(ang) < 2.44140625e-4f)) == 0ull) {
+        // |angle| < 2^-12 on the whole wave (the twist of a step beyond r ~ 30 M): 1 - z/2 rounds to 1.0f
+        // (z/2 < 2^-25: at most the tie, which goes to the even 1.0f) and the cubic term of the sine stays
+        // under a quarter ulp -- the polynomials below return exactly (angle, 1.0f)
+        s = ang;
+        c = 1.0f;
+        return;
+    }
     if (__ballot(!(fabsf(ang) <= 0.0625f)) == 0ull) {
         // the whole wave twists by less than 1/16 rad (every march step beyond r ~ 3 M does): the next
         // terms of both series, x^7 / 5040 and x^6 / 720, stay below 2^-36 and 2^-33 -- far under half an
@@ -469,8 +477,15 @@ __device__ __forceinline__ void glsl_sample_disk(const GlslParams &U, F3 p, F3 p
 // chunks/disk.ts:117-155
 template <int ARITH>
 __device__ __forceinline__ void glsl_sample_jets(const GlslParams &U, F3 p, F3 v, float rh, float dt,
-                                                 float col[3], float &alpha) {
+                                                 float col[3], float &alpha, float r_p = 0.0f) {
     const float jetVerticalPos = fabsf(p.y);
+    if constexpr (ARITH == GRV_ARITH_FAST) {
+        // a ray is inside the jets only within 2 (1 + 0.15 |y|) of the axis, and its axial distance
+        // sqrt(|p|^2 - y^2) is at least |p| - |y|: beyond |p| = 2.01 + 1.31 |y| (the shader's bound with a
+        // margin of 0.01 (1 + |y|), a thousand times the rounding of |p|) nothing below can pass, and one
+        // fma and one compare replace the nine operations of the tests -- which stay as they are
+        if (!(r_p < fmaf(jetVerticalPos, 1.31f, 2.01f))) return;
+    }
     if (!(jetVerticalPos > rh * 1.8f && jetVerticalPos < 10000.0f * 0.8f)) return;
     const float jetWidth = 1.0f + jetVerticalPos * 0.15f;
     float radialFalloff;
@@ -631,30 +646,48 @@ __device__ uint32_t glsl_fragment(const GlslParams &U, uint32_t width, uint32_t 
         int i = 0;
         bool opaque = false, hz = false;
         const float slabH = fminf(U.disk_scale_height, 0.45f); // sample_disk's effH
+        const float r_far = fmaxf(64.0f, rph + 21.0f);
         for (;;) {
             const float r = r_cur;
             hz = r < rh * 1.15f;
             if (!(i < maxSteps) || opaque || hz || r > 10000.0f) break;
             p_prev = p;
-            const float distFactor = 1.0f + r * 0.05f;
-            // (v_med3_f32 is the clamp for lo <= hi: 1.2 distFactor >= 1.2)
-            float dt = __builtin_amdgcn_fmed3f((r - rh) * 0.1f * distFactor, 0.01f, 1.2f * distFactor);
-            // The shader's far-field block (fragment.glsl.ts:152-156) IS `dt = min(dt, 3.0f)` on every radius
-            // the march can hold (1.15 r_h <= r: the horizon test above leaves first).  r > 30: the un-clamped
-            // step 0.1 (r - r_h)(1 + 0.05 r) exceeds the far boost 0.01 + 0.08 (r - 30) by >= 0.67 there (a
-            // quadratic in r without real roots), so max(dt, boost) = dt unless dt sits at its upper clamp
-            // 1.2f distFactor -- and distFactor = fma(r, 0.05f, 1) >= 2.5f makes that >= 3.0f (1.2f x 2.5f is the
-            // exact tie between 3.0f and its successor: round-to-even gives 3.0f), where the shader's
-            // min(., 1.2 * 2.5) returns 3.0f either way.  r <= 30: distFactor <= 2.5f, dt <= 3.0f, a min
-            // changes nothing -- as the shader, which skips the block.  The 3.0f joins the photon-sphere
-            // limit, min(min(dt, 3), lim) = min(dt, min(lim, 3)): one v_min_f32 for a compare, four
-            // operations and a select.  Every f32 radius, for holes from r_h = 1 to 2000:
-            // tests/test_glsl_fast_identities.py.
-            const float sphereProx = fabsf(r - rph);
-            const float lim = fminf(0.01f + sphereProx * 0.15f, 3.0f);
-            dt = fminf(dt, lim);
-            const float hRefinement = smoothstep_t<ARITH>(0.2f, 0.0f, fabsf(p.y));
-            const float cdt = dt * (1.0f - hRefinement * 0.7f);
+            // Far field: when every ray of the wave is beyond r_far = max(64, r_ph + 21) and at least 0.2 off
+            // the equatorial plane, the step size formed below is 3.0f for each of them, exactly -- the
+            // un-clamped step 0.1 (r - r_h)(1 + 0.05 r) >= 0.013 r (1 + 0.05 r) > 3.5 and its upper clamp
+            // 1.2 (1 + 0.05 r) > 5 there, the photon-sphere limit 0.01 + 0.15 |r - r_ph| > 3.16, all cut by the
+            // min with 3.0f, and the plane refinement is the factor 1.0f -- so the seventeen operations that
+            // would find that out are skipped (every f32 radius: tests/test_glsl_fast_identities.py).  Most
+            // steps of a frame are such steps.
+            float dt, cdt;
+            if (__ballot(!(r > r_far && fabsf(p.y) >= 0.2f)) == 0ull) {
+                dt = cdt = 3.0f;
+            } else {
+                const float distFactor = 1.0f + r * 0.05f;
+                // (v_med3_f32 is the clamp for lo <= hi: 1.2 distFactor >= 1.2)
+                dt = __builtin_amdgcn_fmed3f((r - rh) * 0.1f * distFactor, 0.01f, 1.2f * distFactor);
+                // The shader's far-field block (fragment.glsl.ts:152-156) IS `dt = min(dt, 3.0f)` on every
+                // radius the march can hold (1.15 r_h <= r: the horizon test above leaves first).  r > 30: the
+                // un-clamped step exceeds the far boost 0.01 + 0.08 (r - 30) by >= 0.67 there (a quadratic in r
+                // without real roots), so max(dt, boost) = dt unless dt sits at its upper clamp 1.2f distFactor
+                // -- and distFactor = fma(r, 0.05f, 1) >= 2.5f makes that >= 3.0f (1.2f x 2.5f is the exact tie
+                // between 3.0f and its successor: round-to-even gives 3.0f), where the shader's
+                // min(., 1.2 * 2.5) returns 3.0f either way.  r <= 30: distFactor <= 2.5f, dt <= 3.0f, a min
+                // changes nothing -- as the shader, which skips the block.  The 3.0f joins the photon-sphere
+                // limit, min(min(dt, 3), lim) = min(dt, min(lim, 3)): one v_min3_f32 for a compare, four
+                // operations, a select and a min.
+                const float sphereProx = fabsf(r - rph);
+                const float lim = fminf(0.01f + sphereProx * 0.15f, 3.0f);
+                dt = fminf(dt, lim);
+                // the refinement near the equatorial plane: smoothstep(0.2, 0, |y|) is exactly 0 for |y| >= 0.2
+                // and the step then stays dt (dt * (1 - 0 * 0.7) = dt); skipped when no ray of the wave is
+                // that close
+                cdt = dt;
+                if (__ballot(fabsf(p.y) < 0.2f) != 0ull) {
+                    const float hRefinement = smoothstep_t<ARITH>(0.2f, 0.0f, fabsf(p.y));
+                    cdt = dt * (1.0f - hRefinement * 0.7f);
+                }
+            }
             F3 accel{0.0f, 0.0f, 0.0f};
             if (lensing) {
                 accel = glsl_accel_from_geom(geom, p, v, a);
@@ -698,7 +731,7 @@ __device__ uint32_t glsl_fragment(const GlslParams &U, uint32_t width, uint32_t 
                 if (disk) glsl_sample_disk<ARITH>(U, p, p_prev, v, isco, M, a, cdt, col, alpha, r_new);
             }
             if (disk) opaque = alpha > 0.99f;
-            if (jets && !opaque) glsl_sample_jets<ARITH>(U, p, v, rh, dt, col, alpha); // un-refined dt (fragment.glsl.ts:219)
+            if (jets && !opaque) glsl_sample_jets<ARITH>(U, p, v, rh, dt, col, alpha, r_new); // un-refined dt (fragment.glsl.ts:219)
         }
         steps = (uint32_t)i;
         hitHorizon = hitHorizon || (hz && !opaque && i < maxSteps);

@@ -9,6 +9,8 @@ fma steps formed exactly in float64 (the product of two f32 has 48 bits; each su
    the hole: the far boost never binds there, and above r = 30 the upper clamp is >= 3.0f.
 2. The two-term twist polynomials used when the whole wave turns by less than 1/16 rad stay within
    0.51 ulp of sin and 1.01 ulp of cos (no worse than the full FAST polynomials) and within one ulp of them.
+3. The far-field path: beyond r_far = max(64, r_ph + 21) and |y| >= 0.2 the whole step-size head is the
+   constant 3.0f, and below 2^-12 rad the twist polynomials return exactly (angle, 1.0f).
 """
 import numpy as np
 import pytest
@@ -98,3 +100,43 @@ def test_tiny_twist_polynomials():
     assert (np.abs(c2.astype(np.float64) - cf.astype(np.float64)) <= ulp_c).all()
     # and they agree bit for bit on nearly every angle
     assert (s2 == sf).mean() > 0.95 and (c2 == cf).mean() > 0.95
+
+
+def _lim(r, rph):
+    return np.minimum(_fma(np.abs(r - F(rph)), F(0.15), F(0.01)), F(3.0))
+
+
+@pytest.mark.parametrize("rh,rph", [(1.0447, 1.0745), (2.0, 3.0), (1.0447, 3.9), (17.9, 50.0), (140.0, 500.0)])
+def test_far_field_step_is_three(rh, rph):
+    """every f32 radius from r_far to the far exit: clamp, far block, photon-sphere limit and plane
+    refinement (|y| >= 0.2) together give exactly 3.0f -- what the wave-uniform far path assigns"""
+    r_far = max(64.0, float(F(rph) + F(21.0)))
+    n = 0
+    for r in _all_f32(np.nextafter(F(max(r_far, 1.15 * rh)), F(np.inf)), 10000.0):
+        _, dt = _shader_dt(r, rh)
+        dt = np.minimum(dt, _lim(r, rph))
+        assert (dt == F(3.0)).all()
+        n += r.size
+    assert n > 1_000_000
+    # the plane refinement: smoothstep(0.2, 0, |y|) = 0 and the factor 1 - 0 * 0.7 = 1 for |y| >= 0.2
+    y = np.concatenate([np.array([0.2, 0.20000002, 0.25, 1.0, 1e4], F), np.nextafter(F(0.2), F(1.0), dtype=F)[None]])
+    t = np.clip((np.abs(y) - F(0.2)) * F(1.0 / (0.0 - 0.2)), F(0.0), F(1.0))
+    h = t * t * _fma(t, F(-2.0), F(3.0))
+    assert (h == 0).all() and (F(3.0) * _fma(h, F(-0.7), F(1.0)) == F(3.0)).all()
+
+
+def test_twist_below_two_to_the_minus_twelve_is_the_identity_rotation():
+    """|angle| < 2^-12: both polynomial tiers of glsl_fast_sincos return exactly (angle, 1.0f), which is
+    what the first tier assigns.  Every f32 of the top four binades below 2^-12, and a sample below."""
+    lo, hi = F(2.0 ** -16), np.nextafter(F(2.0 ** -12), F(0.0))
+    for chunk in list(_all_f32(lo, hi)) + [(10.0 ** np.random.default_rng(3).uniform(-30, -4.9, 100000)).astype(F)]:
+        for ang in (chunk, -chunk):
+            z = ang * ang
+            s2 = _fma(ang * z, _fma(z, F(8.3333333333e-3), F(-1.6666666667e-1)), ang)
+            c2 = _fma(z * z, F(4.1666666667e-2), _fma(z, F(-0.5), F(1.0)))
+            ps = _fma(z, _fma(z, F(-1.9515295891e-4), F(8.3321608736e-3)), F(-1.6666654611e-1))
+            sf = _fma(ang * z, ps, ang)
+            pc = _fma(z, _fma(z, F(2.443315711809948e-5), F(-1.388731625493765e-3)), F(4.166664568298827e-2))
+            cf = _fma(z * z, pc, _fma(z, F(-0.5), F(1.0)))
+            assert np.array_equal(s2, ang) and np.array_equal(sf, ang)
+            assert (c2 == F(1.0)).all() and (cf == F(1.0)).all()
