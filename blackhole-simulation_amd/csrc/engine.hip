@@ -793,7 +793,7 @@ size_t grv_integrate_ray_relativistic_ex(grv_engine *e, const double *initial_st
     o.max_steps = steps;
     o.escape_radius = 1000.0;
     o.renormalize_interval = 10;
-    o.arith = GRV_ARITH_STRICT;
+    o.arith = e->ray_arith;
     if (!options_valid(o)) { // cannot fail for the fixed options above; kept so a later edit of them is checked
         fail(e, GRV_ERR_INVALID, "integrate_ray_relativistic: invalid options");
         for (int i = 0; i < 8; ++i) out[i] = std::nan("");
@@ -813,7 +813,8 @@ size_t grv_integrate_ray_relativistic_ex(grv_engine *e, const double *initial_st
     SingleRayIn in;
     std::memcpy(in.v, initial_state, sizeof in.v);
     const uint32_t seq = ++e->ray_seq ? e->ray_seq : ++e->ray_seq; // never 0 (the block starts zeroed)
-    st = launch_single_ray(o.metric_kind, P, in, o.initial_step, e->ray_out, seq, e->ray_stream);
+    st = (o.arith == GRV_ARITH_FAST ? launch_single_ray_fast : launch_single_ray)(
+        o.metric_kind, P, in, o.initial_step, e->ray_out, seq, e->ray_stream);
     if (st != hipSuccess) return nan_out("launch", st);
     // poll the sequence word; a ray that runs for seconds falls back to a blocking wait
     const uint32_t *flag = &e->ray_out->seq;
@@ -1055,6 +1056,14 @@ int grv_last_ray_clocks(const grv_engine *e, uint64_t out3[3]) {
     out3[0] = e->ray_out->loop_cycles;
     out3[1] = e->ray_out->loop_ticks;
     out3[2] = e->ray_out->tries;
+    return GRV_OK;
+}
+
+int grv_engine_set_ray_arith(grv_engine *e, int32_t arith) {
+    if (!e) return GRV_ERR_INVALID;
+    if (arith != GRV_ARITH_STRICT && arith != GRV_ARITH_FAST)
+        return fail(e, GRV_ERR_INVALID, "grv_engine_set_ray_arith: invalid arith %d", arith);
+    e->ray_arith = arith;
     return GRV_OK;
 }
 

@@ -75,6 +75,7 @@ struct grv_engine {
     hipStream_t ray_stream = nullptr;
     grvhip::SingleRayOut *ray_out = nullptr; // pinned, host-coherent
     uint32_t ray_seq = 0;
+    int ray_arith = GRV_ARITH_STRICT; // contract of the one-ray entry (grv_engine_set_ray_arith)
 
     // staging buffers for host-pointer entry points
     void *stage_mem = nullptr;

@@ -193,6 +193,8 @@ hipError_t launch_path_strict(int kind, int method, const RayWorkspace &ws, cons
                               hipStream_t s);
 hipError_t launch_single_ray(int kind, const SegmentParams &P, const SingleRayIn &in, double h0,
                              SingleRayOut *out_pinned, uint32_t seq, hipStream_t s);
+hipError_t launch_single_ray_fast(int kind, const SegmentParams &P, const SingleRayIn &in, double h0,
+                                  SingleRayOut *out_pinned, uint32_t seq, hipStream_t s); // kernels_fast.hip
 hipError_t launch_init_states(int kind, const RayWorkspace &ws, const SegmentParams &P,
                               const double *states, double h0, int adaptive, hipStream_t s);
 hipError_t launch_init_pixels(int kind, const RayWorkspace &ws, const SegmentParams &P,

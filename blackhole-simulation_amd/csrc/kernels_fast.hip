@@ -59,6 +59,26 @@ hipError_t launch_segment_fast(int kind, int method, const RayWorkspace &ws,
 #undef GRV_PATH_ARITH
 #undef GRV_PATH_FN
 
+// grv_integrate_ray_relativistic under the FAST contract (grv_engine_set_ray_arith): the same one-launch
+// kernel with the shared-reciprocal right-hand side -- a third of the STRICT instruction count, and a lone
+// wave's time is its instruction count
+hipError_t launch_single_ray_fast(int kind, const SegmentParams &P, const SingleRayIn &in, double h0,
+                                  SingleRayOut *out_pinned, uint32_t seq, hipStream_t s) {
+    switch (kind) {
+    case GRV_METRIC_KERR_KS:
+        hipLaunchKernelGGL((single_ray_kernel<GRV_METRIC_KERR_KS, GRV_ARITH_FAST>), dim3(1), dim3(64), 0, s, P, in, h0, out_pinned, seq);
+        break;
+    case GRV_METRIC_KERR_BL:
+        hipLaunchKernelGGL((single_ray_kernel<GRV_METRIC_KERR_BL, GRV_ARITH_FAST>), dim3(1), dim3(64), 0, s, P, in, h0, out_pinned, seq);
+        break;
+    case GRV_METRIC_SCHWARZSCHILD:
+        hipLaunchKernelGGL((single_ray_kernel<GRV_METRIC_SCHWARZSCHILD, GRV_ARITH_FAST>), dim3(1), dim3(64), 0, s, P, in, h0, out_pinned, seq);
+        break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_wgsl_symplectic_fast(const FrameGeom &G, const WgslParams &P, float *out_rgba,
                                        uint32_t *out_steps, unsigned long long *total_steps,
                                        uint32_t n_slots, hipStream_t s) {

@@ -302,6 +302,8 @@ def load_library():
     L.grv_multi_rank_frame_stats.argtypes = [p, i, C.POINTER(FrameStats)]
     L.grv_last_ray_clocks.restype = i
     L.grv_last_ray_clocks.argtypes = [p, C.POINTER(C.c_uint64 * 3)]
+    L.grv_engine_set_ray_arith.restype = i
+    L.grv_engine_set_ray_arith.argtypes = [p, C.c_int32]
     L.grv_test_set_try_bound.restype = i
     L.grv_test_set_try_bound.argtypes = [p, C.c_uint32]
     L.grv_multi_test_self_exchange.restype = i
@@ -489,6 +491,11 @@ class PhysicsEngine:
         return out[:n].copy()
 
     integratePhotonGeodesic = integrate_ray_relativistic  # BASELINE.json's name for the same export
+
+    def set_ray_arith(self, arith):
+        """Contract of the one-ray entry on this handle: ARITH_STRICT (default, the oracle's bits) or
+        ARITH_FAST (rounding differences only, a third of the latency)."""
+        self._check(self._lib.grv_engine_set_ray_arith(self._h, int(arith)), "set_ray_arith")
 
     # ---- batch extension ----
     def integrate_batch(self, states, options):

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GRV_ABI_VERSION 5
+#define GRV_ABI_VERSION 6
 
 typedef struct grv_engine grv_engine;
 
@@ -181,6 +181,13 @@ size_t grv_integrate_ray_relativistic_ex(grv_engine *e, const double *initial_st
                                          size_t steps, double tolerance, int use_kerr_schild,
                                          double *out, uint32_t *steps_taken, uint8_t *termination,
                                          double *max_drift);
+
+/* Arithmetic contract of grv_integrate_ray_relativistic[_ex] on this handle (an extension: gravitas-wasm
+ * has one arithmetic).  GRV_ARITH_STRICT, the default: the reference's operation order, the oracle's bits.
+ * GRV_ARITH_FAST: the same equations with shared reciprocals and FMA -- rounding differences only (<= 1e-5
+ * relative on the end state, median <= 1e-9: tests/test_full_frame_parity.py) at a third of the
+ * instructions, which for one ray on one wave is a third of the time. */
+int grv_engine_set_ray_arith(grv_engine *e, int32_t arith);
 
 /* the device's own clocks around the try loop of the LAST grv_integrate_ray_relativistic* call:
  * out3 = {shader cycles (s_memtime), ticks of the constant 100 MHz counter (s_memrealtime), integrator

@@ -353,6 +353,27 @@ static napi_value m_set_auto_spin(napi_env env, napi_callback_info info) { /* li
     return NULL;
 }
 
+/* set_ray_arith("strict" | "fast") -- an extension (gravitas-wasm has one arithmetic): the contract of
+ * integrate_ray_relativistic / integratePhotonGeodesic on this engine.  "strict", the default, returns the
+ * reference-order bits; "fast" the same geodesic to rounding (<= 1e-5 relative, median <= 1e-9) in a
+ * third of the time (grv_engine_set_ray_arith). */
+static napi_value m_set_ray_arith(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    engine_box *b = unwrap(env, info, &argc, argv);
+    if (!b) return NULL;
+    char name[16] = {0};
+    size_t len = 0;
+    if (argc < 1 || napi_get_value_string_utf8(env, argv[0], name, sizeof name, &len) != napi_ok ||
+        (strcmp(name, "strict") != 0 && strcmp(name, "fast") != 0)) {
+        napi_throw_type_error(env, NULL, "set_ray_arith: expected \"strict\" or \"fast\"");
+        return NULL;
+    }
+    if (grv_engine_set_ray_arith(b->h, strcmp(name, "fast") == 0 ? GRV_ARITH_FAST : GRV_ARITH_STRICT) != GRV_OK)
+        napi_throw_error(env, NULL, "set_ray_arith failed");
+    return NULL;
+}
+
 static napi_value m_tick_sab(napi_env env, napi_callback_info info) { /* lib.rs:308 */
     size_t argc = 1;
     napi_value argv[1];
@@ -1219,6 +1240,7 @@ static napi_value module_init(napi_env env, napi_value exports) {
         METHOD("compute_g_factor", m_compute_g_factor),
         METHOD("integrate_ray_relativistic", m_integrate_ray),
         METHOD("integratePhotonGeodesic", m_integrate_ray),
+        METHOD("set_ray_arith", m_set_ray_arith),
         METHOD("generate_spectrum_lut", m_generate_spectrum_lut),
         METHOD("generate_disk_lut", m_generate_disk_lut),
         METHOD("compute_shadow_curve", m_compute_shadow_curve),

@@ -120,6 +120,9 @@ export class PhysicsEngine {
   integratePhotonGeodesic(
     initial_state: Float64Array | number[], steps: number, tolerance: number, use_kerr_schild: boolean,
   ): Float64Array;
+  /** extension: arithmetic contract of the two entries above on this engine -- "strict" (default: the
+   *  reference-order bits) or "fast" (the same geodesic to rounding, <= 1e-5 relative, a third of the time) */
+  set_ray_arith(contract: "strict" | "fast"): void;
 
   generate_disk_lut(): Float32Array;
   get_disk_lut_ptr(): number;

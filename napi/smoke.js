@@ -38,6 +38,14 @@ const wasm = require(path.join(__dirname, "blackhole_physics.node"));
   let lit = 0;
   for (let i = 0; i < frame.rgba.length; i += 4) if (frame.rgba[i] + frame.rgba[i + 1] + frame.rgba[i + 2] > 0) lit++;
   res.frame = { rays: frame.rays, acceptedSteps: frame.acceptedSteps, lit: lit, alpha0: frame.rgba[3] };
+  // the one-ray entry under the FAST contract, and back
+  engine.set_ray_arith("fast");
+  res.ray_fast = Array.from(engine.integratePhotonGeodesic(
+    new Float64Array([0, 20, Math.PI / 2, 0, -1, -1, 0, 3.5]), 10000, 1e-8, true));
+  engine.set_ray_arith("strict");
+  res.ray_again = Array.from(engine.integrate_ray_relativistic(
+    new Float64Array([0, 20, Math.PI / 2, 0, -1, -1, 0, 3.5]), 10000, 1e-8, true));
+  try { engine.set_ray_arith("sloppy"); res.bad_arith = "accepted"; } catch (e) { res.bad_arith = e.constructor.name; }
   // the renderers' frame surfaces (WebGLRenderer.render / WebGPURenderer.render)
   const gl = engine.renderWebGLFrame({ width: 64, height: 36, spin: 0.9, maxRaySteps: 200 });
   let glMax = 0;

@@ -149,6 +149,46 @@ def test_fused_single_ray_equals_batch_and_oracle(bh, oracle):
             assert np.array_equal(e.integrate_ray_relativistic(rays[0][0], 200, 1e-8, True), first)
 
 
+def test_single_ray_under_the_fast_contract(bh, oracle):
+    """grv_engine_set_ray_arith(FAST): the one-ray entry runs the FAST kernel -- bitwise the FAST 1-ray
+    batch (same advance_one), the oracle's geodesic to rounding (same class, same step count on these
+    rays, end state within 1e-6) -- and goes back to the oracle's bits under STRICT.  An invalid
+    contract is refused and changes nothing."""
+    rays = [
+        ([0.0, 20.0, np.pi / 2, 0.0, -1.0, -1.0, 0.0, 3.5], 0.9, 10000, 1e-8, True),
+        ([0.0, 20.0, np.pi / 2, 0.0, -1.0, -1.0, 0.0, 3.5], 0.9, 10000, 1e-8, False),
+        ([0.0, 15.0, 1.1, 0.3, -1.0, -0.9, 1.5, -2.0], 0.999, 500, 1e-9, True),
+        ([0.0, 8.0, 0.7, 0.0, -1.0, -1.0, 0.2, 0.1], 0.5, 3, 1e-8, True),
+    ]
+    lib = bh.load_library()
+    for v8, spin, steps, tol, ks in rays:
+        with bh.PhysicsEngine(1.0, spin) as e:
+            strict = e.integrate_ray_relativistic(v8, steps, tol, ks)
+            e.set_ray_arith(bh.ARITH_FAST)
+            a = np.ascontiguousarray(v8, np.float64)
+            fast = np.zeros(8)
+            ns, tm, dr = C.c_uint32(0), C.c_uint8(0), C.c_double(0.0)
+            lib.grv_integrate_ray_relativistic_ex(e._h, a.ctypes.data_as(C.c_void_p), 8, steps, tol, 1 if ks else 0,
+                                                  fast.ctypes.data_as(C.c_void_p), C.byref(ns), C.byref(tm), C.byref(dr))
+            o = bh.engine.default_options(metric_kind=bh.KERR_KS if ks else bh.KERR_BL, tolerance=tol,
+                                          max_steps=steps, arith=bh.ARITH_FAST)
+            b = e.integrate_batch(np.array([v8]), o)
+            assert np.array_equal(fast, b["states"][0]) and ns.value == b["steps"][0] and tm.value == b["term"][0]
+            so = bh.engine.default_options(metric_kind=bh.KERR_KS if ks else bh.KERR_BL, tolerance=tol,
+                                           max_steps=steps, arith=bh.ARITH_STRICT)
+            sb = e.integrate_batch(np.array([v8]), so)
+            assert tm.value == sb["term"][0] and ns.value == sb["steps"][0]
+            scale = np.maximum(np.abs(strict), 1.0)
+            assert (np.abs(fast - strict) / scale).max() < 1e-6, (fast, strict)
+            with pytest.raises(bh.GravitasError):
+                e.set_ray_arith(7)
+            assert np.array_equal(e.integrate_ray_relativistic(v8, steps, tol, ks), fast)   # still FAST
+            e.set_ray_arith(bh.ARITH_STRICT)
+            assert np.array_equal(e.integrate_ray_relativistic(v8, steps, tol, ks), strict)
+        ref = oracle.integrate_ray_relativistic(1.0, spin, v8, steps, tol, ks)
+        assert np.array_equal(strict, np.asarray(ref))
+
+
 def test_distributed_frame_on_one_gpu_is_the_plain_frame(bh, torch_mod):
     """render_frame_distributed without a process group (world 1): the assembled image is the
     row-major frame, not a tile permutation of it (the whole-frame render is already row-major)."""

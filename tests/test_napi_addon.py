@@ -35,6 +35,8 @@ WASM_METHODS = [
     "renderWebGPUFrame", "renderWebGLFrame",
     # bulk / non-blocking entries
     "integrate_batch", "integrateBatch", "integrateBatchAsync", "renderFrameAsync",
+    # contract of the one-ray entry (grv_engine_set_ray_arith)
+    "set_ray_arith",
 ]
 
 pytestmark = pytest.mark.skipif(NODE is None or not os.path.exists(ADDON),
@@ -119,6 +121,8 @@ def test_smoke_js_matches_oracle(oracle):
     ref = oracle.integrate_ray_relativistic(1.0, 0.9, [0, 20, math.pi / 2, 0, -1, -1, 0, 3.5], 10000,
                                             1e-8, True)
     assert np.allclose(res["ray"], ref, rtol=1e-6, atol=1e-6)
+    assert res["ray_again"] == res["ray"] and res["ray_fast"] != res["ray"]      # FAST and back to STRICT
+    assert np.allclose(res["ray_fast"], res["ray"], rtol=1e-6, atol=1e-6) and res["bad_arith"] == "TypeError"
     assert res["echo"] == [1, 2, 3]                                  # lib.rs:429-431
     lut = oracle.blackbody_lut(8, 2, 1e5).reshape(-1)
     assert np.allclose(res["lut0"], lut[28:32], rtol=1e-5)

@@ -36,6 +36,20 @@ if __name__ == "__main__":
             print(json.dumps({"call": "integrate_ray_relativistic", "case": label, "us_per_call": round(dt * 1e6, 1)}), flush=True)
         print(json.dumps({"call": "integrate_ray_relativistic", "case": "per accepted step (224 steps, overhead removed)",
                           "us_per_step": round((res[10000] - res[0]) / 224 * 1e6, 3)}), flush=True)
+        # the same entry under the FAST contract (grv_engine_set_ray_arith): a third of the instructions
+        e.set_ray_arith(bh.ARITH_FAST)
+        e.integrate_ray_relativistic(v, 10000, 1e-8, True)
+        t = time.perf_counter()
+        for _ in range(500):
+            e.integrate_ray_relativistic(v, 10000, 1e-8, True)
+        dtf = (time.perf_counter() - t) / 500
+        clk = (C.c_uint64 * 3)()
+        e._lib.grv_last_ray_clocks(e._h, C.byref(clk))
+        print(json.dumps({"call": "integrate_ray_relativistic", "case": "doc-test ray to termination, FAST contract",
+                          "us_per_call": round(dtf * 1e6, 1), "tries": int(clk[2]),
+                          "cycles_per_try": round(clk[0] / max(clk[2], 1), 1),
+                          "speedup_over_strict": round(res[10000] / dtf, 2)}), flush=True)
+        e.set_ray_arith(bh.ARITH_STRICT)
         for nb in (1, 64, 4096, 262144):
             st = np.tile(v, (nb, 1))
             st[:, 7] = np.linspace(3.0, 4.0, nb) if nb > 1 else 3.5
