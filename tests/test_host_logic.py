@@ -279,3 +279,21 @@ def test_bench_refuses_what_it_cannot_run_before_touching_a_device():
     r = subprocess.run([sys.executable, bench, "--config", "c3", "--arith", "packed"], capture_output=True, text=True,
                        timeout=300, env=env, cwd=ROOT)
     assert r.returncode != 0 and "packed" in r.stderr
+
+
+def test_committed_counter_passes_are_of_the_library_in_the_tree(engine_mod):
+    """profiles/traffic.json is stamped with the code hash of every kernel its PMC passes ran on; the
+    roofline blocks bench.py prints quote it only for the same kernel.  The stamps must be those of the
+    library in the tree, or a bench line would say `stale` -- so a kernel change without new passes
+    fails here, on the CPU, before it reaches a GPU box."""
+    import json
+    import sys
+    sys_path = os.path.join(ROOT, "tools")
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    import kernel_resources as kr
+    t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    lib = engine_mod.library_path()
+    assert len(t["kernels"]) >= 6
+    for name, ent in t["kernels"].items():
+        assert kr.kernel_code_hash(lib, name.split("@")[0]) == ent["code_hash"], name

@@ -72,7 +72,8 @@ def code_objects(path):
 def kernel_code_hash(path, pretty_name):
     """sha256 (first 16 hex digits) of one kernel's machine code + kernel descriptor, located
     through the code object's symbol table.  `pretty_name` as printed by this tool, e.g.
-    'integrate_segment_kernel<1,1,0>'.  Changes whenever the compiled kernel changes and only then:
+    'integrate_segment_kernel<1,1,0>'.  Changes whenever the compiled kernel changes and only then
+    (the descriptor's offset to the code is masked: it depends on the other kernels of the unit):
     profiles/traffic.json is stamped with it and bench.py drops the committed PMC figures when
     the stamp and the library on disk disagree."""
     import hashlib
@@ -98,7 +99,13 @@ def kernel_code_hash(path, pretty_name):
                 o = st_value - sec[3] + sec[4]
                 parts["kd" if name.endswith(".kd") else "text"] = elf[o:o + st_size]
             if "text" in parts:
-                h = hashlib.sha256(parts["text"] + parts.get("kd", b"")).hexdigest()[:16]
+                # the descriptor's KERNEL_CODE_ENTRY_BYTE_OFFSET (bytes 16-23: the distance from the
+                # descriptor to the code) moves whenever ANOTHER kernel of the translation unit changes
+                # size; it is masked so that the stamp follows this kernel's code and resources only
+                kd = bytearray(parts.get("kd", b""))
+                if len(kd) >= 24:
+                    kd[16:24] = b"\0" * 8
+                h = hashlib.sha256(parts["text"] + bytes(kd)).hexdigest()[:16]
                 return h
     return None
 
