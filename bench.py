@@ -26,12 +26,12 @@ fixed and each rank integrates 1/N of the rays.  --scaling weak grows the image 
 (W*gx) x (H*gy), gx*gy = N, instead (every GPU integrates one full frame's worth of rays).
 
 Two hosts drive N > 1, both through the same C ABI and the same 64x64 round-robin tile deal:
-  bare `python bench.py --gpus N`  (--launcher native, the default without a launcher): ONE process,
-      the C ABI's multi-GPU handle (grv_engine_create_multi: a host thread and two streams per device,
-      one RCCL send/recv group per frame) -- the host BASELINE's north_star names;
-  under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (WORLD_SIZE set; or
-      bare with --launcher torchrun): one process per GPU, one grv_engine each, the gather through
-      torch.distributed's nccl backend (= RCCL).
+  under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (WORLD_SIZE set), or a
+      bare `python bench.py --gpus N` (which starts those N ranks itself): one process per GPU, one
+      grv_engine each, the gather through torch.distributed's nccl backend (= RCCL) -- the default;
+  `python bench.py --gpus N --launcher native`: ONE process, the C ABI's multi-GPU handle
+      (grv_engine_create_multi: a host thread and two streams per device, one RCCL send/recv group
+      per frame) -- the host BASELINE's north_star names; explicit until it has run on >= 2 devices.
 Either line carries transport, rccl_version, rank_devices and the per-rank integrate times.
 
 The frame loop holds no host wait: frames are queued back to back, the per-frame counters
@@ -63,6 +63,10 @@ B_RAY = {"c3": 96, "c4": 56, "c2": 56}
 # flops are no longer estimated: they are the hardware's own count of the profiled launch
 # (SQ_INSTS_VALU_FLOPS_* x 64 lanes, profiles/traffic.json -> valu.flops_counted_per_launch), quoted
 # only when the library on disk holds the very kernel the counters were read on
+# SURVEY.md 8(d)'s algorithmic flops per unit, the fallback when no counter pass of the kernel on
+# disk is committed: ~1.3 kflop per accepted RKF45 step (f64), ~0.5 kflop per implicit-midpoint step,
+# ~0.15 kflop per Cartesian-Verlet step
+F_STEP = {"c3": 1300.0, "c4": 500.0, "c2": 500.0, "c2glsl": 150.0}
 KERNEL_OF = {("c3", "fast"): "integrate_segment_kernel<1,1,0>",
              ("c3", "strict"): "integrate_segment_kernel<1,0,0>",
              ("c4", "fast"): "wgsl_symplectic_fast_kernel",
@@ -226,6 +230,83 @@ def committed_pmc(kernel_pretty, lib_path, frame=None):
     return ent, "profiles/traffic.json (code object %s)" % now
 
 
+def roofline_block(cfg, glsl, kernel_pretty, avg_launch_ms, launches_per_frame, ray_steps_per_frame, rays_per_frame,
+                   pmc, pmc_src, same_workload, segment_tries, timing_note):
+    """The roofline object of the JSON line, against the bound that binds.
+
+    The march kernels are register-resident: what bounds them is vector-ALU issue, not HBM (real HBM
+    traffic of the f64 frame kernel: 0.65 % of SURVEY 8(d)'s algorithmic bytes).  So
+      bound    = "fp64_valu" (c3 / c5) or "fp32_valu" (c2 / c4),
+      achieved = flops of one launch / this run's mean launch time (HIP events), in TFLOP/s,
+      peak     = the guide's vector peak for the dtype (78.6 / 157.3 TFLOP/s),
+      frac     = achieved / peak -- always a number.
+    flops of one launch = flops per ray-step x the ray-steps one launch of THIS run processed, where
+    flops per ray-step is the hardware's own count (SQ_INSTS_VALU_FLOPS_* x 64 lanes of the committed
+    rocprofv3 pass, profiles/traffic.json) when that pass was taken on the very code object in the
+    library on disk ("counted"), else SURVEY 8(d)'s algorithmic figure ("algorithmic").
+    SURVEY 8(d)'s byte figure stays beside it as `hbm_nominal` (algorithmic bytes / launch time against
+    8 TB/s: saturated by construction for a kernel that keeps its state in registers) together with
+    the HBM rate the counters saw."""
+    f64 = cfg == "c3"
+    peak_tf = FP64_PEAK_TFLOPS if f64 else FP32_PEAK_TFLOPS
+    bkey = cfg
+    steps_per_launch = ray_steps_per_frame / max(launches_per_frame, 1.0)
+    v = (pmc.get("valu") or {}) if pmc else {}
+    counted = v.get("flops_counted_per_launch")
+    prof_steps = None
+    if counted:
+        # ray-steps of the profiled launch: recorded with the pass (format >= 3); a pass of the same
+        # deterministic workload without the field processed exactly this run's steps
+        prof_steps = pmc.get("ray_steps_per_launch") or (ray_steps_per_frame if same_workload else None)
+    if counted and prof_steps:
+        flops_per_step = counted / prof_steps
+        source = ("counted: SQ_INSTS_VALU_FLOPS_* x 64 lanes of the profiled launch (%s) / its %d ray-steps"
+                  % (pmc_src, int(prof_steps)))
+        kind = "counted"
+    else:
+        flops_per_step = F_STEP["c2glsl" if glsl else cfg]
+        source = "algorithmic: SURVEY 8(d) flops per step (%s)" % pmc_src
+        kind = "algorithmic"
+    flops_per_launch = flops_per_step * steps_per_launch
+    tf = flops_per_launch / (avg_launch_ms * 1e-3) / 1e12
+    bytes_per_launch = (ray_steps_per_frame * B_STEP[bkey] + rays_per_frame * B_RAY[bkey]) / max(launches_per_frame, 1.0)
+    nominal = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
+    # HBM bytes per launch from the counters: the one-launch pass, or the pass of the K-try schedule
+    traffic = None
+    traffic_src = pmc_src
+    if pmc and same_workload and not segment_tries:
+        traffic = pmc.get("hbm_bytes_per_launch")
+    elif pmc and same_workload and segment_tries:
+        seg = pmc.get("segment_tries_%d" % segment_tries)
+        if seg:
+            traffic = seg.get("hbm_bytes_per_launch")
+            traffic_src = pmc_src + ", --segment-tries %d pass" % segment_tries
+        else:
+            traffic_src = "no committed FETCH/WRITE pass of the --segment-tries %d schedule" % segment_tries
+    elif pmc:
+        traffic_src = "not applicable to this run (committed pass: 1 GPU, whole frame, %s)" % pmc_src
+    hbm = {"achieved": round(nominal, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "nominal_frac": round(nominal / HBM_PEAK_GBS, 4),
+           "algorithmic_bytes_per_launch": int(bytes_per_launch),
+           "bytes_model": "SURVEY 8(d): %d B per ray-step + %d B per ray" % (B_STEP[bkey], B_RAY[bkey]),
+           "hbm_measured_GBps": round(traffic / (avg_launch_ms * 1e-3) / 1e9, 1) if traffic else None,
+           "hbm_measured_frac": round(traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+           "reason": "nominal: the bytes a state-through-HBM march would move; this kernel keeps a ray's state in "
+                     "registers from launch to exit%s, so the figure saturates by construction and the kernel is "
+                     "judged on roofline.frac (vector-ALU flops) and valu_issue_frac"
+                     % (" of a segment" if segment_tries else "")}
+    out = {"bound": "fp64_valu" if f64 else "fp32_valu", "achieved": round(tf, 2), "peak": peak_tf,
+           "unit": "TFLOP/s", "frac": round(tf / peak_tf, 4), "traffic": traffic, "traffic_source": traffic_src,
+           "traffic_pass": pmc.get("pass_id") if pmc else None,
+           "kernel": kernel_pretty, "avg_launch_ms": round(avg_launch_ms, 4),
+           "launches_per_frame": launches_per_frame, "ray_steps_per_launch": int(steps_per_launch),
+           "flops_per_ray_step": round(flops_per_step, 1), "flops_per_launch": int(flops_per_launch),
+           "flops_source": kind, "flops_source_detail": source, "timing": timing_note,
+           "valu_issue_frac": v.get("issue_frac") if (pmc and same_workload and not segment_tries) else None,
+           "hbm_nominal": hbm}
+    return out
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: re-run this command line under
     torch.distributed.run with N ranks on this node (one per visible GPU) and pass rank 0's JSON
@@ -341,41 +422,39 @@ def main_native(args, cfg, base_w, base_h):
     elapsed = time.perf_counter() - t0
     st = m.frame_stats()
     total_steps = float(st.accepted_steps)
-    # the dominant kernel of one rank's share, from profiled frames after the timed loop (c3: HIP
-    # events recorded by the library on each rank's launch stream; the slowest rank counts)
-    roofline = None
-    rank_ms = None
-    if cfg == "c3":
-        k = max(args.profile_frames, 1)
-        m.frame_stats_reset()
-        for i in range(k):
-            frame(i, prof)
-            m.synchronize()  # one frame at a time: the events then bracket one launch per rank
-        pst = m.frame_stats()
-        per_rank = [m.rank_frame_stats(r) for r in range(G)]
-        rank_ms = [round(p.integrate_ms / k, 4) for p in per_rank]
-        launches_per_rank = max(pst.launches / G, 1.0)
-        avg_launch_ms = pst.integrate_ms / max(launches_per_rank, 1.0)
-        share_bytes = (pst.accepted_steps / k * B_STEP[cfg] + W * H * B_RAY[cfg]) / G / max(launches_per_rank / k, 1.0)
-        achieved = share_bytes / (avg_launch_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                    "traffic_source": "not applicable to this run (committed pass: 1 GPU, whole frame)",
-                    "kernel": KERNEL_OF[(cfg, args.arith)], "avg_launch_ms": round(avg_launch_ms, 4),
-                    "launches_per_frame": launches_per_rank / k,
-                    "algorithmic_bytes_per_launch": int(share_bytes),
-                    "timing": "%d profiled frames after the timed loop, slowest rank's share (mean share bytes)" % k,
-                    "bound_actual": "fp64_valu_issue"}
+    # the dominant kernel of one rank's share, from profiled frames after the timed loop: HIP events the
+    # library records on each rank's launch stream around its integrate / march launch (c3: profile=1
+    # frames; c4: grv_engine_profile_shader_frames on every rank's engine); the slowest rank counts
+    k = max(args.profile_frames, 1)
+    m.frame_stats_reset()
+    if cfg != "c3":
+        m.profile_shader_frames(True)
+    for i in range(k):
+        frame(i, prof)
+        m.synchronize()  # one frame at a time: the events then bracket one launch per rank
+    per_rank = [m.rank_frame_stats(r) for r in range(G)]
+    if cfg != "c3":
+        m.profile_shader_frames(False)
+    rank_ms = [round(p.integrate_ms / max(p.launches, 1), 4) for p in per_rank]
+    slow = max(range(G), key=lambda r: rank_ms[r])
+    launches_per_frame = max(per_rank[slow].launches / k, 1.0)
+    avg_launch_ms = per_rank[slow].integrate_ms / max(per_rank[slow].launches, 1)
+    kernel_pretty = KERNEL_OF[(cfg, args.arith)]
+    pmc, pmc_src = committed_pmc(kernel_pretty, bh.library_path(), (W, H))
+    same_workload = bool(pmc and G == 1 and (cfg != "c3" or TOL == 1e-8) and (W, H) == tuple(pmc.get("frame", (W, H))))
+    roofline = roofline_block(cfg, False, kernel_pretty, avg_launch_ms, launches_per_frame,
+                              per_rank[slow].accepted_steps / k, W * H / G, pmc, pmc_src, same_workload,
+                              args.segment_tries,
+                              "%d profiled frames after the timed loop, slowest rank's share (rank %d)" % (k, slow))
     line = {
         "metric": "Mray-steps/s", "value": round(total_steps / elapsed / 1e6, 2), "unit": "Mray-steps/s",
         "n_gpus": G, "ranks": m.ranks, "rank_devices": m.rank_devices(),
         "launcher": "native (one process, grv_engine_create_multi)",
         "transport": {bh.TRANSPORT_RCCL: "rccl", bh.TRANSPORT_PEER_COPY: "peer_copy"}.get(m.transport, m.transport),
         "rccl_version": bh.rccl_probe()[0] if m.transport == bh.TRANSPORT_RCCL else None,
-        "rank_integrate_ms": ({"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms,
-                               "source": "HIP events around each rank's integrate launch, mean of %d profiled "
-                                         "frames after the timed loop" % max(args.profile_frames, 1)}
-                              if rank_ms else None),
+        "rank_integrate_ms": {"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms,
+                              "source": "HIP events around each rank's integrate / march launch, mean of %d profiled "
+                                        "frames after the timed loop" % max(args.profile_frames, 1)},
         "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f64" if cfg == "c3" else "f32", "data": "synthetic",
@@ -414,9 +493,9 @@ def main():
                     help="--config c2: the WebGL fragment shader's Verlet march (default, the reference's "
                          "production loop) or the WGSL compute march")
     ap.add_argument("--launcher", choices=["auto", "native", "torchrun"], default="auto",
-                    help="N > 1 host: native = ONE process through the C ABI's multi-GPU handle; torchrun = one "
-                         "process per GPU under torch.distributed.run.  auto: torchrun when started by a launcher "
-                         "(WORLD_SIZE set), native for a bare command")
+                    help="N > 1 host: torchrun (= auto) = one process per GPU under torch.distributed.run, started "
+                         "by this script when no launcher did; native = ONE process through the C ABI's multi-GPU "
+                         "handle (explicit: not yet run on two real devices)")
     ap.add_argument("--tolerance", type=float, default=None, help="RKF45 tolerance of the f64 frame (default 1e-8; c5: 1e-9)")
     ap.add_argument("--arith", choices=["fast", "strict", "packed"], default=None,
                     help="arithmetic contract (default: fast for c3; packed = the FAST contract with two rays per "
@@ -471,7 +550,11 @@ def main():
         raise SystemExit("--config c2 is BASELINE configs[1]: one GPU")
     launched = int(os.environ.get("WORLD_SIZE", "0") or 0) >= 1 and "RANK" in os.environ
     if args.launcher == "auto":
-        args.launcher = "torchrun" if launched else "native"
+        # N > 1 defaults to one process per GPU under torch.distributed.run (the driver's own launch form,
+        # the host the world-size-2 tests cover).  The one-process C-ABI handle (--launcher native) has
+        # never met two real devices (tests/test_gpu_multi_real.py is gated on >= 2 GPUs and has not run):
+        # it stays an explicit choice until a MULTICHIP record shows it green.
+        args.launcher = "torchrun"
     if args.native or (args.gpus > 1 and args.launcher == "native"):
         if launched and int(os.environ["WORLD_SIZE"]) > 1:
             raise SystemExit("--launcher native is one process: do not start it under torch.distributed.run")
@@ -683,53 +766,19 @@ def main():
 
     if rank == 0:
         value = total_steps / elapsed / 1e6
-        # roofline of the dominant kernel: algorithmic bytes of the rays this rank integrated per
-        # launch / mean HIP-event duration of a launch
-        per_frame_bytes = prof_steps_per_frame * B_STEP[cfg] + rays_local * B_RAY[cfg]
+        # roofline of the dominant kernel against the bound that binds it (vector-ALU flops of this rank's
+        # launch / mean HIP-event duration of a launch); SURVEY 8(d)'s byte figure rides along as hbm_nominal
         frames_prof = args.steps if in_loop_profile else max(args.profile_frames, 1)
         launches_per_frame = max(launches / frames_prof, 1.0)
         avg_launch_ms = integ_ms / max(launches, 1)
-        achieved = (per_frame_bytes / launches_per_frame) / (avg_launch_ms * 1e-3) / 1e9
         kernel_pretty = KERNEL_OF[("c4" if wp is not None else cfg, args.arith)]
         if cfg == "c2" and args.arith == "packed":
             kernel_pretty = "wgsl_symplectic_pk_b256_kernel"  # budgets <= 512: the four-wave-block form (kernels_fast.hip)
         pmc, pmc_src = committed_pmc(kernel_pretty, bh.library_path(), (W, H))
-        usable_pmc = pmc if (pmc and world == 1 and not args.segment_tries and (cfg != "c3" or TOL == 1e-8) and
-                             (W, H) == tuple(pmc.get("frame", (W, H)))) else None
-        peak_tf = FP64_PEAK_TFLOPS if cfg == "c3" else FP32_PEAK_TFLOPS
-        nominal_frac = achieved / HBM_PEAK_GBS
-        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(nominal_frac, 4) if nominal_frac <= 1.0 else None,
-                    # achieved / peak as computed, whatever it is (SURVEY 8(d)'s bytes are algorithmic: the
-                    # register-resident kernel does not move them, so on a fast box the figure can pass 1)
-                    "nominal_frac": round(nominal_frac, 4),
-                    "traffic": usable_pmc.get("hbm_bytes_per_launch") if usable_pmc else None,
-                    "traffic_source": pmc_src if usable_pmc or not pmc else
-                    "not applicable to this run (committed pass: 1 GPU, default schedule, %s)" % pmc_src,
-                    "kernel": kernel_pretty,
-                    "avg_launch_ms": round(avg_launch_ms, 4),
-                    "launches_per_frame": launches_per_frame,
-                    "algorithmic_bytes_per_launch": int(per_frame_bytes / launches_per_frame),
-                    "timing": prof_note,
-                    # what actually bounds the register-resident kernel: vector-ALU issue
-                    "bound_actual": "fp64_valu_issue" if cfg == "c3" else "fp32_valu_issue"}
-        if nominal_frac > 1.0:
-            roofline["frac_reason"] = ("SURVEY 8(d)'s %d B per ray-step would be %.2f TB/s, above the HBM peak: the march is "
-                                       "register-resident and does not move them; the kernel is judged on valu_issue_frac"
-                                       % (B_STEP[cfg], achieved / 1e3))
-        if usable_pmc:
-            roofline["hbm_measured_GBps"] = round(usable_pmc["hbm_bytes_per_launch"] / (avg_launch_ms * 1e-3) / 1e9, 1)
-            v = usable_pmc.get("valu") or {}
-            if "issue_frac" in v:
-                # fraction of the chip's VALU issue slots the profiled launch filled:
-                # (SQ_ACTIVE_INST_VALU - SQ_ACTIVE_INST_VALU2) x 4 cycles / (1024 SIMDs x elapsed cycles)
-                roofline["valu_issue_frac"] = v["issue_frac"]
-            if v.get("flops_counted_per_launch"):
-                tf = v["flops_counted_per_launch"] / (avg_launch_ms * 1e-3) / 1e12
-                roofline.update({"counted_tflops": round(tf, 2), "peak_tflops": peak_tf,
-                                 "flops_frac": round(tf / peak_tf, 4),
-                                 "flops_per_ray_step": round(v["flops_counted_per_launch"] / max(prof_steps_per_frame, 1.0), 1),
-                                 "flops_source": "SQ_INSTS_VALU_FLOPS_* x 64 lanes of the profiled launch (%s)" % pmc_src})
+        same_workload = bool(pmc and world == 1 and (cfg != "c3" or TOL == 1e-8) and
+                             (W, H) == tuple(pmc.get("frame", (W, H))))
+        roofline = roofline_block(cfg, glsl, kernel_pretty, avg_launch_ms, launches_per_frame, prof_steps_per_frame,
+                                  rays_local, pmc, pmc_src, same_workload, args.segment_tries, prof_note)
         split = "" if world == 1 else (" split over %d GPUs" % world if args.scaling == "strong"
                                          else " (%dx%d per GPU x %d)" % (base_w, base_h, world))
         workload = workload_text(cfg, W, H, split)

@@ -1,6 +1,8 @@
 // engine.hip -- lifecycle, closed forms, batch / single-ray / frame entry points of the C ABI
 // (include/gravitas_abi.h) on top of the segment kernels.  See engine_internal.hpp.
 #include "engine_internal.hpp"
+
+#include <atomic>
 #include "strict_libm.hpp"
 
 #include <chrono>
@@ -345,7 +347,7 @@ int end_frame_stats(grv_engine *e, hipStream_t s) {
 // Four events of the next profiled frame from the ring (created on demand).  When the ring is
 // full the pending frames are resolved first (one synchronise every kEvRingFrames frames).
 constexpr size_t kEvRingFrames = 1024;
-static int ring_events(grv_engine *e, hipEvent_t **ev4) {
+int ring_events(grv_engine *e, hipEvent_t **ev4) {
     if (e->ev_frames >= kEvRingFrames) {
         const int rc = resolve_frame_events(e);
         if (rc != GRV_OK) return rc;
@@ -536,6 +538,7 @@ void grv_engine_destroy(grv_engine *e) {
         if (W.done) (void)hipEventDestroy(W.done);
     }
     if (e->stage_mem) (void)hipFree(e->stage_mem);
+    if (e->d_march_cursors) (void)hipFree(e->d_march_cursors);
     if (e->path_stage) (void)hipHostFree(e->path_stage);
     if (e->d_lut) (void)hipFree(e->d_lut);
     if (e->d_disk_lut) (void)hipFree(e->d_disk_lut);
@@ -739,10 +742,12 @@ int grv_integrate_paths(grv_engine *e, size_t n, const double *states, const Grv
             GRV_HIP(e, hipMemcpy(out_paths, d_paths, n * max_points * 64, hipMemcpyDeviceToHost));
         } else if (kmax) {
             // ragged rows: the first kmax points of a block of rays leave the device in ONE strided
-            // transfer into pinned staging (<= 64 MiB a block), the rows are cut to length on the host
-            // -- not one blocking copy per ray (thousands of rays from integrate_batch({recordPath}))
+            // transfer into pinned staging (<= 16 MiB a block), the rows are cut to length on the host
+            // -- not one blocking copy per ray (thousands of rays from integrate_batch({recordPath})).
+            // Staging above 4 MiB is handed back when the call ends (a one-off large call must not pin
+            // host memory until grv_engine_destroy); grv_engine_host_bytes reports what is held.
             const size_t row = kmax * 64;
-            size_t rays_per_block = ((size_t)64 << 20) / row;
+            size_t rays_per_block = ((size_t)16 << 20) / row;
             rays_per_block = rays_per_block ? rays_per_block : 1;
             rays_per_block = rays_per_block < n ? rays_per_block : n;
             if (e->path_stage_bytes < rays_per_block * row) {
@@ -761,6 +766,11 @@ int grv_integrate_paths(grv_engine *e, size_t n, const double *states, const Grv
                     const size_t k = out_counts[i0 + i] < max_points ? out_counts[i0 + i] : max_points;
                     if (k) std::memcpy(out_paths + (i0 + i) * max_points * 8, stage + i * row, k * 64);
                 }
+            }
+            if (e->path_stage_bytes > ((size_t)4 << 20)) {
+                (void)hipHostFree(e->path_stage);
+                e->path_stage = nullptr;
+                e->path_stage_bytes = 0;
             }
         }
     }
@@ -846,6 +856,35 @@ size_t grv_integrate_ray_relativistic(grv_engine *e, const double *initial_state
 }
 
 uint32_t grv_tile_pitch(uint32_t width, uint32_t tile_world) { return tile_pitch(width, tile_world); }
+
+// The tile deal, the ONE implementation of it (hosts above the ABI -- distributed.py, the addon --
+// ask, they do not recompute): ids 0 .. pitch * rows - 1, id k -> rank k mod world.
+uint32_t grv_tiles_total(uint32_t width, uint32_t height, uint32_t tile_world) {
+    return tile_pitch(width, tile_world == 0 ? 1u : tile_world) * ((height + 63u) / 64u);
+}
+uint32_t grv_max_tiles_per_rank(uint32_t width, uint32_t height, uint32_t tile_world) {
+    const uint32_t w = tile_world == 0 ? 1u : tile_world;
+    return (grv_tiles_total(width, height, w) + w - 1u) / w;
+}
+uint32_t grv_tiles_of_rank(uint32_t width, uint32_t height, uint32_t tile_world, uint32_t tile_rank,
+                           uint32_t *out_ids, uint32_t capacity) {
+    GrvRenderParams q{};
+    q.width = width;
+    q.height = height;
+    q.tile_world = tile_world == 0 ? 1u : tile_world;
+    q.tile_rank = tile_rank;
+    if (q.tile_rank >= q.tile_world) return 0;
+    FrameGeom G;
+    frame_geometry(q, G);
+    for (uint32_t tl = 0; out_ids && tl < G.n_tiles_local && tl < capacity; ++tl)
+        out_ids[tl] = tl * G.tile_world + G.tile_rank;
+    return G.n_tiles_local;
+}
+void grv_tile_origin(uint32_t tile, uint32_t width, uint32_t tile_world, uint32_t *x0, uint32_t *y0) {
+    const uint32_t pitch = tile_pitch(width, tile_world == 0 ? 1u : tile_world);
+    if (x0) *x0 = (tile % pitch) * 64u;
+    if (y0) *y0 = (tile / pitch) * 64u;
+}
 
 size_t grv_frame_ray_count(const GrvRenderParams *p) {
     if (!p) return 0;
@@ -1036,7 +1075,7 @@ size_t grv_engine_device_bytes(const grv_engine *e) {
     for (const auto &W : e->wset) b += W.bytes;
     if (e->d_lut) b += (size_t)e->lut_w * e->lut_h * 4 * sizeof(float);
     if (e->d_disk_lut) b += 4096 + kDiskLutWidth * sizeof(double);
-    if (e->d_noise) b += 2u * 256u * 256u;
+    if (e->d_noise) b += 2u * 256u * 256u + 256u * 256u * sizeof(float); // two R8 planes + the f32 texel plane
     if (e->rt.mem) b += (size_t)3 * e->rt.w * e->rt.h * 4 * sizeof(float);
     return b;
 }
@@ -1067,10 +1106,34 @@ int grv_engine_set_ray_arith(grv_engine *e, int32_t arith) {
     return GRV_OK;
 }
 
+// Verification hooks answer only after grv_test_hooks_unlock(GRV_TEST_HOOKS_KEY): a stray call from
+// production code cannot truncate rays or reshuffle exchange buffers.
+static std::atomic<bool> g_test_hooks{false};
+int grv_test_hooks_unlock(uint32_t key) {
+    if (key != GRV_TEST_HOOKS_KEY) return GRV_ERR_INVALID;
+    g_test_hooks.store(true);
+    return GRV_OK;
+}
+int grv_test_hooks_unlocked(void) { return g_test_hooks.load() ? 1 : 0; }
+
 int grv_test_set_try_bound(grv_engine *e, uint32_t tries) {
     if (!e) return GRV_ERR_INVALID;
+    if (!g_test_hooks.load())
+        return fail(e, GRV_ERR_INVALID, "grv_test_set_try_bound: verification hooks are locked (grv_test_hooks_unlock)");
     e->try_bound_override = tries;
     return GRV_OK;
+}
+uint32_t grv_test_try_bound(const grv_engine *e) { return e ? e->try_bound_override : 0u; }
+
+int grv_engine_profile_shader_frames(grv_engine *e, int enable) {
+    if (!e) return GRV_ERR_INVALID;
+    e->profile_shader = enable != 0;
+    return GRV_OK;
+}
+
+size_t grv_engine_host_bytes(const grv_engine *e) {
+    if (!e) return 0;
+    return e->path_stage_bytes + sizeof(FrameStatsDev) + 64; // pinned: path staging, counter read-back, ray result
 }
 
 int grv_stats_accumulate(grv_engine *e, int enable) {

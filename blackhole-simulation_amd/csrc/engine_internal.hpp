@@ -108,6 +108,7 @@ struct grv_engine {
     std::vector<hipEvent_t> ev_ring; // 4 per profiled frame, created on demand
     size_t ev_frames = 0;            // profiled frames whose events are still unresolved
     std::vector<uint8_t> ev_loop;    // per pending frame: integrate was timed launch by launch
+    bool profile_shader = false;     // grv_engine_profile_shader_frames: f32 march launches take ring events too
 
     // renderer layer (grv_webgpu_render / grv_webgl_render): full-size RGBA f32 targets
     struct Targets {
@@ -118,6 +119,10 @@ struct grv_engine {
     } rt;
     void *post_mem = nullptr; // bloom render targets (bright, blur ping/pong)
     size_t post_bytes = 0;
+    // resident march grids (engine_types.hpp): 64 self-resetting {claimed, done} cursor pairs, one per
+    // launch in turn (launches in flight on different streams never share a pair)
+    uint32_t *d_march_cursors = nullptr;
+    uint32_t march_turn = 0;
     uint8_t *d_noise = nullptr; // [2][256*256] R planes: u_noiseTex, u_blueNoiseTex
     std::vector<float> disk_lut = std::vector<float>(512, 0.0f); // lut_buffer (lib.rs:50, 65-66)
     std::vector<float> sab;
@@ -176,6 +181,7 @@ struct CallScope {
 // hard bound on the integrator tries of one ray (see run_segments)
 uint32_t try_bound(const grv_engine *e, uint64_t max_steps);
 int resolve_frame_events(grv_engine *e);
+int ring_events(grv_engine *e, hipEvent_t **ev4);
 uint32_t tile_pitch(uint32_t width, uint32_t world);
 void frame_geometry(const GrvRenderParams &p, FrameGeom &G);
 void stats_to_abi(const grv_engine *e, const FrameStatsDev &d, GrvFrameStats *out);
@@ -203,7 +209,29 @@ int run_shader_frame(grv_engine *e, uint32_t width, uint32_t height, uint32_t tw
         const int rc = begin_frame_stats(e, s);
         if (rc != GRV_OK) return rc;
     }
-    GRV_HIP(e, launch(G, (uint32_t)slots, &e->d_stats->accepted_steps));
+    // profiled shader frames: the march launch between two pairs of ring events on its own stream
+    // (resolved by grv_frame_stats into integrate_ms / launches, as for the f64 frame)
+    hipEvent_t *ev4 = nullptr;
+    if (e->profile_shader && e->ev_ok) {
+        const int rc = ring_events(e, &ev4);
+        if (rc != GRV_OK) return rc;
+        GRV_HIP(e, hipEventRecord(ev4[0], s));
+        GRV_HIP(e, hipEventRecord(ev4[1], s));
+    }
+    if (!e->d_march_cursors) {
+        GRV_HIP(e, hipMalloc(reinterpret_cast<void **>(&e->d_march_cursors), 64 * 2 * sizeof(uint32_t)));
+        GRV_HIP(e, hipMemset(e->d_march_cursors, 0, 64 * 2 * sizeof(uint32_t)));
+    }
+    uint32_t *cursor = e->d_march_cursors + 2u * (e->march_turn++ & 63u);
+    GRV_HIP(e, launch(G, (uint32_t)slots, &e->d_stats->accepted_steps, cursor));
+    if (ev4) {
+        GRV_HIP(e, hipEventRecord(ev4[2], s));
+        GRV_HIP(e, hipEventRecord(ev4[3], s));
+        e->ev_loop.resize(e->ev_frames + 1);
+        e->ev_loop[e->ev_frames] = 0;
+        e->ev_frames += 1;
+        e->last_launches += 1;
+    }
     if (total_steps) {
         GRV_HIP(e, hipMemcpyAsync(e->h_stats, e->d_stats, sizeof(FrameStatsDev), hipMemcpyDeviceToHost, s));
         GRV_HIP(e, hipStreamSynchronize(s));

@@ -184,16 +184,20 @@ struct grv_multi {
     std::vector<grv_engine *> eng;
     std::string err;
 
+    int format = GRV_EXCHANGE_RGBA32F; // what travels: RGBA f32 (16 B / pixel) or RGBA binary16 (8 B / pixel)
+
     struct Rank {
         hipStream_t s[2] = {nullptr, nullptr};
-        float *send[2] = {nullptr, nullptr}; // packed tile-order RGBA f32 (ranks >= 1; rank 0 under self_exchange)
+        float *send[2] = {nullptr, nullptr}; // packed tile-order RGBA f32 (ranks >= 1; rank 0 under self_exchange
+                                             // and, RGBA16F, as its f32 render target)
+        void *send16[2] = {nullptr, nullptr}; // RGBA16F: the share as it travels (ranks that exchange)
         hipEvent_t arrived[2] = {nullptr, nullptr}; // this rank's tiles of frame parity b sit in rank 0's slot
     };
     std::vector<Rank> rank;
     size_t slot_px = 0; // pixels per receive slot / send buffer (max tiles of a rank * 4096)
 
     // rank 0 side
-    float *recv[2] = {nullptr, nullptr}; // [G][slot_px][4] per parity
+    float *recv[2] = {nullptr, nullptr}; // [G][slot_px][4] per parity (RGBA16F: [G][slot_px] x 8 B in the same allocation)
     hipStream_t rs[2] = {nullptr, nullptr}; // exchange + unpack streams
     hipEvent_t unpacked[2] = {nullptr, nullptr};
     bool unpacked_rec[2] = {false, false};
@@ -237,17 +241,17 @@ size_t max_tiles_per_rank(uint32_t width, uint32_t height, uint32_t world) {
     return (total + world - 1) / world;
 }
 
-// Buffers sized for a width x height frame split over G ranks (grown on demand; growing waits for
-// the device -- frames of a fixed size never do).
-int ensure_buffers(grv_multi *m, uint32_t width, uint32_t height) {
-    const size_t need = max_tiles_per_rank(width, height, (uint32_t)m->G) * 4096u;
-    if (need <= m->slot_px) return GRV_OK;
+// Waits for the devices and frees every exchange buffer (the next frame allocates for the mode /
+// size then in force).
+int drop_buffers(grv_multi *m) {
     for (int r = 0; r < m->G; ++r) {
         GRVM_HIP(m, hipSetDevice(m->dev[r]));
         GRVM_HIP(m, hipDeviceSynchronize());
         for (int b = 0; b < 2; ++b) {
             if (m->rank[r].send[b]) (void)hipFree(m->rank[r].send[b]);
+            if (m->rank[r].send16[b]) (void)hipFree(m->rank[r].send16[b]);
             m->rank[r].send[b] = nullptr;
+            m->rank[r].send16[b] = nullptr;
         }
     }
     GRVM_HIP(m, hipSetDevice(m->dev[0]));
@@ -257,13 +261,28 @@ int ensure_buffers(grv_multi *m, uint32_t width, uint32_t height) {
         m->unpacked_rec[b] = false;
     }
     m->slot_px = 0;
+    return GRV_OK;
+}
+
+// Buffers sized for a width x height frame split over G ranks (grown on demand; growing waits for
+// the device -- frames of a fixed size never do).
+int ensure_buffers(grv_multi *m, uint32_t width, uint32_t height) {
+    const size_t need = max_tiles_per_rank(width, height, (uint32_t)m->G) * 4096u;
+    if (need <= m->slot_px) return GRV_OK;
+    int rc = drop_buffers(m);
+    if (rc != GRV_OK) return rc;
+    const bool half = m->format == GRV_EXCHANGE_RGBA16F;
+    const size_t wire = half ? 8u : 16u; // bytes per pixel as exchanged
     for (int b = 0; b < 2; ++b)
-        GRVM_HIP(m, hipMalloc(reinterpret_cast<void **>(&m->recv[b]), (size_t)m->G * need * 16u));
+        GRVM_HIP(m, hipMalloc(reinterpret_cast<void **>(&m->recv[b]), (size_t)m->G * need * wire));
     for (int r = 0; r < m->G; ++r) {
-        if (r == 0 && !m->self_exchange) continue; // rank 0 renders into its receive slot
+        const bool direct = (r == 0 && !m->self_exchange); // rank 0's share needs no transport
+        if (direct && !half) continue;                     // ... and, RGBA f32, is rendered into its receive slot
         GRVM_HIP(m, hipSetDevice(m->dev[r]));
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 2; ++b) {
             GRVM_HIP(m, hipMalloc(reinterpret_cast<void **>(&m->rank[r].send[b]), need * 16u));
+            if (half && !direct) GRVM_HIP(m, hipMalloc(&m->rank[r].send16[b], need * 8u));
+        }
     }
     m->slot_px = need;
     return GRV_OK;
@@ -277,11 +296,14 @@ int run_frame(grv_multi *m, uint32_t width, uint32_t height, float *d_rgba, hipS
     if (!d_rgba) return mfail(m, GRV_ERR_INVALID, "null image");
     if (width == 0 || height == 0) return mfail(m, GRV_ERR_INVALID, "empty frame");
     const int G = m->G;
+    const bool half = m->format == GRV_EXCHANGE_RGBA16F;
     if (G == 1 && !m->self_exchange) {
         // one rank: the whole frame is already row-major (GrvFrameBuffers), nothing to exchange
         GRVM_HIP(m, hipSetDevice(m->dev[0]));
         const int rc = render(0, m->eng[0], d_rgba, caller);
         if (rc != GRV_OK) return mfail(m, rc, "rank 0: %s", grv_last_error(m->eng[0]));
+        // RGBA16F: the image a G-rank handle assembles is the half-rounded frame; so is this one
+        if (half) GRVM_HIP(m, launch_post_quantize(d_rgba, width * height, caller));
         m->frame++;
         return GRV_OK;
     }
@@ -298,6 +320,7 @@ int run_frame(grv_multi *m, uint32_t width, uint32_t height, float *d_rgba, hipS
         n_px[r] = grv_frame_ray_count(&geom);
     }
     const bool rccl = m->transport == GRV_TRANSPORT_RCCL;
+    const size_t wire = half ? 8u : 16u;
 
     // every rank: render its share (and, peer-copy transport, push it to rank 0) on its own thread
     rc = m->threads->run([&](int r) -> int {
@@ -306,17 +329,25 @@ int run_frame(grv_multi *m, uint32_t width, uint32_t height, float *d_rgba, hipS
         hipStream_t s = R.s[b];
         // the receive slot of this parity is free once frame - 2 has been unpacked
         if (m->unpacked_rec[b] && hipStreamWaitEvent(s, m->unpacked[b], 0) != hipSuccess) return GRV_ERR_HIP;
-        float *slot = m->recv[b] + (size_t)r * m->slot_px * 4u;
+        // receive slot of rank r: f32 pixels, or (RGBA16F) 8-byte pixels in the same allocation
+        char *slot = reinterpret_cast<char *>(m->recv[b]) + (size_t)r * m->slot_px * wire;
         const bool direct = (r == 0 && !m->self_exchange);
-        float *target = direct ? slot : R.send[b];
+        float *target = (direct && !half) ? reinterpret_cast<float *>(slot) : R.send[b];
         if (n_px[r] > 0) {
             const int st = render(r, m->eng[r], target, s);
             if (st != GRV_OK) return st;
         }
+        const void *wire_src = target;
+        if (half && n_px[r] > 0) {
+            // narrow the share to binary16 where it was rendered: rank 0's straight into its slot
+            void *dst = direct ? static_cast<void *>(slot) : R.send16[b];
+            if (launch_pack_half(target, dst, n_px[r], s) != hipSuccess) return GRV_ERR_HIP;
+            wire_src = dst;
+        }
         if (!direct && !rccl && n_px[r] > 0) {
             const hipError_t st = (m->dev[r] == m->dev[0])
-                                      ? hipMemcpyAsync(slot, target, n_px[r] * 16u, hipMemcpyDeviceToDevice, s)
-                                      : hipMemcpyPeerAsync(slot, m->dev[0], target, m->dev[r], n_px[r] * 16u, s);
+                                      ? hipMemcpyAsync(slot, wire_src, n_px[r] * wire, hipMemcpyDeviceToDevice, s)
+                                      : hipMemcpyPeerAsync(slot, m->dev[0], wire_src, m->dev[r], n_px[r] * wire, s);
             if (st != hipSuccess) return GRV_ERR_HIP;
         }
         // RCCL: the event marks "rendered"; the transfer itself is ordered by ncclRecv on rank 0's stream
@@ -339,9 +370,13 @@ int run_frame(grv_multi *m, uint32_t width, uint32_t height, float *d_rgba, hipS
         ncclResult_t gst = ncclSuccess; // a failed call must not leave the group open: always reach GroupEnd
         for (int r = (m->self_exchange ? 0 : 1); r < G && gst == ncclSuccess; ++r) {
             if (n_px[r] == 0) continue;
-            gst = g_rccl.Send(m->rank[r].send[b], n_px[r] * 4u, ncclFloat, 0, m->comm[r], m->rank[r].s[b]);
+            // four channels per pixel either way: ncclFloat or ncclHalf elements
+            const ncclDataType_t ty = half ? ncclHalf : ncclFloat;
+            const void *src = half ? m->rank[r].send16[b] : static_cast<const void *>(m->rank[r].send[b]);
+            gst = g_rccl.Send(src, n_px[r] * 4u, ty, 0, m->comm[r], m->rank[r].s[b]);
             if (gst == ncclSuccess)
-                gst = g_rccl.Recv(m->recv[b] + (size_t)r * m->slot_px * 4u, n_px[r] * 4u, ncclFloat, r, m->comm[0], rs);
+                gst = g_rccl.Recv(reinterpret_cast<char *>(m->recv[b]) + (size_t)r * m->slot_px * wire, n_px[r] * 4u, ty, r,
+                                  m->comm[0], rs);
         }
         const ncclResult_t gend = g_rccl.GroupEnd();
         if (gst != ncclSuccess) return mfail(m, GRV_ERR_HIP, "ncclSend / ncclRecv failed: %s", g_rccl.GetErrorString(gst));
@@ -355,14 +390,17 @@ int run_frame(grv_multi *m, uint32_t width, uint32_t height, float *d_rgba, hipS
     GRVM_HIP(m, hipStreamWaitEvent(rs, m->caller_ready, 0));
     if (G == 1) {
         // (self-exchange walk) one rank's share is the whole frame, already row-major
-        GRVM_HIP(m, hipMemcpyAsync(d_rgba, m->recv[b], n_px[0] * 16u, hipMemcpyDeviceToDevice, rs));
+        if (half) GRVM_HIP(m, launch_widen_half(m->recv[b], d_rgba, n_px[0], rs));
+        else GRVM_HIP(m, hipMemcpyAsync(d_rgba, m->recv[b], n_px[0] * 16u, hipMemcpyDeviceToDevice, rs));
     } else {
         for (int r = 0; r < G; ++r) {
             if (n_px[r] == 0) continue;
             geom.tile_rank = (uint32_t)r;
             FrameGeom FG;
             frame_geometry(geom, FG);
-            GRVM_HIP(m, launch_unpack_tiles(FG, m->recv[b] + (size_t)r * m->slot_px * 4u, d_rgba, 4u, rs));
+            const char *slot = reinterpret_cast<const char *>(m->recv[b]) + (size_t)r * m->slot_px * wire;
+            if (half) GRVM_HIP(m, launch_unpack_tiles_half(FG, slot, d_rgba, rs));
+            else GRVM_HIP(m, launch_unpack_tiles(FG, slot, d_rgba, 4u, rs));
         }
     }
     GRVM_HIP(m, hipEventRecord(m->unpacked[b], rs));
@@ -393,7 +431,7 @@ int create_common(double mass, double spin, const std::vector<int> &devs, bool v
     if (transport == GRV_TRANSPORT_RCCL && virt && G > 1) // RCCL: one rank per device
         return cfail(GRV_ERR_INVALID, "multi-GPU handle: RCCL takes one rank per device");
     grv_multi *m = new (std::nothrow) grv_multi();
-    if (!m) return GRV_ERR_OOM;
+    if (!m) return cfail(GRV_ERR_OOM, "multi-GPU handle: out of host memory");
     m->G = G;
     m->dev = devs;
     m->virtual_ranks = virt;
@@ -404,30 +442,46 @@ int create_common(double mass, double spin, const std::vector<int> &devs, bool v
         grv_multi_destroy(m);
         return code;
     };
+    // a failed HIP call: its text goes to grv_multi_create_error (no failure leaves the reason empty)
+    hipError_t hst = hipSuccess;
+    auto hip_bail = [&](const char *what, int r) {
+        const int code = cfail(hst == hipErrorOutOfMemory ? GRV_ERR_OOM : GRV_ERR_HIP, "multi-GPU handle: %s (rank %d, device %d): %s",
+                               what, r, devs[r < 0 ? 0 : r], hipGetErrorString(hst));
+        (void)hipGetLastError();
+        return bail(code);
+    };
+#define GRVC_HIP(call, what, r)                      \
+    do {                                             \
+        hst = (call);                                \
+        if (hst != hipSuccess) return hip_bail(what, r); \
+    } while (0)
     for (int r = 0; r < G; ++r) {
         const int rc = grv_engine_create(mass, spin, devs[r], &m->eng[r]);
-        if (rc != GRV_OK) return bail(rc);
-        if (hipSetDevice(devs[r]) != hipSuccess) return bail(GRV_ERR_HIP);
+        if (rc != GRV_OK)
+            return bail(cfail(rc, "multi-GPU handle: grv_engine_create on device %d (rank %d) failed with status %d%s",
+                              devs[r], r, rc, rc == GRV_ERR_NO_DEVICE ? " (no usable HIP device)" : ""));
+        GRVC_HIP(hipSetDevice(devs[r]), "hipSetDevice", r);
         for (int b = 0; b < 2; ++b) {
-            if (hipStreamCreateWithFlags(&m->rank[r].s[b], hipStreamNonBlocking) != hipSuccess) return bail(GRV_ERR_HIP);
-            if (hipEventCreateWithFlags(&m->rank[r].arrived[b], hipEventDisableTiming) != hipSuccess) return bail(GRV_ERR_HIP);
+            GRVC_HIP(hipStreamCreateWithFlags(&m->rank[r].s[b], hipStreamNonBlocking), "hipStreamCreate", r);
+            GRVC_HIP(hipEventCreateWithFlags(&m->rank[r].arrived[b], hipEventDisableTiming), "hipEventCreate", r);
         }
         // peer access rank r -> rank 0 for the push copies (RCCL sets up its own mappings)
         if (r > 0 && devs[r] != devs[0]) {
             int can = 0;
             if (hipDeviceCanAccessPeer(&can, devs[r], devs[0]) == hipSuccess && can) {
-                const hipError_t st = hipDeviceEnablePeerAccess(devs[0], 0);
-                if (st != hipSuccess && st != hipErrorPeerAccessAlreadyEnabled) return bail(GRV_ERR_HIP);
+                hst = hipDeviceEnablePeerAccess(devs[0], 0);
+                if (hst != hipSuccess && hst != hipErrorPeerAccessAlreadyEnabled) return hip_bail("hipDeviceEnablePeerAccess", r);
                 (void)hipGetLastError();
             }
         }
     }
-    if (hipSetDevice(devs[0]) != hipSuccess) return bail(GRV_ERR_HIP);
+    GRVC_HIP(hipSetDevice(devs[0]), "hipSetDevice", 0);
     for (int b = 0; b < 2; ++b) {
-        if (hipStreamCreateWithFlags(&m->rs[b], hipStreamNonBlocking) != hipSuccess) return bail(GRV_ERR_HIP);
-        if (hipEventCreateWithFlags(&m->unpacked[b], hipEventDisableTiming) != hipSuccess) return bail(GRV_ERR_HIP);
+        GRVC_HIP(hipStreamCreateWithFlags(&m->rs[b], hipStreamNonBlocking), "hipStreamCreate (exchange)", 0);
+        GRVC_HIP(hipEventCreateWithFlags(&m->unpacked[b], hipEventDisableTiming), "hipEventCreate (exchange)", 0);
     }
-    if (hipEventCreateWithFlags(&m->caller_ready, hipEventDisableTiming) != hipSuccess) return bail(GRV_ERR_HIP);
+    GRVC_HIP(hipEventCreateWithFlags(&m->caller_ready, hipEventDisableTiming), "hipEventCreate (caller)", 0);
+#undef GRVC_HIP
     if (transport == GRV_TRANSPORT_RCCL) {
         std::lock_guard<std::mutex> lk(g_rccl_mu);
         // never a silent fall back to peer copies: a handle that asked for RCCL (AUTO between real
@@ -442,7 +496,7 @@ int create_common(double mass, double spin, const std::vector<int> &devs, bool v
         }
     }
     m->threads = new (std::nothrow) RankThreads(G);
-    if (!m->threads) return bail(GRV_ERR_OOM);
+    if (!m->threads) return bail(cfail(GRV_ERR_OOM, "multi-GPU handle: out of host memory (rank threads)"));
     *out = m;
     return GRV_OK;
 }
@@ -479,6 +533,7 @@ void grv_multi_destroy(grv_multi *m) {
         (void)hipSetDevice(m->dev[r]);
         for (int b = 0; b < 2; ++b) {
             if (m->rank[r].send[b]) (void)hipFree(m->rank[r].send[b]);
+            if (m->rank[r].send16[b]) (void)hipFree(m->rank[r].send16[b]);
             if (m->rank[r].s[b]) (void)hipStreamDestroy(m->rank[r].s[b]);
             if (m->rank[r].arrived[b]) (void)hipEventDestroy(m->rank[r].arrived[b]);
         }
@@ -524,25 +579,43 @@ int grv_rccl_probe(int *version, char *msg, size_t msg_len) {
 
 int grv_multi_test_self_exchange(grv_multi *m, int enable) {
     if (!m) return GRV_ERR_INVALID;
-    const int rc = grv_multi_synchronize(m);
+    if (!grv_test_hooks_unlocked())
+        return mfail(m, GRV_ERR_INVALID, "grv_multi_test_self_exchange: verification hooks are locked (grv_test_hooks_unlock)");
+    int rc = grv_multi_synchronize(m);
     if (rc != GRV_OK) return rc;
     // the buffers are laid out for the other mode: drop them, the next frame allocates afresh
-    for (int r = 0; r < m->G; ++r) {
-        GRVM_HIP(m, hipSetDevice(m->dev[r]));
-        for (int b = 0; b < 2; ++b) {
-            if (m->rank[r].send[b]) (void)hipFree(m->rank[r].send[b]);
-            m->rank[r].send[b] = nullptr;
-        }
-    }
-    GRVM_HIP(m, hipSetDevice(m->dev[0]));
-    for (int b = 0; b < 2; ++b) {
-        if (m->recv[b]) (void)hipFree(m->recv[b]);
-        m->recv[b] = nullptr;
-        m->unpacked_rec[b] = false;
-    }
-    m->slot_px = 0;
+    rc = drop_buffers(m);
+    if (rc != GRV_OK) return rc;
     m->self_exchange = enable != 0;
     return GRV_OK;
+}
+
+int grv_multi_set_exchange_format(grv_multi *m, int format) {
+    if (!m) return GRV_ERR_INVALID;
+    if (format != GRV_EXCHANGE_RGBA32F && format != GRV_EXCHANGE_RGBA16F)
+        return mfail(m, GRV_ERR_INVALID, "unknown exchange format %d", format);
+    if (format == m->format) return GRV_OK;
+    int rc = grv_multi_synchronize(m);
+    if (rc != GRV_OK) return rc;
+    rc = drop_buffers(m); // sized for the other pixel width
+    if (rc != GRV_OK) return rc;
+    m->format = format;
+    return GRV_OK;
+}
+int grv_multi_exchange_format(const grv_multi *m) { return m ? m->format : -1; }
+size_t grv_multi_exchange_bytes_per_frame(const grv_multi *m, uint32_t width, uint32_t height) {
+    if (!m) return 0;
+    GrvRenderParams geom{};
+    geom.width = width;
+    geom.height = height;
+    geom.tile_world = (uint32_t)m->G;
+    size_t px = 0;
+    for (int r = (m->self_exchange ? 0 : 1); r < m->G; ++r) {
+        geom.tile_rank = (uint32_t)r;
+        px += grv_frame_ray_count(&geom);
+    }
+    if (m->G == 1 && !m->self_exchange) px = 0;
+    return px * (m->format == GRV_EXCHANGE_RGBA16F ? 8u : 16u);
 }
 
 int grv_multi_rank_frame_stats(grv_multi *m, int rank, GrvFrameStats *out) {

@@ -9,6 +9,7 @@
 //   Trajectory fields         gravitas-core/src/geodesic/mod.rs:149-161
 #pragma once
 
+#include <hip/hip_fp16.h>
 #include "geodesic_kernels.hpp"
 
 namespace {
@@ -293,6 +294,44 @@ __global__ __launch_bounds__(kBlock) void unpack_tiles16_kernel(FrameGeom G, con
         const uint32_t tile = tile_local * G.tile_world + G.tile_rank;
         const uint32_t X = (tile % G.tiles_x) * 64u + px, Y = (tile / G.tiles_x) * 64u + py;
         if (X < G.width && Y < G.height) image[(size_t)Y * G.width + X] = packed[pix];
+    }
+}
+
+// The exchange in the reference's own output format (rgba16float storage texture of the compute pass,
+// src/rendering/webgpu/renderer.ts:163-176): a rank's RGBA f32 share -> four binary16 channels per
+// pixel (round to nearest even, the conversion the post chain's post_store applies), 8 B instead of 16
+// on the wire; rank 0 widens them again while it de-interleaves the tiles.
+__device__ __forceinline__ uint2 rgba_to_half4(float4 c) {
+    const uint32_t x = __half_as_ushort(__float2half_rn(c.x)), y = __half_as_ushort(__float2half_rn(c.y));
+    const uint32_t z = __half_as_ushort(__float2half_rn(c.z)), w = __half_as_ushort(__float2half_rn(c.w));
+    return make_uint2(x | (y << 16), z | (w << 16));
+}
+__device__ __forceinline__ float4 half4_to_rgba(uint2 h) {
+    return make_float4(__half2float(__ushort_as_half((unsigned short)(h.x & 0xFFFFu))),
+                       __half2float(__ushort_as_half((unsigned short)(h.x >> 16))),
+                       __half2float(__ushort_as_half((unsigned short)(h.y & 0xFFFFu))),
+                       __half2float(__ushort_as_half((unsigned short)(h.y >> 16))));
+}
+__global__ __launch_bounds__(kBlock) void pack_half_kernel(const float4 *__restrict__ src, uint2 *__restrict__ dst,
+                                                          size_t n_px) {
+    for (size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x; k < n_px; k += (size_t)gridDim.x * kBlock)
+        dst[k] = rgba_to_half4(src[k]);
+}
+__global__ __launch_bounds__(kBlock) void widen_half_kernel(const uint2 *__restrict__ src, float4 *__restrict__ dst,
+                                                           size_t n_px) {
+    for (size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x; k < n_px; k += (size_t)gridDim.x * kBlock)
+        dst[k] = half4_to_rgba(src[k]);
+}
+__global__ __launch_bounds__(kBlock) void unpack_tiles_half_kernel(FrameGeom G, const uint2 *__restrict__ packed,
+                                                                  float4 *__restrict__ image) {
+    const size_t total = (size_t)G.n_tiles_local * 4096u;
+    for (size_t pix = (size_t)blockIdx.x * kBlock + threadIdx.x; pix < total; pix += (size_t)gridDim.x * kBlock) {
+        const uint32_t tile_local = (uint32_t)(pix >> 12);
+        const uint32_t within = (uint32_t)(pix & 4095u);
+        const uint32_t px = within & 63u, py = within >> 6;
+        const uint32_t tile = tile_local * G.tile_world + G.tile_rank;
+        const uint32_t X = (tile % G.tiles_x) * 64u + px, Y = (tile / G.tiles_x) * 64u + py;
+        if (X < G.width && Y < G.height) image[(size_t)Y * G.width + X] = half4_to_rgba(packed[pix]);
     }
 }
 

@@ -892,4 +892,70 @@ void glsl_fragment_kernel(FrameGeom G, GlslParams U,
     add_steps(total_steps, steps);
 }
 
+#ifdef GRV_FAST_UNIT // (the FAST translation unit only)
+// Resident form of the FAST march (engine_types.hpp "resident march grids"): the grid is the waves the
+// chip holds, each wave claims 8x8 pixel blocks until the list is dry.  Same glsl_fragment<FAST> per
+// pixel: images and step counts are those of glsl_fragment_kernel<1> bit for bit.
+#ifndef GRV_GLSL_RESIDENT_ORDER
+#define GRV_GLSL_RESIDENT_ORDER kOrderOutsideIn
+#endif
+// One struct = the kernel-argument segment.  Every claimed block reads its uniforms from that segment
+// again, through a pointer the optimiser cannot see through (scalar loads, served by the scalar cache):
+// nothing of the prologue stays live across the claim loop, so the register allocation inside a pixel
+// is the one of the dispatched kernel -- with the arguments as plain loop-invariant values the loop form
+// spilled 204 B per lane instead of 44.
+struct GlslResidentArgs {
+    FrameGeom G;
+    GlslParams U;
+    float4 *out_rgba;
+    uint32_t *out_steps;
+    unsigned long long *total_steps;
+    uint32_t n_slots;
+    uint32_t *cursor;
+};
+#ifndef GRV_GLSL_RESIDENT_CALL
+#define GRV_GLSL_RESIDENT_CALL 1
+#endif
+typedef const __attribute__((address_space(4))) GlslResidentArgs *GlslResidentArgsPtr;
+// one claimed 8x8 block.  A real call (GRV_GLSL_RESIDENT_CALL): the pixel code gets the register
+// allocation it has as a kernel of its own -- inlined into the claim loop the march loop came out with
+// scalar reloads of uniforms and a scratch reload per step.
+__device__
+#if GRV_GLSL_RESIDENT_CALL
+    __attribute__((noinline))
+#else
+    __forceinline__
+#endif
+    void glsl_resident_block(uint32_t block) {
+    // the kernel-argument segment (the one GlslResidentArgs), taken here rather than passed in: a pointer
+    // argument of a device function travels in VGPRs, and every uniform would become a vector load
+    GlslResidentArgsPtr a4 = (GlslResidentArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    block = (uint32_t)__builtin_amdgcn_readfirstlane((int)block);
+    const GlslResidentArgs &A = *(const GlslResidentArgs *)a4;
+    const uint32_t slot = (block << 6) + (threadIdx.x & 63u);
+    uint32_t X = 0, Y = 0, oi = 0;
+    uint32_t steps = 0;
+    if (slot < A.n_slots && slot_to_pixel(A.G, slot, X, Y, oi)) {
+        float o[3];
+        steps = glsl_fragment<GRV_ARITH_FAST>(A.U, A.G.width, A.G.height, X, Y, o);
+        if (A.out_rgba) A.out_rgba[oi] = make_float4(o[0], o[1], o[2], 1.0f);
+        if (A.out_steps) A.out_steps[oi] = steps;
+    }
+    add_steps(A.total_steps, steps);
+}
+__global__ __launch_bounds__(kMarchBlock) __attribute__((amdgpu_waves_per_eu(GRV_GLSL_FAST_WAVES)))
+void glsl_fragment_resident_kernel(GlslResidentArgs args) {
+    const uint32_t n_blocks = (args.n_slots + 63u) >> 6;
+    for (;;) {
+        const uint32_t c = resident_claim(args.cursor);
+        if (c >= n_blocks) break;
+#if defined(__HIP_DEVICE_COMPILE__)
+        glsl_resident_block(claim_to_block(c, n_blocks, GRV_GLSL_RESIDENT_ORDER));
+#endif
+    }
+    if (threadIdx.x == 0) resident_leave(args.cursor, gridDim.x);
+}
+
+#endif // GRV_FAST_UNIT
+
 } // namespace

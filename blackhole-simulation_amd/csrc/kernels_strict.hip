@@ -154,6 +154,30 @@ hipError_t launch_finalize_frame(const RayWorkspace &ws, const FrameGeom &G, con
     return hipGetLastError();
 }
 
+static uint32_t stream_grid(size_t n) {
+    size_t g = (n + kBlock - 1) / kBlock;
+    return (uint32_t)(g > 16384 ? 16384 : (g ? g : 1));
+}
+hipError_t launch_pack_half(const float *rgba, void *half4, size_t n_px, hipStream_t s) {
+    if (n_px == 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_half_kernel, dim3(stream_grid(n_px)), dim3(kBlock), 0, s,
+                       reinterpret_cast<const float4 *>(rgba), static_cast<uint2 *>(half4), n_px);
+    return hipGetLastError();
+}
+hipError_t launch_widen_half(const void *half4, float *rgba, size_t n_px, hipStream_t s) {
+    if (n_px == 0) return hipSuccess;
+    hipLaunchKernelGGL(widen_half_kernel, dim3(stream_grid(n_px)), dim3(kBlock), 0, s,
+                       static_cast<const uint2 *>(half4), reinterpret_cast<float4 *>(rgba), n_px);
+    return hipGetLastError();
+}
+hipError_t launch_unpack_tiles_half(const FrameGeom &G, const void *packed_half4, float *image, hipStream_t s) {
+    const size_t total = (size_t)G.n_tiles_local * 4096u;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(unpack_tiles_half_kernel, dim3(stream_grid(total)), dim3(kBlock), 0, s, G,
+                       static_cast<const uint2 *>(packed_half4), reinterpret_cast<float4 *>(image));
+    return hipGetLastError();
+}
+
 hipError_t launch_unpack_tiles(const FrameGeom &G, const void *packed, void *image,
                                uint32_t words_per_pixel, hipStream_t s) {
     const size_t total = (size_t)G.n_tiles_local * 4096u * words_per_pixel;

@@ -15,33 +15,35 @@ TILE = 64
 
 
 def tile_pitch(width, world):
-    """Row pitch of the tile ids: the first integer >= ceil(width / 64) coprime with `world`
-    (grv_tile_pitch, include/gravitas_abi.h).  Ids in the pad column(s) hold no pixels."""
-    import math
-    p = (width + TILE - 1) // TILE
-    while world > 1 and math.gcd(p, world) != 1:
-        p += 1
-    return p
+    """Row pitch of the tile ids: the first integer >= ceil(width / 64) coprime with `world`.  Ids in
+    the pad column(s) hold no pixels.  The deal lives in the library (grv_tile_pitch,
+    include/gravitas_abi.h); this module only asks."""
+    return int(_eng.load_library().grv_tile_pitch(int(width), max(int(world), 1)))
 
 
 def tiles_total(width, height, world=1):
-    """Tile ids of the frame as `world` ranks number them (pad columns included)."""
-    return tile_pitch(width, world) * ((height + TILE - 1) // TILE)
+    """Tile ids of the frame as `world` ranks number them (pad columns included): grv_tiles_total."""
+    return int(_eng.load_library().grv_tiles_total(int(width), int(height), max(int(world), 1)))
 
 
 def tiles_of_rank(width, height, world, rank):
-    """Global tile ids rendered by `rank`, in its packed order."""
-    return list(range(rank, tiles_total(width, height, world), world))
+    """Global tile ids rendered by `rank`, in its packed order: grv_tiles_of_rank."""
+    lib = _eng.load_library()
+    n = lib.grv_tiles_of_rank(int(width), int(height), int(world), int(rank), None, 0)
+    ids = (C.c_uint32 * max(n, 1))()
+    lib.grv_tiles_of_rank(int(width), int(height), int(world), int(rank), ids, n)
+    return [int(ids[k]) for k in range(n)]
 
 
 def tile_origin(tile, width, world):
-    """Pixel (x0, y0) of a tile id; x0 >= width for an id in a pad column."""
-    p = tile_pitch(width, world)
-    return (tile % p) * TILE, (tile // p) * TILE
+    """Pixel (x0, y0) of a tile id; x0 >= width for an id in a pad column: grv_tile_origin."""
+    x0, y0 = C.c_uint32(), C.c_uint32()
+    _eng.load_library().grv_tile_origin(int(tile), int(width), max(int(world), 1), C.byref(x0), C.byref(y0))
+    return int(x0.value), int(y0.value)
 
 
 def max_tiles_per_rank(width, height, world):
-    return (tiles_total(width, height, world) + world - 1) // world
+    return int(_eng.load_library().grv_max_tiles_per_rank(int(width), int(height), max(int(world), 1)))
 
 
 def rank_params(params, world, rank):

@@ -178,6 +178,29 @@ def load_library():
     L.grv_integrate_paths_device.argtypes = [p, sz, p, C.POINTER(Options), sz, p, p, p, p, p, p, p]
     L.grv_tile_pitch.restype = C.c_uint32
     L.grv_tile_pitch.argtypes = [C.c_uint32, C.c_uint32]
+    for name, args in (("grv_tiles_total", 3), ("grv_max_tiles_per_rank", 3)):
+        getattr(L, name).restype = C.c_uint32
+        getattr(L, name).argtypes = [C.c_uint32] * args
+    L.grv_tiles_of_rank.restype = C.c_uint32
+    L.grv_tiles_of_rank.argtypes = [C.c_uint32] * 4 + [p, C.c_uint32]
+    L.grv_tile_origin.restype = None
+    L.grv_tile_origin.argtypes = [C.c_uint32] * 3 + [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.grv_engine_host_bytes.restype = sz
+    L.grv_engine_host_bytes.argtypes = [p]
+    L.grv_engine_profile_shader_frames.restype = i
+    L.grv_engine_profile_shader_frames.argtypes = [p, i]
+    L.grv_test_hooks_unlock.restype = i
+    L.grv_test_hooks_unlock.argtypes = [C.c_uint32]
+    L.grv_test_hooks_unlocked.restype = i
+    L.grv_test_hooks_unlocked.argtypes = []
+    L.grv_test_try_bound.restype = C.c_uint32
+    L.grv_test_try_bound.argtypes = [p]
+    L.grv_multi_set_exchange_format.restype = i
+    L.grv_multi_set_exchange_format.argtypes = [p, i]
+    L.grv_multi_exchange_format.restype = i
+    L.grv_multi_exchange_format.argtypes = [p]
+    L.grv_multi_exchange_bytes_per_frame.restype = sz
+    L.grv_multi_exchange_bytes_per_frame.argtypes = [p, C.c_uint32, C.c_uint32]
     L.grv_frame_ray_count.restype = sz
     L.grv_frame_ray_count.argtypes = [C.POINTER(RenderParams)]
     L.grv_render_frame.restype = i
@@ -652,6 +675,13 @@ class PhysicsEngine:
     def device_bytes(self):
         return int(self._lib.grv_engine_device_bytes(self._h))
 
+    def host_bytes(self):
+        return self._lib.grv_engine_host_bytes(self._h)
+
+    def profile_shader_frames(self, enable=True):
+        self._check(self._lib.grv_engine_profile_shader_frames(self._h, 1 if enable else 0),
+                    "engine_profile_shader_frames")
+
     def stats_accumulate(self, enable=True):
         """Frames stop clearing the device-side counters: one frame_stats() after a loop of
         frames reads their sums (no host wait inside the loop)."""
@@ -793,6 +823,16 @@ class PhysicsEngine:
 
 
 TRANSPORT_AUTO, TRANSPORT_RCCL, TRANSPORT_PEER_COPY = 0, 1, 2
+EXCHANGE_RGBA32F, EXCHANGE_RGBA16F = 0, 1
+TEST_HOOKS_KEY = 0x47525654
+
+
+def unlock_test_hooks():
+    """Verification hooks (grv_test_set_try_bound, grv_multi_test_self_exchange) answer only after this
+    call: tests make it, product hosts never do."""
+    rc = load_library().grv_test_hooks_unlock(TEST_HOOKS_KEY)
+    if rc != 0:
+        raise GravitasError("grv_test_hooks_unlock refused the key")
 
 
 class MultiEngine:
@@ -885,6 +925,27 @@ class MultiEngine:
         self._check(self._lib.grv_multi_rank_frame_stats(self._h, int(rank), C.byref(st)), "multi_rank_frame_stats")
         return st
 
+    def profile_shader_frames(self, enable=True):
+        """f32 march frames of every rank take HIP events on the rank's launch stream
+        (grv_engine_profile_shader_frames on each rank's engine)."""
+        for r in range(self.ranks):
+            eng = self._lib.grv_multi_engine(self._h, r)
+            self._check(self._lib.grv_engine_profile_shader_frames(C.c_void_p(eng), 1 if enable else 0),
+                        "engine_profile_shader_frames")
+
+    def set_exchange_format(self, fmt):
+        """EXCHANGE_RGBA32F (default) or EXCHANGE_RGBA16F: the compute pass's own rgba16float output
+        format on the wire, half the bytes of the one exchange."""
+        self._check(self._lib.grv_multi_set_exchange_format(self._h, int(fmt)), "multi_set_exchange_format")
+
+    @property
+    def exchange_format(self):
+        return self._lib.grv_multi_exchange_format(self._h)
+
+    def exchange_bytes_per_frame(self, width, height):
+        return self._lib.grv_multi_exchange_bytes_per_frame(self._h, int(width), int(height))
+
     def test_self_exchange(self, enable=True):
         """Verification hook: rank 0's own share goes through the transport too."""
+        unlock_test_hooks()
         self._check(self._lib.grv_multi_test_self_exchange(self._h, 1 if enable else 0), "multi_test_self_exchange")

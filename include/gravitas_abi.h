@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GRV_ABI_VERSION 6
+#define GRV_ABI_VERSION 7
 
 typedef struct grv_engine grv_engine;
 
@@ -227,6 +227,19 @@ int grv_integrate_paths_device(grv_engine *e, size_t n, const double *d_states, 
 /* ---- frame: pixel->state of src/shaders/compute.wgsl.ts:159-187 + integrate + shading ---- */
 size_t grv_frame_ray_count(const GrvRenderParams *p); /* rays this rank renders */
 uint32_t grv_tile_pitch(uint32_t width, uint32_t tile_world);
+/* The tile deal (physics-engine/_legacy_src/tiling.rs:38-56: row-major 64x64 tile grid; here on the
+ * pitch above and dealt round-robin, id k -> rank k mod tile_world).  Hosts above the ABI ask these
+ * instead of recomputing the deal (blackhole-simulation_amd/distributed.py is thin calls into them):
+ *   grv_tiles_total        ids of the frame, pad column(s) included: pitch * ceil(height / 64)
+ *   grv_max_tiles_per_rank size of a rank's send buffer / receive slot in tiles
+ *   grv_tiles_of_rank      the ids `tile_rank` renders, in its packed order; writes at most `capacity`
+ *                          of them to out_ids (may be NULL) and returns how many there are
+ *   grv_tile_origin        pixel (x0, y0) of an id; x0 >= width for an id in a pad column */
+uint32_t grv_tiles_total(uint32_t width, uint32_t height, uint32_t tile_world);
+uint32_t grv_max_tiles_per_rank(uint32_t width, uint32_t height, uint32_t tile_world);
+uint32_t grv_tiles_of_rank(uint32_t width, uint32_t height, uint32_t tile_world, uint32_t tile_rank,
+                           uint32_t *out_ids, uint32_t capacity);
+void grv_tile_origin(uint32_t tile, uint32_t width, uint32_t tile_world, uint32_t *x0, uint32_t *y0);
 int grv_render_frame(grv_engine *e, const GrvCamera *cam, const GrvRenderParams *p,
                      float *rgba_host, GrvFrameStats *stats);
 int grv_render_frame_device(grv_engine *e, const GrvCamera *cam, const GrvRenderParams *p,
@@ -242,6 +255,13 @@ int grv_frame_stats_reset(grv_engine *e, void *stream);
  * A caller that keeps every frame / batch call on ONE stream holds one ray workspace (~170 B per ray
  * slot); the second one exists only once calls have arrived on two different streams. */
 size_t grv_engine_device_bytes(const grv_engine *e);
+/* page-locked HOST memory the handle holds (ragged-path staging of grv_integrate_paths -- at most
+ * 4 MiB of it survives a call --, the counter read-back block, the one-ray result block), bytes */
+size_t grv_engine_host_bytes(const grv_engine *e);
+/* enable != 0: grv_render_frame_wgsl / _glsl bracket their march launch with HIP events on the
+ * launch stream (resolved by grv_frame_stats into integrate_ms / launches, as profile = 1 does for
+ * the f64 frame).  Off by default: an unprofiled frame records nothing. */
+int grv_engine_profile_shader_frames(grv_engine *e, int enable);
 /* Page-locked host memory for the host-pointer entry points (grv_render_frame, grv_integrate_batch,
  * grv_render_frame_multi, *_render_host): a frame rendered into it leaves the device in one DMA at
  * the full PCIe rate instead of going through the runtime's pageable staging.  The N-API addon hands
@@ -300,6 +320,18 @@ int grv_render_frame_multi_device(grv_multi *m, const GrvCamera *cam, const GrvR
 /* same into host memory (one D2H copy of the assembled image), optional summed statistics */
 int grv_render_frame_multi(grv_multi *m, const GrvCamera *cam, const GrvRenderParams *p,
                            float *rgba_host, GrvFrameStats *stats);
+/* What the ONE exchange per frame carries.  RGBA32F (default): the ranks' f32 pixels, 16 B each.
+ * RGBA16F: four binary16 channels, 8 B per pixel -- the reference's own compute-pass output format
+ * (rgba16float storage texture, src/rendering/webgpu/renderer.ts:163-176; written by
+ * src/shaders/compute.wgsl.ts:147-258): every rank narrows its share (round to nearest even) before
+ * it travels, rank 0 widens it into the caller's f32 image while de-interleaving the tiles.  The
+ * assembled image then equals the one-device frame rounded through binary16 channel by channel,
+ * for any G (G = 1 included), bit for bit.  Changing the format waits for the handle's queued frames.
+ * grv_multi_exchange_bytes_per_frame: bytes that cross between devices for a width x height frame. */
+enum { GRV_EXCHANGE_RGBA32F = 0, GRV_EXCHANGE_RGBA16F = 1 };
+int grv_multi_set_exchange_format(grv_multi *m, int format);
+int grv_multi_exchange_format(const grv_multi *m);
+size_t grv_multi_exchange_bytes_per_frame(const grv_multi *m, uint32_t width, uint32_t height);
 int grv_multi_synchronize(grv_multi *m);
 int grv_multi_stats_accumulate(grv_multi *m, int enable);
 int grv_multi_frame_stats_reset(grv_multi *m);
@@ -312,8 +344,17 @@ int grv_multi_frame_stats(grv_multi *m, GrvFrameStats *stats);
  * never hang the device" exit reachable: such rays end as GRV_TERM_MAXSTEPS.
  * grv_multi_test_self_exchange: rank 0's own share travels through the transport as well (send
  * buffer -> exchange -> receive slot) instead of being rendered into its slot, so that every
- * transport call runs on a one-device box.  Waits for the handle's queued frames. */
+ * transport call runs on a one-device box.  Waits for the handle's queued frames.
+ *
+ * Both hooks are LOCKED in a freshly loaded library and return GRV_ERR_INVALID until the process has
+ * called grv_test_hooks_unlock(GRV_TEST_HOOKS_KEY) (tests do; product hosts never): a stray call
+ * cannot truncate rays or reshuffle exchange buffers.  grv_test_try_bound reads the override back
+ * (0 = none), so a result produced under a hook can be told from a production one. */
+#define GRV_TEST_HOOKS_KEY 0x47525654u /* "GRVT" */
+int grv_test_hooks_unlock(uint32_t key);
+int grv_test_hooks_unlocked(void);
 int grv_test_set_try_bound(grv_engine *e, uint32_t tries);
+uint32_t grv_test_try_bound(const grv_engine *e);
 int grv_multi_test_self_exchange(grv_multi *m, int enable);
 
 /* ---- f32 march loops of the reference's GPU shaders ----

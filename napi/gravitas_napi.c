@@ -55,7 +55,39 @@ typedef struct {
     pthread_mutex_t async_mu;
     int async_pending; /* works queued or running (main thread only) */
     int freed;         /* free() was called while works were pending: the last one to complete cleans up */
+    /* renderFrameAsync({out}): pinned staging images, kept across calls (an async frame loop holds one or
+     * two frames in flight; allocating / freeing page-locked memory per frame costs milliseconds and
+     * serialises on the driver).  Taken and returned on the main thread only. */
+    struct { float *p; size_t bytes; int busy; } stage[2];
 } engine_box;
+
+/* a pinned staging image of at least `bytes`: one of the box's two cached buffers (grown on demand), or --
+ * with both in flight -- a one-off allocation (*idx = -1) */
+static float *stage_acquire(engine_box *b, size_t bytes, int *idx) {
+    for (int k = 0; k < 2; k++)
+        if (!b->stage[k].busy && b->stage[k].p && b->stage[k].bytes >= bytes) {
+            b->stage[k].busy = 1;
+            *idx = k;
+            return b->stage[k].p;
+        }
+    for (int k = 0; k < 2; k++)
+        if (!b->stage[k].busy) {
+            if (b->stage[k].p) grv_host_free(b->stage[k].p);
+            b->stage[k].p = (float *)grv_host_alloc(bytes);
+            b->stage[k].bytes = b->stage[k].p ? bytes : 0;
+            if (!b->stage[k].p) return NULL;
+            b->stage[k].busy = 1;
+            *idx = k;
+            return b->stage[k].p;
+        }
+    *idx = -1;
+    return (float *)grv_host_alloc(bytes);
+}
+static void stage_release(engine_box *b, float *p, int idx) {
+    if (!p) return;
+    if (idx >= 0 && b) b->stage[idx].busy = 0;
+    else grv_host_free(p);
+}
 
 static int slot_acquire(void) {
     for (unsigned k = 0; k < N_SLOTS; ++k)
@@ -124,6 +156,12 @@ static void box_destroy_handles(engine_box *box) {
     if (box->h) grv_engine_destroy(box->h);
     box->multi = box->async_multi = NULL;
     box->async_h = box->h = NULL;
+    for (int k = 0; k < 2; k++) { /* (no work is pending here: none of them is busy) */
+        if (box->stage[k].p) grv_host_free(box->stage[k].p);
+        box->stage[k].p = NULL;
+        box->stage[k].bytes = 0;
+        box->stage[k].busy = 0;
+    }
 }
 
 static void engine_finalize(napi_env env, void *data, void *hint) {
@@ -638,7 +676,8 @@ typedef struct {
      * detached under the work.  So the async forms never hold pointers into it: the input is copied
      * into the work item, and a caller's `out` is filled on the JS thread when the work completes,
      * after checking that its buffer is still attached. */
-    float *own_rgba;   /* pinned staging of an async frame with a caller-supplied `out` */
+    float *own_rgba;   /* pinned staging of an async frame with a caller-supplied `out` (engine_box.stage / one-off) */
+    int own_stage;     /* index into engine_box.stage, -1 = one-off allocation */
     size_t rgba_elems;
     void *own_in;      /* copy of an async batch's input states */
     GrvFrameStats st;
@@ -759,7 +798,7 @@ static napi_value bulk_result(napi_env env, bulk_work *w) {
 }
 
 static void bulk_release(napi_env env, bulk_work *w) {
-    if (w->own_rgba) grv_host_free(w->own_rgba);
+    stage_release(w->box, w->own_rgba, w->own_stage);
     free(w->own_in);
     for (int k = 0; k < w->n_keep; k++) napi_delete_reference(env, w->keep[k]);
     if (w->self_ref) napi_delete_reference(env, w->self_ref);
@@ -920,7 +959,7 @@ static napi_value render_frame_common(napi_env env, napi_callback_info info, int
         }
         wk->rgba = (float *)data;
         if (is_async) { /* see bulk_work.own_rgba: the pool thread renders into staging, not into JS-reachable memory */
-            wk->own_rgba = (float *)grv_host_alloc(n * sizeof(float));
+            wk->own_rgba = stage_acquire(b, n * sizeof(float), &wk->own_stage);
             if (!wk->own_rgba) {
                 free(wk);
                 napi_throw_error(env, NULL, "renderFrameAsync: cannot allocate the staging image");
@@ -941,7 +980,7 @@ static napi_value render_frame_common(napi_env env, napi_callback_info info, int
         wk->rgba = (float *)dst;
     }
     if (!keep_ref(env, wk, rgba)) {
-        if (wk->own_rgba) grv_host_free(wk->own_rgba);
+        stage_release(b, wk->own_rgba, wk->own_stage);
         free(wk);
         napi_throw_error(env, NULL, "renderFrame: reference failed");
         return NULL;

@@ -449,3 +449,259 @@ def test_random_paths_strict_is_bit_exact(engine_mod, oracle, seed):
             assert int(got["counts"][i]) == path.shape[0] == int(t.steps_taken) + 1, tag
             assert np.array_equal(got["paths"][i], path[:cap], equal_nan=True), tag
             assert int(got["term"][i]) == int(t.termination) and int(got["steps"][i]) == int(t.steps_taken), tag
+
+
+# ---------------------------------------------------------------------------------------------------
+# The FAST contracts -- the arithmetic every bench line runs -- under the same randomisation.
+# (reference surface this protects: gravitas-wasm/src/lib.rs:422-464 integrate_ray_relativistic,
+#  gravitas-core/src/geodesic/integrator.rs:72-107 controller corner paths,
+#  src/shaders/blackhole/fragment.glsl.ts:129-221, src/shaders/compute.wgsl.ts:159-255)
+# Bars in the form the fixed-fixture tests use (tests/test_full_frame_parity.py, test_shader_kernels.py):
+#   * rays whose step count equals the oracle's ("matched": the same accept / reject history) carry
+#     the oracle's termination class and end within rounding of its end state;
+#   * the others are COUNTED, BOUNDED and EXPLAINED: one rounding flipped a controller decision, so the
+#     ray ends elsewhere on the SAME geodesic -- with the displacement d lambda along the oracle's tangent
+#     (get_state_derivative at its end state) taken out, what is left is the difference of two RKF45
+#     step sequences along one geodesic, a small multiple of the tolerance.
+# GRV_FUZZ_REPORT=<path> appends every test's measured figures as a JSON line (profiles/r05_fuzz_fast.txt).
+# ---------------------------------------------------------------------------------------------------
+import ctypes as C
+import json
+
+FAST_RAY_BARS = dict(
+    steps_equal_ks=1.0 - 1e-3,     # Kerr-Schild: share of well-posed rays with the oracle's step count
+    steps_equal_other=0.98,        # Boyer-Lindquist / Schwarzschild coordinates: poles and the horizon are singular
+    err_max_matched=1e-5, err_median_matched=1e-8,
+    class_equal_unmatched=0.5,     # an unmatched ray is usually one step early / late on the same geodesic
+)
+
+
+def _report(rec):
+    path = os.environ.get("GRV_FUZZ_REPORT")
+    if path:
+        with open(path, "a") as f:
+            f.write(json.dumps(rec) + "\n")
+
+
+def _well_posed(rng, n, mass, r_lo=2.5, r_hi=70.0):
+    """Finite rays outside the horizon, off the poles: the inputs a renderer produces.  (Hostile rays --
+    NaN, inside the horizon, on the axis -- are the STRICT tests' business: there both contracts either
+    agree bit for bit or disagree about garbage.)"""
+    st = np.zeros((n, 8))
+    st[:, 0] = rng.uniform(-5, 5, n)
+    st[:, 1] = rng.uniform(r_lo, r_hi, n) * mass
+    st[:, 2] = rng.uniform(0.05, np.pi - 0.05, n)
+    st[:, 3] = rng.uniform(-7, 7, n)
+    st[:, 4] = -1.0
+    st[:, 5] = rng.uniform(-1.2, 1.2, n)
+    st[:, 6] = rng.uniform(-6, 6, n) * mass
+    st[:, 7] = rng.uniform(-6, 6, n) * mass
+    return st
+
+
+def _fast_ray_metrics(po, m, tol, a, a_steps, a_term, ref):
+    """FAST end states `a` against the oracle's `ref` (dict of states / steps / term)."""
+    b = ref["states"]
+    ok = np.isfinite(b).all(axis=1) & np.isfinite(a).all(axis=1)
+    n = int(ok.sum())
+    same = ok & (a_steps.astype(np.int64) == ref["steps"].astype(np.int64))
+    err = (np.abs(a - b) / np.maximum(1.0, np.abs(b))).max(axis=1)
+    cls_bad_matched = int((a_term[same] != ref["term"][same]).sum())
+    out = dict(rays=int(a.shape[0]), finite=n, matched=int(same.sum()),
+               steps_equal=float(same.sum() / max(n, 1)), class_mismatch_matched=cls_bad_matched,
+               err_max_matched=float(err[same].max(initial=0.0)),
+               err_median_matched=float(np.median(err[same])) if same.any() else 0.0,
+               nonfinite_disagree=int((np.isfinite(a).all(axis=1) != np.isfinite(b).all(axis=1)).sum()))
+    un = np.flatnonzero(ok & ~same)
+    out["unmatched"] = int(un.size)
+    out["class_equal_unmatched"] = float((a_term[un] == ref["term"][un]).mean()) if un.size else 1.0
+    worst_resid, worst_dlam, explained = 0.0, 0.0, 0
+    for i in un:
+        if a_term[i] != ref["term"][i]:
+            continue
+        sb = po.make_state(list(b[i]))
+        dv = po.lib().orc_state_derivative(C.byref(sb), C.byref(m))
+        tangent = np.array(list(dv.x) + list(dv.p))
+        if not np.isfinite(tangent).all() or tangent[0] == 0.0:
+            continue
+        dlam = (a[i, 0] - b[i, 0]) / tangent[0]
+        resid = float((np.abs(a[i] - (b[i] + dlam * tangent)) / np.maximum(1.0, np.abs(b[i]))).max())
+        explained += 1
+        worst_resid, worst_dlam = max(worst_resid, resid), max(worst_dlam, abs(float(dlam)))
+    out.update(unmatched_same_class=explained, worst_resid_off_the_ray=worst_resid, worst_d_lambda=worst_dlam)
+    return out
+
+
+@pytest.mark.parametrize("seed", range(SEEDS))
+def test_random_batches_fast_stay_inside_the_contract(engine_mod, oracle, seed):
+    """FAST f64 batches (the refill kernel) and the FAST one-ray entry: random mass / spin (incl. +-M,
+    0.999), metric, tolerance 1e-10 ... 1e-5, step budgets, escape radii, renormalisation intervals."""
+    bh, po = engine_mod, oracle
+    rng = np.random.default_rng(41000 + seed)
+    kinds = ((po.KERR_KS, bh.KERR_KS), (po.KERR_KS, bh.KERR_KS), (po.KERR_BL, bh.KERR_BL), (po.SCHWARZSCHILD, bh.SCHWARZSCHILD))
+    for _ in range(6):
+        okind, bkind = kinds[rng.integers(0, 4)]
+        mass = float(rng.choice([1.0, 0.37, 2.5]))
+        spin = 0.0 if okind == po.SCHWARZSCHILD else float(rng.choice([0.0, 0.3, 0.9, 0.999, -0.7, 1.0, -1.0]))
+        tol = float(10.0 ** rng.uniform(-10, -5))
+        kw = dict(method=0, tolerance=tol, initial_step=float(rng.choice([0.01, 0.5, 2.0])),
+                  max_steps=int(rng.choice([60, 250, 2048])), escape_radius=float(rng.choice([1000.0, 200.0, 80.0])),
+                  renormalize_interval=int(rng.choice([1, 3, 10, 1000])))
+        st = _well_posed(rng, 1500, mass)
+        m = po.metric(okind, mass, spin)
+        ref = po.integrate_batch(m, po.options(**kw), st, nthreads=4)
+        with bh.PhysicsEngine(mass, spin) as e:
+            got = e.integrate_batch(st, bh.engine.default_options(metric_kind=bkind, arith=bh.ARITH_FAST, **kw))
+            # the FFI entry under its opt-in FAST contract (lib.rs:422-464; KS / BL by use_kerr_schild)
+            one = None
+            if okind != po.SCHWARZSCHILD:
+                e.set_ray_arith(bh.ARITH_FAST)
+                k = int(rng.integers(0, st.shape[0]))
+                one = (k, e.integrate_ray_relativistic(st[k], kw["max_steps"], tol, okind == po.KERR_KS))
+        met = _fast_ray_metrics(po, m, tol, got["states"], got["steps"], got["term"], ref)
+        tag = dict(seed=seed, kind=int(okind), mass=mass, spin=spin, **kw)
+        _report(dict(test="fast_batch", **tag, **met))
+        bar = FAST_RAY_BARS["steps_equal_ks"] if okind == po.KERR_KS else FAST_RAY_BARS["steps_equal_other"]
+        assert met["steps_equal"] >= bar, (tag, met)
+        assert met["class_mismatch_matched"] == 0 and met["nonfinite_disagree"] == 0, (tag, met)
+        assert met["err_max_matched"] <= FAST_RAY_BARS["err_max_matched"], (tag, met)
+        assert met["err_median_matched"] <= FAST_RAY_BARS["err_median_matched"], (tag, met)
+        # unmatched rays: elsewhere on the same geodesic -- |d lambda| within a few controller steps (|h| <= 10,
+        # integrator.rs:76) and the rest a small multiple of what two step sequences at this tolerance differ by
+        assert met["worst_d_lambda"] <= 40.0, (tag, met)
+        assert met["worst_resid_off_the_ray"] <= 5e-5 + 2e3 * tol, (tag, met)
+        if one is not None:
+            k, out = one
+            ref_one = po.integrate_ray_relativistic(mass, spin, st[k], kw["max_steps"], tol, okind == po.KERR_KS)
+            e1 = float((np.abs(np.asarray(out) - np.asarray(ref_one)) / np.maximum(1.0, np.abs(np.asarray(ref_one)))).max())
+            _report(dict(test="fast_one_ray", **tag, ray=k, rel_err=e1))
+            assert e1 <= 5e-2, (tag, k, e1)  # (its own defaults: h0 = 0.01, escape 1000 -- a ray of the lib.rs entry)
+
+
+@pytest.mark.parametrize("seed", range(SEEDS))
+def test_random_frames_fast_stay_inside_the_contract(engine_mod, oracle, seed):
+    """FAST f64 frames (integrate_segment_kernel<.,FAST,.> + shading): random cameras (on the axis, close
+    in, below the disk), frame shapes with ragged tiles, tolerances, both metrics' coordinates."""
+    import torch
+    bh, po = engine_mod, oracle
+    rng = np.random.default_rng(45000 + seed)
+    for _ in range(3):
+        W, H = int(rng.integers(20, 150)), int(rng.integers(16, 110))
+        r0 = float(rng.choice([8.0, 20.0, 60.0, 300.0]))
+        th, ph = float(rng.choice([0.0, 1e-6, 0.3, np.pi / 2, 1.7, 2.6, np.pi])), float(rng.uniform(0, 2 * np.pi))
+        eye = (r0 * np.sin(th) * np.cos(ph), r0 * np.cos(th), r0 * np.sin(th) * np.sin(ph))
+        spin = float(rng.choice([0.0, 0.5, 0.999, -0.9, 1.0]))
+        kind = [(po.KERR_KS, bh.KERR_KS), (po.KERR_KS, bh.KERR_KS), (po.KERR_BL, bh.KERR_BL)][int(rng.integers(0, 3))]
+        tol = float(10.0 ** rng.uniform(-10, -6))
+        okw = dict(max_steps=int(rng.choice([120, 600, 2048])), tolerance=tol, escape_radius=float(rng.choice([1000.0, 100.0])),
+                   renormalize_interval=int(rng.choice([1, 10])), method=0, initial_step=float(rng.choice([0.01, 1.0])))
+        kw = dict(shading=1, disk_inner=float(rng.choice([0.0, 3.0, 8.0])), disk_outer=float(rng.choice([30.0, 12.0])),
+                  disk_temp=float(rng.choice([9500.0, 3e4])), disk_opacity=float(rng.choice([0.6, 0.95])),
+                  exposure=float(rng.choice([1.0, 0.2])))
+        fovy = float(rng.choice([60.0, 20.0, 110.0]))
+        up = (0.0, 1.0, 0.0) if th not in (0.0, np.pi) else (1.0, 0.0, 0.0)
+        ref = po.render_frame(po.camera_look_at(eye, up=up, fovy_deg=fovy, aspect=W / H),
+                              po.frame_params(W, H, spin=spin, metric_kind=kind[0], opt=po.options(**okw), **kw), None, nthreads=4)
+        n = W * H
+        with bh.PhysicsEngine(1.0, spin) as e:
+            cam = bh.camera_look_at(eye, up=up, fovy_deg=fovy, aspect=W / H)
+            p = bh.render_params(W, H, arith=bh.ARITH_FAST, metric_kind=kind[1], **okw, **kw)
+            rgba = torch.zeros(n, 4, dtype=torch.float32, device="cuda:0")
+            fs = torch.zeros(n, 8, dtype=torch.float64, device="cuda:0")
+            steps = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+            term = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
+            e.render_frame_device(cam, p, rgba, fs, steps, term)
+            torch.cuda.synchronize()
+        m = po.metric(kind[0], 1.0, spin)
+        met = _fast_ray_metrics(po, m, tol, fs.cpu().numpy(), steps.cpu().numpy().astype(np.uint32), term.cpu().numpy(),
+                                dict(states=ref["states"], steps=ref["steps"], term=ref["term"]))
+        peak = max(float(ref["rgba"][..., :3].max()), 1e-30)
+        dpx = np.abs(rgba.cpu().numpy() - ref["rgba"].reshape(-1, 4)).max(axis=1) / peak
+        same = steps.cpu().numpy().astype(np.int64) == ref["steps"].astype(np.int64)
+        met.update(px_max_matched=float(dpx[same].max(initial=0.0)), px_beyond_1e3=float((dpx > 1e-3).mean()))
+        tag = dict(seed=seed, W=W, H=H, r0=r0, theta=th, spin=spin, kind=int(kind[0]), fovy=fovy, **okw)
+        _report(dict(test="fast_frame", **tag, **met))
+        on_axis = th in (0.0, 1e-6, np.pi)   # a camera ON the spin axis looks along the coordinate singularity
+        bar = FAST_RAY_BARS["steps_equal_ks"] if (kind[0] == po.KERR_KS and not on_axis) else FAST_RAY_BARS["steps_equal_other"]
+        assert met["steps_equal"] >= bar, (tag, met)
+        assert met["class_mismatch_matched"] == 0, (tag, met)
+        assert met["err_max_matched"] <= FAST_RAY_BARS["err_max_matched"] and \
+            met["err_median_matched"] <= FAST_RAY_BARS["err_median_matched"], (tag, met)
+        assert met["worst_d_lambda"] <= 40.0 and met["worst_resid_off_the_ray"] <= 5e-5 + 2e3 * tol, (tag, met)
+        # shading follows the end state: matched rays shade to the oracle's pixel within f32 rounding of the lookup
+        assert met["px_max_matched"] <= 1e-3 and met["px_beyond_1e3"] <= 2e-3, (tag, met)
+
+
+@pytest.mark.parametrize("seed", range(SEEDS))
+def test_random_shader_frames_fast_hold_the_fast_bars(engine_mod, oracle, seed):
+    """FAST GLSL march, FAST and packed WGSL march with random uniforms against the shader-order oracle,
+    held to FAST_BARS (tests/test_shader_kernels.py) over the seed's frames together."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_shader_kernels as TS
+    bh, po = engine_mod, oracle
+    rng = np.random.default_rng(49000 + seed)
+    acc = {"glsl": [], "wgsl_fast": [], "wgsl_packed": []}
+    for _ in range(3):
+        W, H = int(rng.integers(120, 260)), int(rng.integers(70, 150))
+        n = W * H
+        spin = float(rng.choice([0.0, 0.3, 0.9, 0.999, -0.8]))
+        mass = float(rng.choice([1.0, 0.5, 2.0]))
+        rgba = torch.zeros(n, 4, dtype=torch.float32, device="cuda:0")
+        steps = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+        with bh.PhysicsEngine(mass, spin) as e:
+            kw = dict(max_ray_steps=int(rng.choice([40, 300, 512])), tone_map=int(rng.integers(0, 2)),
+                      features=int(rng.integers(0, 256)) | bh.GLSL_LENSING, quality=int(rng.choice([1, 1, 2, 0])),
+                      time=float(rng.choice([0.0, 2.5, 137.0])), turbulence=float(rng.choice([-1.0, 0.75])),
+                      zoom=float(rng.choice([30.0, 8.0, 120.0])) * mass, mouse=(float(rng.uniform(0, 1)), float(rng.uniform(0.05, 0.95))),
+                      disk_size=float(rng.choice([15.0, 6.0, 40.0])), disk_density=float(rng.choice([1.0, 5.0, 0.1])),
+                      disk_temp=float(rng.choice([9500.0, 2e4, 1500.0])), lensing_strength=float(rng.choice([1.0, 0.5])),
+                      show_redshift=float(rng.choice([0.0, 0.0, 1.0])))
+            if rng.random() < 0.3:
+                kw["cam_pos"] = tuple(float(x) for x in rng.uniform(-40, 40, 3) * mass)
+                q = rng.normal(size=4)
+                kw["cam_quat"] = tuple(float(x) for x in q / np.linalg.norm(q))
+            gp = bh.glsl_params(W, H, mass, spin, arith=bh.ARITH_FAST, **kw)
+            e.render_frame_glsl(gp, rgba, steps)
+            ref_rgba, ref_steps = po.glsl_frame(po.glsl_params_from(gp), nthreads=4)
+            acc["glsl"].append((rgba.cpu().numpy().reshape(H, W, 4), steps.cpu().numpy().reshape(H, W), ref_rgba, ref_steps,
+                                dict(W=W, H=H, spin=spin, mass=mass, **{k: v for k, v in kw.items() if k not in ("cam_quat",)})))
+            r0 = float(rng.choice([8.0, 30.0, 60.0])) * mass
+            th, ph = float(rng.choice([0.4, np.pi / 2, 1.7, 2.7])), float(rng.uniform(0, 2 * np.pi))
+            eye = (r0 * np.sin(th) * np.cos(ph), r0 * np.cos(th), r0 * np.sin(th) * np.sin(ph))
+            cam = bh.camera_look_at(eye, fovy_deg=float(rng.choice([60.0, 25.0])), aspect=W / H)
+            budget = int(rng.choice([60, 150, 512]))
+            jit = (float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.5, 0.5)))
+            for name, arith in (("wgsl_fast", bh.ARITH_FAST), ("wgsl_packed", bh.ARITH_FAST_PACKED)):
+                wp = bh.wgsl_params(W, H, cam, mass, spin, max_steps=budget, arith=arith, stars=0)
+                wp.jitter[0], wp.jitter[1] = jit
+                e.render_frame_wgsl(wp, rgba, steps)
+                ref_rgba, ref_steps = po.wgsl_frame(po.wgsl_params_from(wp), nthreads=4)
+                acc[name].append((rgba.cpu().numpy().reshape(H, W, 4), steps.cpu().numpy().reshape(H, W), ref_rgba, ref_steps,
+                                  dict(W=W, H=H, spin=spin, mass=mass, r0=r0, theta=th, budget=budget)))
+    for name, frames in acc.items():
+        got = np.concatenate([f[0].reshape(-1, 4) for f in frames])
+        gs = np.concatenate([f[1].ravel() for f in frames])
+        # every frame on its own colour scale (peaks differ by orders of magnitude between uniforms)
+        ref = np.concatenate([(f[2] / max(float(f[2][..., :3].max()), 1e-12)).reshape(-1, 4) for f in frames])
+        gotn = np.concatenate([(f[0] / max(float(f[2][..., :3].max()), 1e-12)).reshape(-1, 4) for f in frames])
+        rs = np.concatenate([f[3].ravel() for f in frames])
+        assert np.isfinite(got).all() == np.isfinite(np.concatenate([f[2].reshape(-1, 4) for f in frames])).all(), name
+        ok = np.isfinite(ref).all(-1) & np.isfinite(gotn).all(-1)
+        ds = np.abs(gs.astype(np.int64) - rs.astype(np.int64))[ok]
+        dc = np.abs(gotn - ref)[ok][:, :3].max(-1) / max(float(ref[ok][:, :3].max()), 1e-12)
+        met = dict(pixels=int(ok.sum()), steps_equal=float((ds == 0).mean()), steps_within_2=float((ds <= 2).mean()),
+                   colour_1e4=float((dc <= 1e-4).mean()), colour_2e3=float((dc <= 2e-3).mean()),
+                   beyond_5e2=float((dc > 5e-2).mean()), colour_max=float(dc.max()))
+        tags = [f[4] for f in frames]
+        _report(dict(test="fast_shader_" + name, seed=seed, frames=tags, **met))
+        for k in ("steps_equal", "steps_within_2", "colour_1e4", "colour_2e3"):
+            assert met[k] >= FAST_SHADER_BARS[k], (name, k, met, tags)
+        assert met["beyond_5e2"] <= FAST_SHADER_BARS["beyond_5e2"], (name, met, tags)
+
+
+# random uniforms (close cameras, thick disks, every feature combination) at 10 000-40 000 pixels a frame:
+# the fixed fixtures' FAST_BARS (steps equal on 99.9 %, colour within 1e-4 of the peak on 99.9 %) with
+# the tail allowance a three-frame sample needs
+FAST_SHADER_BARS = dict(steps_equal=0.995, steps_within_2=0.997, colour_1e4=0.99, colour_2e3=0.995, beyond_5e2=2e-3)

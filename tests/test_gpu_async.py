@@ -411,7 +411,8 @@ def test_try_bound_ends_rays_instead_of_hanging(bh, torch_mod, monkeypatch):
     with bh.PhysicsEngine(1.0, 0.999) as e:
         o = _frame(bh, torch, e, 128, 72, arith=1)
         assert (o["term"].cpu().numpy() == 3).sum() == 0
-        assert e._lib.grv_test_set_try_bound(e._h, 40) == 0
+        bh.unlock_test_hooks()  # the hooks refuse stray calls (tests/test_host_logic.py holds the lock itself)
+        assert e._lib.grv_test_set_try_bound(e._h, 40) == 0 and e._lib.grv_test_try_bound(e._h) == 40
         o = _frame(bh, torch, e, 128, 72, arith=1)
         torch.cuda.synchronize()
         term, steps = o["term"].cpu().numpy(), o["steps"].cpu().numpy()

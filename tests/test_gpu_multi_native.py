@@ -121,6 +121,55 @@ def test_wgsl_march_over_virtual_ranks(bh, torch):
             assert st.accepted_steps == total
 
 
+def _half_rounded(torch, img):
+    """channel by channel through binary16, round to nearest even: what an rgba16float target stores"""
+    return img.to(torch.float16).to(torch.float32)
+
+
+@pytest.mark.parametrize("ranks,w,h", [(1, 200, 130), (2, 200, 130), (4, 512, 288), (8, 960, 540), (3, 333, 77)])
+def test_rgba16f_exchange_assembles_the_half_rounded_frame_bitwise(bh, torch, ranks, w, h):
+    """grv_multi_set_exchange_format(RGBA16F): every rank narrows its share to the compute pass's own
+    output format (rgba16float storage texture, src/rendering/webgpu/renderer.ts:163-176) before the ONE
+    exchange, rank 0 widens while it de-interleaves.  The image is the one-device frame rounded through
+    binary16 -- bit for bit, for any rank count --, the f32 frame and the f32 compute march alike, with
+    frames in flight; the bytes that cross devices are half of the RGBA32F exchange's."""
+    cam, p, want, wst = _whole(bh, torch, w, h, arith=1)
+    want16 = _half_rounded(torch, want)
+    assert not torch.equal(want16, want)   # the rounding is visible: the test can tell the formats apart
+    wp = bh.wgsl_params(w, h, cam, 1.0, 0.999, max_steps=200, arith=bh.ARITH_FAST_PACKED)
+    with bh.PhysicsEngine(1.0, 0.999) as e:
+        wantw = torch.zeros(h, w, 4, dtype=torch.float32, device="cuda:0")
+        e.render_frame_wgsl(wp, wantw)
+    make = (lambda: bh.MultiEngine(1.0, 0.999, devices=[0])) if ranks == 1 else \
+        (lambda: bh.MultiEngine(1.0, 0.999, virtual_ranks=ranks))
+    with make() as m:
+        assert m.exchange_format == bh.EXCHANGE_RGBA32F
+        full = m.exchange_bytes_per_frame(w, h)
+        m.set_exchange_format(bh.EXCHANGE_RGBA16F)
+        assert m.exchange_format == bh.EXCHANGE_RGBA16F and m.exchange_bytes_per_frame(w, h) * 2 == full
+        assert (full > 0) == (ranks > 1)
+        outs = [torch.full((h, w, 4), -7.0, dtype=torch.float32, device="cuda:0") for _ in range(4)]
+        for o in outs:                      # four frames queued back to back: both buffer parities, twice
+            m.render_frame_device(cam, p, o)
+        st = m.frame_stats()
+        for o in outs:
+            assert torch.equal(o.view(torch.int32), want16.view(torch.int32))
+        assert st.accepted_steps == wst.accepted_steps
+        got = torch.zeros(h, w, 4, dtype=torch.float32, device="cuda:0")
+        m.render_frame_wgsl_device(wp, got)
+        m.synchronize()
+        assert torch.equal(got.view(torch.int32), _half_rounded(torch, wantw).view(torch.int32))
+        # host-pointer entry, then back to RGBA32F on the same handle (buffers are re-laid out)
+        img, _ = m.render_frame(cam, p)
+        assert np.array_equal(img.view(np.uint32), want16.cpu().numpy().view(np.uint32))
+        m.set_exchange_format(bh.EXCHANGE_RGBA32F)
+        m.render_frame_device(cam, p, got)
+        m.synchronize()
+        assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+        with pytest.raises(bh.GravitasError):
+            m.set_exchange_format(7)
+
+
 def test_single_rank_handle_is_the_plain_frame(bh, torch):
     cam, p, want, wst = _whole(bh, torch, 320, 180, arith=1)
     with bh.MultiEngine(1.0, 0.999, devices=[0]) as m:
@@ -171,6 +220,14 @@ with bh.MultiEngine(1.0, 0.999, devices=[0], transport=bh.TRANSPORT_RCCL) as m:
         m.render_frame_device(cam, p, got)
         m.synchronize()
         assert torch.equal(got.view(torch.int32), want.view(torch.int32)), k
+    # the same walk with binary16 on the wire (ncclHalf elements)
+    m.set_exchange_format(bh.EXCHANGE_RGBA16F)
+    want16 = want.to(torch.float16).to(torch.float32)
+    for k in range(3):
+        got = torch.zeros(h, w, 4, dtype=torch.float32, device="cuda:0")
+        m.render_frame_device(cam, p, got)
+        m.synchronize()
+        assert torch.equal(got.view(torch.int32), want16.view(torch.int32)), ("rgba16f", k)
 print("RCCL_WALK_OK")
 """
 
@@ -202,9 +259,10 @@ def test_bench_native_drives_the_c_abi_multi_handle():
     """bench.py --native: one process, grv_engine_create_multi (here: virtual ranks on the one GPU),
     same frame and the same accepted steps per frame as the one-rank run."""
     one = _bench_native("--gpus", "1", "--width", "640", "--height", "360", "--steps", "4", "--warmup", "1")
-    # a BARE `python bench.py --gpus 4` (no launcher around it, no flag) is this host: one process,
-    # the C ABI's multi-GPU handle
-    four = _bench_native("--gpus", "4", "--width", "640", "--height", "360", "--steps", "4", "--warmup", "1", flag=())
+    # `--launcher native` is the explicit spelling (a bare `python bench.py --gpus 4` starts four
+    # torch.distributed ranks until the handle has run on two real devices)
+    four = _bench_native("--gpus", "4", "--width", "640", "--height", "360", "--steps", "4", "--warmup", "1",
+                         flag=("--launcher", "native"))
     assert one["n_gpus"] == 1 and four["n_gpus"] == 4 and four["ranks"] == 4 and four["rank_devices"] == [0] * 4
     assert "native" in four["launcher"] and four["transport"] == "peer_copy" and four["rccl_version"] is None
     rk = four["rank_integrate_ms"]
@@ -215,3 +273,11 @@ def test_bench_native_drives_the_c_abi_multi_handle():
     c4 = _bench_native("--gpus", "2", "--config", "c4", "--width", "512", "--height", "288", "--steps", "3",
                        "--warmup", "1")
     assert c4["dtype"] == "f32" and c4["n_gpus"] == 2 and c4["config"]["accepted_steps_per_frame"] > 0
+    # the f32 march is timed rank by rank too (grv_engine_profile_shader_frames)
+    rk = c4["rank_integrate_ms"]
+    assert len(rk["per_rank"]) == 2 and 0 < rk["min"] <= rk["max"]
+    for ln in (one, four, c4):
+        rf = ln["roofline"]
+        assert rf["bound"] in ("fp64_valu", "fp32_valu") and rf["unit"] == "TFLOP/s"
+        assert isinstance(rf["frac"], float) and 0 < rf["frac"] <= 1.0, rf
+        assert rf["flops_source"] in ("counted", "algorithmic") and "hbm_nominal" in rf

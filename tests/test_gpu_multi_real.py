@@ -98,6 +98,27 @@ def test_real_devices_assemble_the_whole_f64_frame_bitwise(bh, torch, G, w, h, a
 
 
 @pytest.mark.parametrize("G", GS)
+def test_rgba16f_exchange_between_real_devices(bh, torch, G):
+    """The exchange in the compute pass's own rgba16float format (renderer.ts:163-176) over RCCL
+    (ncclHalf) and peer copies: the half-rounded one-device frame bit for bit, half the bytes."""
+    w, h = 960, 540
+    cam, p, want, wst = _whole(bh, torch, w, h, arith=1)
+    want16 = want.to(torch.float16).to(torch.float32)
+    for name, tr in _transports(bh):
+        with bh.MultiEngine(1.0, 0.999, devices=list(range(G)), transport=tr) as m:
+            full = m.exchange_bytes_per_frame(w, h)
+            m.set_exchange_format(bh.EXCHANGE_RGBA16F)
+            assert m.exchange_bytes_per_frame(w, h) * 2 == full and full > 0
+            outs = [torch.full((h, w, 4), -7.0, dtype=torch.float32, device="cuda:0") for _ in range(4)]
+            for o in outs:
+                m.render_frame_device(cam, p, o)
+            m.synchronize()
+            for o in outs:
+                assert torch.equal(o.view(torch.int32), want16.view(torch.int32)), name
+            assert m.frame_stats().accepted_steps >= wst.accepted_steps
+
+
+@pytest.mark.parametrize("G", GS)
 def test_auto_transport_between_real_devices_is_rccl(bh, torch, G):
     with bh.MultiEngine(1.0, 0.999, devices=list(range(G))) as m:
         assert m.transport == bh.TRANSPORT_RCCL
@@ -257,12 +278,13 @@ def _bench(G, *args, launcher):
 
 @pytest.mark.parametrize("G", GS)
 def test_bench_runs_G_ranks_on_G_devices_under_both_launchers(G):
-    """`python bench.py --gpus G` bare (the C ABI's multi-GPU handle, one process), with --launcher
-    torchrun, and under the driver's own torch.distributed.run command: G ranks, G distinct devices,
-    RCCL, the accepted steps of the one-GPU frame, per-rank integrate times in the line."""
+    """`python bench.py --gpus G` bare (starts its own G torch.distributed ranks), with --launcher
+    native (the C ABI's multi-GPU handle, one process), and under the driver's own torch.distributed.run
+    command: G ranks, G distinct devices, RCCL, the accepted steps of the one-GPU frame, per-rank
+    integrate times in the line."""
     size = ["--width", "1280", "--height", "720", "--steps", "4", "--warmup", "1"]
     one = _bench(1, *size, "--no-cpu-baseline", launcher="bare")
-    for launcher in ("bare", "torchrun", "driver"):
+    for launcher in ("bare", "native", "driver"):
         ln = _bench(G, *size, launcher=launcher)
         assert ln["n_gpus"] == G and ln["ranks"] == G, launcher
         assert sorted(ln["rank_devices"]) == list(range(G)) and len(set(ln["rank_devices"])) == G, launcher
@@ -271,12 +293,13 @@ def test_bench_runs_G_ranks_on_G_devices_under_both_launchers(G):
         assert ln["scaling"] == "strong" and "split over %d GPUs" % G in ln["config"]["workload"]
         rk = ln["rank_integrate_ms"]
         assert len(rk["per_rank"]) == G and 0 < rk["min"] <= rk["max"], launcher
-        assert ("native" in ln["launcher"]) == (launcher == "bare")
+        assert ("native" in ln["launcher"]) == (launcher == "native")
     c4 = _bench(G, "--config", "c4", "--width", "1024", "--height", "576", "--steps", "3", "--warmup", "1",
-                launcher="bare")
+                launcher="native")
     c4_one = _bench(1, "--config", "c4", "--width", "1024", "--height", "576", "--steps", "3", "--warmup", "1",
                     "--no-cpu-baseline", launcher="bare")
     assert c4["n_gpus"] == G and c4["dtype"] == "f32"
+    assert len(c4["rank_integrate_ms"]["per_rank"]) == G and c4["rank_integrate_ms"]["min"] > 0
     assert c4["config"]["accepted_steps_per_frame"] == c4_one["config"]["accepted_steps_per_frame"]
 
 

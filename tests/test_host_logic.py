@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(engine_mod):
     assert len(names) >= 25
     for n in names:
         assert hasattr(lib, n), "libgravitas_hip.so does not export %s" % n
-    assert lib.grv_abi_version() == 6
+    assert lib.grv_abi_version() == 7
 
 
 def test_no_device_fails_loudly(engine_mod):
@@ -140,6 +140,64 @@ def test_tile_partition_covers_every_pixel_once(engine_mod, w, h, world):
     assert engine_mod.load_library().grv_tile_pitch(w, world) == D.tile_pitch(w, world)
 
 
+@pytest.mark.parametrize("w,h,world", [(3840, 2160, 8), (7680, 4320, 4), (1920, 1080, 2), (200, 130, 3),
+                                       (64, 64, 2), (100, 70, 1), (640, 360, 5), (7680, 4320, 6)])
+def test_tile_deal_exports_match_their_definition(engine_mod, w, h, world):
+    """The library holds the ONE implementation of the tile deal (grv_tile_pitch, grv_tiles_total,
+    grv_tiles_of_rank, grv_tile_origin, grv_max_tiles_per_rank); blackhole_simulation_amd.distributed
+    is thin calls into it.  The definition, restated here as the pin (row-major 64x64 grid of
+    physics-engine/_legacy_src/tiling.rs:38-56 on a pitch coprime with the rank count, id k -> rank
+    k mod world):"""
+    import inspect
+    import math
+    from blackhole_simulation_amd import distributed as D
+    pitch = (w + 63) // 64
+    while world > 1 and math.gcd(pitch, world) != 1:
+        pitch += 1
+    total = pitch * ((h + 63) // 64)
+    lib = engine_mod.load_library()
+    assert lib.grv_tile_pitch(w, world) == pitch == D.tile_pitch(w, world)
+    assert lib.grv_tiles_total(w, h, world) == total == D.tiles_total(w, h, world)
+    assert lib.grv_max_tiles_per_rank(w, h, world) == (total + world - 1) // world == D.max_tiles_per_rank(w, h, world)
+    seen = []
+    for r in range(world):
+        ids = D.tiles_of_rank(w, h, world, r)
+        assert ids == list(range(r, total, world))
+        assert lib.grv_tiles_of_rank(w, h, world, r, None, 0) == len(ids)  # size query writes nothing
+        short = (C.c_uint32 * 2)(0xFFFFFFFF, 0xFFFFFFFF)
+        assert lib.grv_tiles_of_rank(w, h, world, r, short, 1) == len(ids) and short[1] == 0xFFFFFFFF  # capacity kept
+        p = engine_mod.render_params(w, h)
+        rp = D.rank_params(p, world, r)
+        assert lib.grv_frame_ray_count(C.byref(rp)) == (w * h if world == 1 else len(ids) * 4096)
+        seen += ids
+    assert sorted(seen) == list(range(total))
+    assert lib.grv_tiles_of_rank(w, h, world, world, None, 0) == 0  # no such rank
+    for t in (0, 1, pitch - 1, pitch, total - 1):
+        assert D.tile_origin(t, w, world) == ((t % pitch) * 64, (t // pitch) * 64)
+    # thin: the module's deal functions hold no arithmetic of their own
+    for fn in (D.tile_pitch, D.tiles_total, D.tiles_of_rank, D.tile_origin, D.max_tiles_per_rank):
+        src = inspect.getsource(fn)
+        assert "load_library()" in src and "gcd" not in src and "//" not in src and "%" not in src.split('"""')[-1], fn
+
+
+def test_verification_hooks_are_locked_until_the_key_is_given():
+    """grv_test_set_try_bound / grv_multi_test_self_exchange must not answer a stray call: a freshly
+    loaded library refuses them, a wrong key does not unlock, the right one does (own process: the
+    lock is per process)."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import blackhole_simulation_amd as bh\n"
+            "L = bh.load_library()\n"
+            "print('LOCKED', L.grv_test_hooks_unlocked(), L.grv_test_hooks_unlock(1234), L.grv_test_hooks_unlocked())\n"
+            "print('NULL', L.grv_test_set_try_bound(None, 5), L.grv_multi_test_self_exchange(None, 1), L.grv_test_try_bound(None))\n"
+            "bh.unlock_test_hooks()\n"
+            "print('OPEN', L.grv_test_hooks_unlocked())\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "LOCKED 0 1 0" in r.stdout and "NULL 1 1 0" in r.stdout and "OPEN 1" in r.stdout, r.stdout
+
+
 def test_unpack_places_pixels_row_major(engine_mod):
     from blackhole_simulation_amd import distributed as D
     w, h, world = 200, 130, 3
@@ -203,6 +261,43 @@ def test_bench_helpers():
         assert abs(t["hbm_bytes_per_launch"] / t["expected_from_layout_bytes"] - 1.0) < 0.02
     none, why = b.committed_pmc("no_such_kernel", bh.library_path())
     assert none is None and "no committed" in why
+
+
+def test_roofline_block_is_always_a_number_against_the_bound_that_binds():
+    """bench.py's roofline object: bound = the vector ALU of the dtype, frac =
+    flops / launch time / vector peak and never null -- counted flops when a counter pass of the code
+    object on disk is committed, SURVEY 8(d)'s algorithmic flops otherwise; the 8(d) byte figure only
+    as the labelled hbm_nominal sub-block."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod3", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    steps, rays, ms = 1511626085.0, 8294400, 27.2814
+    pmc = {"pass_id": "rXX-test", "frame": [3840, 2160], "hbm_bytes_per_launch": 1410739552,
+           "valu": {"issue_frac": 0.9488, "flops_counted_per_launch": 1286602997696.0}}
+    r = b.roofline_block("c3", False, "integrate_segment_kernel<1,1,0>", ms, 1.0, steps, rays, pmc,
+                         "profiles/traffic.json (code object x)", True, 0, "events")
+    assert r["bound"] == "fp64_valu" and r["unit"] == "TFLOP/s" and r["peak"] == 78.6
+    assert r["flops_source"] == "counted" and abs(r["achieved"] - 1286602997696.0 / (ms * 1e-3) / 1e12) < 0.01
+    assert abs(r["frac"] - r["achieved"] / 78.6) < 1e-3 and 0.55 < r["frac"] < 0.65
+    assert r["traffic"] == 1410739552 and r["valu_issue_frac"] == 0.9488 and r["traffic_pass"] == "rXX-test"
+    h = r["hbm_nominal"]
+    assert h["algorithmic_bytes_per_launch"] == 218470418640 and abs(h["nominal_frac"] - 1.001) < 2e-3
+    assert 45 < h["hbm_measured_GBps"] < 60 and "registers" in h["reason"]
+    # no committed pass for the library on disk: SURVEY 8(d)'s 1.3 kflop per f64 step, still a number
+    r = b.roofline_block("c3", False, "k", ms, 1.0, steps, rays, None, "stale: ...", False, 0, "events")
+    assert r["flops_source"] == "algorithmic" and r["flops_per_ray_step"] == 1300.0
+    assert isinstance(r["frac"], float) and 0 < r["frac"] <= 1.0 and r["traffic"] is None and r["valu_issue_frac"] is None
+    # the K-try schedule: per-launch figures, its own FETCH / WRITE pass when one is committed
+    pmc["segment_tries_16"] = {"hbm_bytes_per_launch": 700000000, "launches_per_frame": 32}
+    r = b.roofline_block("c3", False, "k", 1.0, 32.0, steps, rays, pmc, "profiles/traffic.json", True, 16, "events")
+    assert r["traffic"] == 700000000 and r["ray_steps_per_launch"] == int(steps / 32) and r["valu_issue_frac"] is None
+    assert "segment" in r["traffic_source"]
+    # f32 marches: the FP32 vector peak
+    for cfg, glsl, per in (("c4", False, 500.0), ("c2", False, 500.0), ("c2", True, 150.0)):
+        r = b.roofline_block(cfg, glsl, "k", 2.0, 1.0, 8e8, 2073600, None, "none", False, 0, "events")
+        assert r["bound"] == "fp32_valu" and r["peak"] == 157.3 and r["flops_per_ray_step"] == per
+        assert isinstance(r["frac"], float) and r["hbm_nominal"]["nominal_frac"] > 0
 
 
 def test_stale_pmc_figures_are_dropped(tmp_path, monkeypatch):

@@ -1,0 +1,53 @@
+#!/bin/bash
+# One GPU-box session (run through gpurun): the stages named on the command line, in order, every
+# output under gpurun_out/<tag>/.   usage: tools/gpu_session.sh <tag> <stage> [<stage> ...]
+#   smoke        __graft_entry__.smoke()
+#   tests        the whole -m gpu suite (full-frame parity records written beside the log)
+#   tests:<k>    pytest -m gpu -k <k>
+#   bench        the bench.py line of every BASELINE config (+ the one-stream / wgsl / K = 16 secondaries)
+#   bench:<args> one bench.py line with these arguments (quote them)
+#   fuzz:<n>     tests/test_fuzz_parity.py with GRV_FUZZ_SEEDS=<n>
+#   parity       the full-size parity records (c5, 8K, c4 every pixel)
+#   profile[:<suffixes>]  tools/profile_gpu.sh (counter passes, then traces; see there)
+#   renderers    tools/bench_renderers.py + tools/bench_shaders.py
+#   ab[:<configs>]  interleaved A/B of every ab_libs/lib_*.so (tools/ab_configs.sh; configs ';'-separated)
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+T=${1:-session}; shift || true
+O=$R/gpurun_out/$T
+mkdir -p $O
+cd $R
+for stage in "$@"; do
+  name=${stage%%:*}; arg=""; [ "$stage" != "$name" ] && arg=${stage#*:}
+  echo "== $stage"
+  case $name in
+    smoke) python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log;;
+    tests)
+      if [ -n "$arg" ]; then
+        timeout 2700 python -m pytest tests -m gpu -q -x -k "$arg" > $O/pytest_k.log 2>&1; echo "pytest -k rc=$?" >> $O/pytest_k.log; tail -8 $O/pytest_k.log
+      else
+        GRV_C2_JSON=$O/full_frame_parity_c2.jsonl GRV_PARITY_JSON=$O/full_frame_parity.json timeout 3000 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1
+        echo "pytest rc=$?" >> $O/pytest.log; tail -12 $O/pytest.log
+      fi;;
+    bench)
+      if [ -n "$arg" ]; then
+        tag=$(echo $arg | tr -d ' -'); timeout 900 python bench.py $arg > $O/bench_$tag.json 2> $O/bench_$tag.err; echo "rc=$?"; cut -c1-160 $O/bench_$tag.json
+      else
+        for cfg in "c3" "c2" "c2 --kernel wgsl" "c4" "c5 --steps 5 --warmup 1" "c2 --one-stream" "c2 --kernel wgsl --one-stream" \
+                   "c3 --segment-tries 16 --no-cpu-baseline"; do
+          tag=$(echo $cfg | tr -d ' -'); timeout 900 python bench.py --config $cfg > $O/bench_$tag.json 2> $O/bench_$tag.err; echo "$cfg rc=$?"; cut -c1-130 $O/bench_$tag.json
+        done
+      fi;;
+    fuzz) ( GRV_FUZZ_SEEDS=${arg:-100} timeout 3000 python -m pytest tests/test_fuzz_parity.py -m gpu -q -x 2>&1 | tail -15 ) > $O/fuzz.log 2>&1; cat $O/fuzz.log;;
+    parity)
+      GRV_PARITY_TOL=1e-9 GRV_PARITY_JSON=$O/full_frame_parity_c5.json timeout 1200 python -m pytest tests/test_full_frame_parity.py -m gpu -q 2>&1 | tail -2
+      GRV_PARITY_SIZE=7680x4320 GRV_PARITY_JSON=$O/full_frame_parity_8k.json timeout 2400 python -m pytest tests/test_full_frame_parity.py -m gpu -q 2>&1 | tail -2
+      GRV_C4_STRIDE=1 GRV_C4_JSON=$O/full_frame_parity_c4.jsonl timeout 2400 python -m pytest tests/test_shader_kernels.py -m gpu -q -k test_config4_bench_form 2>&1 | tail -2;;
+    profile) bash tools/profile_gpu.sh prof_$T $(echo $arg | tr ',' ' ') > $O/profile_gpu.log 2>&1; tail -3 $O/profile_gpu.log;;
+    renderers)
+      timeout 600 python tools/bench_renderers.py > $O/renderers.jsonl 2> $O/renderers.err; cut -c1-200 $O/renderers.jsonl
+      timeout 600 python tools/bench_shaders.py > $O/shader_kernels.jsonl 2> $O/shaders.err; cut -c1-160 $O/shader_kernels.jsonl;;
+    ab) AB_CONFIGS="${arg:-c2;c2 --one-stream}" bash tools/ab_configs.sh $T/ab > $O/ab.log 2>&1; tail -40 $O/ab.log;;
+    *) echo "unknown stage $stage";;
+  esac
+done

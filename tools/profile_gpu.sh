@@ -9,6 +9,7 @@
 #   _c2wgsl   bench.py --config c2 --kernel wgsl   wgsl_symplectic_pk_b256_kernel (1920x1080 / 512 steps: the four-wave-block form)
 #   _c5       bench.py --config c5     integrate_segment_kernel<1,0,0> at tol 1e-9 (trace only; the PMC passes are _strict's)
 # usage: tools/profile_gpu.sh <out dir under gpurun_out> [suffixes...]   (default: every suffix; "base" = the "" passes)
+# PROFILE_TAG (default r05) names the records; $OUT/summary holds what is copied into profiles/ afterwards.
 # code_hashes.json stamps the passes with the code objects of the library that ran them
 # (tools/summarize_profiles.py -> profiles/traffic.json; bench.py drops figures whose stamp differs).
 set -u
@@ -46,12 +47,14 @@ OCC="SQ_INSTS_VALU_FLOPS_FP32 SQ_INSTS_VALU_FLOPS_FP64 SQ_INSTS_VALU_FLOPS_FP32_
 CLS64="SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU2 SQ_THREAD_CYCLES_VALU"
 # memory-side instruction counts: the GLSL march fetches noise texels and spills 72 B per lane
 MEM="SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_FLAT SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_WAVE_CYCLES"
-for sfx in base _strict _c4 _c4fast _c2 _c2wgsl _c5; do
+# Order: every counter pass first, then profiles/traffic.json is rebuilt ON THE BOX from them
+# (tools/summarize_profiles.py -> $OUT/summary, copied over the box's profiles/traffic.json), and only then
+# the kernel traces: the bench line each trace record embeds therefore quotes the counter pass of this
+# very session (its pass id is in the line), never a file that is overwritten later.
+TAG=${PROFILE_TAG:-r05}
+for sfx in base _strict _c4 _c4fast _c2 _c2wgsl; do
   want $sfx || continue
   extra=$(extra_of $sfx); tag=$sfx; [ $sfx == base ] && tag=""
-  steps="--steps 5 --warmup 1"; [ $sfx == base ] && steps="--steps 10 --warmup 2"
-  run trace$tag --kernel-trace --stats -- $steps $extra
-  [ $sfx == _c5 ] && continue
   run pmc_fetch$tag --pmc FETCH_SIZE -- --steps 2 --warmup 1 $extra
   run pmc_write$tag --pmc WRITE_SIZE -- --steps 2 --warmup 1 $extra
   run pmc_sq$tag    --pmc $SQ -- --steps 2 --warmup 1 $extra
@@ -60,11 +63,22 @@ for sfx in base _strict _c4 _c4fast _c2 _c2wgsl _c5; do
   run pmc_occ$tag --pmc $OCC -- --steps 2 --warmup 1 $extra
   case $sfx in _c2|_c2wgsl) run pmc_mem$tag --pmc $MEM -- --steps 2 --warmup 1 $extra;; esac
 done
-if want k16; then
-  run trace_k16    --kernel-trace --stats -- --steps 10 --warmup 2 --segment-tries 16
+if want k16 || want base; then  # the base entry carries the K = 16 schedule's traffic: re-taken with it
   run pmc_fetch_k16 --pmc FETCH_SIZE -- --steps 2 --warmup 1 --segment-tries 16
   run pmc_write_k16 --pmc WRITE_SIZE -- --steps 2 --warmup 1 --segment-tries 16
 fi
+mkdir -p $OUT/summary
+cp $R/profiles/traffic.json $OUT/summary/traffic.json 2>/dev/null
+( cd $R && python tools/summarize_profiles.py $OUT $OUT/summary $TAG > $OUT/summarize_pmc.log 2>&1 )
+cp $OUT/summary/traffic.json $R/profiles/traffic.json
+for sfx in base _strict _c4 _c4fast _c2 _c2wgsl _c5; do
+  want $sfx || continue
+  extra=$(extra_of $sfx); tag=$sfx; [ $sfx == base ] && tag=""
+  steps="--steps 5 --warmup 1"; [ $sfx == base ] && steps="--steps 10 --warmup 2"
+  run trace$tag --kernel-trace --stats -- $steps $extra
+done
+( want k16 || want base ) && run trace_k16 --kernel-trace --stats -- --steps 10 --warmup 2 --segment-tries 16
+( cd $R && python tools/summarize_profiles.py $OUT $OUT/summary $TAG > $OUT/summarize.log 2>&1 ); tail -3 $OUT/summarize.log
 # the microbenchmark: costs in shader cycles (plain runs), and the same binary under the class counters
 # (which counter does a mnemonic land in, what do SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES say per instruction)
 if want microbench && hipcc -O2 --offload-arch=gfx950 $R/tools/valu_microbench.hip -o /tmp/valu_microbench 2> $OUT/valu_microbench_build.err; then

@@ -93,16 +93,41 @@ def _avg(label, counter, needle):
     return None
 
 
+def _bench_line(label):
+    """the bench.py line a pass printed (one JSON line), or None"""
+    try:
+        for ln in open(os.path.join(SRC, label + "_bench.json")):
+            if ln.startswith("{"):
+                return json.loads(ln)
+    except Exception:
+        pass
+    return None
+
+
+def _steps_per_launch(label):
+    ln = _bench_line(label)
+    if not ln:
+        return None
+    try:
+        return int(ln["config"]["accepted_steps_per_frame"] / max(ln["roofline"]["launches_per_frame"], 1.0))
+    except Exception:
+        return None
+
+
+# every entry names the pass it came from: "<tag>-<session directory>"; bench.py prints it
+# (roofline.traffic_pass), so a committed bench record says which counter pass it quoted
+PASS_ID = "%s-%s" % (TAG, os.path.basename(os.path.normpath(SRC)))
 hashes = {}
 hp = os.path.join(SRC, "code_hashes.json")
 if os.path.exists(hp):
     hashes = json.load(open(hp))
 tpath = os.path.join(DST, "traffic.json")
-traffic = {"format": 2, "kernels": {}}
+traffic = {"format": 3, "kernels": {}}
 if os.path.exists(tpath):
     old = json.load(open(tpath))
-    if old.get("format") == 2:
+    if old.get("format") in (2, 3):
         traffic = old
+        traffic["format"] = 3
 
 # (pretty name, substring of the demangled name in the trace, pass suffix, frame, layout bytes)
 CASES = [("integrate_segment_kernel<1,1,0>", "integrate_segment_kernel<1, 1, 0>", "", [3840, 2160], 8355840 * (92 + 76)),
@@ -121,7 +146,9 @@ for pretty, needle, sfx, frame, layout in CASES:
     # (/opt/skills/guides/MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 64 B per 128-B request
     # on coalesced streaming reads -> x2.  Cross-check for the f64 frame: 8 355 840 slots x 92 B
     # read = 0.769 GB, x 76 B written = 0.635 GB.
-    ent = {"name": needle, "code_hash": hashes.get(pretty.split("@")[0]), "frame": frame,
+    ent = {"name": needle, "code_hash": hashes.get(pretty.split("@")[0]), "frame": frame, "pass_id": PASS_ID,
+           # accepted ray-steps one launch of the profiled workload processed (bench line of the pmc_occ run)
+           "ray_steps_per_launch": _steps_per_launch("pmc_occ" + sfx) or _steps_per_launch("pmc_fetch" + sfx),
            "command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline" +
                       {"": "", "_strict": " --arith strict", "_c4": " --config c4", "_c4fast": " --config c4 --arith fast",
                        "_c2": " --config c2", "_c2wgsl": " --config c2 --kernel wgsl"}[sfx],
@@ -135,7 +162,10 @@ for pretty, needle, sfx, frame, layout in CASES:
             ent["segment_tries_16"] = {"fetch_size_kib_raw_avg_per_launch": f2,
                                        "write_size_kib_avg_per_launch": w2,
                                        "hbm_bytes_per_launch": int((2.0 * f2 + w2) * 1024),
-                                       "launches_per_frame": 32}
+                                       "launches_per_frame": ((_bench_line("pmc_fetch_k16") or {}).get("roofline") or {})
+                                       .get("launches_per_frame", 32),
+                                       "command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE -- python bench.py "
+                                                  "--steps 2 --warmup 1 --no-cpu-baseline --segment-tries 16"}
     # what actually bounds the kernel: VALU issue.  A gfx950 SIMD issues one VALU instruction per
     # quad-cycle (4 cycles) -- f64, packed f32, conversions, compares, selects alike --, transcendentals
     # hold it 2 (f32) / 4 (f64) quad-cycles, and two full-rate 32-bit ops can share one (calibrated with
