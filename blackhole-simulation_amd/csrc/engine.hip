@@ -383,6 +383,44 @@ int resolve_frame_events(grv_engine *e) {
     return GRV_OK;
 }
 
+int begin_march_order(grv_engine *e, int kind, uint32_t n_blocks, uint64_t key, hipStream_t s, MarchSched *out,
+                      int *parity) {
+    const int b = (int)(e->march_frames[kind]++ & 1u);
+    grv_engine::MarchOrder &M = e->march_order[kind][b];
+    if (!M.ready) GRV_HIP(e, hipEventCreateWithFlags(&M.ready, hipEventDisableTiming));
+    // behind the sort (perhaps queued on another stream) that last wrote this parity's order
+    if (M.ready_rec) GRV_HIP(e, hipStreamWaitEvent(s, M.ready, 0));
+    if (M.n_blocks < n_blocks) {
+        if (M.mem) {
+            GRV_HIP(e, hipEventSynchronize(M.ready)); // its last user has finished before it is freed
+            (void)hipFree(M.mem);
+        }
+        M.mem = nullptr;
+        M.n_blocks = 0;
+        M.key = 0;
+        GRV_HIP(e, hipMalloc(reinterpret_cast<void **>(&M.mem), (size_t)2 * n_blocks * sizeof(uint32_t)));
+        M.n_blocks = n_blocks;
+    }
+    if (M.key != key) { // first frame of this geometry: natural order, no forecast yet
+        GRV_HIP(e, launch_march_order_identity(M.mem + M.n_blocks, M.mem, n_blocks, s));
+        M.key = key;
+    }
+    M.cur = n_blocks;
+    out->cost = M.mem;
+    out->order = M.mem + M.n_blocks;
+    *parity = b;
+    return GRV_OK;
+}
+
+int finish_march_order(grv_engine *e, int kind, int parity, hipStream_t s) {
+    grv_engine::MarchOrder &M = e->march_order[kind][parity];
+    // the next frame of this parity starts its longest blocks first
+    GRV_HIP(e, launch_march_rank(M.mem, M.mem + M.n_blocks, M.cur, s));
+    GRV_HIP(e, hipEventRecord(M.ready, s));
+    M.ready_rec = true;
+    return GRV_OK;
+}
+
 int ensure_lut(grv_engine *e, uint32_t w, uint32_t h, double tmax, hipStream_t s) {
     if (e->d_lut && e->lut_w == w && e->lut_h == h && e->lut_tmax == tmax) {
         GRV_HIP(e, hipStreamWaitEvent(s, e->lut_ready, 0)); // generated on another stream, perhaps
@@ -538,7 +576,11 @@ void grv_engine_destroy(grv_engine *e) {
         if (W.done) (void)hipEventDestroy(W.done);
     }
     if (e->stage_mem) (void)hipFree(e->stage_mem);
-    if (e->d_march_cursors) (void)hipFree(e->d_march_cursors);
+    for (auto &kind : e->march_order)
+        for (auto &M : kind) {
+            if (M.mem) (void)hipFree(M.mem);
+            if (M.ready) (void)hipEventDestroy(M.ready);
+        }
     if (e->path_stage) (void)hipHostFree(e->path_stage);
     if (e->d_lut) (void)hipFree(e->d_lut);
     if (e->d_disk_lut) (void)hipFree(e->d_disk_lut);

@@ -119,10 +119,18 @@ struct grv_engine {
     } rt;
     void *post_mem = nullptr; // bloom render targets (bright, blur ping/pong)
     size_t post_bytes = 0;
-    // resident march grids (engine_types.hpp): 64 self-resetting {claimed, done} cursor pairs, one per
-    // launch in turn (launches in flight on different streams never share a pair)
-    uint32_t *d_march_cursors = nullptr;
-    uint32_t march_turn = 0;
+    // measured-cost dispatch order of the FAST marches (engine_types.hpp MarchSched): per march kind (0 GLSL,
+    // 1 packed WGSL) and frame parity one {cost, order} pair; a frame reads the order its parity's previous
+    // frame produced.  `ready` orders a user on another stream behind the sort that wrote the order.
+    struct MarchOrder {
+        uint32_t *mem = nullptr; // [2][n_blocks]: cost, order
+        uint32_t n_blocks = 0;   // allocated entries per array
+        uint32_t cur = 0;        // blocks of the frame in flight
+        uint64_t key = 0;        // frame geometry the order was measured on
+        hipEvent_t ready = nullptr;
+        bool ready_rec = false;
+    } march_order[2][2];
+    uint32_t march_frames[2] = {0, 0};
     uint8_t *d_noise = nullptr; // [2][256*256] R planes: u_noiseTex, u_blueNoiseTex
     std::vector<float> disk_lut = std::vector<float>(512, 0.0f); // lut_buffer (lib.rs:50, 65-66)
     std::vector<float> sab;
@@ -189,9 +197,15 @@ void stats_to_abi(const grv_engine *e, const FrameStatsDev &d, GrvFrameStats *ou
 // SAB offsets in f32 elements (lib.rs:36-40)
 constexpr size_t kOffControl = 0, kOffCamera = 64, kOffPhysics = 128, kOffTelemetry = 256, kOffLuts = 2048;
 
+// {order, cost} of the next frame of march `kind` (0 GLSL, 1 packed WGSL) with n_blocks blocks on stream s
+// (n_blocks == 0: no measured order for this form); finish_march_order queues the sort behind the march
+int begin_march_order(grv_engine *e, int kind, uint32_t n_blocks, uint64_t key, hipStream_t s, grvhip::MarchSched *out, int *parity);
+int finish_march_order(grv_engine *e, int kind, int parity, hipStream_t s);
+
 template <typename Launch>
 int run_shader_frame(grv_engine *e, uint32_t width, uint32_t height, uint32_t tw, uint32_t tr,
-                     uint64_t *total_steps, hipStream_t s, Launch &&launch) {
+                     uint64_t *total_steps, hipStream_t s, int kind, uint32_t sched_blocks_of_slots(uint32_t, int32_t),
+                     int32_t budget, Launch &&launch) {
     if (width == 0 || height == 0) return fail(e, GRV_ERR_INVALID, "empty frame");
     if (tw >= 1 && tr >= tw) return fail(e, GRV_ERR_INVALID, "tile_rank >= tile_world"); // 0 = whole frame
     GRV_HIP(e, hipSetDevice(e->device));
@@ -218,12 +232,19 @@ int run_shader_frame(grv_engine *e, uint32_t width, uint32_t height, uint32_t tw
         GRV_HIP(e, hipEventRecord(ev4[0], s));
         GRV_HIP(e, hipEventRecord(ev4[1], s));
     }
-    if (!e->d_march_cursors) {
-        GRV_HIP(e, hipMalloc(reinterpret_cast<void **>(&e->d_march_cursors), 64 * 2 * sizeof(uint32_t)));
-        GRV_HIP(e, hipMemset(e->d_march_cursors, 0, 64 * 2 * sizeof(uint32_t)));
+    MarchSched sched{nullptr, nullptr};
+    int parity = -1;
+    const uint32_t sched_blocks = sched_blocks_of_slots ? sched_blocks_of_slots((uint32_t)slots, budget) : 0u;
+    if (sched_blocks) {
+        const uint64_t key = ((uint64_t)width << 40) ^ ((uint64_t)height << 16) ^ ((uint64_t)tw << 8) ^ tr ^ ((uint64_t)sched_blocks << 1);
+        const int rc = begin_march_order(e, kind, sched_blocks, key, s, &sched, &parity);
+        if (rc != GRV_OK) return rc;
     }
-    uint32_t *cursor = e->d_march_cursors + 2u * (e->march_turn++ & 63u);
-    GRV_HIP(e, launch(G, (uint32_t)slots, &e->d_stats->accepted_steps, cursor));
+    GRV_HIP(e, launch(G, (uint32_t)slots, &e->d_stats->accepted_steps, sched));
+    if (parity >= 0) {
+        const int rc = finish_march_order(e, kind, parity, s);
+        if (rc != GRV_OK) return rc;
+    }
     if (ev4) {
         GRV_HIP(e, hipEventRecord(ev4[2], s));
         GRV_HIP(e, hipEventRecord(ev4[3], s));

@@ -108,10 +108,11 @@ int grv_render_frame_wgsl(grv_engine *e, const GrvWgslParams *p, float *d_rgba, 
     P.max_steps = p->max_steps;
     P.stars = p->stars;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return run_shader_frame(e, p->width, p->height, p->tile_world, p->tile_rank, total_steps, s,
-                            [&](const FrameGeom &G, uint32_t n, unsigned long long *tot, uint32_t *cursor) {
+    return run_shader_frame(e, p->width, p->height, p->tile_world, p->tile_rank, total_steps, s, 1,
+                            p->arith == GRV_ARITH_FAST_PACKED ? march_blocks_pk : nullptr, P.max_steps,
+                            [&](const FrameGeom &G, uint32_t n, unsigned long long *tot, MarchSched sched) {
                                 if (p->arith == GRV_ARITH_FAST_PACKED)
-                                    return launch_wgsl_symplectic_pk(G, P, d_rgba, d_steps, tot, n, cursor, e->n_cu, s);
+                                    return launch_wgsl_symplectic_pk(G, P, d_rgba, d_steps, tot, n, sched, s);
                                 return p->arith == GRV_ARITH_FAST
                                            ? launch_wgsl_symplectic_fast(G, P, d_rgba, d_steps, tot, n, s)
                                            : launch_wgsl_symplectic(G, P, d_rgba, d_steps, tot, n, s);
@@ -159,10 +160,11 @@ int grv_render_frame_glsl(grv_engine *e, const GrvGlslParams *p, float *d_rgba, 
     P.blue_r = e->d_noise + 256 * 256;
     P.noise_f = reinterpret_cast<const float *>(e->d_noise + 2 * 256 * 256);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return run_shader_frame(e, p->width, p->height, p->tile_world, p->tile_rank, total_steps, s,
-                            [&](const FrameGeom &G, uint32_t n, unsigned long long *tot, uint32_t *cursor) {
+    return run_shader_frame(e, p->width, p->height, p->tile_world, p->tile_rank, total_steps, s, 0,
+                            p->arith == GRV_ARITH_FAST ? +[](uint32_t n, int32_t) { return march_blocks_glsl(n); } : nullptr, 0,
+                            [&](const FrameGeom &G, uint32_t n, unsigned long long *tot, MarchSched sched) {
                                 return p->arith == GRV_ARITH_FAST
-                                           ? launch_glsl_fragment_fast(G, P, d_rgba, d_steps, tot, n, cursor, e->n_cu, s)
+                                           ? launch_glsl_fragment_fast(G, P, d_rgba, d_steps, tot, n, sched, s)
                                            : launch_glsl_fragment(G, P, d_rgba, d_steps, tot, n, s);
                             });
 }

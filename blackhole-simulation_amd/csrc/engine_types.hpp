@@ -65,44 +65,20 @@ __device__ __forceinline__ uint32_t dispatch_block_f64(uint32_t b, uint32_t nb, 
     return order ? centre_out_block(b, nb) : b;
 #endif
 }
-// ---- resident march grids (the f32 FAST marches of a frame) -------------------------------------------
-// A 1080p march is a 1-2 ms launch of 16 000-32 000 one-wave work items: dispatched as that many
-// workgroups it pays the dispatcher once per item and ends in a tail whose last waves run alone on
-// their SIMDs (no partner to pair with: half the issue rate).  The resident form launches as many waves
-// as the chip holds at once; every wave CLAIMS 8x8 pixel blocks from a device cursor (one atomic per
-// block, taken only when the wave is free: a claim made ahead would hold a block hostage at the tail)
-// until the list runs dry.  `order` maps the claim count to the block, so the blocks known to be long
-// are claimed first and the launch's tail is made of the cheapest ones:
-//   kOrderNatural    claim c -> block c
-//   kOrderCentreOut  the middle of the block list first (WGSL march: its long rays wind around the hole)
-//   kOrderOutsideIn  the ends of the list first, the middle last (GLSL march: every ray that escapes runs
-//                    the whole step budget, the short ones are the horizon / opaque-disk rays of the middle)
-// The cursor pair {claimed, waves done} resets itself: the last wave to leave zeroes both, so a frame
-// costs no memset launch.  A pixel's arithmetic does not depend on the wave that runs it: images and
-// step counts are bit for bit those of the dispatched grid.
-enum { kOrderNatural = 0, kOrderCentreOut = 1, kOrderOutsideIn = 2 };
-__device__ __forceinline__ uint32_t claim_to_block(uint32_t c, uint32_t nb, int order) {
-    if (order == kOrderCentreOut) return centre_out_block(c, nb);
-    if (order == kOrderOutsideIn) return centre_out_block(nb - 1u - c, nb);
-    return c;
-}
-// next block of this wave (wave-uniform), or >= n_blocks when the list is dry
-__device__ __forceinline__ uint32_t resident_claim(uint32_t *cursor) {
-    uint32_t c = 0;
-    if ((threadIdx.x & 63u) == 0u) c = atomicAdd(cursor, 1u);
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-}
-// a block leaves (call from ONE lane of it): the last of the launch's blocks re-arms the cursor pair for the
-// next launch that uses it
-__device__ __forceinline__ void resident_leave(uint32_t *cursor, uint32_t n_waves) {
-    {
-        if (atomicAdd(cursor + 1, 1u) == n_waves - 1u) {
-            cursor[0] = 0u;
-            cursor[1] = 0u;
-            __threadfence();
-        }
-    }
-}
+// ---- measured-cost dispatch order of the dispatched FAST marches ------------------------------------------
+// Workgroups start in blockIdx order.  `order` (a permutation of the frame's blocks, device memory) says
+// which block a workgroup takes; `cost` receives every block's duration on the constant-rate clock.  After
+// the march a one-workgroup counting sort turns the costs into the next frame's order, longest first
+// (longest-processing-time-first list scheduling: the launch's tail is then made of the cheapest blocks).
+// A renderer's frames resemble their predecessors, so last frame's durations are this frame's forecast; any
+// permutation gives the same image -- only the launch's length changes.  Either pointer may be null
+// (natural / centre-out order, nothing recorded).
+struct MarchSched {
+    const uint32_t *order;
+    uint32_t *cost;
+};
+hipError_t launch_march_order_identity(uint32_t *order, uint32_t *cost, uint32_t n, hipStream_t s);
+hipError_t launch_march_rank(const uint32_t *cost, uint32_t *order, uint32_t n, hipStream_t s);
 constexpr int kMaxCrossRec = 4;
 
 // flags word: bits 0-2 termination, bit 3 forced-min-step pending, bits 4-7 crossing
@@ -333,13 +309,15 @@ hipError_t launch_bloom_fast(uint32_t w, uint32_t h, const float *scene, float t
 hipError_t launch_blit_reinhard_fast(uint32_t w, uint32_t h, const float *src, float *dst, hipStream_t s);
 hipError_t launch_blit_reinhard(uint32_t w, uint32_t h, const float *src, float *dst, hipStream_t s);
 // ---- launcher (kernels_fast.hip: -ffp-contract=fast) ----
-// (cursor: one of the engine's self-resetting {claimed, done} pairs, for the resident-grid forms)
 hipError_t launch_glsl_fragment_fast(const FrameGeom &G, const GlslParams &P, float *out_rgba,
                                      uint32_t *out_steps, unsigned long long *total_steps,
-                                     uint32_t n_slots, uint32_t *cursor, int n_cu, hipStream_t s);
+                                     uint32_t n_slots, MarchSched sched, hipStream_t s);
 hipError_t launch_wgsl_symplectic_pk(const FrameGeom &G, const WgslParams &P, float *out_rgba,
                                      uint32_t *out_steps, unsigned long long *total_steps,
-                                     uint32_t n_slots, uint32_t *cursor, int n_cu, hipStream_t s);
+                                     uint32_t n_slots, MarchSched sched, hipStream_t s);
+// blocks (= entries of MarchSched's arrays) of the dispatched forms of the two marches for n_slots slots
+uint32_t march_blocks_glsl(uint32_t n_slots);
+uint32_t march_blocks_pk(uint32_t n_slots, int32_t max_steps);
 hipError_t launch_wgsl_symplectic_fast(const FrameGeom &G, const WgslParams &P, float *out_rgba,
                                        uint32_t *out_steps, unsigned long long *total_steps,
                                        uint32_t n_slots, hipStream_t s);

@@ -872,14 +872,28 @@ __device__ uint32_t glsl_fragment(const GlslParams &U, uint32_t width, uint32_t 
 #ifndef GRV_GLSL_FAST_WAVES
 #define GRV_GLSL_FAST_WAVES 8
 #endif
+// Measurement instrument, compiled only into an A/B library (-DGRV_MARCH_TIMELINE; tools/march_timeline.py):
+// every wave of the FAST march records {start, end} on the constant-rate clock, its hardware id and its
+// step count, so that the launch's ramp, steady state and tail can be drawn wave by wave.
+#ifdef GRV_MARCH_TIMELINE
+__device__ unsigned long long *g_march_timeline = nullptr; // [waves][4]
+#endif
 template <int ARITH>
 __global__ __launch_bounds__(kMarchBlock) __attribute__((amdgpu_waves_per_eu(ARITH == GRV_ARITH_FAST ? GRV_GLSL_FAST_WAVES : 1)))
 void glsl_fragment_kernel(FrameGeom G, GlslParams U,
                                                                float4 *__restrict__ out_rgba,
                                                                uint32_t *__restrict__ out_steps,
                                                                unsigned long long *total_steps,
-                                                               uint32_t n_slots) {
-    const uint32_t slot = blockIdx.x * kMarchBlock + threadIdx.x;
+                                                               uint32_t n_slots, MarchSched sched) {
+#ifdef GRV_MARCH_TIMELINE
+    const unsigned long long tl0 = wall_clock64();
+#endif
+    // measured-cost dispatch order (engine_types.hpp MarchSched); the shader-order form is dispatched in
+    // natural order: its launcher passes nulls, and the compiler sees so
+    constexpr bool kSched = ARITH == GRV_ARITH_FAST;
+    const unsigned long long sched_t0 = (kSched && sched.cost) ? wall_clock64() : 0ull;
+    const uint32_t block = (kSched && sched.order) ? sched.order[blockIdx.x] : blockIdx.x;
+    const uint32_t slot = block * kMarchBlock + threadIdx.x;
     uint32_t X = 0, Y = 0, oi = 0;
     const bool valid = slot < n_slots && slot_to_pixel(G, slot, X, Y, oi);
     uint32_t steps = 0;
@@ -890,72 +904,21 @@ void glsl_fragment_kernel(FrameGeom G, GlslParams U,
         if (out_steps) out_steps[oi] = steps;
     }
     add_steps(total_steps, steps);
-}
-
-#ifdef GRV_FAST_UNIT // (the FAST translation unit only)
-// Resident form of the FAST march (engine_types.hpp "resident march grids"): the grid is the waves the
-// chip holds, each wave claims 8x8 pixel blocks until the list is dry.  Same glsl_fragment<FAST> per
-// pixel: images and step counts are those of glsl_fragment_kernel<1> bit for bit.
-#ifndef GRV_GLSL_RESIDENT_ORDER
-#define GRV_GLSL_RESIDENT_ORDER kOrderOutsideIn
-#endif
-// One struct = the kernel-argument segment.  Every claimed block reads its uniforms from that segment
-// again, through a pointer the optimiser cannot see through (scalar loads, served by the scalar cache):
-// nothing of the prologue stays live across the claim loop, so the register allocation inside a pixel
-// is the one of the dispatched kernel -- with the arguments as plain loop-invariant values the loop form
-// spilled 204 B per lane instead of 44.
-struct GlslResidentArgs {
-    FrameGeom G;
-    GlslParams U;
-    float4 *out_rgba;
-    uint32_t *out_steps;
-    unsigned long long *total_steps;
-    uint32_t n_slots;
-    uint32_t *cursor;
-};
-#ifndef GRV_GLSL_RESIDENT_CALL
-#define GRV_GLSL_RESIDENT_CALL 1
-#endif
-typedef const __attribute__((address_space(4))) GlslResidentArgs *GlslResidentArgsPtr;
-// one claimed 8x8 block.  A real call (GRV_GLSL_RESIDENT_CALL): the pixel code gets the register
-// allocation it has as a kernel of its own -- inlined into the claim loop the march loop came out with
-// scalar reloads of uniforms and a scratch reload per step.
-__device__
-#if GRV_GLSL_RESIDENT_CALL
-    __attribute__((noinline))
-#else
-    __forceinline__
-#endif
-    void glsl_resident_block(uint32_t block) {
-    // the kernel-argument segment (the one GlslResidentArgs), taken here rather than passed in: a pointer
-    // argument of a device function travels in VGPRs, and every uniform would become a vector load
-    GlslResidentArgsPtr a4 = (GlslResidentArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
-    block = (uint32_t)__builtin_amdgcn_readfirstlane((int)block);
-    const GlslResidentArgs &A = *(const GlslResidentArgs *)a4;
-    const uint32_t slot = (block << 6) + (threadIdx.x & 63u);
-    uint32_t X = 0, Y = 0, oi = 0;
-    uint32_t steps = 0;
-    if (slot < A.n_slots && slot_to_pixel(A.G, slot, X, Y, oi)) {
-        float o[3];
-        steps = glsl_fragment<GRV_ARITH_FAST>(A.U, A.G.width, A.G.height, X, Y, o);
-        if (A.out_rgba) A.out_rgba[oi] = make_float4(o[0], o[1], o[2], 1.0f);
-        if (A.out_steps) A.out_steps[oi] = steps;
+    if (kSched && sched.cost && threadIdx.x == 0) sched.cost[block] = (uint32_t)(wall_clock64() - sched_t0);
+#ifdef GRV_MARCH_TIMELINE
+    if (ARITH == GRV_ARITH_FAST && g_march_timeline) {
+        unsigned long long v = steps;
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63u) == 0u) {
+            unsigned long long *t = g_march_timeline + 4ull * blockIdx.x;
+            t[0] = tl0;
+            t[1] = wall_clock64();
+            t[2] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | // HW_ID
+                   ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32); // XCC_ID
+            t[3] = v;
+        }
     }
-    add_steps(A.total_steps, steps);
-}
-__global__ __launch_bounds__(kMarchBlock) __attribute__((amdgpu_waves_per_eu(GRV_GLSL_FAST_WAVES)))
-void glsl_fragment_resident_kernel(GlslResidentArgs args) {
-    const uint32_t n_blocks = (args.n_slots + 63u) >> 6;
-    for (;;) {
-        const uint32_t c = resident_claim(args.cursor);
-        if (c >= n_blocks) break;
-#if defined(__HIP_DEVICE_COMPILE__)
-        glsl_resident_block(claim_to_block(c, n_blocks, GRV_GLSL_RESIDENT_ORDER));
 #endif
-    }
-    if (threadIdx.x == 0) resident_leave(args.cursor, gridDim.x);
 }
-
-#endif // GRV_FAST_UNIT
 
 } // namespace

@@ -1,7 +1,6 @@
 // kernels_fast.hip -- FAST arithmetic contract: compiled with -ffp-contract=fast.
 // Instantiates the segment kernel with the shared-reciprocal Kerr-Schild
 // right-hand side (kerr_device.hpp: rhs_ks_fast) and FMA contraction.
-#define GRV_FAST_UNIT 1
 #include "geodesic_kernels.hpp"
 #include "wgsl_fast_kernel.hpp"
 #include "wgsl_pk_kernel.hpp"
@@ -89,84 +88,51 @@ hipError_t launch_wgsl_symplectic_fast(const FrameGeom &G, const WgslParams &P, 
     return hipGetLastError();
 }
 
-namespace {
-// blocks of `kern` the device holds at once (cached per kernel; gfx950 only)
-template <typename K> uint32_t resident_blocks(K kern, int block, int n_cu, std::atomic<int> &cache, hipError_t &st) {
-    int per_cu = cache.load(std::memory_order_relaxed);
-    st = hipSuccess;
-    if (per_cu == 0) {
-        int v = 0;
-        st = hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kern, block, 0);
-        if (st != hipSuccess) return 0;
-        per_cu = v > 0 ? v : 1;
-        cache.store(per_cu, std::memory_order_relaxed);
-    }
-    return (uint32_t)per_cu * (uint32_t)(n_cu > 0 ? n_cu : 256);
-}
-} // namespace
-
-// A/B switches of the resident march grids (engine_types.hpp): 0 = the dispatched grids of rounds 1-4
-#ifndef GRV_GLSL_RESIDENT
-#define GRV_GLSL_RESIDENT 0
-#endif
-#ifndef GRV_PK_RESIDENT
-#define GRV_PK_RESIDENT 0
-#endif
-#ifndef GRV_RESIDENT_GRID_FACTOR
-#define GRV_RESIDENT_GRID_FACTOR 1
-#endif
-#ifndef GRV_PK_DISPATCH_ONE_WAVE
-#define GRV_PK_DISPATCH_ONE_WAVE 0
+// A/B switch: 0 = blocks start in natural (GLSL) / centre-out (WGSL) order, nothing recorded
+#ifndef GRV_MARCH_LPT
+#define GRV_MARCH_LPT 1
 #endif
 
 hipError_t launch_glsl_fragment_fast(const FrameGeom &G, const GlslParams &P, float *out_rgba,
                                      uint32_t *out_steps, unsigned long long *total_steps,
-                                     uint32_t n_slots, uint32_t *cursor, int n_cu, hipStream_t s) {
+                                     uint32_t n_slots, MarchSched sched, hipStream_t s) {
     if (n_slots == 0) return hipSuccess;
-    const uint32_t need = (n_slots + kMarchBlock - 1) / kMarchBlock;
-#if GRV_GLSL_RESIDENT
-    static std::atomic<int> cache{0};
-    hipError_t st;
-    const uint32_t resident = GRV_RESIDENT_GRID_FACTOR * resident_blocks(glsl_fragment_resident_kernel, kMarchBlock, n_cu, cache, st);
-    if (st != hipSuccess) return st;
-    const GlslResidentArgs args{G, P, reinterpret_cast<float4 *>(out_rgba), out_steps, total_steps, n_slots, cursor};
-    hipLaunchKernelGGL(glsl_fragment_resident_kernel, dim3(need < resident ? need : resident), dim3(kMarchBlock), 0, s, args);
-#else
-    hipLaunchKernelGGL((glsl_fragment_kernel<GRV_ARITH_FAST>), dim3(need), dim3(kMarchBlock), 0, s, G, P,
-                       reinterpret_cast<float4 *>(out_rgba), out_steps, total_steps, n_slots);
-#endif
+    hipLaunchKernelGGL((glsl_fragment_kernel<GRV_ARITH_FAST>), dim3((n_slots + kMarchBlock - 1) / kMarchBlock),
+                       dim3(kMarchBlock), 0, s, G, P, reinterpret_cast<float4 *>(out_rgba), out_steps, total_steps,
+                       n_slots, sched);
     return hipGetLastError();
 }
 
 hipError_t launch_wgsl_symplectic_pk(const FrameGeom &G, const WgslParams &P, float *out_rgba,
                                      uint32_t *out_steps, unsigned long long *total_steps,
-                                     uint32_t n_slots, uint32_t *cursor, int n_cu, hipStream_t s) {
+                                     uint32_t n_slots, MarchSched sched, hipStream_t s) {
     if (n_slots == 0) return hipSuccess;
     const uint32_t pairs = (n_slots + 1u) / 2u;
-    // long marches (budget > 512, the 8K frame of config 4: a 15 ms launch has no tail to speak of):
-    // dispatched one-wave blocks; short ones: the resident grid
-    if (P.max_steps > 512) {
+    // long marches: one-wave blocks; short ones: four-wave blocks (wgsl_pk_kernel.hpp)
+    if (P.max_steps > 512)
         hipLaunchKernelGGL(wgsl_symplectic_pk_kernel, dim3((pairs + kMarchBlock - 1) / kMarchBlock), dim3(kMarchBlock), 0, s,
-                           G, P, reinterpret_cast<float4 *>(out_rgba), out_steps, total_steps, n_slots);
-        return hipGetLastError();
-    }
-#if GRV_PK_RESIDENT
-    static std::atomic<int> cache{0};
-    hipError_t st;
-    const uint32_t resident = GRV_RESIDENT_GRID_FACTOR * resident_blocks(wgsl_symplectic_pk_resident_kernel, kPkResBlock, n_cu, cache, st);
-    if (st != hipSuccess) return st;
-    const uint32_t need = (pairs + kPkResBlock - 1) / kPkResBlock;
-    const PkResidentArgs args{G, P, reinterpret_cast<float4 *>(out_rgba), out_steps, total_steps, n_slots, cursor};
-    hipLaunchKernelGGL(wgsl_symplectic_pk_resident_kernel, dim3(need < resident ? need : resident), dim3(kPkResBlock), 0, s, args);
-#elif GRV_PK_DISPATCH_ONE_WAVE
-    hipLaunchKernelGGL(wgsl_symplectic_pk_kernel, dim3((pairs + kMarchBlock - 1) / kMarchBlock), dim3(kMarchBlock), 0, s,
-                       G, P, reinterpret_cast<float4 *>(out_rgba), out_steps, total_steps, n_slots);
-#else
-    hipLaunchKernelGGL(wgsl_symplectic_pk_b256_kernel, dim3((pairs + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
-                       G, P, reinterpret_cast<float4 *>(out_rgba), out_steps, total_steps, n_slots);
-#endif
+                           G, P, reinterpret_cast<float4 *>(out_rgba), out_steps, total_steps, n_slots, sched);
+    else
+        hipLaunchKernelGGL(wgsl_symplectic_pk_b256_kernel, dim3((pairs + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
+                           G, P, reinterpret_cast<float4 *>(out_rgba), out_steps, total_steps, n_slots, sched);
     return hipGetLastError();
 }
+
+// entries of MarchSched's arrays for a frame (0: this form takes no measured order).  The long packed march
+// (budget > 512: the 8K frame of config 4, a 15 ms launch whose tail is 1 % of it) keeps centre-out.
+uint32_t march_blocks_glsl(uint32_t n_slots) { return GRV_MARCH_LPT ? (n_slots + kMarchBlock - 1) / kMarchBlock : 0u; }
+uint32_t march_blocks_pk(uint32_t n_slots, int32_t max_steps) {
+    if (!GRV_MARCH_LPT || max_steps > 512) return 0u;
+    return ((n_slots + 1u) / 2u + kBlock - 1) / kBlock;
+}
+
+#ifdef GRV_MARCH_TIMELINE
+// instrument hook of an A/B library only (never in the product build): where glsl_fragment_kernel<FAST>
+// writes its per-wave records; nullptr switches them off
+extern "C" int grv_debug_set_march_timeline(unsigned long long *d_buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_march_timeline), &d_buf, sizeof d_buf);
+}
+#endif
 
 namespace {
 inline uint32_t at_least_1(uint32_t x) { return x ? x : 1u; }

@@ -212,7 +212,61 @@ hipError_t launch_glsl_fragment(const FrameGeom &G, const GlslParams &P, float *
                               uint32_t n_slots, hipStream_t s) {
     if (n_slots == 0) return hipSuccess;
     hipLaunchKernelGGL((glsl_fragment_kernel<GRV_ARITH_STRICT>), dim3((n_slots + kMarchBlock - 1) / kMarchBlock), dim3(kMarchBlock), 0, s,
-                       G, P, reinterpret_cast<float4 *>(out_rgba), out_steps, total_steps, n_slots);
+                       G, P, reinterpret_cast<float4 *>(out_rgba), out_steps, total_steps, n_slots, MarchSched{nullptr, nullptr});
+    return hipGetLastError();
+}
+
+namespace {
+// ---- measured-cost dispatch order (engine_types.hpp MarchSched) ----
+__global__ __launch_bounds__(kBlock) void march_order_identity_kernel(uint32_t *order, uint32_t *cost, uint32_t n) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        order[i] = i;
+        cost[i] = 0u;
+    }
+}
+// One workgroup: counting sort of the blocks by cost, longest first.  1024 buckets of 128 ticks (1.28 us on
+// the 100 MHz clock; anything beyond 1.3 ms shares the top bucket).  Whatever the costs are, `order` is a
+// permutation of [0, n): every block of the frame is dispatched exactly once.
+__global__ __launch_bounds__(1024) void march_rank_kernel(const uint32_t *__restrict__ cost, uint32_t *__restrict__ order,
+                                                          uint32_t n) {
+    __shared__ uint32_t hist[1024];
+    __shared__ uint32_t scan[1024];
+    const uint32_t t = threadIdx.x;
+    hist[t] = 0u;
+    __syncthreads();
+    for (uint32_t i = t; i < n; i += 1024u) {
+        const uint32_t b = cost[i] >> 7;
+        atomicAdd(&hist[b < 1023u ? b : 1023u], 1u);
+    }
+    __syncthreads();
+    // exclusive prefix over the buckets taken from the top: scan[t] = blocks in buckets above t's
+    const uint32_t mine = hist[1023u - t];
+    scan[t] = mine;
+    __syncthreads();
+    for (uint32_t off = 1u; off < 1024u; off <<= 1) {
+        const uint32_t v = t >= off ? scan[t - off] : 0u;
+        __syncthreads();
+        scan[t] += v;
+        __syncthreads();
+    }
+    hist[1023u - t] = scan[t] - mine; // first position of bucket (1023 - t)
+    __syncthreads();
+    for (uint32_t i = t; i < n; i += 1024u) {
+        const uint32_t b = cost[i] >> 7;
+        order[atomicAdd(&hist[b < 1023u ? b : 1023u], 1u)] = i;
+    }
+}
+} // namespace
+
+hipError_t launch_march_order_identity(uint32_t *order, uint32_t *cost, uint32_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    uint32_t g = (n + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(march_order_identity_kernel, dim3(g > 1024 ? 1024 : g), dim3(kBlock), 0, s, order, cost, n);
+    return hipGetLastError();
+}
+hipError_t launch_march_rank(const uint32_t *cost, uint32_t *order, uint32_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(march_rank_kernel, dim3(1), dim3(1024), 0, s, cost, order, n);
     return hipGetLastError();
 }
 

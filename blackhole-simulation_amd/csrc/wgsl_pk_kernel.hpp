@@ -8,7 +8,6 @@
 #pragma once
 
 #include "wgsl_fast_kernel.hpp"
-#include "shader_common.hpp"
 
 #ifndef GRV_PK_WAVES
 #define GRV_PK_WAVES 4 // waves per SIMD the packed march is compiled for (5 spills: measured slower)
@@ -162,7 +161,8 @@ __device__ __forceinline__ void pk_shade(float rb, float M, float a, float isco,
 // profiles/r03_shader_kernels.jsonl.
 __global__ __launch_bounds__(kMarchBlock) __attribute__((amdgpu_waves_per_eu(GRV_PK_WAVES, GRV_PK_WAVES)))
 void wgsl_symplectic_pk_kernel(FrameGeom G, WgslParams P, float4 *__restrict__ out_rgba,
-                               uint32_t *__restrict__ out_steps, unsigned long long *total_steps, uint32_t n_slots) {
+                               uint32_t *__restrict__ out_steps, unsigned long long *total_steps, uint32_t n_slots,
+                               MarchSched sched) {
 #define GRV_PK_BODY_BLOCK kMarchBlock
 #include "wgsl_pk_body.inc"
 #undef GRV_PK_BODY_BLOCK
@@ -170,72 +170,10 @@ void wgsl_symplectic_pk_kernel(FrameGeom G, WgslParams P, float4 *__restrict__ o
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GRV_PK_WAVES, GRV_PK_WAVES)))
 void wgsl_symplectic_pk_b256_kernel(FrameGeom G, WgslParams P, float4 *__restrict__ out_rgba,
                                     uint32_t *__restrict__ out_steps, unsigned long long *total_steps,
-                                    uint32_t n_slots) {
+                                    uint32_t n_slots, MarchSched sched) {
 #define GRV_PK_BODY_BLOCK kBlock
 #include "wgsl_pk_body.inc"
 #undef GRV_PK_BODY_BLOCK
-}
-
-// Resident form (engine_types.hpp "resident march grids"): one-wave blocks, every wave claims pairs of
-// 8x8 pixel blocks (two rays per lane) centre-out until the list is dry.  Same body, same pixels.
-#ifndef GRV_PK_RESIDENT_ORDER
-#define GRV_PK_RESIDENT_ORDER kOrderCentreOut
-#endif
-// (arguments as ONE struct = the kernel-argument segment, read again for every claimed block through an
-// opaque pointer: see glsl_fragment_resident_kernel)
-struct PkResidentArgs {
-    FrameGeom G;
-    WgslParams P;
-    float4 *out_rgba;
-    uint32_t *out_steps;
-    unsigned long long *total_steps;
-    uint32_t n_slots;
-    uint32_t *cursor;
-};
-// threads per block of the resident form (A/B: 64 = every wave claims for itself, 256 = four waves share a claim)
-#ifndef GRV_PK_RESIDENT_BLOCK
-#define GRV_PK_RESIDENT_BLOCK 64
-#endif
-constexpr int kPkResBlock = GRV_PK_RESIDENT_BLOCK;
-__global__ __launch_bounds__(kPkResBlock) __attribute__((amdgpu_waves_per_eu(GRV_PK_WAVES, GRV_PK_WAVES)))
-void wgsl_symplectic_pk_resident_kernel(PkResidentArgs args) {
-    const uint32_t n_blocks = ((args.n_slots + 1u) / 2u + kPkResBlock - 1u) / kPkResBlock;
-    for (;;) {
-#if GRV_PK_RESIDENT_BLOCK == 64
-        const uint32_t c = resident_claim(args.cursor);
-#else
-        __shared__ uint32_t s_claim;
-        if (threadIdx.x == 0) s_claim = atomicAdd(args.cursor, 1u);
-        __syncthreads();
-        const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_claim);
-        __syncthreads();
-#endif
-        if (c >= n_blocks) break;
-#if defined(__HIP_DEVICE_COMPILE__)
-        typedef const __attribute__((address_space(4))) PkResidentArgs *ArgsPtr;
-        ArgsPtr a4 = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
-        asm volatile("" : "+s"(a4));
-        const PkResidentArgs &A = *(const PkResidentArgs *)a4;
-#else
-        const PkResidentArgs &A = args;
-#endif
-        const FrameGeom &G = A.G;
-        const WgslParams &P = A.P;
-        float4 *__restrict__ const out_rgba = A.out_rgba;
-        uint32_t *__restrict__ const out_steps = A.out_steps;
-        const uint32_t n_slots = A.n_slots;
-        const uint32_t pk_block = claim_to_block(c, n_blocks, GRV_PK_RESIDENT_ORDER);
-        uint32_t pk_wave_steps = 0;
-        {
-#define GRV_PK_BODY_BLOCK kPkResBlock
-#define GRV_PK_BODY_RESIDENT
-#include "wgsl_pk_body.inc"
-#undef GRV_PK_BODY_RESIDENT
-#undef GRV_PK_BODY_BLOCK
-        }
-        add_steps(A.total_steps, pk_wave_steps);
-    }
-    if (threadIdx.x == 0) resident_leave(args.cursor, gridDim.x);
 }
 
 } // namespace

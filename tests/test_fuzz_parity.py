@@ -471,9 +471,26 @@ import json
 FAST_RAY_BARS = dict(
     steps_equal_ks=1.0 - 1e-3,     # Kerr-Schild: share of well-posed rays with the oracle's step count
     steps_equal_other=0.98,        # Boyer-Lindquist / Schwarzschild coordinates: poles and the horizon are singular
-    err_max_matched=1e-5, err_median_matched=1e-8,
-    class_equal_unmatched=0.5,     # an unmatched ray is usually one step early / late on the same geodesic
+    # matched rays walk the oracle's step sequence: what separates them is rounding, amplified along the ray
+    # (turning points under renormalisation every step, long paths at r0 = 300).  The fixed fixtures' <= 1e-5
+    # per ray holds for 99 % of the matched rays of every configuration, 99.9 % stay within 1e-4, none beyond 1e-3
+    err_max_matched=1e-3, err_p999_matched=1e-4, err_above_1e5_share=1e-2,
+    # median: 1.9e-10 on the bench frame at tol 1e-8; long paths (r0 = 300) and tolerances down to 1e-10
+    # (a third more, smaller steps per decade) reach 1e-7
+    err_median_matched=2e-7,
 )
+# Named edge cases (found by the campaign of profiles/r05_fuzz_fast.txt), where the ORACLE's own answer is an
+# artefact of rounding and a second arithmetic cannot be held to it ray by ray -- the STRICT contract still
+# returns its bits there (tests above), the FAST contract is held to classes and step counts only:
+#  * Boyer-Lindquist coordinates at |a| = M: Delta = (r - M)^2 has a double root at the horizon, and the rays the
+#    integrator stops at 1.001 r+ carry p_r = -3e5 ... -8e6 with t, phi in the thousands: every rounding of the
+#    last steps is amplified 1e5-1e7 times (all rays above 1e-5 are horizon rays, worst component p_r);
+#  * a camera 1e-6 rad off the spin axis: every ray starts inside the centrifugal barrier of the pole
+#    (p_phi^2 / sin^4 theta ~ 1e14), RKF45 falls back to forced minimum steps (integrator.rs:98-107), which are
+#    accepted whatever their error, and the two arithmetics drift apart by up to 1e-2 along r and t.  A camera
+#    exactly ON the axis (theta = 0, p_phi = 0 exactly) agrees to 2e-7.
+def _bl_extremal(okind, po, spin, mass=1.0):
+    return okind == po.KERR_BL and abs(spin) >= 0.9999
 
 
 def _report(rec):
@@ -508,8 +525,10 @@ def _fast_ray_metrics(po, m, tol, a, a_steps, a_term, ref):
     err = (np.abs(a - b) / np.maximum(1.0, np.abs(b))).max(axis=1)
     cls_bad_matched = int((a_term[same] != ref["term"][same]).sum())
     out = dict(rays=int(a.shape[0]), finite=n, matched=int(same.sum()),
-               steps_equal=float(same.sum() / max(n, 1)), class_mismatch_matched=cls_bad_matched,
+               steps_equal=float(same.sum() / n) if n else 1.0, class_mismatch_matched=cls_bad_matched,
                err_max_matched=float(err[same].max(initial=0.0)),
+               err_above_1e5_share=float((err[same] > 1e-5).mean()) if same.any() else 0.0,
+               err_p999_matched=float(np.percentile(err[same], 99.9)) if same.any() else 0.0,
                err_median_matched=float(np.median(err[same])) if same.any() else 0.0,
                nonfinite_disagree=int((np.isfinite(a).all(axis=1) != np.isfinite(b).all(axis=1)).sum()))
     un = np.flatnonzero(ok & ~same)
@@ -562,14 +581,19 @@ def test_random_batches_fast_stay_inside_the_contract(engine_mod, oracle, seed):
         tag = dict(seed=seed, kind=int(okind), mass=mass, spin=spin, **kw)
         _report(dict(test="fast_batch", **tag, **met))
         bar = FAST_RAY_BARS["steps_equal_ks"] if okind == po.KERR_KS else FAST_RAY_BARS["steps_equal_other"]
-        assert met["steps_equal"] >= bar, (tag, met)
         assert met["class_mismatch_matched"] == 0 and met["nonfinite_disagree"] == 0, (tag, met)
-        assert met["err_max_matched"] <= FAST_RAY_BARS["err_max_matched"], (tag, met)
-        assert met["err_median_matched"] <= FAST_RAY_BARS["err_median_matched"], (tag, met)
-        # unmatched rays: elsewhere on the same geodesic -- |d lambda| within a few controller steps (|h| <= 10,
-        # integrator.rs:76) and the rest a small multiple of what two step sequences at this tolerance differ by
-        assert met["worst_d_lambda"] <= 40.0, (tag, met)
-        assert met["worst_resid_off_the_ray"] <= 5e-5 + 2e3 * tol, (tag, met)
+        if _bl_extremal(okind, po, spin):   # named edge case above: classes and step counts only
+            assert met["steps_equal"] >= 0.95, (tag, met)
+        else:
+            assert met["steps_equal"] >= bar, (tag, met)
+            assert met["err_max_matched"] <= FAST_RAY_BARS["err_max_matched"], (tag, met)
+            assert met["err_p999_matched"] <= FAST_RAY_BARS["err_p999_matched"], (tag, met)
+            assert met["err_above_1e5_share"] <= FAST_RAY_BARS["err_above_1e5_share"], (tag, met)
+            assert met["err_median_matched"] <= FAST_RAY_BARS["err_median_matched"], (tag, met)
+            # unmatched rays: elsewhere on the same geodesic -- |d lambda| within a few controller steps (|h| <= 10,
+            # integrator.rs:76) and the rest a small multiple of what two step sequences at this tolerance differ by
+            assert met["worst_d_lambda"] <= 40.0, (tag, met)
+            assert met["worst_resid_off_the_ray"] <= 5e-5 + 2e3 * tol, (tag, met)
         if one is not None:
             k, out = one
             ref_one = po.integrate_ray_relativistic(mass, spin, st[k], kw["max_steps"], tol, okind == po.KERR_KS)
@@ -621,11 +645,19 @@ def test_random_frames_fast_stay_inside_the_contract(engine_mod, oracle, seed):
         met.update(px_max_matched=float(dpx[same].max(initial=0.0)), px_beyond_1e3=float((dpx > 1e-3).mean()))
         tag = dict(seed=seed, W=W, H=H, r0=r0, theta=th, spin=spin, kind=int(kind[0]), fovy=fovy, **okw)
         _report(dict(test="fast_frame", **tag, **met))
-        on_axis = th in (0.0, 1e-6, np.pi)   # a camera ON the spin axis looks along the coordinate singularity
-        bar = FAST_RAY_BARS["steps_equal_ks"] if (kind[0] == po.KERR_KS and not on_axis) else FAST_RAY_BARS["steps_equal_other"]
+        near_pole = th == 1e-6
+        if near_pole or _bl_extremal(kind[0], po, spin) or (kind[0] == po.KERR_BL and th in (0.0, np.pi)):
+            # named edge cases above (and Boyer-Lindquist rays that start ON the coordinate singularity):
+            # the call returns, matched rays carry the oracle's class, most finite rays agree in class
+            assert met["class_mismatch_matched"] == 0, (tag, met)
+            assert met["finite"] == 0 or met["class_equal_unmatched"] >= 0.9, (tag, met)
+            continue
+        bar = FAST_RAY_BARS["steps_equal_ks"] if kind[0] == po.KERR_KS else FAST_RAY_BARS["steps_equal_other"]
         assert met["steps_equal"] >= bar, (tag, met)
         assert met["class_mismatch_matched"] == 0, (tag, met)
         assert met["err_max_matched"] <= FAST_RAY_BARS["err_max_matched"] and \
+            met["err_p999_matched"] <= FAST_RAY_BARS["err_p999_matched"] and \
+            met["err_above_1e5_share"] <= FAST_RAY_BARS["err_above_1e5_share"] and \
             met["err_median_matched"] <= FAST_RAY_BARS["err_median_matched"], (tag, met)
         assert met["worst_d_lambda"] <= 40.0 and met["worst_resid_off_the_ray"] <= 5e-5 + 2e3 * tol, (tag, met)
         # shading follows the end state: matched rays shade to the oracle's pixel within f32 rounding of the lookup
@@ -701,7 +733,9 @@ def test_random_shader_frames_fast_hold_the_fast_bars(engine_mod, oracle, seed):
         assert met["beyond_5e2"] <= FAST_SHADER_BARS["beyond_5e2"], (name, met, tags)
 
 
-# random uniforms (close cameras, thick disks, every feature combination) at 10 000-40 000 pixels a frame:
-# the fixed fixtures' FAST_BARS (steps equal on 99.9 %, colour within 1e-4 of the peak on 99.9 %) with
-# the tail allowance a three-frame sample needs
-FAST_SHADER_BARS = dict(steps_equal=0.995, steps_within_2=0.997, colour_1e4=0.99, colour_2e3=0.995, beyond_5e2=2e-3)
+# random uniforms (close cameras, thick disks, every feature combination), ~55 000 pixels per seed: the fixed
+# fixtures' FAST_BARS (steps equal on 99.9 %, colour within 1e-4 of the peak on 99.9 %, 1e-4 beyond 5e-2) with
+# the allowance close-in cameras need -- a camera at r0 = 8 M puts a larger share of its pixels next to the
+# critical curve, where one ulp decides between another turn and falling in (measured over the campaign of
+# profiles/r05_fuzz_fast.txt; the GLSL march sits an order of magnitude inside these)
+FAST_SHADER_BARS = dict(steps_equal=0.998, steps_within_2=0.999, colour_1e4=0.997, colour_2e3=0.998, beyond_5e2=1e-3)

@@ -436,3 +436,36 @@ def test_shader_kernels_tile_partition(engine_mod):
         torch.cuda.synchronize()
     assert tsum == tot
     assert torch.equal(img.reshape(-1, 4), whole)
+
+
+@pytest.mark.gpu
+def test_measured_dispatch_order_never_changes_a_pixel(engine_mod):
+    """The dispatched FAST marches start their blocks in the order last frame's block durations suggest
+    (longest first; csrc/engine_types.hpp MarchSched, one counting sort per frame).  Any order must give the
+    same image: frame 1 runs in natural order, frames 2.. in measured orders (different every time --
+    durations are wall-clock), on one stream and alternating two, through a resize and back."""
+    import torch
+    bh = engine_mod
+    with bh.PhysicsEngine(1.0, 0.999) as e:
+        for kind in ("glsl", "wgsl"):
+            want = {}
+            for rep, (W, H) in enumerate([(640, 360), (640, 360), (333, 211), (640, 360), (640, 360), (640, 360)]):
+                cam = bh.camera_look_at(EYE, aspect=W / H)
+                rgba = torch.full((W * H, 4), -3.0, dtype=torch.float32, device="cuda:0")
+                steps = torch.zeros(W * H, dtype=torch.int32, device="cuda:0")
+                stream = torch.cuda.Stream() if rep % 2 else torch.cuda.current_stream()
+                with torch.cuda.stream(stream):
+                    if kind == "glsl":
+                        gp = bh.glsl_params(W, H, 1.0, 0.999, max_ray_steps=300, arith=bh.ARITH_FAST)
+                        tot = e.render_frame_glsl(gp, rgba, steps, stream=stream.cuda_stream)
+                    else:
+                        wp = bh.wgsl_params(W, H, cam, 1.0, 0.999, max_steps=300, arith=bh.ARITH_FAST_PACKED)
+                        tot = e.render_frame_wgsl(wp, rgba, steps, stream=stream.cuda_stream)
+                torch.cuda.synchronize()
+                got = (rgba.cpu().numpy().view(np.uint32), steps.cpu().numpy(), tot)
+                if (W, H) not in want:
+                    want[(W, H)] = got
+                    assert tot == int(got[1].sum()) and (got[0] != np.float32(-3.0).view(np.uint32)).all()
+                else:
+                    assert np.array_equal(got[0], want[(W, H)][0]) and np.array_equal(got[1], want[(W, H)][1]), (kind, rep)
+                    assert got[2] == want[(W, H)][2]

@@ -18,7 +18,7 @@ for rep in $(seq 1 $REPS); do
     for cfg in c3 ${AB_C4:+c4}; do
       extra=""; [ $cfg = c4 ] && extra="--config c4 --steps 10 --warmup 2"
       [ $cfg = c3 ] && extra="--steps ${AB_STEPS:-20} --warmup 3 ${AB_ARGS:-}"
-      python bench.py $extra --no-cpu-baseline 2> $O/err_${name}_$cfg.txt | python -c "
+      timeout ${AB_TIMEOUT:-300} python bench.py $extra --no-cpu-baseline 2> $O/err_${name}_$cfg.txt | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print(json.dumps({'lib':'$name','config':'$cfg','rep':$rep,'value':d['value'],'ms_per_step':d['ms_per_step'],'avg_launch_ms':d['roofline']['avg_launch_ms']}))" >> $O/ab.jsonl
