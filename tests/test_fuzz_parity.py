@@ -599,7 +599,7 @@ def test_random_batches_fast_stay_inside_the_contract(engine_mod, oracle, seed):
             ref_one = po.integrate_ray_relativistic(mass, spin, st[k], kw["max_steps"], tol, okind == po.KERR_KS)
             e1 = float((np.abs(np.asarray(out) - np.asarray(ref_one)) / np.maximum(1.0, np.abs(np.asarray(ref_one)))).max())
             _report(dict(test="fast_one_ray", **tag, ray=k, rel_err=e1))
-            assert e1 <= 5e-2, (tag, k, e1)  # (its own defaults: h0 = 0.01, escape 1000 -- a ray of the lib.rs entry)
+            assert e1 <= 1e-4, (tag, k, e1)  # (its own defaults: h0 = 0.01, escape 1000 -- a ray of the lib.rs entry; measured <= 2e-6)
 
 
 @pytest.mark.parametrize("seed", range(SEEDS))

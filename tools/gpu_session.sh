@@ -7,6 +7,8 @@
 #   bench        the bench.py line of every BASELINE config (+ the one-stream / wgsl / K = 16 secondaries)
 #   bench:<args> one bench.py line with these arguments (quote them)
 #   fuzz:<n>     tests/test_fuzz_parity.py with GRV_FUZZ_SEEDS=<n>
+#   fuzzfast:<n> its FAST-contract tests only, figures of every test appended to fuzz_fast_report.jsonl
+#   timeline     tools/march_timeline.py on ab_libs/tl_base.so and tl_lpt.so (built with -DGRV_MARCH_TIMELINE)
 #   parity       the full-size parity records (c5, 8K, c4 every pixel)
 #   profile[:<suffixes>]  tools/profile_gpu.sh (counter passes, then traces; see there)
 #   renderers    tools/bench_renderers.py + tools/bench_shaders.py
@@ -38,7 +40,9 @@ for stage in "$@"; do
           tag=$(echo $cfg | tr -d ' -'); timeout 900 python bench.py --config $cfg > $O/bench_$tag.json 2> $O/bench_$tag.err; echo "$cfg rc=$?"; cut -c1-130 $O/bench_$tag.json
         done
       fi;;
-    fuzz) ( GRV_FUZZ_SEEDS=${arg:-100} timeout 3000 python -m pytest tests/test_fuzz_parity.py -m gpu -q -x 2>&1 | tail -15 ) > $O/fuzz.log 2>&1; cat $O/fuzz.log;;
+    fuzz) ( GRV_FUZZ_SEEDS=${arg:-100} GRV_FUZZ_REPORT=$O/fuzz_fast_report.jsonl timeout 3000 python -m pytest tests/test_fuzz_parity.py -m gpu -q --timeout 900 2>&1 | tail -25 ) > $O/fuzz.log 2>&1; cat $O/fuzz.log;;
+    fuzzfast) ( GRV_FUZZ_SEEDS=${arg:-500} GRV_FUZZ_REPORT=$O/fuzz_fast_report.jsonl timeout 3000 python -m pytest tests/test_fuzz_parity.py -m gpu -q --timeout 900 -k "fast_stay or fast_hold" 2>&1 | tail -25 ) > $O/fuzzfast.log 2>&1; cat $O/fuzzfast.log;;
+    timeline) for t in base lpt; do timeout 300 python tools/march_timeline.py ab_libs/tl_$t.so --frames 5 > $O/timeline_$t.json 2> $O/timeline_$t.err; echo "timeline $t rc=$?"; done;;
     parity)
       GRV_PARITY_TOL=1e-9 GRV_PARITY_JSON=$O/full_frame_parity_c5.json timeout 1200 python -m pytest tests/test_full_frame_parity.py -m gpu -q 2>&1 | tail -2
       GRV_PARITY_SIZE=7680x4320 GRV_PARITY_JSON=$O/full_frame_parity_8k.json timeout 2400 python -m pytest tests/test_full_frame_parity.py -m gpu -q 2>&1 | tail -2

@@ -32,7 +32,7 @@ PY
 run() { # label, rocprof args..., -- bench args
   local label=$1; shift
   local rp=(); while [ "$1" != "--" ]; do rp+=("$1"); shift; done; shift
-  ( cd $R && rocprofv3 "${rp[@]}" -d $OUT/$label -o bench -- python bench.py "$@" --no-cpu-baseline > $OUT/${label}_bench.json 2> $OUT/$label.err )
+  ( cd $R && timeout 600 rocprofv3 "${rp[@]}" -d $OUT/$label -o bench -- python bench.py "$@" --no-cpu-baseline > $OUT/${label}_bench.json 2> $OUT/$label.err )
   # rocprofv3 nests the database under <host>/: lift it to where summarize_profiles.py looks
   db=$(find $OUT/$label -name "bench_results.db" | head -1); [ -n "$db" ] && [ "$db" != "$OUT/$label/bench_results.db" ] && mv "$db" $OUT/$label/bench_results.db
 }
@@ -84,7 +84,7 @@ done
 if want microbench && hipcc -O2 --offload-arch=gfx950 $R/tools/valu_microbench.hip -o /tmp/valu_microbench 2> $OUT/valu_microbench_build.err; then
   for w in 1 2 4 8; do /tmp/valu_microbench $w > $OUT/valu_costs_w$w.json 2>> $OUT/valu_microbench.err; done
   mb() { local label=$1; shift
-    rocprofv3 "$@" -d $OUT/$label -o bench -- /tmp/valu_microbench 4 > /dev/null 2> $OUT/$label.err
+    timeout 300 rocprofv3 "$@" -d $OUT/$label -o bench -- /tmp/valu_microbench 4 > /dev/null 2> $OUT/$label.err
     db=$(find $OUT/$label -name "bench_results.db" | head -1); [ -n "$db" ] && [ "$db" != "$OUT/$label/bench_results.db" ] && mv "$db" $OUT/$label/bench_results.db; }
   mb mb_cls32 --pmc $CLS32
   mb mb_cls64 --pmc $CLS64
