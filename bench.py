@@ -390,6 +390,8 @@ def main_native(args, cfg, base_w, base_h):
         raise SystemExit(3)
     if m.ranks != G:
         raise SystemExit("--gpus %d but the handle has %d ranks" % (G, m.ranks))
+    if args.exchange == "rgba16f":
+        m.set_exchange_format(bh.EXCHANGE_RGBA16F)
     torch.cuda.set_device(0)
     W, H = base_w, base_h
     th = np.deg2rad(97.0)
@@ -467,6 +469,7 @@ def main_native(args, cfg, base_w, base_h):
                                 % ("RCCL send/recv-group" if m.transport == bh.TRANSPORT_RCCL else "peer-copy")
                    if G > 1 else "single GPU",
                    "virtual_ranks_on_one_device": bool(one_device),
+                   "exchange": args.exchange, "exchange_bytes_per_frame": m.exchange_bytes_per_frame(W, H),
                    "rays": W * H, "accepted_steps_per_frame": int(total_steps / args.steps),
                    "host_waits_in_frame_loop": 0 if not args.segment_tries else "one per segment",
                    "frames_in_flight": 2},
@@ -521,6 +524,10 @@ def main():
                          "send/recv group per frame) instead of N torch.distributed ranks")
     ap.add_argument("--transport", choices=["auto", "rccl", "peer"], default="auto",
                     help="--native: exchange transport (auto: RCCL between real devices)")
+    ap.add_argument("--exchange", choices=["rgba32f", "rgba16f"], default="rgba32f",
+                    help="N > 1: what the one gather carries -- f32 pixels (default) or the reference compute pass's "
+                         "own rgba16float format (renderer.ts:163-176): half the bytes, the assembled image is the frame "
+                         "rounded through binary16")
     args = ap.parse_args()
     cfg = args.config
     global TOL, KERNEL
@@ -656,17 +663,20 @@ def main():
     stream = streams[0].cuda_stream
     # all buffers live outside the frame loop: the padded send buffer doubles as the render
     # target, rank 0 additionally holds the receive slots and the assembled image
-    tg = D.TileGather(params, world, rank, 4, torch.float32, torch.device("cuda", local_rank)) \
+    half = args.exchange == "rgba16f" and use_dist
+    tg = D.TileGather(params, world, rank, 4, torch.float16 if half else torch.float32, torch.device("cuda", local_rank)) \
         if use_dist else None
     overlap = tg is not None and not args.no_overlap
     if overlap:
         tg.enable_pipeline()  # second send buffer: frame i's gather runs under frame i+1's kernels
-    bufs = [tg.local_view(n_local)] * 2 if tg else \
+    # (rgba16f exchange: the kernels render f32 into their own targets; the share is narrowed -- one rounding to
+    # nearest even, torch's f32 -> f16 copy -- into the send buffer that travels)
+    bufs = [tg.local_view(n_local)] * 2 if (tg and not half) else \
         [torch.empty((n_local, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
     eng.stats_accumulate(True)  # counters stay in HBM across frames: no read-back in the loop
 
     def dev_unpack(rparams, r, packed, image):
-        eng.unpack_tiles_device(rparams, r, packed, image, 16, torch.cuda.current_stream().cuda_stream)
+        eng.unpack_tiles_device(rparams, r, packed, image, 8 if half else 16, torch.cuda.current_stream().cuda_stream)
 
     # c4 at N = 1: bracket each march launch with events on the launch stream (torch's current
     # stream is the stream handed to the engine), resolved after the loop
@@ -690,8 +700,10 @@ def main():
 
     def one_frame(i, profiled):
         with torch.cuda.stream(streams[i % 2]):
-            target = tg.pipelined_view(i, n_local) if overlap else bufs[i % 2]
+            target = tg.pipelined_view(i, n_local) if (overlap and not half) else bufs[i % 2]
             render(target, profiled)
+            if half:  # narrow the share into the buffer that travels
+                (tg.pipelined_view(i, n_local) if overlap else tg.local_view(n_local)).copy_(target)
             if overlap:
                 tg.submit(i, dev_unpack, force_collective=True)  # finish frame i-1's exchange, start frame i's
             elif tg:
@@ -805,6 +817,7 @@ def main():
                        "rays": total_rays, "accepted_steps_per_frame": int(total_steps / args.steps),
                        "host_waits_in_frame_loop": 0 if not args.segment_tries else "one per segment",
                        "frames_in_flight": 2 if two else 1,
+                       **({"exchange": args.exchange} if world > 1 else {}),
                        **({"exchange_backend": backend} if backend != "nccl" else {})},
             "roofline": roofline,
         }

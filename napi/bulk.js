@@ -56,6 +56,34 @@ const now = () => { const t = process.hrtime(); return t[0] * 1e3 + t[1] / 1e6; 
   const pinned = new Float32Array(wasm.allocPinned(96 * 54 * 16));
   const fp = engine.renderFrame({ width: 96, height: 54, eye: [59.55, -7.31, 0.0], devices: 1, out: pinned });
   const same = (a, c) => a.length === c.length && a.every((v, i) => Object.is(v, c[i]));
+  // the exchange in the compute pass's own rgba16float format: the one-device frame rounded through binary16
+  const f4h = engine.renderFrame({ width: 96, height: 54, eye: [59.55, -7.31, 0.0], virtualRanks: 4, exchange: "rgba16f" });
+  const hb = new Float32Array(1), hu = new Uint32Array(hb.buffer);
+  const toHalf = (x) => {  // round to nearest even through binary16; every step below is exact in doubles
+    hb[0] = x;
+    const bits = hu[0], neg = bits >>> 31, e = (bits >>> 23) & 255;
+    if (e === 255) return x;
+    let val;
+    if (e - 127 > 15) val = Infinity;
+    else if (e - 127 >= -14) {  // normal half: keep ten mantissa bits
+      let m = bits & 0x7fffff;
+      const rem = m & 0x1fff, lsb = (m >>> 13) & 1;
+      m = (m >>> 13) + ((rem > 0x1000 || (rem === 0x1000 && lsb)) ? 1 : 0);
+      val = (1 + m / 1024) * Math.pow(2, e - 127);
+      if (val > 65504) val = Infinity;
+    } else {  // subnormal half: a multiple of 2^-24
+      const q = Math.abs(x) * Math.pow(2, 24);
+      let k = Math.floor(q);
+      const d = q - k;
+      if (d > 0.5 || (d === 0.5 && (k & 1))) k += 1;
+      val = k * Math.pow(2, -24);
+    }
+    return neg ? -val : val;
+  };
+  const f4back = engine.renderFrame({ width: 96, height: 54, eye: [59.55, -7.31, 0.0], virtualRanks: 4 });
+  res.frames_half = { equal_rounded: f4h.rgba.every((v, i) => Object.is(v, Math.fround(toHalf(f1.rgba[i])))),
+                      differs_from_f32: !f4h.rgba.every((v, i) => Object.is(v, f1.rgba[i])),
+                      back_to_f32: f4back.rgba.every((v, i) => Object.is(v, f1.rgba[i])) };
   res.frames = { steps1: f1.acceptedSteps, steps4: f4.acceptedSteps, devices4: f4.devices,
                  ranks_equal: same(f1.rgba, f4.rgba), async_ranks_equal: same(f1.rgba, fa2.rgba),
                  pinned_equal: same(f1.rgba, pinned), pinned_is_out: fp.rgba === pinned || fp.rgba.buffer === pinned.buffer };

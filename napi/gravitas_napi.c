@@ -669,6 +669,7 @@ typedef struct {
     GrvCamera cam;
     GrvRenderParams p;
     int devices, virtual_ranks;
+    int exchange;   /* GRV_EXCHANGE_*: what the one exchange of a multi-rank frame carries */
     int transport;  /* GRV_TRANSPORT_* the frame's tiles travelled through; 0 = one device, no exchange */
     float *rgba;    /* W*H*4: memory of the result's ArrayBuffer, or own_rgba */
     /* The *Async forms run on a pool thread while JS keeps running: memory JS can reach in the
@@ -746,6 +747,7 @@ static void bulk_execute(bulk_work *w) {
         const int ranks = w->virtual_ranks > 0 ? w->virtual_ranks : w->devices;
         if (ranks > 1 || w->virtual_ranks > 0) {
             w->rc = multi_for(mslot, mr, mv, ranks, w->virtual_ranks > 0, w->mass, w->spin, w->err, sizeof w->err);
+            if (w->rc == GRV_OK) w->rc = grv_multi_set_exchange_format(*mslot, w->exchange);
             if (w->rc == GRV_OK) {
                 w->transport = grv_multi_transport(*mslot);
                 w->rc = grv_render_frame_multi(*mslot, &w->cam, &w->p, w->rgba, &w->st);
@@ -882,6 +884,8 @@ static int keep_ref(napi_env env, bulk_work *w, napi_value v) {
  *   devices: n      the image plane is tiled over the first n HIP devices (one gather of finished
  *                   tiles to device 0, RCCL over xGMI; include/gravitas_abi.h grv_engine_create_multi);
  *   virtualRanks: n the same assembly path with n ranks on device 0 (one-GPU hosts, tests);
+ *   exchange: "rgba16f"  the gather carries the compute pass's own rgba16float format (renderer.ts:163-176): half
+ *                   the bytes, the image is the one-device frame rounded through binary16 (default "rgba32f");
  *   out             render into a caller-owned array -- with allocPinned() memory the frame
  *                   leaves the device in one DMA and no copy is made on the JS side.
  * renderFrameAsync(opts) -> Promise of the same object: the frame runs on the libuv pool with an
@@ -923,6 +927,11 @@ static napi_value render_frame_common(napi_env env, napi_callback_info info, int
     wk->spin = b->spin;
     wk->devices = (int)devices;
     wk->virtual_ranks = (int)vranks;
+    {
+        char ex[16];
+        wk->exchange = (obj_str(env, argv[0], "exchange", ex, sizeof ex) && strcmp(ex, "rgba16f") == 0) ? GRV_EXCHANGE_RGBA16F
+                                                                                                      : GRV_EXCHANGE_RGBA32F;
+    }
     double eye[3] = {0.0, 0.0, 60.0}, target[3] = {0.0, 0.0, 0.0}, up[3] = {0.0, 1.0, 0.0};
     obj_vec3(env, argv[0], "eye", eye);
     obj_vec3(env, argv[0], "target", target);

@@ -36,6 +36,9 @@ export interface RenderFrameOptions {
   devices?: number;
   /** the same assembly path with n ranks on device 0 (one-GPU hosts, tests) */
   virtualRanks?: number;
+  /** what the gather of a multi-device frame carries: f32 pixels (default) or the compute pass's own
+   *  rgba16float format (half the bytes; the image is the one-device frame rounded through binary16) */
+  exchange?: "rgba32f" | "rgba16f";
   /** render into this array (width*height*4) instead of a fresh one */
   out?: Float32Array;
 }

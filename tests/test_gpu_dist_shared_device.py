@@ -79,6 +79,17 @@ def _worker(rank, world, port, w, h, arith, out_path):
             st = eng.frame_stats(streams[0].cuda_stream)
             steps = torch.tensor([float(st.accepted_steps)], dtype=torch.float64, device=dev)
             dist.all_reduce(steps)
+            # the exchange in the compute pass's rgba16float format (bench.py --exchange rgba16f): the share is
+            # rendered in f32, narrowed once into the half send buffer, gathered, de-interleaved 8 B per pixel
+            eng.stats_accumulate(False)
+            tg3 = D.TileGather(params, world, rank, 4, torch.float16, dev)
+            scratch = torch.zeros(n_local, 4, dtype=torch.float32, device=dev)
+            eng.render_frame_device(cam, rp, rgba=scratch, stream=torch.cuda.current_stream().cuda_stream)
+            tg3.local_view(n_local).copy_(scratch)
+            img16 = tg3.run(lambda rparams, r, packed, image: eng.unpack_tiles_device(
+                rparams, r, packed, image, 8, torch.cuda.current_stream().cuda_stream))
+            torch.cuda.synchronize()
+            half_image = img16.float().cpu().numpy().copy() if rank == 0 else None
             if rank == 0:
                 # the whole frame on this GPU, one rank
                 whole = torch.zeros(w * h, 4, dtype=torch.float32, device=dev)
@@ -87,7 +98,8 @@ def _worker(rank, world, port, w, h, arith, out_path):
                 wst = eng.frame_stats()
                 torch.cuda.synchronize()
                 np.savez(out_path, whole=whole.cpu().numpy().reshape(h, w, 4), images=np.stack(images),
-                         steps_sum=float(steps.item()), steps_whole=float(wst.accepted_steps))
+                         steps_sum=float(steps.item()), steps_whole=float(wst.accepted_steps),
+                         half_image=half_image, whole_half=whole.half().float().cpu().numpy().reshape(h, w, 4))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -103,6 +115,9 @@ def test_ranks_sharing_one_gpu_assemble_the_whole_frame_bitwise(tmp_path, engine
     for img in r["images"]:
         assert np.array_equal(img.view(np.uint32), r["whole"].view(np.uint32))
     assert r["steps_sum"] == 4 * r["steps_whole"]  # four accumulated frames, every ray counted once
+    # rgba16f exchange: the whole frame rounded through binary16, bit for bit
+    assert np.array_equal(r["half_image"].view(np.uint32), r["whole_half"].view(np.uint32))
+    assert not np.array_equal(r["half_image"], r["whole"])
 
 
 def _bench(world, *args, launcher=False):
@@ -173,6 +188,10 @@ def test_bench_strong_split_runs_with_several_ranks(world):
     assert many["config"]["accepted_steps_per_frame"] == one["config"]["accepted_steps_per_frame"]
     assert many["config"]["frames_in_flight"] == 2 and many["config"]["host_waits_in_frame_loop"] == 0
     assert "split over %d GPUs" % world in many["config"]["workload"]
+    assert many["config"]["exchange"] == "rgba32f"
+    half = _bench(world, "--width", "640", "--height", "360", "--steps", "4", "--warmup", "1", "--exchange", "rgba16f")
+    assert half["config"]["exchange"] == "rgba16f" and half["n_gpus"] == world
+    assert half["config"]["accepted_steps_per_frame"] == one["config"]["accepted_steps_per_frame"]
     assert many["value"] > 0 and many["roofline"]["avg_launch_ms"] > 0
     assert "cpu_baseline" not in many
 

@@ -215,6 +215,9 @@ def test_bulk_js_batch_async_and_multi_device_entries(oracle, tmp_path):
     f = res["frames"]
     assert f["ranks_equal"] and f["async_ranks_equal"] and f["pinned_equal"] and f["pinned_is_out"]
     assert f["steps1"] == f["steps4"] and f["devices4"] == 4 and f["update_reaches_ranks"]
+    # renderFrame({exchange: "rgba16f"}): the gather in the compute pass's rgba16float format (renderer.ts:163-176)
+    fh = res["frames_half"]
+    assert fh["equal_rounded"] and fh["differs_from_f32"] and fh["back_to_f32"], fh
     am = res["async_memory"]  # the async forms never hold pointers into memory JS can reach meanwhile
     assert am["out_filled"] and am["input_copy"] and am["detached_rejected"] and "detached" in am["detached_rejected"]
     e = res["errors"]

@@ -469,3 +469,43 @@ def test_measured_dispatch_order_never_changes_a_pixel(engine_mod):
                 else:
                     assert np.array_equal(got[0], want[(W, H)][0]) and np.array_equal(got[1], want[(W, H)][1]), (kind, rep)
                     assert got[2] == want[(W, H)][2]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arith", [1, 2])
+def test_fast_marches_on_the_disk_edge_knife_edge(engine_mod, oracle, arith):
+    """Named edge case of the randomised FAST campaign (profiles/r05_fuzz_fast.txt).  A camera IN the
+    equatorial plane at EXACTLY the disk's outer radius: theta0 = pi/2 makes the crossing test
+    (theta_before - pi/2)(theta_after - pi/2) <= 0 true on the very first step of every ray, and whether that
+    crossing shades depends on `r_before < 30.0` (compute.wgsl.ts:216-217) with r_before = |camera| = 30 to the
+    ulp -- shader order (correctly rounded sqrt) gets 30.000002 and shades nothing, the FAST forms' |camera|
+    comes out one ulp lower and every pixel of the frame starts with a disk sample.  Both are the shader's
+    algorithm on an input that sits on its discontinuity: the FAST frame must equal, to FAST_BARS, the
+    shader-order frame of the camera moved 3e-7 (relative) inwards -- or the one at 30 itself."""
+    import torch
+    W, H, budget = 213, 134, 512
+    th, ph = np.pi / 2, 5.151
+    frames = {}
+    for name, r0 in (("at", 30.0), ("inside", 30.0 * (1.0 - 3e-7))):
+        eye = (r0 * np.sin(th) * np.cos(ph), r0 * np.cos(th), r0 * np.sin(th) * np.sin(ph))
+        cam = engine_mod.camera_look_at(eye, fovy_deg=25.0, aspect=W / H)
+        gp = engine_mod.wgsl_params(W, H, cam, 1.0, 0.999, max_steps=budget, arith=arith, stars=0)
+        frames[name] = oracle.wgsl_frame(oracle.wgsl_params_from(gp), nthreads=4)
+        if name == "at":
+            with engine_mod.PhysicsEngine(1.0, 0.999) as e:
+                rgba = torch.zeros(W * H, 4, dtype=torch.float32, device="cuda:0")
+                steps = torch.zeros(W * H, dtype=torch.int32, device="cuda:0")
+                e.render_frame_wgsl(gp, rgba, steps)
+                got = (rgba.cpu().numpy().reshape(H, W, 4), steps.cpu().numpy().reshape(H, W))
+    # the two shader-order frames differ all over (the first-step sample is there or not) ...
+    d = np.abs(frames["at"][0] - frames["inside"][0])[..., :3].max(-1)
+    assert (d > 1e-3).mean() > 0.5
+    # ... and the FAST frame is one of them
+    errs = []
+    for name in ("at", "inside"):
+        try:
+            _compare(got[0], got[1], frames[name][0], frames[name][1])
+            return
+        except AssertionError as exc:
+            errs.append((name, str(exc)[:200]))
+    raise AssertionError(errs)

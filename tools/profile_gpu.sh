@@ -92,5 +92,9 @@ if want microbench && hipcc -O2 --offload-arch=gfx950 $R/tools/valu_microbench.h
   mb mb_occ --pmc $OCC
 fi
 find $OUT -name "*.csv" -delete
-find $OUT -name "*.db" | head -40
+# the rocpd databases stay on the box (gpurun merges at most 64 MiB back): what travels is $OUT/summary
+# (traffic.json, rNN_pmc_counters.json, rNN_trace_*_kernel_stats.txt), the bench lines and the .err files
+find $OUT -name "*.db" | wc -l
+find $OUT -name "*.db" -delete
+find $OUT -mindepth 1 -type d -empty -delete
 du -sh $OUT
