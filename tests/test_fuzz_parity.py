@@ -769,7 +769,7 @@ def test_random_shader_frames_fast_hold_the_fast_bars(engine_mod, oracle, seed):
                                 dict(W=W, H=H, spin=spin, mass=mass, **{k: v for k, v in kw.items() if k not in ("cam_quat",)})))
             # (not 30 M: a camera in the equatorial plane at exactly the disk's outer radius is the knife edge of
             #  tests/test_shader_kernels.py::test_fast_marches_on_the_disk_edge_knife_edge)
-            r0 = float(rng.choice([8.0, 31.0, 60.0])) * mass
+            r0 = float(rng.choice([8.0, 31.0, 61.0])) * mass
             th, ph = float(rng.choice([0.4, np.pi / 2, 1.7, 2.7])), float(rng.uniform(0, 2 * np.pi))
             eye = (r0 * np.sin(th) * np.cos(ph), r0 * np.cos(th), r0 * np.sin(th) * np.sin(ph))
             cam = bh.camera_look_at(eye, fovy_deg=float(rng.choice([60.0, 25.0])), aspect=W / H)

@@ -24,6 +24,9 @@ for cfg in c3 c4; do
       [ $n -eq 1 ] && [ $launcher = torchrun ] && continue
       timeout 900 python bench.py --config $cfg --gpus $n --launcher $launcher --no-cpu-baseline \
           2> $O/err_${cfg}_${n}_$launcher.txt | tee -a $O/scale.jsonl | cut -c1-220
+      # the same point with the gather in the compute pass's own rgba16float format (half the exchange)
+      [ $n -gt 1 ] && timeout 900 python bench.py --config $cfg --gpus $n --launcher $launcher --no-cpu-baseline --exchange rgba16f \
+          2> $O/err_${cfg}_${n}_${launcher}_h.txt | tee -a $O/scale_rgba16f.jsonl | cut -c1-220
     done
   done
 done
