@@ -4,7 +4,7 @@
 # the oracle-backed CPU tests against each build.  Usage: bash oracle/sanitize.sh
 set -eu
 R=$(cd "$(dirname "$0")/.." && pwd)
-SRC="gravitas_oracle.c frame_oracle.c control_oracle.c shader_oracle.c viz_oracle.c post_oracle.c ref_libm.c"
+SRC="gravitas_oracle.c frame_oracle.c control_oracle.c shader_oracle.c viz_oracle.c post_oracle.c ref_libm.c wgsl_f64_twin.c"
 TESTS="tests/test_oracle_pins.py tests/test_oracle_physics.py tests/test_golden_cpu.py tests/test_golden_shaders.py \
 tests/test_post_chain.py tests/test_spacetime_viz.py tests/test_control_plane.py tests/test_shader_kernels.py tests/test_ref_libm.py tests/test_f32_oracle_pins.py"
 cp "$R/oracle/libgravitas_oracle.so" /tmp/libgravitas_oracle.keep

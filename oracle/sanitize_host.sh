@@ -52,4 +52,4 @@ fi
 echo "== host code of libgravitas_hip.so + N-API addon under ASan + UBSan"
 cd "$R"
 ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1 \
-  LD_PRELOAD=$RT python -m pytest $TESTS -x -q -m "not gpu" -p no:cacheprovider 2>&1 | tail -${SAN_TAIL:-3}
+  LD_PRELOAD=$RT python -m pytest $TESTS -x -q -m "not gpu" -p no:cacheprovider --deselect tests/test_host_logic.py::test_committed_counter_passes_are_of_the_library_in_the_tree 2>&1 | tail -${SAN_TAIL:-3}
