@@ -231,7 +231,7 @@ def committed_pmc(kernel_pretty, lib_path, frame=None):
 
 
 def roofline_block(cfg, glsl, kernel_pretty, avg_launch_ms, launches_per_frame, ray_steps_per_frame, rays_per_frame,
-                   pmc, pmc_src, same_workload, segment_tries, timing_note):
+                   pmc, pmc_src, same_workload, segment_tries, timing_note, same_frame=None):
     """The roofline object of the JSON line, against the bound that binds.
 
     The march kernels are register-resident: what bounds them is vector-ALU issue, not HBM (real HBM
@@ -272,10 +272,16 @@ def roofline_block(cfg, glsl, kernel_pretty, avg_launch_ms, launches_per_frame, 
     bytes_per_launch = (ray_steps_per_frame * B_STEP[bkey] + rays_per_frame * B_RAY[bkey]) / max(launches_per_frame, 1.0)
     nominal = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
     # HBM bytes per launch from the counters: the one-launch pass, or the pass of the K-try schedule
+    # (the f64 frame kernel's HBM bytes are set by the workspace layout -- 92 B read + 76 B written per slot --, not
+    #  by how many steps a ray takes: the pass of the same frame size holds for another tolerance as well)
     traffic = None
     traffic_src = pmc_src
-    if pmc and same_workload and not segment_tries:
+    if same_frame is None:
+        same_frame = same_workload
+    if pmc and not segment_tries and (same_workload or (cfg == "c3" and same_frame)):
         traffic = pmc.get("hbm_bytes_per_launch")
+        if not same_workload:
+            traffic_src = pmc_src + "; layout-determined, quoted from the tol = 1e-8 pass of the same frame"
     elif pmc and same_workload and segment_tries:
         seg = pmc.get("segment_tries_%d" % segment_tries)
         if seg:
@@ -789,8 +795,9 @@ def main():
         pmc, pmc_src = committed_pmc(kernel_pretty, bh.library_path(), (W, H))
         same_workload = bool(pmc and world == 1 and (cfg != "c3" or TOL == 1e-8) and
                              (W, H) == tuple(pmc.get("frame", (W, H))))
+        same_frame = bool(pmc and world == 1 and (W, H) == tuple(pmc.get("frame", (W, H))))
         roofline = roofline_block(cfg, glsl, kernel_pretty, avg_launch_ms, launches_per_frame, prof_steps_per_frame,
-                                  rays_local, pmc, pmc_src, same_workload, args.segment_tries, prof_note)
+                                  rays_local, pmc, pmc_src, same_workload, args.segment_tries, prof_note, same_frame)
         split = "" if world == 1 else (" split over %d GPUs" % world if args.scaling == "strong"
                                          else " (%dx%d per GPU x %d)" % (base_w, base_h, world))
         workload = workload_text(cfg, W, H, split)
