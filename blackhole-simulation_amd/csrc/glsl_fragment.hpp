@@ -647,11 +647,13 @@ __device__ uint32_t glsl_fragment(const GlslParams &U, uint32_t width, uint32_t 
         bool opaque = false, hz = false;
         const float slabH = fminf(U.disk_scale_height, 0.45f); // sample_disk's effH
         const float r_far = fmaxf(64.0f, rph + 21.0f);
-        for (;;) {
+        // Two Verlet steps per loop pass on two position registers sets (old -> new, new -> old): the loop keeps
+        // ONE exit (the second step is a plain divergent `if`; a ray that must leave before it skips it and
+        // leaves at the next top test), and the three moves `p_prev = p` of every step are gone.  Same
+        // operations step for step: pixels and step counts bit for bit (tools/ab_glsl_identical.py).
+        F3 qa = p, qb = p;
+        auto verlet = [&](const F3 &pc, F3 &pn) __attribute__((always_inline)) {
             const float r = r_cur;
-            hz = r < rh * 1.15f;
-            if (!(i < maxSteps) || opaque || hz || r > 10000.0f) break;
-            p_prev = p;
             // Far field: when every ray of the wave is beyond r_far = max(64, r_ph + 21) and at least 0.2 off
             // the equatorial plane, the step size formed below is 3.0f for each of them, exactly -- the
             // un-clamped step 0.1 (r - r_h)(1 + 0.05 r) >= 0.013 r (1 + 0.05 r) > 3.5 and its upper clamp
@@ -660,7 +662,7 @@ __device__ uint32_t glsl_fragment(const GlslParams &U, uint32_t width, uint32_t 
             // would find that out are skipped (every f32 radius: tests/test_glsl_fast_identities.py).  Most
             // steps of a frame are such steps.
             float dt, cdt;
-            if (__ballot(!(r > r_far && fabsf(p.y) >= 0.2f)) == 0ull) {
+            if (__ballot(!(r > r_far && fabsf(pc.y) >= 0.2f)) == 0ull) {
                 dt = cdt = 3.0f;
             } else {
                 const float distFactor = 1.0f + r * 0.05f;
@@ -683,29 +685,29 @@ __device__ uint32_t glsl_fragment(const GlslParams &U, uint32_t width, uint32_t 
                 // and the step then stays dt (dt * (1 - 0 * 0.7) = dt); skipped when no ray of the wave is
                 // that close
                 cdt = dt;
-                if (__ballot(fabsf(p.y) < 0.2f) != 0ull) {
-                    const float hRefinement = smoothstep_t<ARITH>(0.2f, 0.0f, fabsf(p.y));
+                if (__ballot(fabsf(pc.y) < 0.2f) != 0ull) {
+                    const float hRefinement = smoothstep_t<ARITH>(0.2f, 0.0f, fabsf(pc.y));
                     cdt = dt * (1.0f - hRefinement * 0.7f);
                 }
             }
             F3 accel{0.0f, 0.0f, 0.0f};
             if (lensing) {
-                accel = glsl_accel_from_geom(geom, p, v, a);
+                accel = glsl_accel_from_geom(geom, pc, v, a);
                 glsl_rot<ARITH>(geom.drag * cdt, v.x, v.z);
             }
             const float k2 = 0.5f * cdt * cdt * U.lensing_strength;
-            p = F3{fmaf(accel.x, k2, fmaf(v.x, cdt, p.x)), fmaf(accel.y, k2, fmaf(v.y, cdt, p.y)),
-                   fmaf(accel.z, k2, fmaf(v.z, cdt, p.z))};
+            pn = F3{fmaf(accel.x, k2, fmaf(v.x, cdt, pc.x)), fmaf(accel.y, k2, fmaf(v.y, cdt, pc.y)),
+                    fmaf(accel.z, k2, fmaf(v.z, cdt, pc.z))};
             float r_new;
             if (lensing) {
-                geom = glsl_geom_fast(p, M, a);
+                geom = glsl_geom_fast(pn, M, a);
                 r_new = geom.rho2 * geom.rs;
             } else {
-                r_new = length_t<ARITH>(p);
+                r_new = length_t<ARITH>(pn);
             }
             r_cur = r_new;
             if (lensing && alpha < 0.95f) {
-                const F3 accel_new = glsl_accel_from_geom(geom, p, v, a);
+                const F3 accel_new = glsl_accel_from_geom(geom, pn, v, a);
                 const float kv = 0.5f * cdt * U.lensing_strength;
                 v = F3{fmaf(accel.x + accel_new.x, kv, v.x), fmaf(accel.y + accel_new.y, kv, v.y),
                        fmaf(accel.z + accel_new.z, kv, v.z)};
@@ -719,20 +721,28 @@ __device__ uint32_t glsl_fragment(const GlslParams &U, uint32_t width, uint32_t 
             }
             // the plane-crossing counter and the disk sample only matter on the few steps that cross the
             // equatorial plane or land inside the slab |y| < r effH (sample_disk returns at once otherwise:
-            // without a crossing its sample point is p and its radius r_new): two products and two compares
+            // without a crossing its sample point is pn and its radius r_new): two products and two compares
             // decide that, and everything else sits behind ONE branch (the empty asm keeps the optimiser
             // from turning the block back into selects issued on every step)
-            const bool crossed = p_prev.y * p.y < 0.0f;
-            const bool in_slab = fabsf(p.y) < r_new * slabH;
+            const bool crossed = pc.y * pn.y < 0.0f;
+            const bool in_slab = fabsf(pn.y) < r_new * slabH;
             if (crossed || (disk && in_slab)) {
                 asm volatile("" ::: "memory");
                 if (crossed && r_new < rph * 2.0f && r_new > rh)
                     photonCrossings = photonCrossings + 1 < 3 ? photonCrossings + 1 : 3;
-                if (disk) glsl_sample_disk<ARITH>(U, p, p_prev, v, isco, M, a, cdt, col, alpha, r_new);
+                if (disk) glsl_sample_disk<ARITH>(U, pn, pc, v, isco, M, a, cdt, col, alpha, r_new);
             }
             if (disk) opaque = alpha > 0.99f;
-            if (jets && !opaque) glsl_sample_jets<ARITH>(U, p, v, rh, dt, col, alpha, r_new); // un-refined dt (fragment.glsl.ts:219)
+            if (jets && !opaque) glsl_sample_jets<ARITH>(U, pn, v, rh, dt, col, alpha, r_new); // un-refined dt (fragment.glsl.ts:219)
+        };
+        for (;;) {
+            hz = r_cur < rh * 1.15f;
+            if (!(i < maxSteps) || opaque || hz || r_cur > 10000.0f) break;
+            verlet(qa, qb);
+            const bool hz2 = r_cur < rh * 1.15f;
+            if (i < maxSteps && !opaque && !hz2 && !(r_cur > 10000.0f)) verlet(qb, qa);
         }
+        p = (i & 1) ? qb : qa;
         steps = (uint32_t)i;
         hitHorizon = hitHorizon || (hz && !opaque && i < maxSteps);
         (void)prevY;
@@ -872,6 +882,7 @@ __device__ uint32_t glsl_fragment(const GlslParams &U, uint32_t width, uint32_t 
 #ifndef GRV_GLSL_FAST_WAVES
 #define GRV_GLSL_FAST_WAVES 8
 #endif
+
 // Measurement instrument, compiled only into an A/B library (-DGRV_MARCH_TIMELINE; tools/march_timeline.py):
 // every wave of the FAST march records {start, end} on the constant-rate clock, its hardware id and its
 // step count, so that the launch's ramp, steady state and tail can be drawn wave by wave.
