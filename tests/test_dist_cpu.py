@@ -1,5 +1,5 @@
-"""world_size-2 gloo test of the N>1 path: tile partition -> one gather to rank 0 ->
-de-interleave.  The per-rank renderer is replaced by a deterministic CPU fill so
+"""gloo tests (world size 2, 3 and 4 incl. ranks that own no tile) of the N>1 path: tile partition -> one
+gather to rank 0 -> de-interleave.  The per-rank renderer is replaced by a deterministic CPU fill so
 the test checks exactly the distributed plumbing bench.py uses on GPUs."""
 import os
 import socket
@@ -68,18 +68,19 @@ def _worker(rank, world, port, w, h, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("w,h", [(200, 130), (256, 128)])
-def test_two_rank_tile_gather(tmp_path, w, h):
+# world 3: an odd deal; world 4 on 100x60: two tiles in all, ranks 2 and 3 own none and still take part
+@pytest.mark.parametrize("world,w,h", [(2, 200, 130), (2, 256, 128), (3, 200, 130), (4, 100, 60)])
+def test_tile_gather_over_gloo_ranks(tmp_path, world, w, h):
     import torch.multiprocessing as mp
     out = str(tmp_path / "img.npy")
-    mp.spawn(_worker, args=(2, _free_port(), w, h, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), w, h, out), nprocs=world, join=True)
     img = np.load(out)
     ys, xs = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
     assert np.array_equal(img[..., 0], xs) and np.array_equal(img[..., 1], ys)
     assert np.all(img[..., 3] == 1.0)
     sys.path.insert(0, ROOT)
     from blackhole_simulation_amd import distributed as D
-    owner = ((ys // 64) * D.tile_pitch(w, 2) + xs // 64) % 2
+    owner = ((ys // 64) * D.tile_pitch(w, world) + xs // 64) % world
     assert np.array_equal(img[..., 2], owner)  # round-robin tile -> rank map
 
 
