@@ -790,8 +790,6 @@ def main():
         launches_per_frame = max(launches / frames_prof, 1.0)
         avg_launch_ms = integ_ms / max(launches, 1)
         kernel_pretty = KERNEL_OF[("c4" if wp is not None else cfg, args.arith)]
-        if cfg == "c2" and args.arith == "packed":
-            kernel_pretty = "wgsl_symplectic_pk_b256_kernel"  # budgets <= 512: the four-wave-block form (kernels_fast.hip)
         pmc, pmc_src = committed_pmc(kernel_pretty, bh.library_path(), (W, H))
         same_workload = bool(pmc and world == 1 and (cfg != "c3" or TOL == 1e-8) and
                              (W, H) == tuple(pmc.get("frame", (W, H))))

@@ -108,22 +108,18 @@ hipError_t launch_wgsl_symplectic_pk(const FrameGeom &G, const WgslParams &P, fl
                                      uint32_t n_slots, MarchSched sched, hipStream_t s) {
     if (n_slots == 0) return hipSuccess;
     const uint32_t pairs = (n_slots + 1u) / 2u;
-    // long marches: one-wave blocks; short ones: four-wave blocks (wgsl_pk_kernel.hpp)
-    if (P.max_steps > 512)
-        hipLaunchKernelGGL(wgsl_symplectic_pk_kernel, dim3((pairs + kMarchBlock - 1) / kMarchBlock), dim3(kMarchBlock), 0, s,
-                           G, P, reinterpret_cast<float4 *>(out_rgba), out_steps, total_steps, n_slots, sched);
-    else
-        hipLaunchKernelGGL(wgsl_symplectic_pk_b256_kernel, dim3((pairs + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
-                           G, P, reinterpret_cast<float4 *>(out_rgba), out_steps, total_steps, n_slots, sched);
+    hipLaunchKernelGGL(wgsl_symplectic_pk_kernel, dim3((pairs + kMarchBlock - 1) / kMarchBlock), dim3(kMarchBlock), 0, s,
+                       G, P, reinterpret_cast<float4 *>(out_rgba), out_steps, total_steps, n_slots, sched);
     return hipGetLastError();
 }
 
 // entries of MarchSched's arrays for a frame (0: this form takes no measured order).  The long packed march
-// (budget > 512: the 8K frame of config 4, a 15 ms launch whose tail is 1 % of it) keeps centre-out.
+// (budget > 512: the 8K frame of config 4, a 15 ms launch whose tail is 1 % of it) keeps centre-out: the
+// measured-cost order loses 3.5 % there (259 200 blocks to sort and look up, profiles/r05_ab_pk_long_cost_order.jsonl).
 uint32_t march_blocks_glsl(uint32_t n_slots) { return GRV_MARCH_LPT ? (n_slots + kMarchBlock - 1) / kMarchBlock : 0u; }
 uint32_t march_blocks_pk(uint32_t n_slots, int32_t max_steps) {
     if (!GRV_MARCH_LPT || max_steps > 512) return 0u;
-    return ((n_slots + 1u) / 2u + kBlock - 1) / kBlock;
+    return ((n_slots + 1u) / 2u + kMarchBlock - 1) / kMarchBlock;
 }
 
 #ifdef GRV_MARCH_TIMELINE

@@ -19,7 +19,7 @@
 #include "geodesic_kernels.hpp"
 
 // the horizon exit of the FAST f32 marches: !(r >= r_stop), so that a non-finite state leaves as well
-// (wgsl_pk_body.inc); GRV_F32_NAN_EXIT=0 compiles the shader's literal r < r_stop for A/B runs
+// (wgsl_pk_kernel.hpp); GRV_F32_NAN_EXIT=0 compiles the shader's literal r < r_stop for A/B runs
 #ifndef GRV_F32_NAN_EXIT
 #define GRV_F32_NAN_EXIT 1
 #endif
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(kMarchBlock) __attribute__((amdgpu_waves_per_eu(GRV
         int i = 0;
         bool opaque = false, below = false, far = false;
         for (;;) {
-            below = GRV_F32_BELOW(r, r_stop); // NaN leaves here too: see wgsl_pk_body.inc
+            below = GRV_F32_BELOW(r, r_stop); // NaN leaves here too: see wgsl_pk_kernel.hpp
             far = r > 100.0f;
             if (!(i < P.max_steps) || opaque || below || far) break;
             const float r_before = r, th_before = th;

@@ -153,27 +153,141 @@ __device__ __forceinline__ void pk_shade(float rb, float M, float a, float isco,
     alpha += target_opacity * mri_sat;
 }
 
-// Two launch shapes of the same march (wgsl_pk_body.inc).  One-wave blocks (kMarchBlock) give a finished
-// wave's slot back at once: on long marches, where a few waves of a block run on after the others, that
-// is worth 10 % (8K x 1024 steps: 285 -> 314 G ray-steps/s).  On short ones the dispatcher's per-block
-// cost shows instead (1080p x 512 steps: 230 G with four-wave blocks, 213 G with one-wave blocks); the
-// launcher (kernels_fast.hip) picks by the step budget.  A/B on one box: profiles/r03_ab_march_block.jsonl,
-// profiles/r03_shader_kernels.jsonl.
+// One-wave blocks (kMarchBlock): a finished wave's slot goes back at once.  On long marches, where a few waves
+// of a block would run on after the others, that is worth 10 % (8K x 1024 steps: 285 -> 314 G ray-steps/s,
+// profiles/r03_ab_march_block.jsonl).  Short marches (1080p x 512 steps) used to prefer four-wave blocks
+// (230 G against 213 G in natural order); with the measured-cost dispatch order the finer blocks are the
+// better schedule there as well (+2.0 % / +1.5 %, profiles/r05_ab_pk_short_one_wave.jsonl), and the four-wave
+// form is gone.  (The body stays written straight into the kernel: a shared __device__ function taking the
+// uniform blocks by reference compiled to 128 VGPRs and ran 5 % slower: 122 VGPRs.)
 __global__ __launch_bounds__(kMarchBlock) __attribute__((amdgpu_waves_per_eu(GRV_PK_WAVES, GRV_PK_WAVES)))
 void wgsl_symplectic_pk_kernel(FrameGeom G, WgslParams P, float4 *__restrict__ out_rgba,
                                uint32_t *__restrict__ out_steps, unsigned long long *total_steps, uint32_t n_slots,
                                MarchSched sched) {
-#define GRV_PK_BODY_BLOCK kMarchBlock
-#include "wgsl_pk_body.inc"
-#undef GRV_PK_BODY_BLOCK
-}
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GRV_PK_WAVES, GRV_PK_WAVES)))
-void wgsl_symplectic_pk_b256_kernel(FrameGeom G, WgslParams P, float4 *__restrict__ out_rgba,
-                                    uint32_t *__restrict__ out_steps, unsigned long long *total_steps,
-                                    uint32_t n_slots, MarchSched sched) {
-#define GRV_PK_BODY_BLOCK kBlock
-#include "wgsl_pk_body.inc"
-#undef GRV_PK_BODY_BLOCK
+    const unsigned long long sched_t0 = sched.cost ? wall_clock64() : 0ull;
+    const uint32_t pk_block = sched.order ? sched.order[blockIdx.x] : dispatch_block(blockIdx.x, gridDim.x);
+    const uint32_t pair = pk_block * kMarchBlock + threadIdx.x;
+    const uint32_t slot0 = 2u * pair;
+    const float PI = 3.14159265f;
+    // camera terms shared by every ray (compute.wgsl.ts:170-178)
+    const float cx = P.position[0], cy = P.position[1], cz = P.position[2];
+    const float r0 = sqrtf(cx * cx + cy * cy + cz * cz);
+    const float theta0 = acosf(fminf(fmaxf(cy / r0, -1.0f), 1.0f));
+    const float phi0 = atan2f(cz, cx);
+    const float st = sinf(theta0), ct = cosf(theta0), sp = sinf(phi0), cp = cosf(phi0);
+
+    float pr0, pth0, pph0, pr1, pth1, pph1;
+    uint32_t oi0, oi1;
+    const bool v0 = pk_init_slot(G, P, slot0, n_slots, r0, st, ct, sp, cp, pr0, pth0, pph0, oi0);
+    const bool v1 = pk_init_slot(G, P, slot0 + 1u, n_slots, r0, st, ct, sp, cp, pr1, pth1, pph1, oi1);
+
+    const float M = P.mass;
+    const float a = P.spin * M;
+    const Wf32Hole bh{M, a, a * a, 2.0f * M};
+    const float disc = M * M - a * a;
+    const float rh = disc < 0.0f ? M : M + sqrtf(disc);
+    const float absS = fabsf(fminf(fmaxf(a / M, -0.999f), 0.999f));
+    const float z1 = 1.0f + powf(1.0f - absS * absS, 1.0f / 3.0f) *
+                                (powf(1.0f + absS, 1.0f / 3.0f) + powf(1.0f - absS, 1.0f / 3.0f));
+    const float z2 = sqrtf(3.0f * absS * absS + z1 * z1);
+    const float isco = M * (3.0f + z2 - sqrtf((3.0f - z1) * (3.0f + z1 + 2.0f * z2)));
+    const float r_stop = rh * 1.001f;
+
+    f2_t r = pk_splat(r0), th = pk_splat(theta0);
+    f2_t p_r = f2_t{pr0, pr1}, p_th = f2_t{pth0, pth1};
+    const f2_t p_ph = f2_t{pph0, pph1};
+    const PkConsts c{p_ph, p_ph * p_ph, p_ph * a, p_ph * (2.0f * a)};
+    float col[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+    float alpha[2] = {0.0f, 0.0f};
+    uint32_t steps[2] = {0u, 0u};
+    bool live[2] = {v0, v1};
+
+    for (int i = 0; i < P.max_steps; ++i) {
+        // loop-top exits of the shader, per ray
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float rk = k ? r.y : r.x;
+            // !(r >= r_stop), not r < r_stop: a ray that crosses the polar axis blows up in the shader's
+            // spherical coordinates (sin^2 clamped at 1e-12, compute.wgsl.ts:49) in every arithmetic; the
+            // shader order and a double evaluation land on a huge negative r there and leave through
+            // this test, the FAST forms land on NaN, which must leave through it too -- or the ray marches
+            // its whole budget as NaN (profiles/r04_c4_budget_rays.json: 3 200 such rays at 8K)
+            if (live[k] && (GRV_F32_BELOW(rk, r_stop) || alpha[k] > 0.99f)) live[k] = false;
+            if (live[k] && rk > 100.0f) { // star hash of the escape branch, compute.wgsl.ts:199-206
+                if (P.stars) {
+                    const float sx = k ? p_r.y : p_r.x, sy = (k ? p_th.y : p_th.x) / rk,
+                                sz = (k ? p_ph.y : p_ph.x) / (rk * fmaxf(st, 1e-4f));
+                    const float inv = __builtin_amdgcn_rsqf(sx * sx + sy * sy + sz * sz);
+                    const float sn = sinf((sx * 12.9898f + sy * 78.233f + sz * 45.164f) * inv) * 43758.5453f;
+                    if (sn - floorf(sn) > 0.999f)
+                        for (int q = 0; q < 3; ++q) col[k][q] += 1.0f * (1.0f - alpha[k]);
+                }
+                live[k] = false;
+            }
+        }
+        if (__ballot(live[0] || live[1]) == 0ull) break;
+        if (live[0] || live[1]) {
+            const f2_t r_before = r, th_before = th;
+            f2_t h = (r - rh) * 0.15f;
+            h = f2_t{fminf(fmaxf(h.x, 0.05f), 1.0f), fminf(fmaxf(h.y, 0.05f), 1.0f)};
+            const f2_t hh = h * 0.5f;
+            PkDeriv d = pk_rhs(bh, c, r, th, p_r, p_th);
+            f2_t mr = pk_fma(d.dr, hh, r), mth = pk_fma(d.dth, hh, th);
+            f2_t mpr = pk_fma(d.dpr, hh, p_r), mpth = pk_fma(d.dpth, hh, p_th);
+            d = pk_rhs(bh, c, mr, mth, mpr, mpth);
+            mr = pk_fma(d.dr, hh, r);
+            mth = pk_fma(d.dth, hh, th);
+            mpr = pk_fma(d.dpr, hh, p_r);
+            mpth = pk_fma(d.dpth, hh, p_th);
+            d = pk_rhs(bh, c, mr, mth, mpr, mpth);
+#if GRV_PK_FREEZE_BY_STEP
+            // a finished ray stays where it ended: its step is 0 (two selects per pair instead of eight;
+            // x + 0 d = x for every finite derivative, and a frozen ray's state is read by nothing but
+            // the guarded loop-top tests)
+            const f2_t hs = f2_t{live[0] ? h.x : 0.0f, live[1] ? h.y : 0.0f};
+            r = pk_fma(d.dr, hs, r);
+            th = pk_fma(d.dth, hs, th);
+            p_r = pk_fma(d.dpr, hs, p_r);
+            p_th = pk_fma(d.dpth, hs, p_th);
+#else
+            const i2_t m = i2_t{live[0] ? 1 : 0, live[1] ? 1 : 0};
+            r = pk_sel(m, pk_fma(d.dr, h, r), r); // a finished ray stays where it ended
+            th = pk_sel(m, pk_fma(d.dth, h, th), th);
+            p_r = pk_sel(m, pk_fma(d.dpr, h, p_r), p_r);
+            p_th = pk_sel(m, pk_fma(d.dpth, h, p_th), p_th);
+#endif
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (!live[k]) continue;
+                ++steps[k];
+                const float rb = k ? r_before.y : r_before.x;
+                const float tb = k ? th_before.y : th_before.x, tn = k ? th.y : th.x;
+                if ((tb - PI * 0.5f) * (tn - PI * 0.5f) <= 0.0f && rb > isco && rb < 30.0f)
+                    pk_shade(rb, M, a, isco, k ? p_ph.y : p_ph.x, col[k], alpha[k]);
+            }
+        }
+    }
+    if (v0) {
+        if (out_rgba) out_rgba[oi0] = make_float4(col[0][0], col[0][1], col[0][2], 1.0f);
+        if (out_steps) out_steps[oi0] = steps[0];
+    }
+    if (v1) {
+        if (out_rgba) out_rgba[oi1] = make_float4(col[1][0], col[1][1], col[1][2], 1.0f);
+        if (out_steps) out_steps[oi1] = steps[1];
+    }
+    __shared__ unsigned long long s_w[kMarchBlock / 64];
+    unsigned long long v = (unsigned long long)steps[0] + steps[1];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63u) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long tot = 0;
+#pragma unroll
+        for (int w = 0; w < kMarchBlock / 64; ++w) tot += s_w[w];
+        if (tot) atomicAdd(total_steps, tot);
+        if (sched.cost) sched.cost[pk_block] = (uint32_t)(wall_clock64() - sched_t0);
+    }
 }
 
 } // namespace

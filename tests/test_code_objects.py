@@ -77,7 +77,7 @@ def test_headline_kernel_keeps_three_waves_per_simd(kernels):
 
 
 def test_no_hot_kernel_uses_scratch(kernels):
-    for part in ("integrate_segment_kernel", "integrate_refill_kernel", "wgsl_symplectic_pk_kernel", "wgsl_symplectic_pk_b256_kernel",
+    for part in ("integrate_segment_kernel", "integrate_refill_kernel", "wgsl_symplectic_pk_kernel",
                  "init_from_pixels_kernel",
                  "init_from_states_kernel", "finalize_frame_kernel", "finalize_batch_kernel", "taa_resolve_kernel",
                  "ataa_resolve_kernel", "bloom_", "blit_reinhard_kernel"):
@@ -95,8 +95,8 @@ def test_f32_fast_marches_keep_their_occupancy(kernels):
     # waves: +2.3 / +5.3 / +6.3 % on the 1080p default preset, profiles/r04_ab_glsl_waves.jsonl); its
     # ~70 B of scratch sit inside the disk / jet sampling branches (two step instances per loop pass since the
     # ping-pong form of round 5), none in a block every pass executes
-    for part, limit, scratch in (("wgsl_symplectic_pk_kernel", 128, 0), ("wgsl_symplectic_pk_b256_kernel", 128, 0),
-                                 ("wgsl_symplectic_fast_kernel", 72, 0), ("glsl_fragment_kernelILi1E", 64, 72)):
+    for part, limit, scratch in (("wgsl_symplectic_pk_kernel", 128, 0), ("wgsl_symplectic_fast_kernel", 72, 0),
+                                 ("glsl_fragment_kernelILi1E", 64, 72)):
         (kd,) = _find(kernels, part)
         assert kd[".vgpr_count"] + kd.get(".agpr_count", 0) <= limit, (part, kd[".vgpr_count"])
         assert kd[".private_segment_fixed_size"] <= scratch, (part, kd[".private_segment_fixed_size"])
@@ -144,9 +144,9 @@ def test_glsl_fast_march_keeps_its_scratch_to_the_sampling_bodies(engine_mod):
 
 
 def test_march_kernels_launch_one_wave_blocks(kernels):
-    # one-wave blocks for the f32 marches (engine_types.hpp kMarchBlock; 8K x 1024 steps: +10 % measured),
-    # the four-wave form of the packed march for short step budgets
-    for part, size in (("wgsl_symplectic_pk_kernel", 64), ("wgsl_symplectic_pk_b256_kernel", 256),
+    # one-wave blocks for the f32 marches (engine_types.hpp kMarchBlock; 8K x 1024 steps: +10 % measured; short
+    # budgets too since the measured-cost dispatch order, profiles/r05_ab_pk_short_one_wave.jsonl)
+    for part, size in (("wgsl_symplectic_pk_kernel", 64),
                        ("wgsl_symplectic_fast_kernel", 64), ("wgsl_symplectic_kernel", 64), ("glsl_fragment_kernelILi1E", 64),
                        ("glsl_fragment_kernelILi0E", 64)):
         (kd,) = _find(kernels, part)

@@ -6,7 +6,7 @@
 #   _c4       bench.py --config c4     wgsl_symplectic_pk_kernel        (f32 march of the scaling config, two rays per lane)
 #   _c4fast   bench.py --config c4 --arith fast   wgsl_symplectic_fast_kernel  (one ray per lane)
 #   _c2       bench.py --config c2     glsl_fragment_kernel<1>          (BASELINE configs[1]: the WebGL shader's Verlet march, FAST)
-#   _c2wgsl   bench.py --config c2 --kernel wgsl   wgsl_symplectic_pk_b256_kernel (1920x1080 / 512 steps: the four-wave-block form)
+#   _c2wgsl   bench.py --config c2 --kernel wgsl   wgsl_symplectic_pk_kernel at 1920x1080 / 512 steps (filed as wgsl_symplectic_pk_kernel@1920x1080)
 #   _c5       bench.py --config c5     integrate_segment_kernel<1,0,0> at tol 1e-9 (trace only; the PMC passes are _strict's)
 # usage: tools/profile_gpu.sh <out dir under gpurun_out> [suffixes...]   (default: every suffix; "base" = the "" passes)
 # PROFILE_TAG (default r05) names the records; $OUT/summary holds what is copied into profiles/ afterwards.
@@ -26,7 +26,7 @@ sys.path.insert(0, "$R"); sys.path.insert(0, "$R/tools")
 import kernel_resources as kr
 lib = "$R/blackhole-simulation_amd/libgravitas_hip.so"
 names = ["integrate_segment_kernel<1,1,0>", "integrate_segment_kernel<1,0,0>", "wgsl_symplectic_fast_kernel",
-         "wgsl_symplectic_pk_kernel", "wgsl_symplectic_pk_b256_kernel", "glsl_fragment_kernel<1>", "glsl_fragment_kernel<0>"]
+         "wgsl_symplectic_pk_kernel", "glsl_fragment_kernel<1>", "glsl_fragment_kernel<0>"]
 json.dump({n: kr.kernel_code_hash(lib, n) for n in names}, open("$OUT/code_hashes.json", "w"), indent=1)
 PY
 run() { # label, rocprof args..., -- bench args

@@ -137,7 +137,7 @@ CASES = [("integrate_segment_kernel<1,1,0>", "integrate_segment_kernel<1, 1, 0>"
          # BASELINE configs[1]: the 1080p / 512-step marches (a kernel measured at a second frame size is filed
          # under "<kernel>@<W>x<H>"; bench.py looks that key up first)
          ("glsl_fragment_kernel<1>", "glsl_fragment_kernel<1>", "_c2", [1920, 1080], None),
-         ("wgsl_symplectic_pk_b256_kernel", "wgsl_symplectic_pk_b256_kernel", "_c2wgsl", [1920, 1080], None)]
+         ("wgsl_symplectic_pk_kernel@1920x1080", "wgsl_symplectic_pk_kernel", "_c2wgsl", [1920, 1080], None)]
 for pretty, needle, sfx, frame, layout in CASES:
     f, w = _avg("pmc_fetch" + sfx, "FETCH_SIZE", needle), _avg("pmc_write" + sfx, "WRITE_SIZE", needle)
     if f is None or w is None:
