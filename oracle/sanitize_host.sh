@@ -32,14 +32,15 @@ restore() {
 }
 trap restore EXIT
 
-for tu in kernels_strict kernels_fast control_plane spacetime_viz engine engine_shaders engine_control engine_multi; do
+for tu in kernels_strict kernels_fast kernels_fast_f64 control_plane spacetime_viz engine engine_shaders engine_control engine_multi; do
   fp="-ffp-contract=off"
   [ $tu = kernels_fast ] && fp="-ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt"
+  [ $tu = kernels_fast_f64 ] && fp="-ffp-contract=fast"
   (cd "$CS" && $HIPCC -O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $fp $XSAN \
       -I/opt/rocm/include -c $tu.hip -o $B/$tu.o) &
 done
 wait
-$HIPCC --offload-arch=gfx950 -shared -fPIC $SAN -shared-libsan -o "$LIB" $B/kernels_strict.o $B/kernels_fast.o \
+$HIPCC --offload-arch=gfx950 -shared -fPIC $SAN -shared-libsan -o "$LIB" $B/kernels_strict.o $B/kernels_fast.o $B/kernels_fast_f64.o \
     $B/control_plane.o $B/spacetime_viz.o $B/engine.o $B/engine_shaders.o $B/engine_control.o $B/engine_multi.o -ldl -lpthread
 # -asan-globals=0 on the addon only: its merged string literals land on odd addresses, which ASan's
 # global registration refuses under node; stack and heap checking (the argument buffers, the arena)
