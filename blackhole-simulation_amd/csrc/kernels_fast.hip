@@ -1,6 +1,6 @@
-// kernels_fast.hip -- FAST arithmetic contract of the f32 shader kernels (marches, post chain): compiled with
-// -ffp-contract=fast and reciprocal-based f32 divide / sqrt.  The f64 geodesic kernels of the same contract are
-// kernels_fast_f64.hip.
+// kernels_fast.hip -- FAST arithmetic contract (-ffp-contract=fast; reciprocal-based f32 divide / sqrt): the f32
+// shader kernels (marches, post chain) and the latency-bound f64 kernels (refill, recorded paths, the one-ray entry).
+// The f64 frame kernel of the same contract is kernels_fast_f64.hip (other scheduling flags).
 #include "geodesic_kernels.hpp"
 #include "wgsl_fast_kernel.hpp"
 #include "wgsl_pk_kernel.hpp"
@@ -12,6 +12,38 @@
 #include "post_fast_kernels.hpp"
 
 namespace grvhip {
+
+#define GRV_REFILL_ARITH GRV_ARITH_FAST
+#define GRV_REFILL_FN launch_refill_fast
+#include "refill_launch.inc"
+#undef GRV_REFILL_ARITH
+#undef GRV_REFILL_FN
+
+#define GRV_PATH_ARITH GRV_ARITH_FAST
+#define GRV_PATH_FN launch_path_fast
+#include "path_launch.inc"
+#undef GRV_PATH_ARITH
+#undef GRV_PATH_FN
+
+// grv_integrate_ray_relativistic under the FAST contract (grv_engine_set_ray_arith): the same one-launch
+// kernel with the shared-reciprocal right-hand side -- a third of the STRICT instruction count, and a lone
+// wave's time is its instruction count
+hipError_t launch_single_ray_fast(int kind, const SegmentParams &P, const SingleRayIn &in, double h0,
+                                  SingleRayOut *out_pinned, uint32_t seq, hipStream_t s) {
+    switch (kind) {
+    case GRV_METRIC_KERR_KS:
+        hipLaunchKernelGGL((single_ray_kernel<GRV_METRIC_KERR_KS, GRV_ARITH_FAST>), dim3(1), dim3(64), 0, s, P, in, h0, out_pinned, seq);
+        break;
+    case GRV_METRIC_KERR_BL:
+        hipLaunchKernelGGL((single_ray_kernel<GRV_METRIC_KERR_BL, GRV_ARITH_FAST>), dim3(1), dim3(64), 0, s, P, in, h0, out_pinned, seq);
+        break;
+    case GRV_METRIC_SCHWARZSCHILD:
+        hipLaunchKernelGGL((single_ray_kernel<GRV_METRIC_SCHWARZSCHILD, GRV_ARITH_FAST>), dim3(1), dim3(64), 0, s, P, in, h0, out_pinned, seq);
+        break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
 
 hipError_t launch_wgsl_symplectic_fast(const FrameGeom &G, const WgslParams &P, float *out_rgba,
                                        uint32_t *out_steps, unsigned long long *total_steps,

@@ -1,11 +1,11 @@
-// kernels_fast_f64.hip -- FAST arithmetic contract of the f64 geodesic kernels (-ffp-contract=fast): the segment,
-// refill, path and one-ray kernels with the shared-reciprocal Kerr-Schild right-hand side (kerr_device.hpp:
-// rhs_ks_geom) and FMA contraction.  Its own translation unit because it is compiled WITHOUT the post-RA machine
-// scheduler (-mllvm -enable-post-misched=0, Makefile): the RKF45 try loop issues 1.6 % faster in the order the
-// pre-RA scheduler leaves (profiles/r05_ab_f64_post_ra_sched.jsonl) -- same instructions, same results.
+// kernels_fast_f64.hip -- the frame kernel of the FAST f64 contract (-ffp-contract=fast): integrate_segment_kernel
+// with the shared-reciprocal Kerr-Schild right-hand side (kerr_device.hpp: rhs_ks_geom) and FMA contraction.  Its own
+// translation unit because it is compiled WITHOUT the post-RA machine scheduler (-mllvm -enable-post-misched=0,
+// Makefile): at three full waves per SIMD the RKF45 try loop runs 1.6-2.1 % faster in the order the pre-RA scheduler
+// leaves (profiles/r05_ab_f64_post_ra_sched.jsonl) -- same instructions, same results.  The latency-bound FAST f64
+// kernels (refill for small batches, recorded paths, the one-ray entry: a lone wave wants the interleaving the
+// post-RA pass provides, 373 against 398 us on the doc-test ray) stay in kernels_fast.hip.
 #include "geodesic_kernels.hpp"
-#include <atomic>
-#include <cstring>
 
 namespace grvhip {
 
@@ -41,38 +41,6 @@ hipError_t launch_segment_fast(int kind, int method, const RayWorkspace &ws,
     case GRV_METRIC_SCHWARZSCHILD: return by_method<GRV_METRIC_SCHWARZSCHILD>(method, ws, P, live_in, n_live, live_out, live_out_count, s);
     default: return hipErrorInvalidValue;
     }
-}
-
-#define GRV_REFILL_ARITH GRV_ARITH_FAST
-#define GRV_REFILL_FN launch_refill_fast
-#include "refill_launch.inc"
-#undef GRV_REFILL_ARITH
-#undef GRV_REFILL_FN
-
-#define GRV_PATH_ARITH GRV_ARITH_FAST
-#define GRV_PATH_FN launch_path_fast
-#include "path_launch.inc"
-#undef GRV_PATH_ARITH
-#undef GRV_PATH_FN
-
-// grv_integrate_ray_relativistic under the FAST contract (grv_engine_set_ray_arith): the same one-launch
-// kernel with the shared-reciprocal right-hand side -- a third of the STRICT instruction count, and a lone
-// wave's time is its instruction count
-hipError_t launch_single_ray_fast(int kind, const SegmentParams &P, const SingleRayIn &in, double h0,
-                                  SingleRayOut *out_pinned, uint32_t seq, hipStream_t s) {
-    switch (kind) {
-    case GRV_METRIC_KERR_KS:
-        hipLaunchKernelGGL((single_ray_kernel<GRV_METRIC_KERR_KS, GRV_ARITH_FAST>), dim3(1), dim3(64), 0, s, P, in, h0, out_pinned, seq);
-        break;
-    case GRV_METRIC_KERR_BL:
-        hipLaunchKernelGGL((single_ray_kernel<GRV_METRIC_KERR_BL, GRV_ARITH_FAST>), dim3(1), dim3(64), 0, s, P, in, h0, out_pinned, seq);
-        break;
-    case GRV_METRIC_SCHWARZSCHILD:
-        hipLaunchKernelGGL((single_ray_kernel<GRV_METRIC_SCHWARZSCHILD, GRV_ARITH_FAST>), dim3(1), dim3(64), 0, s, P, in, h0, out_pinned, seq);
-        break;
-    default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
 }
 
 } // namespace grvhip
