@@ -492,8 +492,10 @@ def main_native(args, cfg, base_w, base_h):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed frames (default 20; --config c2: 300 -- its frames are 1-2 ms, and a 20-frame window "
+                         "still sits on the GPU's clock ramp: profiles/r05_bench_window.jsonl)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed frames before them (default 3; --config c2: 60)")
     ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c3",
                     help="c2 = BASELINE configs[1] (1080p f32 march, 512 steps, one GPU), "
                          "c3 = BASELINE configs[2] (the headline), c4 = configs[3] (8K f32 march), c5 = configs[4]: "
@@ -536,6 +538,10 @@ def main():
                          "rounded through binary16")
     args = ap.parse_args()
     cfg = args.config
+    if args.steps is None:
+        args.steps = 300 if cfg == "c2" else 20
+    if args.warmup is None:
+        args.warmup = 60 if cfg == "c2" else 3
     global TOL, KERNEL
     KERNEL = args.kernel
     label = BASELINE_LABEL[cfg]

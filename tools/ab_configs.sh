@@ -15,7 +15,9 @@ for rep in $(seq 1 ${AB_REPS:-3}); do
   for so in ab_libs/lib_*.so; do
     name=$(basename $so .so); cp $so $LIB
     for cfg in "${CFGS[@]}"; do
-      timeout ${AB_TIMEOUT:-240} python bench.py --config $cfg --steps ${AB_STEPS:-10} --warmup 2 --no-cpu-baseline 2> $O/err.txt | python -c "
+      sw="--steps ${AB_STEPS:-10} --warmup 2"
+      case "$cfg" in c2*) sw="--steps ${AB_STEPS_C2:-300} --warmup 60";; esac  # 1-2 ms frames: a short window sits on the clock ramp
+      timeout ${AB_TIMEOUT:-240} python bench.py --config $cfg $sw --no-cpu-baseline 2> $O/err.txt | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print(json.dumps({'lib':'$name','config':'$cfg','rep':$rep,'value':d['value'],'ms_per_step':d['ms_per_step'],'avg_launch_ms':d['roofline']['avg_launch_ms'],'steps_per_frame':d['config']['accepted_steps_per_frame']}))" >> $O/ab.jsonl
