@@ -12,6 +12,8 @@
 #   parity       the full-size parity records (c5, 8K, c4 every pixel)
 #   profile[:<suffixes>]  tools/profile_gpu.sh (counter passes, then traces; see there)
 #   renderers    tools/bench_renderers.py + tools/bench_shaders.py
+#   identical    tools/ab_glsl_identical.py under every ab_libs/lib_*.so: three 1080p GLSL presets, every later library's
+#                pixels and step counts compared bit for bit with the first one's
 #   ab[:<configs>]  interleaved A/B of every ab_libs/lib_*.so (tools/ab_configs.sh; configs ';'-separated)
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -51,6 +53,12 @@ for stage in "$@"; do
     renderers)
       timeout 600 python tools/bench_renderers.py > $O/renderers.jsonl 2> $O/renderers.err; cut -c1-200 $O/renderers.jsonl
       timeout 600 python tools/bench_shaders.py > $O/shader_kernels.jsonl 2> $O/shaders.err; cut -c1-160 $O/shader_kernels.jsonl;;
+    identical)
+      cp blackhole-simulation_amd/libgravitas_hip.so /tmp/lib_keep.so; first=""
+      for so in ab_libs/lib_*.so; do n=$(basename $so .so); cp $so blackhole-simulation_amd/libgravitas_hip.so
+        timeout 300 python tools/ab_glsl_identical.py /tmp/ident_$n.npz 2> $O/identical_$n.err
+        if [ -z "$first" ]; then first=$n; else echo "$n vs $first: $(python tools/ab_glsl_identical.py /tmp/ident_$first.npz /tmp/ident_$n.npz)" | tee -a $O/identical.txt; fi
+      done; cp /tmp/lib_keep.so blackhole-simulation_amd/libgravitas_hip.so;;
     ab) AB_CONFIGS="${arg:-c2;c2 --one-stream}" bash tools/ab_configs.sh $T/ab > $O/ab.log 2>&1; tail -40 $O/ab.log;;
     *) echo "unknown stage $stage";;
   esac
