@@ -503,18 +503,30 @@ constexpr int kSegmentWavesMin = (KIND == GRV_METRIC_KERR_KS && METHOD == GRV_ME
 #ifndef GRV_WS_RELOAD
 #define GRV_WS_RELOAD 1
 #endif
-// threads per block of the segment kernel (A/B switch; see kMarchBlock in engine_types.hpp)
+// Threads per block of the segment kernel: a property of the launch (blockDim.x, read where it is needed), not of
+// the code.  The one-launch schedule starts one-wave blocks -- a finished wave's slot goes back to the dispatcher at
+// once instead of waiting for the slowest of four: c3 +1.1 %, c5 +1.1 % (profiles/r05_ab_segment_block.jsonl) --,
+// the compacting schedule four-wave blocks (one atomic per block on the live-list counter: one-wave blocks
+// cost it 2 %).  kSegBlock is the larger of the two (launch bound, LDS of the append).
 #ifndef GRV_SEGMENT_BLOCK
 #define GRV_SEGMENT_BLOCK 256
 #endif
+#ifndef GRV_SEGMENT_BLOCK_ONE_LAUNCH
+#define GRV_SEGMENT_BLOCK_ONE_LAUNCH 64
+#endif
 constexpr int kSegBlock = GRV_SEGMENT_BLOCK;
+constexpr int kSegBlockOneLaunch = GRV_SEGMENT_BLOCK_ONE_LAUNCH;
+// the launch shape of a segment launch: no live list to append to = the one-launch schedule
+__host__ inline uint32_t segment_block_threads(const uint32_t *live_out) {
+    return live_out ? (uint32_t)kSegBlock : (uint32_t)kSegBlockOneLaunch;
+}
 
 template <int KIND, int ARITH, int METHOD>
 __global__ __launch_bounds__(kSegBlock) __attribute__((amdgpu_waves_per_eu(kSegmentWavesMin<KIND, METHOD>)))
 void integrate_segment_kernel(
     RayWorkspace ws, SegmentParams P, const uint32_t *__restrict__ live_in, uint32_t n_live,
     uint32_t *__restrict__ live_out, uint32_t *__restrict__ live_out_count) {
-    const uint32_t k = dispatch_block_f64(blockIdx.x, gridDim.x, P.block_order) * kSegBlock + threadIdx.x;
+    const uint32_t k = dispatch_block_f64(blockIdx.x, gridDim.x, P.block_order) * blockDim.x + threadIdx.x;
     const bool have = k < n_live;
     const uint32_t slot = have ? (live_in ? live_in[k] : k) : 0u;
 
@@ -569,8 +581,7 @@ void integrate_segment_kernel(
         __syncthreads();
         if (threadIdx.x == 0) {
             uint32_t total = 0;
-#pragma unroll
-            for (int w = 0; w < kSegBlock / 64; ++w) total += s_wave_cnt[w];
+            for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) total += s_wave_cnt[w];
             s_base = total ? atomicAdd(live_out_count, total) : 0u;
         }
         __syncthreads();
