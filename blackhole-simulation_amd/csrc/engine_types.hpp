@@ -15,8 +15,8 @@ constexpr int kBlock = 256;
 // shader): ONE wave.  A march wave's lanes run 35..1024 steps and its slot (registers, wave slot) goes
 // back to the dispatcher only when its whole block has ended; with four-wave blocks the packed march
 // measured 287 G ray-steps/s on the 8K config-4 frame, with one-wave blocks 308 G (A/B on one box,
-// profiles/r03_ab_march_block.jsonl).  The f64 segment kernel keeps kBlock: its waves live 40x longer
-// and neighbouring 8x8 blocks end together (one-wave blocks: +0.35 %, and slower on small shares).
+// profiles/r03_ab_march_block.jsonl).  The f64 segment kernel chooses per launch (geodesic_kernels.hpp:
+// segment_block_threads): one-wave blocks for one-launch frames of 1.5 M rays and more (+1.1 %), kBlock otherwise.
 #ifndef GRV_MARCH_BLOCK
 #define GRV_MARCH_BLOCK 64
 #endif

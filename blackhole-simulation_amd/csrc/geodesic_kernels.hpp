@@ -516,9 +516,12 @@ constexpr int kSegmentWavesMin = (KIND == GRV_METRIC_KERR_KS && METHOD == GRV_ME
 #endif
 constexpr int kSegBlock = GRV_SEGMENT_BLOCK;
 constexpr int kSegBlockOneLaunch = GRV_SEGMENT_BLOCK_ONE_LAUNCH;
-// the launch shape of a segment launch: no live list to append to = the one-launch schedule
-__host__ inline uint32_t segment_block_threads(const uint32_t *live_out) {
-    return live_out ? (uint32_t)kSegBlock : (uint32_t)kSegBlockOneLaunch;
+// the launch shape of a segment launch: no live list to append to = the one-launch schedule.  Small launches
+// (a rank's eighth of the 4K frame, 1.04 M rays, with two frames in flight: 3.56 against 3.64 ms) still prefer
+// four-wave blocks; from 2 M rays on one-wave blocks are level or ahead (profiles/r05_rank_share_segment_block.txt)
+constexpr uint32_t kSegOneWaveMinRays = 3u << 19; // 1 572 864
+__host__ inline uint32_t segment_block_threads(const uint32_t *live_out, uint32_t n_live) {
+    return (live_out || n_live < kSegOneWaveMinRays) ? (uint32_t)kSegBlock : (uint32_t)kSegBlockOneLaunch;
 }
 
 template <int KIND, int ARITH, int METHOD>

@@ -13,7 +13,7 @@ cp $LIB /tmp/lib_orig.so
 for so in ab_libs/lib_*.so; do
   name=$(basename $so .so)
   cp $so $LIB
-  python tools/bench_rank_share.py c4 packed > $O/rank_share_${name}_c4.jsonl 2> $O/err_${name}_c4.txt
+  [ -n "${RS_SKIP_C4:-}" ] || python tools/bench_rank_share.py c4 packed > $O/rank_share_${name}_c4.jsonl 2> $O/err_${name}_c4.txt
   python tools/bench_rank_share.py c3 > $O/rank_share_${name}_c3.jsonl 2> $O/err_${name}_c3.txt
 done
 cp /tmp/lib_orig.so $LIB
