@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box: every ab_libs/lib_*.so takes the in-tree library's place in turn and
 # tools/bench_rank_share.py measures the per-rank shares of the strong split (c3, c4 packed) with it:
-# gpurun_out/$1/rank_share_<lib>_<cfg>.jsonl
+# gpurun_out/$1/rank_share_<lib>_<cfg>.jsonl   (RS_SKIP_C4=1: the c3 shares only)
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 T=${1:-abrs}
