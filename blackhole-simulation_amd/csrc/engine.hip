@@ -593,6 +593,7 @@ void grv_engine_destroy(grv_engine *e) {
     if (e->lut_ready) (void)hipEventDestroy(e->lut_ready);
     if (e->stats_cleared) (void)hipEventDestroy(e->stats_cleared);
     if (e->disk_lut_ready) (void)hipEventDestroy(e->disk_lut_ready);
+    if (e->chain_done) (void)hipEventDestroy(e->chain_done);
     if (e->h_counters) (void)hipHostFree(e->h_counters);
     if (e->h_stats) (void)hipHostFree(e->h_stats);
     if (e->ray_stream) {
@@ -1181,6 +1182,13 @@ size_t grv_engine_host_bytes(const grv_engine *e) {
 int grv_stats_accumulate(grv_engine *e, int enable) {
     if (!e) return GRV_ERR_INVALID;
     e->stats_accum = enable != 0;
+    return GRV_OK;
+}
+
+int grv_engine_synchronize(grv_engine *e) {
+    if (!e) return GRV_ERR_INVALID;
+    GRV_HIP(e, hipSetDevice(e->device));
+    GRV_HIP(e, hipDeviceSynchronize());
     return GRV_OK;
 }
 

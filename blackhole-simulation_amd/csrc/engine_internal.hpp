@@ -119,6 +119,10 @@ struct grv_engine {
     } rt;
     void *post_mem = nullptr; // bloom render targets (bright, blur ping/pong)
     size_t post_bytes = 0;
+    // renderer-layer calls that arrive on different image streams (engine_images.hip) follow each other
+    // through the history targets and the bloom scratch: each waits for the end of the previous one
+    hipEvent_t chain_done = nullptr;
+    bool chain_rec = false;
     // measured-cost dispatch order of the FAST marches (engine_types.hpp MarchSched): per march kind (0 GLSL,
     // 1 packed WGSL) and frame parity one {cost, order} pair; a frame reads the order its parity's previous
     // frame produced.  `ready` orders a user on another stream behind the sort that wrote the order.

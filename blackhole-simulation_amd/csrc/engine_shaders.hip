@@ -238,7 +238,6 @@ int grv_post_bloom(grv_engine *e, const GrvBloomParams *p, const float *d_scene,
     const size_t need = bloom_scratch_floats(p->width, p->height) * sizeof(float);
     if (need > e->post_bytes) {
         if (e->post_mem) (void)hipFree(e->post_mem);
-    if (e->rt.mem) (void)hipFree(e->rt.mem);
         e->post_mem = nullptr;
         e->post_bytes = 0;
         GRV_HIP(e, hipMalloc(&e->post_mem, need));

@@ -289,6 +289,48 @@ def load_library():
     L.grv_generate_embedding_mesh.argtypes = [p, d, d, sz, sz, p]
     L.grv_generate_ergosphere_mesh.restype = i
     L.grv_generate_ergosphere_mesh.argtypes = [p, sz, sz, p]
+    # device images (ABI 8)
+    L.grv_image_create.restype = i
+    L.grv_image_create.argtypes = [p, C.c_uint32, C.c_uint32, C.POINTER(p)]
+    L.grv_image_destroy.argtypes = [p]
+    L.grv_image_width.restype = C.c_uint32
+    L.grv_image_width.argtypes = [p]
+    L.grv_image_height.restype = C.c_uint32
+    L.grv_image_height.argtypes = [p]
+    L.grv_image_bytes.restype = sz
+    L.grv_image_bytes.argtypes = [p]
+    L.grv_image_data.restype = p
+    L.grv_image_data.argtypes = [p]
+    L.grv_image_stream.restype = p
+    L.grv_image_stream.argtypes = [p]
+    L.grv_image_last_error.restype = C.c_char_p
+    L.grv_image_last_error.argtypes = [p]
+    L.grv_render_frame_image.restype = i
+    L.grv_render_frame_image.argtypes = [p, C.POINTER(Camera), C.POINTER(RenderParams), p]
+    L.grv_render_frame_glsl_image.restype = i
+    L.grv_render_frame_glsl_image.argtypes = [p, C.POINTER(GlslParams), p]
+    L.grv_render_frame_wgsl_image.restype = i
+    L.grv_render_frame_wgsl_image.argtypes = [p, C.POINTER(WgslParams), p]
+    L.grv_webgl_render_image.restype = i
+    L.grv_webgl_render_image.argtypes = [p, C.POINTER(GlslParams), C.c_int32, C.c_int32, p]
+    L.grv_webgpu_render_image.restype = i
+    L.grv_webgpu_render_image.argtypes = [p, p, p, C.c_int32, C.c_int32, p]
+    L.grv_post_bloom_image.restype = i
+    L.grv_post_bloom_image.argtypes = [p, C.POINTER(BloomParams), p, p]
+    L.grv_post_taa_resolve_image.restype = i
+    L.grv_post_taa_resolve_image.argtypes = [p, C.POINTER(TaaParams), p, p, p]
+    L.grv_image_read_async.restype = i
+    L.grv_image_read_async.argtypes = [p, p, sz]
+    L.grv_image_read.restype = i
+    L.grv_image_read.argtypes = [p, p, sz]
+    L.grv_image_wait.restype = i
+    L.grv_image_wait.argtypes = [p]
+    L.grv_image_query.restype = i
+    L.grv_image_query.argtypes = [p]
+    L.grv_image_frame_stats.restype = i
+    L.grv_image_frame_stats.argtypes = [p, C.POINTER(FrameStats)]
+    L.grv_engine_synchronize.restype = i
+    L.grv_engine_synchronize.argtypes = [p]
     L.grv_engine_create_multi.restype = i
     L.grv_engine_create_multi.argtypes = [d, d, C.c_uint64, i, C.POINTER(p)]
     L.grv_engine_create_multi_virtual.restype = i
@@ -448,6 +490,64 @@ def unpack_tiles(params, rank, packed, channels, dtype):
     if rc != 0:
         raise GravitasError("grv_unpack_tiles: %s" % _STATUS.get(rc, rc))
     return img
+
+
+class DeviceImage:
+    """A W x H RGBA f32 image in HBM with a stream of its own (include/gravitas_abi.h "device images"):
+    the texture the reference's renderers hold between passes (webgpu/renderer.ts:280-411).  Frames and
+    post passes into it are queued; pixels cross PCIe in read() only."""
+
+    def __init__(self, engine, width, height):
+        self._lib = engine._lib
+        h = C.c_void_p()
+        engine._check(self._lib.grv_image_create(engine._h, int(width), int(height), C.byref(h)), "image_create")
+        self._h = h
+        self.width, self.height = int(width), int(height)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.grv_image_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self._lib.grv_image_last_error(self._h)
+            raise GravitasError("%s: %s: %s" % (what, _STATUS.get(rc, rc), msg.decode() if msg else ""))
+
+    @property
+    def data_ptr(self):
+        return self._lib.grv_image_data(self._h)
+
+    @property
+    def stream(self):
+        return self._lib.grv_image_stream(self._h)
+
+    def read(self, out=None):
+        """-> float32 [h, w, 4] (one D2H behind everything queued on the image)"""
+        if out is None:
+            out = np.empty((self.height, self.width, 4), np.float32)
+        self._check(self._lib.grv_image_read(self._h, _np_ptr(out), out.size), "image_read")
+        return out
+
+    def wait(self):
+        self._check(self._lib.grv_image_wait(self._h), "image_wait")
+
+    def ready(self):
+        q = self._lib.grv_image_query(self._h)
+        if q < 0:
+            self._check(-q, "image_query")
+        return q == 1
+
+    def stats(self):
+        st = FrameStats()
+        self._check(self._lib.grv_image_frame_stats(self._h, C.byref(st)), "image_frame_stats")
+        return st
 
 
 class PhysicsEngine:
@@ -665,6 +765,47 @@ class PhysicsEngine:
             setattr(p, k, v)
         self._check(self._lib.grv_post_bloom(self._h, C.byref(p), _dev_ptr(scene), _dev_ptr(out),
                                              stream), "post_bloom")
+
+    # ---- device images (ABI 8): frames and post passes that stay in HBM ----
+    def create_image(self, width, height):
+        return DeviceImage(self, width, height)
+
+    def render_frame_image(self, cam, params, image):
+        self._check(self._lib.grv_render_frame_image(self._h, C.byref(cam), C.byref(params), image._h),
+                    "render_frame_image")
+
+    def render_frame_glsl_image(self, params, image):
+        self._check(self._lib.grv_render_frame_glsl_image(self._h, C.byref(params), image._h), "render_frame_glsl_image")
+
+    def render_frame_wgsl_image(self, params, image):
+        self._check(self._lib.grv_render_frame_wgsl_image(self._h, C.byref(params), image._h), "render_frame_wgsl_image")
+
+    def webgl_render_image(self, params, image, bloom=True, camera_moving=False):
+        self._check(self._lib.grv_webgl_render_image(self._h, C.byref(params), int(bool(bloom)),
+                                                     int(bool(camera_moving)), image._h), "webgl_render_image")
+
+    def webgpu_render_image(self, camera_uniforms, physics_params, image, max_steps=150, arith=ARITH_STRICT):
+        cu = np.ascontiguousarray(camera_uniforms, np.float32)
+        pp = np.ascontiguousarray(physics_params, np.float32)
+        self._check(self._lib.grv_webgpu_render_image(self._h, _np_ptr(cu), _np_ptr(pp), int(max_steps), int(arith),
+                                                      image._h), "webgpu_render_image")
+
+    def post_bloom_image(self, scene, out, **kw):
+        p = BloomParams()
+        self._lib.grv_bloom_params_default(scene.width, scene.height, C.byref(p))
+        for k, v in kw.items():
+            setattr(p, k, v)
+        self._check(self._lib.grv_post_bloom_image(self._h, C.byref(p), scene._h, out._h), "post_bloom_image")
+
+    def post_taa_resolve_image(self, current, history, out, blend_factor=0.75, camera_moving=False,
+                               half_storage=True, arith=ARITH_STRICT):
+        p = TaaParams(current.width, current.height, float(blend_factor), int(bool(camera_moving)),
+                      int(bool(half_storage)), int(arith))
+        self._check(self._lib.grv_post_taa_resolve_image(self._h, C.byref(p), current._h, history._h, out._h),
+                    "post_taa_resolve_image")
+
+    def synchronize(self):
+        self._check(self._lib.grv_engine_synchronize(self._h), "engine_synchronize")
 
     def frame_stats(self, stream=None):
         st = FrameStats()

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GRV_ABI_VERSION 7
+#define GRV_ABI_VERSION 8
 
 typedef struct grv_engine grv_engine;
 
@@ -250,6 +250,8 @@ int grv_frame_stats(grv_engine *e, void *stream, GrvFrameStats *stats);
 /* enable != 0: frame / batch / shader-frame calls stop clearing the device-side counters, so a
  * loop of frames accumulates them in HBM and one grv_frame_stats after the loop reads the sums */
 int grv_stats_accumulate(grv_engine *e, int enable);
+/* waits for everything queued on the engine's device (every stream, every image) */
+int grv_engine_synchronize(grv_engine *e);
 int grv_frame_stats_reset(grv_engine *e, void *stream);
 /* device memory the handle holds right now (ray workspaces, tables, staging, render targets), bytes.
  * A caller that keeps every frame / batch call on ONE stream holds one ray workspace (~170 B per ray
@@ -509,6 +511,57 @@ int grv_webgl_render_host(grv_engine *e, const GrvGlslParams *p, int32_t bloom_e
 /* drop the history textures and frame counters (renderer resize / re-creation) */
 void grv_renderer_reset(grv_engine *e);
 uint32_t grv_renderer_frame_count(const grv_engine *e);
+
+/* ---- device images: what a frame loop above the ABI holds between passes (ABI 8) ----
+ * The reference's per-frame callers never hold host pixels: WebGPURenderer.render keeps the compute
+ * pass's output in `computeTexture`, resolves it against the history textures and blits
+ * (src/rendering/webgpu/renderer.ts:280-411); WebGLRenderer.render goes scene target -> reprojection ->
+ * bloom -> screen (src/rendering/webgl/renderer.ts:173-422); the worker moves the 8 KB SAB block only
+ * (src/workers/physics.worker.ts:111-176).  A grv_image is that texture: W x H RGBA f32 in HBM on the
+ * engine's device, with a stream of its own.  Frames and post passes INTO an image are queued on the
+ * image's stream and the call returns at once; a host that alternates two images keeps two frames in
+ * flight.  Pixels cross PCIe only in grv_image_read*.  An image survives the engine that created it
+ * (it holds no pointer to it); images are consumed by engines on the same device only.
+ *
+ * Thread rule: engine calls are single-threaded as everywhere in this ABI; grv_image_read_async /
+ * _wait / _query / _read / _frame_stats touch the image alone, so one thread may wait for (or read) an
+ * image while another queues the next frame into ANOTHER image through the engine. */
+typedef struct grv_image grv_image;
+int grv_image_create(grv_engine *e, uint32_t width, uint32_t height, grv_image **out);
+void grv_image_destroy(grv_image *img); /* waits for the work queued on it */
+uint32_t grv_image_width(const grv_image *img);
+uint32_t grv_image_height(const grv_image *img);
+size_t grv_image_bytes(const grv_image *img);
+float *grv_image_data(grv_image *img);   /* device pointer, [height][width][4] f32 */
+void *grv_image_stream(grv_image *img);  /* hipStream_t its producers are queued on */
+const char *grv_image_last_error(const grv_image *img);
+/* grv_render_frame_device / grv_render_frame_glsl / grv_render_frame_wgsl with the image as the RGBA
+ * target (whole frames: tile_world 0 or 1; p->width x p->height must be the image's size) */
+int grv_render_frame_image(grv_engine *e, const GrvCamera *cam, const GrvRenderParams *p, grv_image *img);
+int grv_render_frame_glsl_image(grv_engine *e, const GrvGlslParams *p, grv_image *img);
+int grv_render_frame_wgsl_image(grv_engine *e, const GrvWgslParams *p, grv_image *img);
+/* the two renderers presenting into an image; successive frames are ordered through the engine's
+ * history targets whatever streams their images own */
+int grv_webgl_render_image(grv_engine *e, const GrvGlslParams *p, int32_t bloom_enabled,
+                           int32_t camera_moving, grv_image *screen);
+int grv_webgpu_render_image(grv_engine *e, const float camera_uniforms[88], const float physics_params[8],
+                            int32_t max_steps, int32_t arith, grv_image *screen);
+/* post passes on images: queued on `out`'s stream behind the producers of the inputs; a later
+ * producer of an input waits for this pass */
+int grv_post_bloom_image(grv_engine *e, const GrvBloomParams *p, grv_image *scene, grv_image *out);
+int grv_post_taa_resolve_image(grv_engine *e, const GrvTaaParams *p, grv_image *current,
+                               grv_image *history, grv_image *out);
+/* D2H of the first `elems` floats behind everything queued on the image: _async queues the copy
+ * (page-locked `host` memory: one DMA at the PCIe rate) and returns; grv_image_wait blocks until the
+ * image's stream is idle; grv_image_query: 1 idle, 0 busy, < 0 = -status; grv_image_read = both */
+int grv_image_read_async(grv_image *img, float *host, size_t elems);
+int grv_image_wait(grv_image *img);
+int grv_image_query(grv_image *img);
+int grv_image_read(grv_image *img, float *host, size_t elems);
+/* counters of the frame that last wrote the image (copied behind its last kernel; with
+ * grv_stats_accumulate: the running sums at that point).  Waits for the image only.  Event times and
+ * `launches` are not part of it (0). */
+int grv_image_frame_stats(grv_image *img, GrvFrameStats *stats);
 
 /* camera helpers (gl-matrix lookAt/perspective as src/components/canvas/WebGPUCanvas.tsx:143-157) */
 void grv_camera_look_at(const double eye[3], const double target[3], const double up[3],

@@ -59,7 +59,57 @@ typedef struct {
      * two frames in flight; allocating / freeing page-locked memory per frame costs milliseconds and
      * serialises on the driver).  Taken and returned on the main thread only. */
     struct { float *p; size_t bytes; int busy; } stage[2];
+    /* renderFrameAsync on one device: the frame is rendered into one of two device images of the async
+     * handle and copied out on that image's stream, so frame i's D2H runs under frame i+1's kernels
+     * (guarded by async_mu; users = works between queueing on the image and the end of their wait) */
+    grv_image *async_img[2];
+    int async_img_users[2];
+    int async_turn;
 } engine_box;
+
+/* ---- page-locked host blocks handed to JS by allocPinned() ----
+ * Kept in a registry so that (1) an `out` array that lives inside one is recognised: the DMA of an async
+ * frame / image read then lands in it directly, no staging copy on the JS thread; (2) a block is freed
+ * only when its ArrayBuffer has been collected AND no queued work still writes into it -- detaching or
+ * transferring the buffer while a frame is in flight can therefore never free memory under the DMA. */
+typedef struct pinned_block {
+    uint8_t *p;
+    size_t bytes;
+    int refs; /* queued works writing into it */
+    int dead; /* its ArrayBuffer was collected */
+    struct pinned_block *next;
+} pinned_block;
+static pinned_block *g_pinned = NULL;
+static pthread_mutex_t g_pinned_mu = PTHREAD_MUTEX_INITIALIZER;
+
+static void pinned_drop_locked(pinned_block *blk) {
+    for (pinned_block **q = &g_pinned; *q; q = &(*q)->next)
+        if (*q == blk) {
+            *q = blk->next;
+            break;
+        }
+    grv_host_free(blk->p);
+    free(blk);
+}
+/* the registry block that holds [ptr, ptr + bytes), with a reference taken; NULL if there is none */
+static pinned_block *pinned_acquire(const void *ptr, size_t bytes) {
+    pinned_block *hit = NULL;
+    pthread_mutex_lock(&g_pinned_mu);
+    for (pinned_block *q = g_pinned; q; q = q->next)
+        if (!q->dead && (const uint8_t *)ptr >= q->p && (const uint8_t *)ptr + bytes <= q->p + q->bytes) {
+            q->refs++;
+            hit = q;
+            break;
+        }
+    pthread_mutex_unlock(&g_pinned_mu);
+    return hit;
+}
+static void pinned_release(pinned_block *blk) {
+    if (!blk) return;
+    pthread_mutex_lock(&g_pinned_mu);
+    if (--blk->refs == 0 && blk->dead) pinned_drop_locked(blk);
+    pthread_mutex_unlock(&g_pinned_mu);
+}
 
 /* a pinned staging image of at least `bytes`: one of the box's two cached buffers (grown on demand), or --
  * with both in flight -- a one-off allocation (*idx = -1) */
@@ -150,13 +200,18 @@ static napi_value mk_f64(napi_env env, double d) {
 }
 
 static void box_destroy_handles(engine_box *box) {
+    for (int k = 0; k < 2; k++) { /* (no work is pending here: nobody waits on them) */
+        if (box->async_img[k]) grv_image_destroy(box->async_img[k]);
+        box->async_img[k] = NULL;
+        box->async_img_users[k] = 0;
+    }
     if (box->multi) grv_multi_destroy(box->multi);
     if (box->async_multi) grv_multi_destroy(box->async_multi);
     if (box->async_h) grv_engine_destroy(box->async_h);
     if (box->h) grv_engine_destroy(box->h);
     box->multi = box->async_multi = NULL;
     box->async_h = box->h = NULL;
-    for (int k = 0; k < 2; k++) { /* (no work is pending here: none of them is busy) */
+    for (int k = 0; k < 2; k++) { /* (no work is pending here: every work released its staging before this runs) */
         if (box->stage[k].p) grv_host_free(box->stage[k].p);
         box->stage[k].p = NULL;
         box->stage[k].bytes = 0;
@@ -681,6 +736,7 @@ typedef struct {
     int own_stage;     /* index into engine_box.stage, -1 = one-off allocation */
     size_t rgba_elems;
     void *own_in;      /* copy of an async batch's input states */
+    pinned_block *pin; /* `out` lies in allocPinned() memory: the async frame's DMA lands in it directly (reference held) */
     GrvFrameStats st;
     /* batch */
     size_t n;
@@ -753,6 +809,44 @@ static void bulk_execute(bulk_work *w) {
                 w->rc = grv_render_frame_multi(*mslot, &w->cam, &w->p, w->rgba, &w->st);
                 if (w->rc != GRV_OK) snprintf(w->err, sizeof w->err, "%s", grv_multi_last_error(*mslot));
             }
+        } else if (w->is_async) {
+            /* queue the frame and its D2H on one of the handle's two images, let go of the handle, THEN
+             * wait: the next work queues its kernels (other image, other stream) under this frame's copy */
+            grv_image *img = NULL;
+            int slot = (b->async_turn ^= 1), priv = 0;
+            if (b->async_img[slot] && (grv_image_width(b->async_img[slot]) != w->p.width ||
+                                       grv_image_height(b->async_img[slot]) != w->p.height)) {
+                if (b->async_img_users[slot] == 0) {
+                    grv_image_destroy(b->async_img[slot]);
+                    b->async_img[slot] = NULL;
+                } else {
+                    priv = 1; /* another size is still in flight on this slot: an image of its own for this work */
+                }
+            }
+            if (priv) w->rc = grv_image_create(h, w->p.width, w->p.height, &img);
+            else {
+                if (!b->async_img[slot]) w->rc = grv_image_create(h, w->p.width, w->p.height, &b->async_img[slot]);
+                img = b->async_img[slot];
+            }
+            if (w->rc == GRV_OK) w->rc = grv_render_frame_image(h, &w->cam, &w->p, img);
+            if (w->rc != GRV_OK) snprintf(w->err, sizeof w->err, "%s", grv_last_error(h));
+            if (w->rc == GRV_OK) {
+                w->rc = grv_image_read_async(img, w->rgba, (size_t)w->p.width * w->p.height * 4);
+                if (w->rc != GRV_OK) snprintf(w->err, sizeof w->err, "%s", grv_image_last_error(img));
+            }
+            if (!priv && img) b->async_img_users[slot]++;
+            pthread_mutex_unlock(&b->async_mu);
+            if (img) { /* (waits even after a failed read: kernels are queued on it) */
+                const int rc2 = w->rc == GRV_OK ? grv_image_frame_stats(img, &w->st) : grv_image_wait(img);
+                if (w->rc == GRV_OK && rc2 != GRV_OK) {
+                    w->rc = rc2;
+                    snprintf(w->err, sizeof w->err, "%s", grv_image_last_error(img));
+                }
+                w->st.launches = 1;
+            }
+            pthread_mutex_lock(&b->async_mu);
+            if (priv) grv_image_destroy(img);
+            else if (img) b->async_img_users[slot]--;
         } else {
             w->rc = grv_render_frame(h, &w->cam, &w->p, w->rgba, &w->st);
             if (w->rc != GRV_OK) snprintf(w->err, sizeof w->err, "%s", grv_last_error(h));
@@ -801,6 +895,7 @@ static napi_value bulk_result(napi_env env, bulk_work *w) {
 
 static void bulk_release(napi_env env, bulk_work *w) {
     stage_release(w->box, w->own_rgba, w->own_stage);
+    pinned_release(w->pin);
     free(w->own_in);
     for (int k = 0; k < w->n_keep; k++) napi_delete_reference(env, w->keep[k]);
     if (w->self_ref) napi_delete_reference(env, w->self_ref);
@@ -816,6 +911,19 @@ static void bulk_async_complete(napi_env env, napi_status status, void *data) {
     bulk_work *w = (bulk_work *)data;
     engine_box *b = w->box;
     napi_value res = NULL;
+    if (status == napi_ok && w->rc == GRV_OK && w->pin) {
+        /* the DMA went straight into allocPinned() memory (kept alive by the registry reference); an `out`
+         * that was detached or transferred meanwhile is reported the same way as in the staged form */
+        napi_value ta;
+        napi_typedarray_type ty;
+        size_t len = 0;
+        void *data = NULL;
+        if (!(napi_get_reference_value(env, w->keep[0], &ta) == napi_ok && ta &&
+              napi_get_typedarray_info(env, ta, &ty, &len, &data, NULL, NULL) == napi_ok && data && len >= w->rgba_elems)) {
+            w->rc = GRV_ERR_INVALID;
+            snprintf(w->err, sizeof w->err, "renderFrameAsync: `out` was detached or transferred while the frame was queued");
+        }
+    }
     if (status == napi_ok && w->rc == GRV_OK && w->own_rgba) {
         /* caller-supplied `out`: look at it again NOW -- a buffer transferred or detached while the work
          * was queued reports no data / a shorter length, and the promise rejects instead of writing freed memory */
@@ -842,8 +950,9 @@ static void bulk_async_complete(napi_env env, napi_status status, void *data) {
     }
     napi_delete_async_work(env, w->work);
     b->async_pending--;
-    if (b->freed && b->async_pending == 0) box_destroy_handles(b); /* free() came while works were queued */
-    bulk_release(env, w);
+    const int last = b->freed && b->async_pending == 0;
+    bulk_release(env, w); /* hands the work's staging image back first: box_destroy_handles frees only idle ones */
+    if (last) box_destroy_handles(b); /* free() came while works were queued */
 }
 
 /* queue (async) or run (sync) a filled work item; returns the promise / the result object */
@@ -890,6 +999,9 @@ static int keep_ref(napi_env env, bulk_work *w, napi_value v) {
  *                   leaves the device in one DMA and no copy is made on the JS side.
  * renderFrameAsync(opts) -> Promise of the same object: the frame runs on the libuv pool with an
  * engine handle of its own, so a worker's tick (physics.worker.ts:111-176) is never held. */
+static int wants_image(napi_env env, napi_value opts);
+static napi_value render_frame_to_image(napi_env env, engine_box *b, napi_value opts, const GrvCamera *cam,
+                                        const GrvRenderParams *p);
 static napi_value render_frame_common(napi_env env, napi_callback_info info, int is_async) {
     size_t argc = 1;
     napi_value argv[1], self;
@@ -950,6 +1062,16 @@ static napi_value render_frame_common(napi_env env, napi_callback_info info, int
         p->disk_profile = strcmp(buf, "pageThorne") == 0 ? GRV_DISK_PROFILE_PAGE_THORNE : GRV_DISK_PROFILE_SHORTCUT;
     if (obj_str(env, argv[0], "arith", buf, sizeof buf))
         p->opt.arith = strcmp(buf, "strict") == 0 ? GRV_ARITH_STRICT : GRV_ARITH_FAST;
+    if (wants_image(env, argv[0])) { /* keepOnDevice / image: queued into a device image, nothing crosses PCIe */
+        napi_value res = NULL;
+        if (is_async || wk->devices > 1 || wk->virtual_ranks > 0)
+            napi_throw_type_error(env, NULL, "renderFrame: keepOnDevice / image is the synchronous one-device form "
+                                             "(the call only queues; there is nothing to await)");
+        else
+            res = render_frame_to_image(env, b, argv[0], &wk->cam, &wk->p);
+        free(wk);
+        return res;
+    }
     const size_t n = (size_t)w * h * 4;
     napi_value rgba;
     bool has = false;
@@ -967,7 +1089,9 @@ static napi_value render_frame_common(napi_env env, napi_callback_info info, int
             return NULL;
         }
         wk->rgba = (float *)data;
-        if (is_async) { /* see bulk_work.own_rgba: the pool thread renders into staging, not into JS-reachable memory */
+        wk->rgba_elems = n;
+        if (is_async) wk->pin = pinned_acquire(data, n * sizeof(float));
+        if (is_async && !wk->pin) { /* see bulk_work.own_rgba: the pool thread renders into staging, not into JS-reachable memory */
             wk->own_rgba = stage_acquire(b, n * sizeof(float), &wk->own_stage);
             if (!wk->own_rgba) {
                 free(wk);
@@ -990,6 +1114,7 @@ static napi_value render_frame_common(napi_env env, napi_callback_info info, int
     }
     if (!keep_ref(env, wk, rgba)) {
         stage_release(b, wk->own_rgba, wk->own_stage);
+        pinned_release(wk->pin);
         free(wk);
         napi_throw_error(env, NULL, "renderFrame: reference failed");
         return NULL;
@@ -1111,13 +1236,617 @@ static napi_value integrate_batch_common(napi_env env, napi_callback_info info, 
 static napi_value m_integrate_batch(napi_env env, napi_callback_info info) { return integrate_batch_common(env, info, 0); }
 static napi_value m_integrate_batch_async(napi_env env, napi_callback_info info) { return integrate_batch_common(env, info, 1); }
 
+/* ---------------------------------------------------------------------------------------------
+ * Device-resident frames (include/gravitas_abi.h "device images").
+ *
+ *   const img = engine.createImage(w, h)                    -> DeviceImage
+ *   engine.renderFrame({..., keepOnDevice: true})           -> {image: DeviceImage (new), width, height, queued: true}
+ *   engine.renderFrame({..., image: img})                   -> the same into an image the caller keeps
+ *   engine.renderShaderFrame({kernel: "glsl"|"wgsl", width, height, maxSteps, arith, image})
+ *   engine.renderWebGLFrame({..., image}) / renderWebGPUFrame(cu, pp, {image})
+ *   engine.postBloom(scene, out, {intensity?, threshold?, blurPasses?, fast?}) / engine.postTaa(cur, hist, out, {...})
+ *   img.read(out?) / engine.readImage(img, out?)            -> Float32Array (the one D2H; allocPinned memory: one DMA)
+ *   img.readAsync(out)                                      -> Promise (out must live in allocPinned() memory)
+ *   img.stats()                                             -> {rays, acceptedSteps, ...} of the frame that wrote it
+ *   img.ready() / img.wait() / img.free()
+ *   engine.statsAccumulate(on) / frameStats() / frameStatsReset() / synchronize()
+ *
+ * None of the render / post calls waits for the GPU: they queue on the image's stream and return, so
+ * a JS frame loop that alternates two images keeps two frames in flight exactly as the reference's
+ * renderer keeps submitting command buffers (src/rendering/webgpu/renderer.ts:280-411).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    grv_image *img;
+    uint32_t w, h;
+    int pending; /* readAsync works queued (main thread only) */
+    int freed;   /* free() arrived while reads were pending: the last one destroys the image */
+} image_box;
+
+static napi_ref g_image_ctor = NULL;
+
+static void image_finalize(napi_env env, void *data, void *hint) {
+    (void)env;
+    (void)hint;
+    image_box *ib = (image_box *)data;
+    if (ib) {
+        if (ib->img) grv_image_destroy(ib->img); /* (a pending read holds a reference to the object) */
+        free(ib);
+    }
+}
+static napi_value image_ctor(napi_env env, napi_callback_info info) {
+    napi_value self;
+    NAPI_OK(napi_get_cb_info(env, info, NULL, NULL, &self, NULL));
+    return self; /* wrapped by wrap_image(); a bare `new DeviceImage()` has no device memory and every method says so */
+}
+static image_box *image_of(napi_env env, napi_value v) {
+    image_box *ib = NULL;
+    napi_valuetype t;
+    if (napi_typeof(env, v, &t) != napi_ok || t != napi_object) return NULL;
+    if (napi_unwrap(env, v, (void **)&ib) != napi_ok || !ib || !ib->img) return NULL;
+    /* (an engine object unwraps too: tell them apart by the constructor) */
+    napi_value ctor;
+    bool is = false;
+    if (!g_image_ctor || napi_get_reference_value(env, g_image_ctor, &ctor) != napi_ok ||
+        napi_instanceof(env, v, ctor, &is) != napi_ok || !is) return NULL;
+    return ib;
+}
+static napi_value wrap_image(napi_env env, grv_image *img) {
+    napi_value ctor, obj;
+    image_box *ib = (image_box *)calloc(1, sizeof *ib);
+    if (!ib || !g_image_ctor || napi_get_reference_value(env, g_image_ctor, &ctor) != napi_ok ||
+        napi_new_instance(env, ctor, 0, NULL, &obj) != napi_ok) {
+        free(ib);
+        grv_image_destroy(img);
+        napi_throw_error(env, NULL, "DeviceImage: cannot create the object");
+        return NULL;
+    }
+    ib->img = img;
+    ib->w = grv_image_width(img);
+    ib->h = grv_image_height(img);
+    if (napi_wrap(env, obj, ib, image_finalize, NULL, NULL) != napi_ok) {
+        free(ib);
+        grv_image_destroy(img);
+        napi_throw_error(env, NULL, "DeviceImage: cannot wrap the object");
+        return NULL;
+    }
+    napi_set_named_property(env, obj, "width", mk_f64(env, ib->w));
+    napi_set_named_property(env, obj, "height", mk_f64(env, ib->h));
+    napi_set_named_property(env, obj, "bytes", mk_f64(env, (double)grv_image_bytes(img)));
+    return obj;
+}
+
+/* the image a render call writes: opts.image, or a new one under opts.keepOnDevice; *created tells which */
+static image_box *target_image(napi_env env, engine_box *b, napi_value opts, uint32_t w, uint32_t h, napi_value *obj,
+                               const char *who) {
+    bool has = false;
+    char msg[160];
+    if (napi_has_named_property(env, opts, "image", &has) == napi_ok && has) {
+        if (napi_get_named_property(env, opts, "image", obj) != napi_ok) return NULL;
+        image_box *ib = image_of(env, *obj);
+        if (!ib) {
+            snprintf(msg, sizeof msg, "%s: image must be a live DeviceImage (engine.createImage)", who);
+            napi_throw_type_error(env, NULL, msg);
+            return NULL;
+        }
+        if (ib->w != w || ib->h != h) {
+            snprintf(msg, sizeof msg, "%s: a %u x %u frame into an image of %u x %u", who, w, h, ib->w, ib->h);
+            napi_throw_range_error(env, NULL, msg);
+            return NULL;
+        }
+        return ib;
+    }
+    grv_image *img = NULL;
+    if (grv_image_create(b->h, w, h, &img) != GRV_OK) {
+        napi_throw_error(env, NULL, grv_last_error(b->h));
+        return NULL;
+    }
+    *obj = wrap_image(env, img);
+    if (!*obj) return NULL;
+    image_box *ib = NULL;
+    napi_unwrap(env, *obj, (void **)&ib);
+    return ib;
+}
+static int wants_image(napi_env env, napi_value opts) {
+    bool has = false;
+    if (napi_has_named_property(env, opts, "image", &has) == napi_ok && has) return 1;
+    return obj_flag(env, opts, "keepOnDevice");
+}
+static napi_value queued_result(napi_env env, napi_value image_obj, uint32_t w, uint32_t h) {
+    napi_value out, t;
+    if (napi_create_object(env, &out) != napi_ok) return NULL;
+    napi_set_named_property(env, out, "image", image_obj);
+    napi_set_named_property(env, out, "width", mk_f64(env, w));
+    napi_set_named_property(env, out, "height", mk_f64(env, h));
+    napi_set_named_property(env, out, "rays", mk_f64(env, (double)w * h));
+    napi_get_boolean(env, true, &t);
+    napi_set_named_property(env, out, "queued", t);
+    return out;
+}
+
+static napi_value m_create_image(napi_env env, napi_callback_info info) {
+    size_t argc = 2;
+    napi_value argv[2];
+    engine_box *b = unwrap(env, info, &argc, argv);
+    if (!b) return NULL;
+    const double w = argc > 0 ? arg_f64(env, argv[0]) : 0.0, h = argc > 1 ? arg_f64(env, argv[1]) : 0.0;
+    if (!(w >= 1.0 && h >= 1.0 && w * h <= 134217728.0)) {
+        napi_throw_range_error(env, NULL, "createImage: width/height out of range");
+        return NULL;
+    }
+    grv_image *img = NULL;
+    if (grv_image_create(b->h, (uint32_t)w, (uint32_t)h, &img) != GRV_OK) {
+        napi_throw_error(env, NULL, grv_last_error(b->h));
+        return NULL;
+    }
+    return wrap_image(env, img);
+}
+
+static image_box *this_image(napi_env env, napi_callback_info info, size_t *argc, napi_value *argv, napi_value *self) {
+    image_box *ib = NULL;
+    if (napi_get_cb_info(env, info, argc, argv, self, NULL) != napi_ok) return NULL;
+    if (napi_unwrap(env, *self, (void **)&ib) != napi_ok || !ib || !ib->img) {
+        napi_throw_error(env, NULL, "DeviceImage: no device memory behind this object (freed, or not made by createImage)");
+        return NULL;
+    }
+    return ib;
+}
+
+/* the Float32Array a read lands in: `v` if given (checked), else a new one; *data its memory */
+static napi_value read_target(napi_env env, napi_value v, int given, size_t n, float **data, const char *who) {
+    napi_value ta;
+    if (given) {
+        napi_typedarray_type ty;
+        size_t len = 0;
+        void *d = NULL;
+        bool is_ta = false;
+        if (napi_is_typedarray(env, v, &is_ta) != napi_ok || !is_ta ||
+            napi_get_typedarray_info(env, v, &ty, &len, &d, NULL, NULL) != napi_ok || ty != napi_float32_array || len < n) {
+            char msg[128];
+            snprintf(msg, sizeof msg, "%s: out must be a Float32Array of width*height*4 elements", who);
+            napi_throw_type_error(env, NULL, msg);
+            return NULL;
+        }
+        *data = (float *)d;
+        return v;
+    }
+    napi_value ab;
+    void *d;
+    if (napi_create_arraybuffer(env, n * sizeof(float), &d, &ab) != napi_ok ||
+        napi_create_typedarray(env, napi_float32_array, n, ab, 0, &ta) != napi_ok) {
+        napi_throw_error(env, NULL, "read: cannot allocate the image");
+        return NULL;
+    }
+    *data = (float *)d;
+    return ta;
+}
+static napi_value image_read_into(napi_env env, image_box *ib, napi_value out, int given) {
+    const size_t n = (size_t)ib->w * ib->h * 4;
+    float *dst = NULL;
+    napi_value ta = read_target(env, out, given, n, &dst, "DeviceImage.read");
+    if (!ta) return NULL;
+    if (grv_image_read(ib->img, dst, n) != GRV_OK) {
+        napi_throw_error(env, NULL, grv_image_last_error(ib->img));
+        return NULL;
+    }
+    return ta;
+}
+static napi_value im_read(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1], self;
+    image_box *ib = this_image(env, info, &argc, argv, &self);
+    if (!ib) return NULL;
+    napi_valuetype t = napi_undefined;
+    if (argc > 0) napi_typeof(env, argv[0], &t);
+    return image_read_into(env, ib, argc > 0 ? argv[0] : NULL, argc > 0 && t != napi_undefined && t != napi_null);
+}
+/* engine.readImage(img, out?) */
+static napi_value m_read_image(napi_env env, napi_callback_info info) {
+    size_t argc = 2;
+    napi_value argv[2];
+    engine_box *b = unwrap(env, info, &argc, argv);
+    if (!b) return NULL;
+    image_box *ib = argc > 0 ? image_of(env, argv[0]) : NULL;
+    if (!ib) {
+        napi_throw_type_error(env, NULL, "readImage(image, out?): image must be a live DeviceImage");
+        return NULL;
+    }
+    napi_valuetype t = napi_undefined;
+    if (argc > 1) napi_typeof(env, argv[1], &t);
+    return image_read_into(env, ib, argc > 1 ? argv[1] : NULL, argc > 1 && t != napi_undefined && t != napi_null);
+}
+
+typedef struct {
+    image_box *ib;
+    pinned_block *pin;
+    size_t n;
+    int rc;
+    char err[256];
+    napi_ref self_ref, out_ref;
+    napi_deferred deferred;
+    napi_async_work work;
+} read_work;
+static void read_async_execute(napi_env env, void *data) {
+    (void)env;
+    read_work *w = (read_work *)data;
+    w->rc = grv_image_wait(w->ib->img); /* the copy was queued on the JS thread: this only waits (image-only call) */
+    if (w->rc != GRV_OK) snprintf(w->err, sizeof w->err, "%s", grv_image_last_error(w->ib->img));
+}
+static void read_async_complete(napi_env env, napi_status status, void *data) {
+    read_work *w = (read_work *)data;
+    napi_value out = NULL;
+    if (status == napi_ok && w->rc == GRV_OK) napi_get_reference_value(env, w->out_ref, &out);
+    if (out) {
+        napi_resolve_deferred(env, w->deferred, out);
+    } else {
+        napi_value msg, err;
+        napi_create_string_utf8(env, w->err[0] ? w->err : "readAsync failed", NAPI_AUTO_LENGTH, &msg);
+        napi_create_error(env, NULL, msg, &err);
+        napi_reject_deferred(env, w->deferred, err);
+    }
+    napi_delete_async_work(env, w->work);
+    pinned_release(w->pin);
+    if (--w->ib->pending == 0 && w->ib->freed && w->ib->img) {
+        grv_image_destroy(w->ib->img);
+        w->ib->img = NULL;
+    }
+    napi_delete_reference(env, w->self_ref);
+    napi_delete_reference(env, w->out_ref);
+    free(w);
+}
+/* img.readAsync(out) -> Promise<out>: the D2H is queued behind the image's producers at once; the promise
+ * settles when it has landed.  `out` must live in allocPinned() memory: the DMA writes it while JS runs. */
+static napi_value im_read_async(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1], self, promise, name;
+    image_box *ib = this_image(env, info, &argc, argv, &self);
+    if (!ib) return NULL;
+    const size_t n = (size_t)ib->w * ib->h * 4;
+    float *dst = NULL;
+    if (argc < 1 || !read_target(env, argv[0], 1, n, &dst, "DeviceImage.readAsync")) {
+        if (argc < 1) napi_throw_type_error(env, NULL, "DeviceImage.readAsync(out): out is required");
+        return NULL;
+    }
+    pinned_block *pin = pinned_acquire(dst, n * sizeof(float));
+    if (!pin) {
+        napi_throw_type_error(env, NULL, "DeviceImage.readAsync: out must live in allocPinned() memory (use read(out) otherwise)");
+        return NULL;
+    }
+    read_work *w = (read_work *)calloc(1, sizeof *w);
+    if (!w) {
+        pinned_release(pin);
+        napi_throw_error(env, NULL, "out of memory");
+        return NULL;
+    }
+    w->ib = ib;
+    w->pin = pin;
+    w->n = n;
+    if (grv_image_read_async(ib->img, dst, n) != GRV_OK) {
+        napi_throw_error(env, NULL, grv_image_last_error(ib->img));
+        pinned_release(pin);
+        free(w);
+        return NULL;
+    }
+    if (napi_create_promise(env, &w->deferred, &promise) != napi_ok ||
+        napi_create_reference(env, self, 1, &w->self_ref) != napi_ok ||
+        napi_create_reference(env, argv[0], 1, &w->out_ref) != napi_ok ||
+        napi_create_string_utf8(env, "gravitas.read", NAPI_AUTO_LENGTH, &name) != napi_ok ||
+        napi_create_async_work(env, NULL, name, read_async_execute, read_async_complete, w, &w->work) != napi_ok ||
+        napi_queue_async_work(env, w->work) != napi_ok) {
+        grv_image_wait(ib->img); /* the copy is queued: let it land before the block may go */
+        pinned_release(pin);
+        if (w->self_ref) napi_delete_reference(env, w->self_ref);
+        if (w->out_ref) napi_delete_reference(env, w->out_ref);
+        free(w);
+        napi_throw_error(env, NULL, "cannot queue async work");
+        return NULL;
+    }
+    ib->pending++;
+    return promise;
+}
+static napi_value stats_object(napi_env env, const GrvFrameStats *st) {
+    napi_value out, tc;
+    if (napi_create_object(env, &out) != napi_ok || napi_create_array_with_length(env, 5, &tc) != napi_ok) return NULL;
+    napi_set_named_property(env, out, "rays", mk_f64(env, (double)st->rays));
+    napi_set_named_property(env, out, "acceptedSteps", mk_f64(env, (double)st->accepted_steps));
+    napi_set_named_property(env, out, "rkfTries", mk_f64(env, (double)st->rkf_tries));
+    napi_set_named_property(env, out, "crossings", mk_f64(env, (double)st->crossings));
+    napi_set_named_property(env, out, "maxDrift", mk_f64(env, st->max_drift));
+    napi_set_named_property(env, out, "launches", mk_f64(env, (double)st->launches));
+    napi_set_named_property(env, out, "integrateMs", mk_f64(env, (double)st->integrate_ms));
+    for (uint32_t k = 0; k < 5; k++) napi_set_element(env, tc, k, mk_f64(env, (double)st->term_count[k]));
+    napi_set_named_property(env, out, "termCount", tc);
+    return out;
+}
+static napi_value im_stats(napi_env env, napi_callback_info info) {
+    size_t argc = 0;
+    napi_value self;
+    image_box *ib = this_image(env, info, &argc, NULL, &self);
+    if (!ib) return NULL;
+    GrvFrameStats st;
+    if (grv_image_frame_stats(ib->img, &st) != GRV_OK) {
+        napi_throw_error(env, NULL, grv_image_last_error(ib->img));
+        return NULL;
+    }
+    return stats_object(env, &st);
+}
+static napi_value im_wait(napi_env env, napi_callback_info info) {
+    size_t argc = 0;
+    napi_value self;
+    image_box *ib = this_image(env, info, &argc, NULL, &self);
+    if (!ib) return NULL;
+    if (grv_image_wait(ib->img) != GRV_OK) {
+        napi_throw_error(env, NULL, grv_image_last_error(ib->img));
+        return NULL;
+    }
+    return self;
+}
+static napi_value im_ready(napi_env env, napi_callback_info info) {
+    size_t argc = 0;
+    napi_value self, v;
+    image_box *ib = this_image(env, info, &argc, NULL, &self);
+    if (!ib) return NULL;
+    const int q = grv_image_query(ib->img);
+    if (q < 0) {
+        napi_throw_error(env, NULL, grv_image_last_error(ib->img));
+        return NULL;
+    }
+    napi_get_boolean(env, q == 1, &v);
+    return v;
+}
+static napi_value im_free(napi_env env, napi_callback_info info) {
+    size_t argc = 0;
+    napi_value self;
+    image_box *ib = NULL;
+    NAPI_OK(napi_get_cb_info(env, info, &argc, NULL, &self, NULL));
+    if (napi_unwrap(env, self, (void **)&ib) == napi_ok && ib && ib->img) {
+        if (ib->pending > 0) ib->freed = 1; /* the last pending read destroys it */
+        else {
+            grv_image_destroy(ib->img);
+            ib->img = NULL;
+        }
+    }
+    return NULL;
+}
+
+/* renderFrame({..., keepOnDevice | image}): the f64 frame into a device image, queued, nothing waited for */
+static napi_value render_frame_to_image(napi_env env, engine_box *b, napi_value opts, const GrvCamera *cam,
+                                        const GrvRenderParams *p) {
+    napi_value obj;
+    image_box *ib = target_image(env, b, opts, p->width, p->height, &obj, "renderFrame");
+    if (!ib) return NULL;
+    if (grv_render_frame_image(b->h, cam, p, ib->img) != GRV_OK) {
+        napi_throw_error(env, NULL, grv_last_error(b->h));
+        return NULL;
+    }
+    return queued_result(env, obj, p->width, p->height);
+}
+
+/* renderShaderFrame({kernel: "glsl" | "wgsl", width, height, maxSteps?, arith?: "fast"|"strict"|"packed",
+ *                    eye?/target?/up?/fovY? (wgsl camera), spin?, mass?, zoom?, time?, features?, image | keepOnDevice,
+ *                    out?})
+ * ONE f32 march launch -- the GLSL fragment march (fragment.glsl.ts:40-334, BASELINE configs[1]) or the WGSL
+ * compute march (compute.wgsl.ts:147-258, configs[3]) -- without the renderers' post chain.  With an image
+ * the call queues and returns {image, queued: true}; otherwise -> {rgba: Float32Array, acceptedSteps}. */
+static napi_value m_render_shader_frame(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    engine_box *b = unwrap(env, info, &argc, argv);
+    if (!b) return NULL;
+    napi_valuetype t;
+    if (argc < 1 || napi_typeof(env, argv[0], &t) != napi_ok || t != napi_object) {
+        napi_throw_type_error(env, NULL, "renderShaderFrame expects an options object");
+        return NULL;
+    }
+    const uint32_t w = (uint32_t)obj_f64(env, argv[0], "width", 256), h = (uint32_t)obj_f64(env, argv[0], "height", 256);
+    if (w == 0 || h == 0 || (uint64_t)w * h > (1ull << 27)) {
+        napi_throw_range_error(env, NULL, "renderShaderFrame: width/height out of range");
+        return NULL;
+    }
+    char kernel[16] = "glsl", arith[16] = "fast";
+    obj_str(env, argv[0], "kernel", kernel, sizeof kernel);
+    if (!kernel[0]) strcpy(kernel, "glsl");
+    obj_str(env, argv[0], "arith", arith, sizeof arith);
+    const int is_glsl = strcmp(kernel, "glsl") == 0;
+    if (!is_glsl && strcmp(kernel, "wgsl") != 0) {
+        napi_throw_type_error(env, NULL, "renderShaderFrame: kernel must be \"glsl\" or \"wgsl\"");
+        return NULL;
+    }
+    const int ar = strcmp(arith, "strict") == 0 ? GRV_ARITH_STRICT : strcmp(arith, "packed") == 0 ? GRV_ARITH_FAST_PACKED : GRV_ARITH_FAST;
+    const double mass = obj_f64(env, argv[0], "mass", b->mass), spin = obj_f64(env, argv[0], "spin", b->spin);
+    GrvGlslParams gp;
+    GrvWgslParams wp;
+    if (is_glsl) {
+        if (ar == GRV_ARITH_FAST_PACKED) {
+            napi_throw_type_error(env, NULL, "renderShaderFrame: arith \"packed\" is the two-rays-per-lane form of the WGSL march");
+            return NULL;
+        }
+        grv_glsl_params_default(w, h, mass, spin, &gp);
+        gp.zoom = (float)obj_f64(env, argv[0], "zoom", gp.zoom);
+        gp.time = (float)obj_f64(env, argv[0], "time", 0.0);
+        gp.max_ray_steps = (int32_t)obj_f64(env, argv[0], "maxSteps", gp.max_ray_steps);
+        gp.features = (uint32_t)obj_f64(env, argv[0], "features", (double)gp.features);
+        double mouse[3] = {gp.mouse[0], gp.mouse[1], 0.0};
+        obj_vec3(env, argv[0], "mouse", mouse);
+        gp.mouse[0] = (float)mouse[0];
+        gp.mouse[1] = (float)mouse[1];
+        gp.arith = ar;
+    } else {
+        GrvCamera cam;
+        double eye[3] = {0.0, 0.0, 60.0}, target[3] = {0.0, 0.0, 0.0}, up[3] = {0.0, 1.0, 0.0};
+        obj_vec3(env, argv[0], "eye", eye);
+        obj_vec3(env, argv[0], "target", target);
+        obj_vec3(env, argv[0], "up", up);
+        grv_camera_look_at(eye, target, up, obj_f64(env, argv[0], "fovY", 60.0) * (3.14159265358979323846 / 180.0),
+                           (double)w / (double)h, &cam);
+        grv_wgsl_params_default(w, h, &cam, mass, spin, &wp);
+        wp.max_steps = (int32_t)obj_f64(env, argv[0], "maxSteps", (double)wp.max_steps);
+        wp.arith = ar;
+    }
+    if (wants_image(env, argv[0])) {
+        napi_value obj;
+        image_box *ib = target_image(env, b, argv[0], w, h, &obj, "renderShaderFrame");
+        if (!ib) return NULL;
+        const int rc = is_glsl ? grv_render_frame_glsl_image(b->h, &gp, ib->img) : grv_render_frame_wgsl_image(b->h, &wp, ib->img);
+        if (rc != GRV_OK) {
+            napi_throw_error(env, NULL, grv_last_error(b->h));
+            return NULL;
+        }
+        return queued_result(env, obj, w, h);
+    }
+    /* host form: through a temporary image (one D2H) */
+    grv_image *img = NULL;
+    if (grv_image_create(b->h, w, h, &img) != GRV_OK) {
+        napi_throw_error(env, NULL, grv_last_error(b->h));
+        return NULL;
+    }
+    int rc = is_glsl ? grv_render_frame_glsl_image(b->h, &gp, img) : grv_render_frame_wgsl_image(b->h, &wp, img);
+    if (rc != GRV_OK) {
+        napi_throw_error(env, NULL, grv_last_error(b->h));
+        grv_image_destroy(img);
+        return NULL;
+    }
+    const size_t n = (size_t)w * h * 4;
+    float *dst = NULL;
+    bool has = false;
+    napi_value outv = NULL, ta, res;
+    if (napi_has_named_property(env, argv[0], "out", &has) == napi_ok && has) napi_get_named_property(env, argv[0], "out", &outv);
+    ta = read_target(env, outv, has, n, &dst, "renderShaderFrame");
+    GrvFrameStats st;
+    memset(&st, 0, sizeof st);
+    if (ta) {
+        rc = grv_image_read(img, dst, n);
+        if (rc == GRV_OK) rc = grv_image_frame_stats(img, &st);
+        if (rc != GRV_OK) napi_throw_error(env, NULL, grv_image_last_error(img));
+    }
+    grv_image_destroy(img);
+    if (!ta || rc != GRV_OK) return NULL;
+    NAPI_OK(napi_create_object(env, &res));
+    napi_set_named_property(env, res, "rgba", ta);
+    napi_set_named_property(env, res, "width", mk_f64(env, w));
+    napi_set_named_property(env, res, "height", mk_f64(env, h));
+    napi_set_named_property(env, res, "acceptedSteps", mk_f64(env, (double)st.accepted_steps));
+    return res;
+}
+
+/* postBloom(scene: DeviceImage, out: DeviceImage, {intensity?, threshold?, blurPasses?, halfStorage?, fast?}) -> out
+ * BloomManager.applyBloomToTexture (src/rendering/bloom.ts:443-583) between two device images */
+static napi_value m_post_bloom(napi_env env, napi_callback_info info) {
+    size_t argc = 3;
+    napi_value argv[3];
+    engine_box *b = unwrap(env, info, &argc, argv);
+    if (!b) return NULL;
+    image_box *src = argc > 0 ? image_of(env, argv[0]) : NULL, *dst = argc > 1 ? image_of(env, argv[1]) : NULL;
+    if (!src || !dst) {
+        napi_throw_type_error(env, NULL, "postBloom(scene, out, opts?): scene and out must be live DeviceImages");
+        return NULL;
+    }
+    GrvBloomParams p;
+    grv_bloom_params_default(src->w, src->h, &p);
+    napi_valuetype t;
+    if (argc > 2 && napi_typeof(env, argv[2], &t) == napi_ok && t == napi_object) {
+        p.intensity = (float)obj_f64(env, argv[2], "intensity", p.intensity);
+        p.threshold = (float)obj_f64(env, argv[2], "threshold", p.threshold);
+        p.blur_passes = (int32_t)obj_f64(env, argv[2], "blurPasses", p.blur_passes);
+        p.half_storage = (int32_t)obj_f64(env, argv[2], "halfStorage", p.half_storage);
+        if (obj_flag(env, argv[2], "fast")) p.arith = GRV_ARITH_FAST;
+    }
+    if (grv_post_bloom_image(b->h, &p, src->img, dst->img) != GRV_OK) {
+        napi_throw_error(env, NULL, grv_last_error(b->h));
+        return NULL;
+    }
+    return argv[1];
+}
+/* postTaa(current, history, out, {blendFactor?, cameraMoving?, halfStorage?, fast?}) -> out
+ * ReprojectionManager.resolve (src/rendering/reprojection.ts:196-262) */
+static napi_value m_post_taa(napi_env env, napi_callback_info info) {
+    size_t argc = 4;
+    napi_value argv[4];
+    engine_box *b = unwrap(env, info, &argc, argv);
+    if (!b) return NULL;
+    image_box *cur = argc > 0 ? image_of(env, argv[0]) : NULL, *hist = argc > 1 ? image_of(env, argv[1]) : NULL,
+              *dst = argc > 2 ? image_of(env, argv[2]) : NULL;
+    if (!cur || !hist || !dst) {
+        napi_throw_type_error(env, NULL, "postTaa(current, history, out, opts?): three live DeviceImages");
+        return NULL;
+    }
+    GrvTaaParams p;
+    memset(&p, 0, sizeof p);
+    p.width = cur->w;
+    p.height = cur->h;
+    p.blend_factor = 0.75f;
+    p.half_storage = 1;
+    p.arith = GRV_ARITH_STRICT;
+    napi_valuetype t;
+    if (argc > 3 && napi_typeof(env, argv[3], &t) == napi_ok && t == napi_object) {
+        p.blend_factor = (float)obj_f64(env, argv[3], "blendFactor", p.blend_factor);
+        p.camera_moving = obj_flag(env, argv[3], "cameraMoving");
+        p.half_storage = (int32_t)obj_f64(env, argv[3], "halfStorage", p.half_storage);
+        if (obj_flag(env, argv[3], "fast")) p.arith = GRV_ARITH_FAST;
+    }
+    if (grv_post_taa_resolve_image(b->h, &p, cur->img, hist->img, dst->img) != GRV_OK) {
+        napi_throw_error(env, NULL, grv_last_error(b->h));
+        return NULL;
+    }
+    return argv[2];
+}
+
+/* statsAccumulate(on), frameStats() -> {rays, acceptedSteps, ...}, frameStatsReset(), synchronize():
+ * grv_stats_accumulate / grv_frame_stats / grv_frame_stats_reset of the synchronous handle.  With
+ * accumulation on, a loop of queued frames needs no read-back: frameStats() after the loop waits for the
+ * device and returns the sums (what bench.py does around its timed region). */
+static napi_value m_stats_accumulate(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    engine_box *b = unwrap(env, info, &argc, argv);
+    if (!b) return NULL;
+    bool on = true;
+    if (argc > 0) napi_coerce_to_bool(env, argv[0], &argv[0]), napi_get_value_bool(env, argv[0], &on);
+    grv_stats_accumulate(b->h, on ? 1 : 0);
+    return NULL;
+}
+static napi_value m_frame_stats(napi_env env, napi_callback_info info) {
+    size_t argc = 0;
+    engine_box *b = unwrap(env, info, &argc, NULL);
+    if (!b) return NULL;
+    GrvFrameStats st;
+    if (grv_frame_stats(b->h, NULL, &st) != GRV_OK) {
+        napi_throw_error(env, NULL, grv_last_error(b->h));
+        return NULL;
+    }
+    return stats_object(env, &st);
+}
+static napi_value m_frame_stats_reset(napi_env env, napi_callback_info info) {
+    size_t argc = 0;
+    engine_box *b = unwrap(env, info, &argc, NULL);
+    if (!b) return NULL;
+    if (grv_frame_stats_reset(b->h, NULL) != GRV_OK) {
+        napi_throw_error(env, NULL, grv_last_error(b->h));
+        return NULL;
+    }
+    return NULL;
+}
+static napi_value m_synchronize(napi_env env, napi_callback_info info) {
+    size_t argc = 0;
+    engine_box *b = unwrap(env, info, &argc, NULL);
+    if (!b) return NULL;
+    if (grv_engine_synchronize(b->h) != GRV_OK) {
+        napi_throw_error(env, NULL, grv_last_error(b->h));
+        return NULL;
+    }
+    return NULL;
+}
+
 /* allocPinned(bytes) -> ArrayBuffer over page-locked host memory (grv_host_alloc): a
  * `new Float32Array(buf)` passed as renderFrame({out}) receives the frame in one DMA, with no copy
  * on the JS side.  Freed when the ArrayBuffer is collected. */
 static void pinned_finalize(napi_env env, void *data, void *hint) {
     (void)env;
-    (void)hint;
-    grv_host_free(data);
+    (void)data;
+    pinned_block *blk = (pinned_block *)hint;
+    pthread_mutex_lock(&g_pinned_mu);
+    blk->dead = 1;
+    if (blk->refs == 0) pinned_drop_locked(blk); /* else: the last queued work that writes into it frees it */
+    pthread_mutex_unlock(&g_pinned_mu);
 }
 static napi_value f_alloc_pinned(napi_env env, napi_callback_info info) {
     size_t argc = 1;
@@ -1129,12 +1858,22 @@ static napi_value f_alloc_pinned(napi_env env, napi_callback_info info) {
         return NULL;
     }
     void *p = grv_host_alloc((size_t)bytes);
-    if (!p) {
+    pinned_block *blk = p ? (pinned_block *)calloc(1, sizeof *blk) : NULL;
+    if (!p || !blk) {
+        grv_host_free(p);
         napi_throw_error(env, NULL, "allocPinned: hipHostMalloc failed (no HIP device?)");
         return NULL;
     }
-    if (napi_create_external_arraybuffer(env, p, (size_t)bytes, pinned_finalize, NULL, &buf) != napi_ok) {
-        grv_host_free(p);
+    blk->p = (uint8_t *)p;
+    blk->bytes = (size_t)bytes;
+    pthread_mutex_lock(&g_pinned_mu);
+    blk->next = g_pinned;
+    g_pinned = blk;
+    pthread_mutex_unlock(&g_pinned_mu);
+    if (napi_create_external_arraybuffer(env, p, (size_t)bytes, pinned_finalize, blk, &buf) != napi_ok) {
+        pthread_mutex_lock(&g_pinned_mu);
+        pinned_drop_locked(blk);
+        pthread_mutex_unlock(&g_pinned_mu);
         napi_throw_error(env, NULL, "allocPinned: cannot wrap the allocation");
         return NULL;
     }
@@ -1177,6 +1916,21 @@ static napi_value m_render_webgpu_frame(napi_env env, napi_callback_info info) {
             napi_get_named_property(env, argv[2], "arith", &v) == napi_ok &&
             napi_get_value_string_utf8(env, v, buf, sizeof buf, &len) == napi_ok)
             arith = strcmp(buf, "fast") == 0 ? GRV_ARITH_FAST : GRV_ARITH_STRICT;
+    }
+    if (argc > 2 && napi_typeof(env, argv[2], &t) == napi_ok && t == napi_object && wants_image(env, argv[2])) {
+        napi_value obj; /* present into a device image: queued, nothing waited for */
+        const uint32_t w = (uint32_t)blocks[1][2], h = (uint32_t)blocks[1][3];
+        if (w == 0 || h == 0 || (uint64_t)w * h > (1ull << 27)) {
+            napi_throw_range_error(env, NULL, "renderWebGPUFrame: resolution out of range");
+            return NULL;
+        }
+        image_box *ib = target_image(env, b, argv[2], w, h, &obj, "renderWebGPUFrame");
+        if (!ib) return NULL;
+        if (grv_webgpu_render_image(b->h, blocks[0], blocks[1], max_steps, arith, ib->img) != GRV_OK) {
+            napi_throw_error(env, NULL, grv_last_error(b->h));
+            return NULL;
+        }
+        return queued_result(env, obj, w, h);
     }
     const size_t n = (size_t)(uint32_t)blocks[1][2] * (uint32_t)blocks[1][3] * 4;
     napi_value ab, ta;
@@ -1221,6 +1975,16 @@ static napi_value m_render_webgl_frame(napi_env env, napi_callback_info info) {
     p.arith = obj_f64(env, argv[0], "fast", 0.0) != 0.0 ? GRV_ARITH_FAST : GRV_ARITH_STRICT;
     const int bloom = obj_f64(env, argv[0], "bloom", 1.0) != 0.0;
     const int moving = obj_f64(env, argv[0], "cameraMoving", 0.0) != 0.0;
+    if (wants_image(env, argv[0])) {
+        napi_value obj;
+        image_box *ib = target_image(env, b, argv[0], w, h, &obj, "renderWebGLFrame");
+        if (!ib) return NULL;
+        if (grv_webgl_render_image(b->h, &p, bloom, moving, ib->img) != GRV_OK) {
+            napi_throw_error(env, NULL, grv_last_error(b->h));
+            return NULL;
+        }
+        return queued_result(env, obj, w, h);
+    }
     const size_t n = (size_t)w * h * 4;
     napi_value ab, ta;
     void *dst;
@@ -1232,6 +1996,7 @@ static napi_value m_render_webgl_frame(napi_env env, napi_callback_info info) {
     NAPI_OK(napi_create_typedarray(env, napi_float32_array, n, ab, 0, &ta));
     return ta;
 }
+
 
 static napi_value m_free(napi_env env, napi_callback_info info) { /* wasm-bindgen's .free() */
     size_t argc = 0;
@@ -1320,8 +2085,30 @@ static napi_value module_init(napi_env env, napi_value exports) {
         METHOD("integrateBatchAsync", m_integrate_batch_async),
         METHOD("renderWebGPUFrame", m_render_webgpu_frame),
         METHOD("renderWebGLFrame", m_render_webgl_frame),
+        METHOD("createImage", m_create_image),
+        METHOD("renderShaderFrame", m_render_shader_frame),
+        METHOD("readImage", m_read_image),
+        METHOD("postBloom", m_post_bloom),
+        METHOD("postTaa", m_post_taa),
+        METHOD("statsAccumulate", m_stats_accumulate),
+        METHOD("frameStats", m_frame_stats),
+        METHOD("frameStatsReset", m_frame_stats_reset),
+        METHOD("synchronize", m_synchronize),
         METHOD("free", m_free),
     };
+    napi_property_descriptor iprops[] = {
+        METHOD("read", im_read),
+        METHOD("readAsync", im_read_async),
+        METHOD("stats", im_stats),
+        METHOD("wait", im_wait),
+        METHOD("ready", im_ready),
+        METHOD("free", im_free),
+    };
+    napi_value icls;
+    NAPI_OK(napi_define_class(env, "DeviceImage", NAPI_AUTO_LENGTH, image_ctor, NULL, sizeof iprops / sizeof iprops[0],
+                              iprops, &icls));
+    NAPI_OK(napi_create_reference(env, icls, 1, &g_image_ctor));
+    NAPI_OK(napi_set_named_property(env, exports, "DeviceImage", icls));
     napi_value cls, fn;
     NAPI_OK(napi_define_class(env, "PhysicsEngine", NAPI_AUTO_LENGTH, engine_new, NULL,
                               sizeof props / sizeof props[0], props, &cls));

@@ -39,8 +39,14 @@ export interface RenderFrameOptions {
   /** what the gather of a multi-device frame carries: f32 pixels (default) or the compute pass's own
    *  rgba16float format (half the bytes; the image is the one-device frame rounded through binary16) */
   exchange?: "rgba32f" | "rgba16f";
-  /** render into this array (width*height*4) instead of a fresh one */
+  /** render into this array (width*height*4) instead of a fresh one; renderFrameAsync into allocPinned()
+   *  memory receives the DMA directly (no staging copy), two calls in flight overlap copy and kernels */
   out?: Float32Array;
+  /** keep the frame in HBM: the (synchronous, one-device) call queues the frame into a new DeviceImage and
+   *  returns a QueuedFrame at once */
+  keepOnDevice?: boolean;
+  /** the same into an image the caller keeps (createImage): a frame loop alternates two of them */
+  image?: DeviceImage;
 }
 
 export interface IntegrateBatchOptions {
@@ -102,6 +108,9 @@ export interface WebGLFrameOptions {
   bloom?: number;
   cameraMoving?: number;
   fast?: number;
+  /** present into a device image (queued; returns QueuedFrame) */
+  image?: DeviceImage;
+  keepOnDevice?: boolean;
 }
 
 export class PhysicsEngine {
@@ -158,8 +167,8 @@ export class PhysicsEngine {
   compute_proper_distance(r1: number, r2: number, n_steps: number): number;
 
   /** f64 RKF45 frame (pixel -> ray of compute.wgsl.ts:159-187) */
-  renderFrame(options: RenderFrameOptions): RenderFrameResult;
-  render_frame(options: RenderFrameOptions): RenderFrameResult;
+  renderFrame(options: RenderFrameOptions): RenderFrameResult | QueuedFrame;
+  render_frame(options: RenderFrameOptions): RenderFrameResult | QueuedFrame;
   /** the same frame on the libuv pool (an engine handle of its own): the caller's loop is not held */
   renderFrameAsync(options: RenderFrameOptions): Promise<RenderFrameResult>;
   /** n independent integrate() calls (geodesic/mod.rs:180-253) in one launch; states = 8 n f64 */
@@ -169,8 +178,54 @@ export class PhysicsEngine {
   /** WebGPURenderer.render with the 352-byte / 32-byte uniform blocks (src/types/webgpu.ts:67-116) */
   renderWebGPUFrame(
     cameraUniforms: Float32Array, physicsParams: Float32Array,
-    options?: { maxSteps?: number; arith?: "fast" | "strict" },
-  ): Float32Array;
+    options?: { maxSteps?: number; arith?: "fast" | "strict"; image?: DeviceImage; keepOnDevice?: boolean },
+  ): Float32Array | QueuedFrame;
   /** WebGLRenderer.render's scene + TAA + bloom chain */
-  renderWebGLFrame(options: WebGLFrameOptions): Float32Array;
+  renderWebGLFrame(options: WebGLFrameOptions): Float32Array | QueuedFrame;
+
+  // ---- device-resident frames (include/gravitas_abi.h "device images") ----
+  // renderFrame / renderShaderFrame / renderWebGLFrame / renderWebGPUFrame with {image} or {keepOnDevice: true}
+  // return QueuedFrame at once: the frame stays in HBM as the renderers' textures do upstream
+  // (webgpu/renderer.ts:280-411); pixels cross PCIe in DeviceImage.read / readAsync only.
+  createImage(width: number, height: number): DeviceImage;
+  /** one f32 march launch (GLSL fragment march, configs[1]; WGSL compute march, configs[3]) without the post chain */
+  renderShaderFrame(options: ShaderFrameOptions): QueuedFrame | { rgba: Float32Array; width: number; height: number; acceptedSteps: number };
+  readImage(image: DeviceImage, out?: Float32Array): Float32Array;
+  /** BloomManager.applyBloomToTexture (bloom.ts:443-583) between two device images; returns `out` */
+  postBloom(scene: DeviceImage, out: DeviceImage, options?: { intensity?: number; threshold?: number; blurPasses?: number; halfStorage?: number; fast?: boolean }): DeviceImage;
+  /** ReprojectionManager.resolve (reprojection.ts:196-262); returns `out` */
+  postTaa(current: DeviceImage, history: DeviceImage, out: DeviceImage, options?: { blendFactor?: number; cameraMoving?: boolean; halfStorage?: number; fast?: boolean }): DeviceImage;
+  /** counters stay in HBM across frames; frameStats() after a loop returns the sums */
+  statsAccumulate(on: boolean): void;
+  frameStats(): FrameStats;
+  frameStatsReset(): void;
+  /** waits for everything queued on the engine's device */
+  synchronize(): void;
+}
+
+export interface FrameStats {
+  rays: number; acceptedSteps: number; rkfTries: number; crossings: number; maxDrift: number;
+  launches: number; integrateMs: number; termCount: number[];
+}
+export interface QueuedFrame { image: DeviceImage; width: number; height: number; rays: number; queued: true }
+export interface ShaderFrameOptions {
+  kernel?: "glsl" | "wgsl"; width: number; height: number; maxSteps?: number; arith?: "fast" | "strict" | "packed";
+  eye?: [number, number, number]; target?: [number, number, number]; up?: [number, number, number]; fovY?: number;
+  mass?: number; spin?: number; zoom?: number; time?: number; features?: number; mouse?: [number, number];
+  image?: DeviceImage; keepOnDevice?: boolean; out?: Float32Array;
+}
+/** W x H RGBA f32 in HBM with a stream of its own; made by createImage or a {keepOnDevice: true} call */
+export class DeviceImage {
+  readonly width: number;
+  readonly height: number;
+  readonly bytes: number;
+  /** the one D2H, behind everything queued on the image (allocPinned memory: one DMA) */
+  read(out?: Float32Array): Float32Array;
+  /** queued at once, settles when the copy has landed; `out` must live in allocPinned() memory */
+  readAsync(out: Float32Array): Promise<Float32Array>;
+  /** counters of the frame that last wrote the image (waits for this image only) */
+  stats(): FrameStats;
+  wait(): DeviceImage;
+  ready(): boolean;
+  free(): void;
 }

@@ -14,3 +14,6 @@ const addon = require(process.env.BLACKHOLE_PHYSICS_ADDON || "../blackhole_physi
 export default addon.default;
 export const PhysicsEngine = addon.PhysicsEngine;
 export const init_hooks = addon.init_hooks;
+// extensions of this engine (device-resident frames, page-locked host memory)
+export const DeviceImage = addon.DeviceImage;
+export const allocPinned = addon.allocPinned;

@@ -1,0 +1,239 @@
+"""Device images (include/gravitas_abi.h, ABI 8): the texture a frame loop above the ABI holds
+between passes (the reference's renderers keep computeTexture / history / scene targets on the GPU,
+src/rendering/webgpu/renderer.ts:280-411, src/rendering/webgl/renderer.ts:173-422).
+
+The image entry points add ordering (a stream per image, events between producers and consumers)
+around the pointer entry points, never arithmetic: every test here requires the image form to return
+the pointer form's bits, with frames in flight on different streams."""
+import hashlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+W, H = 192, 108
+TH = np.deg2rad(97.0)
+EYE = (60.0 * np.sin(TH), 60.0 * np.cos(TH), 0.0)
+
+
+def _ptr_frame(bh, eng, cam, p):
+    import torch
+    n = p.width * p.height
+    rgba = torch.zeros(n, 4, dtype=torch.float32, device="cuda")
+    eng.render_frame_device(cam, p, rgba)
+    st = eng.frame_stats()
+    return rgba.cpu().numpy().reshape(p.height, p.width, 4), st
+
+
+def test_f64_frame_into_an_image_equals_the_pointer_form(engine_mod):
+    bh = engine_mod
+    with bh.PhysicsEngine(1.0, 0.999) as eng:
+        cam = bh.camera_look_at(EYE, aspect=W / H)
+        p = bh.render_params(W, H, arith=bh.ARITH_FAST, tolerance=1e-8)
+        want, st = _ptr_frame(bh, eng, cam, p)
+        img = eng.create_image(W, H)
+        eng.render_frame_image(cam, p, img)
+        ist = img.stats()                      # waits for this image only
+        got = img.read()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        assert (ist.rays, ist.accepted_steps, ist.rkf_tries) == (st.rays, st.accepted_steps, st.rkf_tries)
+        assert list(ist.term_count) == list(st.term_count) and ist.max_drift == st.max_drift
+        assert img.ready()
+        img.close()
+
+
+def test_two_images_in_flight_keep_their_own_frames_and_counters(engine_mod):
+    """A frame loop alternates two images (two streams, the engine's two ray workspaces and two counter
+    blocks): every image must hold ITS frame and ITS frame's counters, whatever is queued behind it."""
+    bh = engine_mod
+    eyes = [(60.0 * np.sin(t), 60.0 * np.cos(t), 0.0) for t in np.deg2rad([97.0, 60.0, 30.0, 120.0, 85.0, 97.0])]
+    with bh.PhysicsEngine(1.0, 0.999) as eng:
+        p = bh.render_params(W, H, arith=bh.ARITH_FAST, tolerance=1e-8)
+        want = []
+        for e in eyes:
+            f, st = _ptr_frame(bh, eng, bh.camera_look_at(e, aspect=W / H), p)
+            want.append((f, st.accepted_steps))
+        assert len({w[1] for w in want}) >= 4  # the cameras really differ
+        imgs = [eng.create_image(W, H), eng.create_image(W, H)]
+        got = []
+        for i, e in enumerate(eyes):          # queue, never wait: frame i+1 is queued before frame i is looked at
+            if i >= 2:
+                k = i % 2
+                got.append((imgs[k].read().copy(), imgs[k].stats().accepted_steps))
+            eng.render_frame_image(bh.camera_look_at(e, aspect=W / H), p, imgs[i % 2])
+        for i in (len(eyes) - 2, len(eyes) - 1):
+            got.append((imgs[i % 2].read().copy(), imgs[i % 2].stats().accepted_steps))
+        for i, ((gf, gs), (wf, ws)) in enumerate(zip(got, want)):
+            assert gs == ws, i
+            assert np.array_equal(gf.view(np.uint32), wf.view(np.uint32)), i
+        # accumulated counters over a queued loop = the sum (what a bench loop reads once at the end)
+        eng.stats_accumulate(True)
+        eng.frame_stats_reset()
+        for i, e in enumerate(eyes):
+            eng.render_frame_image(bh.camera_look_at(e, aspect=W / H), p, imgs[i % 2])
+        assert eng.frame_stats().accepted_steps == sum(w[1] for w in want)
+        eng.stats_accumulate(False)
+
+
+@pytest.mark.parametrize("kernel,arith", [("glsl", 1), ("glsl", 0), ("wgsl", 2), ("wgsl", 1), ("wgsl", 0)])
+def test_shader_frames_into_images(engine_mod, kernel, arith):
+    import torch
+    bh = engine_mod
+    with bh.PhysicsEngine(1.0, 0.999) as eng:
+        n = W * H
+        rgba = torch.zeros(n, 4, dtype=torch.float32, device="cuda")
+        if kernel == "glsl":
+            gp = bh.glsl_params(W, H, 1.0, 0.999, max_ray_steps=200, arith=arith)
+            tot = eng.render_frame_glsl(gp, rgba)
+        else:
+            wp = bh.wgsl_params(W, H, bh.camera_look_at(EYE, aspect=W / H), 1.0, 0.999, max_steps=200, arith=arith)
+            tot = eng.render_frame_wgsl(wp, rgba)
+        want = rgba.cpu().numpy().reshape(H, W, 4)
+        imgs = [eng.create_image(W, H), eng.create_image(W, H)]
+        for k in range(4):                    # frames in flight on two streams (measured dispatch order included)
+            if kernel == "glsl":
+                eng.render_frame_glsl_image(gp, imgs[k % 2])
+            else:
+                eng.render_frame_wgsl_image(wp, imgs[k % 2])
+        for im in imgs:
+            assert im.stats().accepted_steps == tot
+            assert np.array_equal(im.read().view(np.uint32), want.view(np.uint32))
+
+
+def test_post_passes_between_images_equal_the_pointer_forms(engine_mod):
+    import torch
+    bh = engine_mod
+    rng = np.random.default_rng(7)
+    a = (rng.random((H, W, 4), dtype=np.float32) ** 3 * 4.0).astype(np.float32)
+    b = (rng.random((H, W, 4), dtype=np.float32) ** 3 * 4.0).astype(np.float32)
+    with bh.PhysicsEngine(1.0, 0.9) as eng:
+        gp = bh.glsl_params(W, H, 1.0, 0.9, max_ray_steps=150, arith=bh.ARITH_FAST)
+        cur, hist, out, out2 = (eng.create_image(W, H) for _ in range(4))
+        eng.render_frame_glsl_image(gp, cur)
+        gp2 = bh.glsl_params(W, H, 1.0, 0.9, max_ray_steps=150, arith=bh.ARITH_FAST, time=0.7)
+        eng.render_frame_glsl_image(gp2, hist)
+        for arith in (bh.ARITH_STRICT, bh.ARITH_FAST):
+            # image forms: out <- taa(cur, hist) on out's stream; out2 <- bloom(out) on out2's stream
+            eng.post_taa_resolve_image(cur, hist, out, arith=arith)
+            eng.post_bloom_image(out, out2, arith=arith)
+            # ... and the producers run again at once: they must wait for the passes that still read them
+            eng.render_frame_glsl_image(gp, cur)
+            eng.render_frame_glsl_image(gp2, hist)
+            got_taa, got_bloom = out.read().copy(), out2.read().copy()
+            dc = torch.from_numpy(cur.read()).cuda()
+            dh = torch.from_numpy(hist.read()).cuda()
+            dt = torch.zeros_like(dc)
+            db = torch.zeros_like(dc)
+            eng.post_taa_resolve(W, H, dc, dh, dt, arith=arith)
+            eng.post_bloom(W, H, dt, db, arith=arith)
+            torch.cuda.synchronize()
+            assert np.array_equal(got_taa.view(np.uint32), dt.cpu().numpy().view(np.uint32))
+            assert np.array_equal(got_bloom.view(np.uint32), db.cpu().numpy().view(np.uint32))
+        with pytest.raises(bh.GravitasError):
+            eng.post_bloom_image(out, out)
+        with pytest.raises(bh.GravitasError):
+            eng.post_taa_resolve_image(cur, hist, cur)
+    del a, b
+
+
+def test_renderers_presenting_into_alternating_images(engine_mod):
+    """The renderer layer's history lives in the engine; successive frames presented into images with
+    different streams must see each other's history exactly as one stream would."""
+    import torch
+    bh = engine_mod
+    w, h = 160, 90
+    seq = [dict(time=0.1 * i) for i in range(5)]
+    with bh.PhysicsEngine(1.0, 0.9) as ref, bh.PhysicsEngine(1.0, 0.9) as eng:
+        want = []
+        scr = torch.zeros(h, w, 4, dtype=torch.float32, device="cuda")
+        for kw in seq:
+            gp = bh.glsl_params(w, h, 1.0, 0.9, arith=bh.ARITH_FAST, **kw)
+            ref.webgl_render(gp, scr, bloom=True, camera_moving=False)
+            want.append(scr.cpu().numpy().copy())
+        imgs = [eng.create_image(w, h), eng.create_image(w, h), eng.create_image(w, h)]
+        got = {}
+        for i, kw in enumerate(seq):
+            gp = bh.glsl_params(w, h, 1.0, 0.9, arith=bh.ARITH_FAST, **kw)
+            k = i % 3
+            if i >= 3:
+                got[i - 3] = imgs[k].read().copy()
+            eng.webgl_render_image(gp, imgs[k], bloom=True, camera_moving=False)
+        for i in range(len(seq) - 3, len(seq)):
+            got[i] = imgs[i % 3].read().copy()
+        for i in range(len(seq)):
+            assert np.array_equal(got[i].view(np.uint32), want[i].view(np.uint32)), i
+
+
+def test_webgpu_renderer_into_images(engine_mod):
+    import torch
+    from test_renderers import camera_block
+    bh = engine_mod
+    w, h = 96, 54
+    with bh.PhysicsEngine(1.0, 0.9) as ref, bh.PhysicsEngine(1.0, 0.9) as eng:
+        pp = np.zeros(8, np.float32)
+        pp[0], pp[1], pp[2], pp[3], pp[5] = 1.0, 0.9, w, h, 0.016
+        scr = torch.zeros(h, w, 4, dtype=torch.float32, device="cuda")
+        imgs = [eng.create_image(w, h), eng.create_image(w, h)]
+        eyes = [(0.0, 3.0, 40.0), (1.0, 3.0, 40.0), (2.0, 3.0, 40.0), (3.0, 3.0, 40.0)]
+        want = []
+        for i, e in enumerate(eyes):
+            cu = camera_block(bh, e, eyes[max(i - 1, 0)])
+            ref.webgpu_render(cu, pp, scr, max_steps=150, arith=bh.ARITH_FAST_PACKED)
+            want.append(scr.cpu().numpy().copy())
+            eng.webgpu_render_image(cu, pp, imgs[i % 2], max_steps=150, arith=bh.ARITH_FAST_PACKED)
+            if i >= 1:
+                pass
+        assert np.array_equal(imgs[0].read().view(np.uint32), want[2].view(np.uint32))
+        assert np.array_equal(imgs[1].read().view(np.uint32), want[3].view(np.uint32))
+
+
+def test_image_lifetime_and_refusals(engine_mod):
+    bh = engine_mod
+    eng = bh.PhysicsEngine(1.0, 0.999)
+    cam = bh.camera_look_at(EYE, aspect=W / H)
+    p = bh.render_params(W, H, arith=bh.ARITH_FAST)
+    img = eng.create_image(W, H)
+    with pytest.raises(bh.GravitasError):
+        img.stats()                            # nothing rendered yet
+    eng.render_frame_image(cam, p, img)
+    small = eng.create_image(64, 36)
+    with pytest.raises(bh.GravitasError, match="into an image"):
+        eng.render_frame_image(cam, p, small)
+    q = bh.render_params(W, H, arith=bh.ARITH_FAST, tile_world=2, tile_rank=1)
+    with pytest.raises(bh.GravitasError, match="whole frame"):
+        eng.render_frame_image(cam, q, img)
+    with pytest.raises(bh.GravitasError):
+        eng.create_image(0, 10)
+    want = img.read().copy()
+    steps = img.stats().accepted_steps
+    eng.close()                                # an image holds no pointer to its engine
+    assert np.array_equal(img.read(), want) and img.stats().accepted_steps == steps
+    digest = hashlib.sha256(want.tobytes()).hexdigest()
+    assert len(digest) == 64
+    img.close()
+    small.close()
+
+
+def test_post_bloom_growing_its_scratch_leaves_the_renderer_targets_alone(engine_mod):
+    """Regression: grv_post_bloom used to free the renderer's history targets when it grew the bloom
+    scratch, leaving grv_webgl_render with dangling pointers on the next frame."""
+    import torch
+    bh = engine_mod
+    w, h = 96, 54
+    with bh.PhysicsEngine(1.0, 0.9) as ref, bh.PhysicsEngine(1.0, 0.9) as eng:
+        scr = torch.zeros(h, w, 4, dtype=torch.float32, device="cuda")
+        want = []
+        for i in range(3):
+            ref.webgl_render(bh.glsl_params(w, h, 1.0, 0.9, arith=bh.ARITH_FAST, time=0.2 * i), scr)
+            want.append(scr.cpu().numpy().copy())
+        eng.webgl_render(bh.glsl_params(w, h, 1.0, 0.9, arith=bh.ARITH_FAST, time=0.0), scr)
+        assert np.array_equal(scr.cpu().numpy().view(np.uint32), want[0].view(np.uint32))
+        big_in = torch.rand(4 * h, 4 * w, 4, dtype=torch.float32, device="cuda")
+        big_out = torch.zeros_like(big_in)
+        eng.post_bloom(4 * w, 4 * h, big_in, big_out)        # grows the scratch
+        junk = [torch.full((h, w, 4), 7.0, dtype=torch.float32, device="cuda") for _ in range(8)]  # reuse freed blocks
+        for i in (1, 2):
+            eng.webgl_render(bh.glsl_params(w, h, 1.0, 0.9, arith=bh.ARITH_FAST, time=0.2 * i), scr)
+            assert np.array_equal(scr.cpu().numpy().view(np.uint32), want[i].view(np.uint32)), i
+        del junk

@@ -41,7 +41,7 @@ def test_native_library_is_the_hip_build(bh):
     """Fail loudly if the in-tree HIP extension is missing: nothing else can run the path."""
     assert os.path.exists(bh.library_path())
     lib = bh.load_library()
-    assert lib.grv_abi_version() == 7
+    assert lib.grv_abi_version() == 8
     with bh.PhysicsEngine(1.0, 0.9) as e:
         assert abs(e.compute_horizon() - 1.4358898943540672) < 1e-15
 

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(engine_mod):
     assert len(names) >= 25
     for n in names:
         assert hasattr(lib, n), "libgravitas_hip.so does not export %s" % n
-    assert lib.grv_abi_version() == 7
+    assert lib.grv_abi_version() == 8
 
 
 def test_no_device_fails_loudly(engine_mod):

@@ -37,6 +37,9 @@ WASM_METHODS = [
     "integrate_batch", "integrateBatch", "integrateBatchAsync", "renderFrameAsync",
     # contract of the one-ray entry (grv_engine_set_ray_arith)
     "set_ray_arith",
+    # device-resident frames (ABI 8 device images): VERDICT r5 item 1
+    "createImage", "renderShaderFrame", "readImage", "postBloom", "postTaa", "statsAccumulate", "frameStats",
+    "frameStatsReset", "synchronize",
 ]
 
 pytestmark = pytest.mark.skipif(NODE is None or not os.path.exists(ADDON),
@@ -53,7 +56,7 @@ def test_addon_loads_and_exports_the_wasm_bindgen_surface():
               "p:Object.getOwnPropertyNames(m.PhysicsEngine.prototype),d:typeof m.default}))" % ADDON)
     assert r.returncode == 0, r.stderr
     got = json.loads(r.stdout)
-    assert {"PhysicsEngine", "default", "init_hooks", "allocPinned"} <= set(got["k"]) and got["d"] == "function"
+    assert {"PhysicsEngine", "DeviceImage", "default", "init_hooks", "allocPinned"} <= set(got["k"]) and got["d"] == "function"
     missing = [m for m in WASM_METHODS if m not in got["p"]]
     assert not missing, missing
 
@@ -76,13 +79,15 @@ def test_esm_shim_reexports_the_addon(tmp_path):
 def test_type_declarations_match_the_addon():
     """napi/shim/blackhole_physics.d.ts (what wasm-pack would emit) declares what the addon exports."""
     dts = open(os.path.join(ROOT, "napi", "shim", "blackhole_physics.d.ts")).read()
-    cls = dts[dts.index("export class PhysicsEngine"):]
-    declared = set(re.findall(r"^  (\w+)\(", cls, flags=re.M)) - {"constructor"}
-    r = _node("const m=require(%r);console.log(JSON.stringify(Object.getOwnPropertyNames("
-              "m.PhysicsEngine.prototype)))" % ADDON)
-    assert r.returncode == 0, r.stderr
-    have = set(json.loads(r.stdout)) - {"constructor"}
-    assert declared == have, (declared ^ have)
+    for name in ("PhysicsEngine", "DeviceImage"):
+        cls = dts[dts.index("export class %s" % name):]
+        cls = cls[:cls.index("\n}\n") + 3]
+        declared = set(re.findall(r"^  (\w+)\(", cls, flags=re.M)) - {"constructor"}
+        r = _node("const m=require(%r);console.log(JSON.stringify(Object.getOwnPropertyNames("
+                  "m.%s.prototype)))" % (ADDON, name))
+        assert r.returncode == 0, r.stderr
+        have = set(json.loads(r.stdout)) - {"constructor"}
+        assert declared == have, (name, declared ^ have)
 
 
 def test_method_list_is_the_reference_ffi(oracle):

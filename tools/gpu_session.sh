@@ -14,6 +14,8 @@
 #   renderers    tools/bench_renderers.py + tools/bench_shaders.py
 #   identical    tools/ab_glsl_identical.py under every ab_libs/lib_*.so: three 1080p GLSL presets, every later library's
 #                pixels and step counts compared bit for bit with the first one's
+#   frames[:<args>]  napi/bench_frames.js for c3 and c2 (the frame loops driven from Node through the addon), each next to
+#                bench.py's line of the same config on the same box
 #   ab[:<configs>]  interleaved A/B of every ab_libs/lib_*.so (tools/ab_configs.sh; configs ';'-separated)
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -59,6 +61,11 @@ for stage in "$@"; do
         timeout 300 python tools/ab_glsl_identical.py /tmp/ident_$n.npz 2> $O/identical_$n.err
         if [ -z "$first" ]; then first=$n; else echo "$n vs $first: $(python tools/ab_glsl_identical.py /tmp/ident_$first.npz /tmp/ident_$n.npz)" | tee -a $O/identical.txt; fi
       done; cp /tmp/lib_keep.so blackhole-simulation_amd/libgravitas_hip.so;;
+    frames)
+      for cfg in c3 c2; do
+        timeout 900 python bench.py --config $cfg --no-cpu-baseline > $O/frames_benchpy_$cfg.json 2> $O/frames_benchpy_$cfg.err; echo "bench.py $cfg rc=$?"; cut -c1-120 $O/frames_benchpy_$cfg.json
+        timeout 900 node napi/bench_frames.js --config $cfg $arg --out $O/napi_frames_$cfg.jsonl > $O/napi_frames_$cfg.log 2>&1; echo "bench_frames.js $cfg rc=$?"; cut -c1-150 $O/napi_frames_$cfg.log
+      done;;
     ab) AB_CONFIGS="${arg:-c2;c2 --one-stream}" bash tools/ab_configs.sh $T/ab > $O/ab.log 2>&1; tail -40 $O/ab.log;;
     *) echo "unknown stage $stage";;
   esac
