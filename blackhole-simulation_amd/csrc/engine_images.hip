@@ -7,22 +7,37 @@
 // gets the same shape here: a frame is rendered INTO a grv_image that stays in HBM, the post chain
 // consumes images, and pixels cross PCIe only when grv_image_read* is called.
 //
-// An image owns a stream: its producers are queued there and the calls return at once, so a frame
-// loop that alternates two images keeps two frames in flight (the engine then alternates its two ray
-// workspaces, engine_internal.hpp WorkSet).  Every image also keeps the counters of the frame that
-// last wrote it (a 96-byte copy queued behind the frame's last kernel), so a host reads a frame's
-// accepted steps without synchronising anything but that image.
+// An image's producers are queued on its compute stream and the calls return at once.  Images with
+// streams of their own are written concurrently: a frame loop that alternates two of them keeps two
+// frames in flight (the engine then alternates its two ray workspaces, engine_internal.hpp WorkSet) --
+// the drain of one 1080p march under the head of the next.  Images created with grv_image_create_shared
+// are written in queue order on one stream.  Reads (D2H) run on a copy stream per image, so the DMA of
+// frame i runs under the kernels of frame i+1 either way.  Every image also keeps the counters of the
+// frame that last wrote it (a 96-byte copy queued behind the frame's last kernel), so a host reads a
+// frame's accepted steps without synchronising anything but that image.
 #include "engine_internal.hpp"
+
+#include <atomic>
+
+// a compute stream images can share (grv_image_create_shared): its kernels then run in queue order
+struct ImageStream {
+    hipStream_t s = nullptr;
+    int device = 0;
+    std::atomic<int> refs{1};
+};
 
 struct grv_image {
     int device = 0;
     uint32_t w = 0, h = 0;
     float *d = nullptr;            // [h][w][4] f32
     size_t bytes = 0;
-    hipStream_t s = nullptr;       // producers and reads of this image
-    hipEvent_t ready = nullptr;    // end of the last producer / read queued on s
-    hipEvent_t consumed = nullptr; // end of the last reader that sits on ANOTHER stream
-    bool ready_rec = false, consumed_rec = false;
+    ImageStream *cs = nullptr;     // compute stream: producers of this image (own, or shared with other images)
+    hipStream_t s = nullptr;       // == cs->s
+    hipStream_t copy_s = nullptr;  // D2H reads of this image (created by the first read): never behind another image's kernels
+    hipEvent_t ready = nullptr;    // end of the last producer queued on s
+    hipEvent_t copied = nullptr;   // end of the last read queued on copy_s
+    hipEvent_t consumed = nullptr; // end of the last reader kernel that sits on ANOTHER stream
+    bool ready_rec = false, copied_rec = false, consumed_rec = false;
     grvhip::FrameStatsDev *h_stats = nullptr; // pinned: counters of the frame that last wrote the image
     bool has_stats = false;
     std::string err;
@@ -53,6 +68,7 @@ int ifail(grv_image *img, int code, const char *fmt, ...) {
 // a producer is about to write `img` on img->s: behind the readers other streams queued on it
 int begin_write(grv_engine *e, grv_image *img) {
     if (img->consumed_rec) GRV_HIP(e, hipStreamWaitEvent(img->s, img->consumed, 0));
+    if (img->copied_rec) GRV_HIP(e, hipStreamWaitEvent(img->s, img->copied, 0)); // a D2H still reading it
     return GRV_OK;
 }
 int end_write(grv_engine *e, grv_image *img) {
@@ -105,12 +121,15 @@ int snapshot_stats(grv_engine *e, grv_image *img) {
 
 extern "C" {
 
-int grv_image_create(grv_engine *e, uint32_t width, uint32_t height, grv_image **out) {
+static int image_create(grv_engine *e, uint32_t width, uint32_t height, grv_image *stream_of, grv_image **out) {
     if (!e) return GRV_ERR_INVALID;
     if (!out) return fail(e, GRV_ERR_INVALID, "null argument");
     *out = nullptr;
     if (width == 0 || height == 0 || (uint64_t)width * height > (1ull << 27))
         return fail(e, GRV_ERR_INVALID, "grv_image_create: %u x %u out of range", width, height);
+    if (stream_of && stream_of->device != e->device)
+        return fail(e, GRV_ERR_INVALID, "grv_image_create_shared: the stream's image lives on device %d, the engine on %d",
+                    stream_of->device, e->device);
     GRV_HIP(e, hipSetDevice(e->device));
     grv_image *img = new (std::nothrow) grv_image();
     if (!img) return fail(e, GRV_ERR_OOM, "grv_image_create: out of host memory");
@@ -119,9 +138,24 @@ int grv_image_create(grv_engine *e, uint32_t width, uint32_t height, grv_image *
     img->h = height;
     img->bytes = (size_t)width * height * 4 * sizeof(float);
     hipError_t st = hipMalloc(reinterpret_cast<void **>(&img->d), img->bytes);
-    if (st == hipSuccess) st = hipStreamCreateWithFlags(&img->s, hipStreamNonBlocking);
-    if (st == hipSuccess) st = hipEventCreateWithFlags(&img->ready, hipEventDisableTiming);
-    if (st == hipSuccess) st = hipEventCreateWithFlags(&img->consumed, hipEventDisableTiming);
+    if (st == hipSuccess) {
+        if (stream_of) {
+            img->cs = stream_of->cs;
+            img->cs->refs.fetch_add(1);
+        } else {
+            img->cs = new (std::nothrow) ImageStream();
+            if (!img->cs) st = hipErrorOutOfMemory;
+            else {
+                img->cs->device = e->device;
+                st = hipStreamCreateWithFlags(&img->cs->s, hipStreamNonBlocking);
+            }
+        }
+    }
+    if (st == hipSuccess) img->s = img->cs->s;
+    // blocking-sync events: a host thread waiting for an image sleeps instead of spinning
+    if (st == hipSuccess) st = hipEventCreateWithFlags(&img->ready, hipEventDisableTiming | hipEventBlockingSync);
+    if (st == hipSuccess) st = hipEventCreateWithFlags(&img->copied, hipEventDisableTiming | hipEventBlockingSync);
+    if (st == hipSuccess) st = hipEventCreateWithFlags(&img->consumed, hipEventDisableTiming | hipEventBlockingSync);
     if (st == hipSuccess) st = hipHostMalloc(reinterpret_cast<void **>(&img->h_stats), sizeof(FrameStatsDev), hipHostMallocDefault);
     if (st != hipSuccess) {
         grv_image_destroy(img);
@@ -133,14 +167,32 @@ int grv_image_create(grv_engine *e, uint32_t width, uint32_t height, grv_image *
     return GRV_OK;
 }
 
+int grv_image_create(grv_engine *e, uint32_t width, uint32_t height, grv_image **out) {
+    return image_create(e, width, height, nullptr, out);
+}
+int grv_image_create_shared(grv_engine *e, uint32_t width, uint32_t height, grv_image *stream_of, grv_image **out) {
+    if (e && !stream_of) return fail(e, GRV_ERR_INVALID, "null argument");
+    return image_create(e, width, height, stream_of, out);
+}
+
 void grv_image_destroy(grv_image *img) {
     if (!img) return;
     (void)hipSetDevice(img->device);
-    if (img->s) (void)hipStreamSynchronize(img->s);
-    if (img->consumed_rec) (void)hipEventSynchronize(img->consumed); // readers on other streams
+    // everything that touches THIS image (not the later work of images sharing its stream)
+    if (img->ready_rec) (void)hipEventSynchronize(img->ready);
+    if (img->copied_rec) (void)hipEventSynchronize(img->copied);
+    if (img->consumed_rec) (void)hipEventSynchronize(img->consumed);
     if (img->d) (void)hipFree(img->d);
-    if (img->s) (void)hipStreamDestroy(img->s);
+    if (img->copy_s) (void)hipStreamDestroy(img->copy_s);
+    if (img->cs && img->cs->refs.fetch_sub(1) == 1) {
+        if (img->cs->s) {
+            (void)hipStreamSynchronize(img->cs->s);
+            (void)hipStreamDestroy(img->cs->s);
+        }
+        delete img->cs;
+    }
     if (img->ready) (void)hipEventDestroy(img->ready);
+    if (img->copied) (void)hipEventDestroy(img->copied);
     if (img->consumed) (void)hipEventDestroy(img->consumed);
     if (img->h_stats) (void)hipHostFree(img->h_stats);
     delete img;
@@ -295,16 +347,21 @@ int grv_image_read_async(grv_image *img, float *host, size_t elems) {
     if (!host) return ifail(img, GRV_ERR_INVALID, "null argument");
     if (elems > img->bytes / sizeof(float)) return ifail(img, GRV_ERR_INVALID, "read of %zu floats from an image of %zu", elems, img->bytes / sizeof(float));
     IMG_HIP(img, hipSetDevice(img->device));
-    IMG_HIP(img, hipMemcpyAsync(host, img->d, elems * sizeof(float), hipMemcpyDeviceToHost, img->s));
-    IMG_HIP(img, hipEventRecord(img->ready, img->s));
-    img->ready_rec = true;
+    // on the image's own copy stream, behind its last producer: the compute stream (perhaps shared with
+    // other images) goes on with the next frame's kernels while the DMA runs
+    if (!img->copy_s) IMG_HIP(img, hipStreamCreateWithFlags(&img->copy_s, hipStreamNonBlocking));
+    if (img->ready_rec) IMG_HIP(img, hipStreamWaitEvent(img->copy_s, img->ready, 0));
+    IMG_HIP(img, hipMemcpyAsync(host, img->d, elems * sizeof(float), hipMemcpyDeviceToHost, img->copy_s));
+    IMG_HIP(img, hipEventRecord(img->copied, img->copy_s));
+    img->copied_rec = true;
     return GRV_OK;
 }
 
 int grv_image_wait(grv_image *img) {
     if (!img) return GRV_ERR_INVALID;
     IMG_HIP(img, hipSetDevice(img->device));
-    IMG_HIP(img, hipStreamSynchronize(img->s));
+    if (img->ready_rec) IMG_HIP(img, hipEventSynchronize(img->ready));
+    if (img->copied_rec) IMG_HIP(img, hipEventSynchronize(img->copied));
     return GRV_OK;
 }
 
@@ -316,19 +373,24 @@ int grv_image_read(grv_image *img, float *host, size_t elems) {
 int grv_image_query(grv_image *img) {
     if (!img) return -GRV_ERR_INVALID;
     if (hipSetDevice(img->device) != hipSuccess) return -GRV_ERR_HIP;
-    const hipError_t st = hipStreamQuery(img->s);
-    if (st == hipSuccess) return 1;
-    if (st == hipErrorNotReady) return 0;
-    img->err = std::string("hipStreamQuery: ") + hipGetErrorString(st);
-    return -GRV_ERR_HIP;
+    for (int k = 0; k < 2; ++k) {
+        if (!(k == 0 ? img->ready_rec : img->copied_rec)) continue;
+        const hipError_t st = hipEventQuery(k == 0 ? img->ready : img->copied);
+        if (st == hipErrorNotReady) return 0;
+        if (st != hipSuccess) {
+            img->err = std::string("hipEventQuery: ") + hipGetErrorString(st);
+            return -GRV_ERR_HIP;
+        }
+    }
+    return 1;
 }
 
 int grv_image_frame_stats(grv_image *img, GrvFrameStats *stats) {
     if (!img) return GRV_ERR_INVALID;
     if (!stats) return ifail(img, GRV_ERR_INVALID, "null argument");
     if (!img->has_stats) return ifail(img, GRV_ERR_INVALID, "no frame was rendered into this image (or a post pass wrote it last)");
-    const int rc = grv_image_wait(img);
-    if (rc != GRV_OK) return rc;
+    IMG_HIP(img, hipSetDevice(img->device));
+    IMG_HIP(img, hipEventSynchronize(img->ready)); // the counters' copy sits before it on the compute stream
     std::memset(stats, 0, sizeof *stats);
     const FrameStatsDev &d = *img->h_stats;
     stats->rays = d.rays;

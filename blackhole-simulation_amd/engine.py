@@ -292,6 +292,8 @@ def load_library():
     # device images (ABI 8)
     L.grv_image_create.restype = i
     L.grv_image_create.argtypes = [p, C.c_uint32, C.c_uint32, C.POINTER(p)]
+    L.grv_image_create_shared.restype = i
+    L.grv_image_create_shared.argtypes = [p, C.c_uint32, C.c_uint32, p, C.POINTER(p)]
     L.grv_image_destroy.argtypes = [p]
     L.grv_image_width.restype = C.c_uint32
     L.grv_image_width.argtypes = [p]
@@ -497,10 +499,14 @@ class DeviceImage:
     the texture the reference's renderers hold between passes (webgpu/renderer.ts:280-411).  Frames and
     post passes into it are queued; pixels cross PCIe in read() only."""
 
-    def __init__(self, engine, width, height):
+    def __init__(self, engine, width, height, stream_of=None):
         self._lib = engine._lib
         h = C.c_void_p()
-        engine._check(self._lib.grv_image_create(engine._h, int(width), int(height), C.byref(h)), "image_create")
+        if stream_of is not None:  # written on that image's compute stream, in queue order
+            engine._check(self._lib.grv_image_create_shared(engine._h, int(width), int(height), stream_of._h,
+                                                            C.byref(h)), "image_create_shared")
+        else:
+            engine._check(self._lib.grv_image_create(engine._h, int(width), int(height), C.byref(h)), "image_create")
         self._h = h
         self.width, self.height = int(width), int(height)
 
@@ -534,6 +540,13 @@ class DeviceImage:
             out = np.empty((self.height, self.width, 4), np.float32)
         self._check(self._lib.grv_image_read(self._h, _np_ptr(out), out.size), "image_read")
         return out
+
+    def read_async(self, out):
+        """queue the D2H into `out` (a pinned torch tensor or numpy array of h*w*4 float32) on the image's copy
+        stream; wait() / ready() tell when it has landed"""
+        ptr = out.data_ptr() if hasattr(out, "data_ptr") else out.ctypes.data
+        n = out.numel() if hasattr(out, "numel") else out.size
+        self._check(self._lib.grv_image_read_async(self._h, C.c_void_p(ptr), int(n)), "image_read_async")
 
     def wait(self):
         self._check(self._lib.grv_image_wait(self._h), "image_wait")
@@ -767,8 +780,8 @@ class PhysicsEngine:
                                              stream), "post_bloom")
 
     # ---- device images (ABI 8): frames and post passes that stay in HBM ----
-    def create_image(self, width, height):
-        return DeviceImage(self, width, height)
+    def create_image(self, width, height, stream_of=None):
+        return DeviceImage(self, width, height, stream_of)
 
     def render_frame_image(self, cam, params, image):
         self._check(self._lib.grv_render_frame_image(self._h, C.byref(cam), C.byref(params), image._h),

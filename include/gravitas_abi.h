@@ -528,6 +528,14 @@ uint32_t grv_renderer_frame_count(const grv_engine *e);
  * image while another queues the next frame into ANOTHER image through the engine. */
 typedef struct grv_image grv_image;
 int grv_image_create(grv_engine *e, uint32_t width, uint32_t height, grv_image **out);
+/* an image whose producers are queued on `stream_of`'s compute stream instead of one of its own:
+ * images sharing a stream are written in queue order (frame i+1's kernels start when frame i's have
+ * finished), while every image still reads back on a copy stream of its own -- the rotation a host uses
+ * to move every frame to host memory: frame i's D2H runs under frame i+1's kernels.  (Images with
+ * streams of their own are written concurrently: two frames share the chip, the drain of one launch
+ * under the head of the next -- what the short 1080p marches want.) */
+int grv_image_create_shared(grv_engine *e, uint32_t width, uint32_t height, grv_image *stream_of,
+                            grv_image **out);
 void grv_image_destroy(grv_image *img); /* waits for the work queued on it */
 uint32_t grv_image_width(const grv_image *img);
 uint32_t grv_image_height(const grv_image *img);
@@ -551,9 +559,11 @@ int grv_webgpu_render_image(grv_engine *e, const float camera_uniforms[88], cons
 int grv_post_bloom_image(grv_engine *e, const GrvBloomParams *p, grv_image *scene, grv_image *out);
 int grv_post_taa_resolve_image(grv_engine *e, const GrvTaaParams *p, grv_image *current,
                                grv_image *history, grv_image *out);
-/* D2H of the first `elems` floats behind everything queued on the image: _async queues the copy
- * (page-locked `host` memory: one DMA at the PCIe rate) and returns; grv_image_wait blocks until the
- * image's stream is idle; grv_image_query: 1 idle, 0 busy, < 0 = -status; grv_image_read = both */
+/* D2H of the first `elems` floats behind the image's last producer, on the image's own copy stream:
+ * _async queues the copy (page-locked `host` memory: one DMA at the PCIe rate) and returns; a later
+ * producer of the image waits for it.  grv_image_wait blocks until the image's last producer and last
+ * read have finished (not for later work of images sharing its stream); grv_image_query: 1 finished,
+ * 0 busy, < 0 = -status; grv_image_read = _read_async + _wait */
 int grv_image_read_async(grv_image *img, float *host, size_t elems);
 int grv_image_wait(grv_image *img);
 int grv_image_query(grv_image *img);

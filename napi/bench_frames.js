@@ -22,7 +22,7 @@ const wasm = require(path.join(__dirname, "blackhole_physics.node"));
 
 function parseArgs(argv) {
   const a = { config: "c3", form: "all", steps: null, warmup: null, inFlight: null, eye: null, out: null,
-              width: 0, height: 0 };
+              width: 0, height: 0, readImages: 2 };
   for (let i = 2; i < argv.length; i++) {
     const k = argv[i], v = argv[i + 1];
     if (k === "--config") { a.config = v; i++; }
@@ -32,6 +32,7 @@ function parseArgs(argv) {
     else if (k === "--in-flight") { a.inFlight = parseInt(v, 10); i++; }
     else if (k === "--eye") { a.eye = v.split(",").map(Number); i++; }
     else if (k === "--out") { a.out = v; i++; }
+    else if (k === "--read-images") { a.readImages = parseInt(v, 10); i++; }
     else if (k === "--width") { a.width = parseInt(v, 10); i++; }
     else if (k === "--height") { a.height = parseInt(v, 10); i++; }
     else throw new Error("unknown argument " + k);
@@ -102,10 +103,15 @@ async function main() {
 
   // ---- (b') device image + one asynchronous D2H per frame into pinned memory ----
   if (want("read")) {
-    const n = 2, imgs = [], outs = [];
-    for (let k = 0; k < n; k++) { imgs.push(engine.createImage(W, H)); outs.push(new Float32Array(wasm.allocPinned(W * H * 16))); }
+    // `nfl` compute streams (bench.py's frames in flight), two images in rotation on each: image k is written on
+    // stream k % nfl in queue order and read back on its own copy stream
+    const n = args.readImages * nfl, imgs = [], outs = [];
+    for (let k = 0; k < n; k++) {
+      imgs.push(k < nfl ? engine.createImage(W, H) : engine.createImage(W, H, { streamOf: imgs[k % nfl] }));
+      outs.push(new Float32Array(wasm.allocPinned(W * H * 16)));
+    }
     engine.statsAccumulate(true);
-    const pend = [null, null];
+    const pend = new Array(n).fill(null);
     const step = async (i) => {
       const k = i % n;
       if (pend[k]) { await pend[k]; pend[k] = null; }     // image k / buffer k are free again
@@ -113,7 +119,7 @@ async function main() {
       pend[k] = imgs[k].readAsync(outs[k]);               // queued behind the frame on the image's stream
     };
     for (let i = 0; i < Wm; i++) await step(i);
-    await Promise.all(pend.filter(Boolean)); pend[0] = pend[1] = null;
+    await Promise.all(pend.filter(Boolean)); pend.fill(null);
     engine.synchronize();
     engine.frameStatsReset();
     engine.synchronize();
@@ -125,7 +131,7 @@ async function main() {
     engine.statsAccumulate(false);
     emit("read", t1 - t0, st.acceptedSteps, K,
          { pixels: "every frame copied to page-locked host memory (image.readAsync), frame i's D2H under frame i+1's kernels",
-           d2h_bytes_per_frame: W * H * 16 });
+           d2h_bytes_per_frame: W * H * 16, images_in_rotation: n, compute_streams: nfl });
     imgs.forEach((im) => im.free());
   }
 

@@ -60,7 +60,8 @@ typedef struct {
      * serialises on the driver).  Taken and returned on the main thread only. */
     struct { float *p; size_t bytes; int busy; } stage[2];
     /* renderFrameAsync on one device: the frame is rendered into one of two device images of the async
-     * handle and copied out on that image's stream, so frame i's D2H runs under frame i+1's kernels
+     * handle (one compute stream) and copied out on that image's copy stream, so frame i's D2H runs under
+     * frame i+1's kernels
      * (guarded by async_mu; users = works between queueing on the image and the end of their wait) */
     grv_image *async_img[2];
     int async_img_users[2];
@@ -825,7 +826,9 @@ static void bulk_execute(bulk_work *w) {
             }
             if (priv) w->rc = grv_image_create(h, w->p.width, w->p.height, &img);
             else {
-                if (!b->async_img[slot]) w->rc = grv_image_create(h, w->p.width, w->p.height, &b->async_img[slot]);
+                if (!b->async_img[slot]) /* one compute stream for both: frames in queue order, each D2H under the next frame's kernels */
+                    w->rc = b->async_img[slot ^ 1] ? grv_image_create_shared(h, w->p.width, w->p.height, b->async_img[slot ^ 1], &b->async_img[slot])
+                                                   : grv_image_create(h, w->p.width, w->p.height, &b->async_img[slot]);
                 img = b->async_img[slot];
             }
             if (w->rc == GRV_OK) w->rc = grv_render_frame_image(h, &w->cam, &w->p, img);
@@ -1363,9 +1366,11 @@ static napi_value queued_result(napi_env env, napi_value image_obj, uint32_t w, 
     return out;
 }
 
+/* createImage(width, height, {streamOf?: DeviceImage}): with streamOf the new image is written on that image's
+ * compute stream (frames in queue order; each image still reads back on a copy stream of its own) */
 static napi_value m_create_image(napi_env env, napi_callback_info info) {
-    size_t argc = 2;
-    napi_value argv[2];
+    size_t argc = 3;
+    napi_value argv[3];
     engine_box *b = unwrap(env, info, &argc, argv);
     if (!b) return NULL;
     const double w = argc > 0 ? arg_f64(env, argv[0]) : 0.0, h = argc > 1 ? arg_f64(env, argv[1]) : 0.0;
@@ -1373,8 +1378,21 @@ static napi_value m_create_image(napi_env env, napi_callback_info info) {
         napi_throw_range_error(env, NULL, "createImage: width/height out of range");
         return NULL;
     }
-    grv_image *img = NULL;
-    if (grv_image_create(b->h, (uint32_t)w, (uint32_t)h, &img) != GRV_OK) {
+    grv_image *img = NULL, *share = NULL;
+    napi_valuetype t;
+    bool has = false;
+    if (argc > 2 && napi_typeof(env, argv[2], &t) == napi_ok && t == napi_object &&
+        napi_has_named_property(env, argv[2], "streamOf", &has) == napi_ok && has) {
+        napi_value so;
+        image_box *sb = napi_get_named_property(env, argv[2], "streamOf", &so) == napi_ok ? image_of(env, so) : NULL;
+        if (!sb) {
+            napi_throw_type_error(env, NULL, "createImage: streamOf must be a live DeviceImage");
+            return NULL;
+        }
+        share = sb->img;
+    }
+    if ((share ? grv_image_create_shared(b->h, (uint32_t)w, (uint32_t)h, share, &img)
+               : grv_image_create(b->h, (uint32_t)w, (uint32_t)h, &img)) != GRV_OK) {
         napi_throw_error(env, NULL, grv_last_error(b->h));
         return NULL;
     }

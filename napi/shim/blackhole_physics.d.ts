@@ -187,7 +187,9 @@ export class PhysicsEngine {
   // renderFrame / renderShaderFrame / renderWebGLFrame / renderWebGPUFrame with {image} or {keepOnDevice: true}
   // return QueuedFrame at once: the frame stays in HBM as the renderers' textures do upstream
   // (webgpu/renderer.ts:280-411); pixels cross PCIe in DeviceImage.read / readAsync only.
-  createImage(width: number, height: number): DeviceImage;
+  /** streamOf: write the new image on that image's compute stream (frames in queue order); without it the image
+   *  gets a stream of its own (frames into different images run concurrently) */
+  createImage(width: number, height: number, options?: { streamOf?: DeviceImage }): DeviceImage;
   /** one f32 march launch (GLSL fragment march, configs[1]; WGSL compute march, configs[3]) without the post chain */
   renderShaderFrame(options: ShaderFrameOptions): QueuedFrame | { rgba: Float32Array; width: number; height: number; acceptedSteps: number };
   readImage(image: DeviceImage, out?: Float32Array): Float32Array;

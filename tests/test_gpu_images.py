@@ -76,6 +76,49 @@ def test_two_images_in_flight_keep_their_own_frames_and_counters(engine_mod):
         eng.stats_accumulate(False)
 
 
+def test_images_sharing_a_compute_stream_rotate_under_their_own_copies(engine_mod):
+    """grv_image_create_shared: frames into images of one compute stream run in queue order; every image
+    reads back on its own copy stream into page-locked memory while later frames are already queued, and a
+    producer of an image waits for the D2H that still reads it."""
+    import torch
+    bh = engine_mod
+    thetas = np.deg2rad([97.0, 60.0, 30.0, 120.0, 85.0, 45.0, 100.0])
+    eyes = [(60.0 * np.sin(t), 60.0 * np.cos(t), 0.0) for t in thetas]
+    with bh.PhysicsEngine(1.0, 0.999) as eng:
+        p = bh.render_params(W, H, arith=bh.ARITH_FAST, tolerance=1e-8)
+        want = [_ptr_frame(bh, eng, bh.camera_look_at(e, aspect=W / H), p) for e in eyes]
+        a = eng.create_image(W, H)
+        imgs = [a, eng.create_image(W, H, stream_of=a), eng.create_image(W, H, stream_of=a)]
+        assert imgs[0].stream == imgs[1].stream == imgs[2].stream
+        other = eng.create_image(W, H)
+        assert other.stream != a.stream
+        outs = [torch.zeros(H, W, 4, dtype=torch.float32).pin_memory() for _ in imgs]
+        got = {}
+        for i, e in enumerate(eyes):
+            k = i % 3
+            if i >= 3:                       # the read of frame i-3 was queued three frames ago
+                imgs[k].wait()
+                got[i - 3] = (outs[k].numpy().copy(), imgs[k].stats().accepted_steps)
+            eng.render_frame_image(bh.camera_look_at(e, aspect=W / H), p, imgs[k])
+            imgs[k].read_async(outs[k])
+            # overwrite attempt while that read may still be in flight: must land AFTER it
+            if i == 4:
+                eng.render_frame_image(bh.camera_look_at(eyes[0], aspect=W / H), p, imgs[k])
+                imgs[k].wait()
+                assert np.array_equal(outs[k].numpy().view(np.uint32), want[4][0].view(np.uint32))
+                assert np.array_equal(imgs[k].read().view(np.uint32), want[0][0].view(np.uint32))
+                eng.render_frame_image(bh.camera_look_at(e, aspect=W / H), p, imgs[k])
+                imgs[k].read_async(outs[k])
+        for i in range(len(eyes) - 3, len(eyes)):
+            k = i % 3
+            imgs[k].wait()
+            assert imgs[k].ready()
+            got[i] = (outs[k].numpy().copy(), imgs[k].stats().accepted_steps)
+        for i, (wf, wst) in enumerate(want):
+            assert got[i][1] == wst.accepted_steps, i
+            assert np.array_equal(got[i][0].view(np.uint32), wf.view(np.uint32)), i
+
+
 @pytest.mark.parametrize("kernel,arith", [("glsl", 1), ("glsl", 0), ("wgsl", 2), ("wgsl", 1), ("wgsl", 0)])
 def test_shader_frames_into_images(engine_mod, kernel, arith):
     import torch
