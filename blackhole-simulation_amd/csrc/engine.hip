@@ -560,7 +560,6 @@ int grv_engine_create(double mass, double spin, int device, grv_engine **out) {
     if (hipHostMalloc(reinterpret_cast<void **>(&e->ray_out), sizeof(SingleRayOut),
                       hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) return bail(GRV_ERR_OOM);
     std::memset(e->ray_out, 0, sizeof(SingleRayOut));
-    if (hipStreamCreateWithFlags(&e->ray_stream, hipStreamNonBlocking) != hipSuccess) return bail(GRV_ERR_HIP);
     e->ev_ok = true;
     for (auto &ev : e->ev)
         if (hipEventCreate(&ev) != hipSuccess) e->ev_ok = false;
@@ -866,6 +865,12 @@ size_t grv_integrate_ray_relativistic_ex(grv_engine *e, const double *initial_st
     SingleRayIn in;
     std::memcpy(in.v, initial_state, sizeof in.v);
     const uint32_t seq = ++e->ray_seq ? e->ray_seq : ++e->ray_seq; // never 0 (the block starts zeroed)
+    // the one-ray entry's own stream, created by its first call: the runtime multiplexes streams onto a few
+    // hardware queues, and an engine that only renders frames should not take one of them
+    if (!e->ray_stream) {
+        st = hipStreamCreateWithFlags(&e->ray_stream, hipStreamNonBlocking);
+        if (st != hipSuccess) return nan_out("hipStreamCreate", st);
+    }
     st = (o.arith == GRV_ARITH_FAST ? launch_single_ray_fast : launch_single_ray)(
         o.metric_kind, P, in, o.initial_step, e->ray_out, seq, e->ray_stream);
     if (st != hipSuccess) return nan_out("launch", st);

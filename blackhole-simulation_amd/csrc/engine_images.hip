@@ -37,7 +37,8 @@ struct grv_image {
     hipEvent_t ready = nullptr;    // end of the last producer queued on s
     hipEvent_t copied = nullptr;   // end of the last read queued on copy_s
     hipEvent_t consumed = nullptr; // end of the last reader kernel that sits on ANOTHER stream
-    bool ready_rec = false, copied_rec = false, consumed_rec = false;
+    std::atomic<bool> ready_rec{false}, copied_rec{false};
+    bool consumed_rec = false;
     grvhip::FrameStatsDev *h_stats = nullptr; // pinned: counters of the frame that last wrote the image
     bool has_stats = false;
     std::string err;
@@ -365,9 +366,22 @@ int grv_image_wait(grv_image *img) {
     return GRV_OK;
 }
 
+// The blocking read waits for the producers on the HOST and only then queues the copy: its copy stream
+// never holds a barrier packet.  (The runtime multiplexes streams onto a few hardware queues; a copy stream
+// that shares one with a compute stream would otherwise park its "wait for the frame" barrier in front of
+// that stream's next kernels -- measured: every other frame of a rotation started a copy late.)
 int grv_image_read(grv_image *img, float *host, size_t elems) {
-    const int rc = grv_image_read_async(img, host, elems);
-    return rc != GRV_OK ? rc : grv_image_wait(img);
+    if (!img) return GRV_ERR_INVALID;
+    if (!host) return ifail(img, GRV_ERR_INVALID, "null argument");
+    if (elems > img->bytes / sizeof(float)) return ifail(img, GRV_ERR_INVALID, "read of %zu floats from an image of %zu", elems, img->bytes / sizeof(float));
+    IMG_HIP(img, hipSetDevice(img->device));
+    if (img->ready_rec) IMG_HIP(img, hipEventSynchronize(img->ready));
+    if (!img->copy_s) IMG_HIP(img, hipStreamCreateWithFlags(&img->copy_s, hipStreamNonBlocking));
+    IMG_HIP(img, hipMemcpyAsync(host, img->d, elems * sizeof(float), hipMemcpyDeviceToHost, img->copy_s));
+    IMG_HIP(img, hipEventRecord(img->copied, img->copy_s));
+    img->copied_rec = true;
+    IMG_HIP(img, hipEventSynchronize(img->copied));
+    return GRV_OK;
 }
 
 int grv_image_query(grv_image *img) {

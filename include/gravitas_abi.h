@@ -559,11 +559,18 @@ int grv_webgpu_render_image(grv_engine *e, const float camera_uniforms[88], cons
 int grv_post_bloom_image(grv_engine *e, const GrvBloomParams *p, grv_image *scene, grv_image *out);
 int grv_post_taa_resolve_image(grv_engine *e, const GrvTaaParams *p, grv_image *current,
                                grv_image *history, grv_image *out);
-/* D2H of the first `elems` floats behind the image's last producer, on the image's own copy stream:
- * _async queues the copy (page-locked `host` memory: one DMA at the PCIe rate) and returns; a later
- * producer of the image waits for it.  grv_image_wait blocks until the image's last producer and last
- * read have finished (not for later work of images sharing its stream); grv_image_query: 1 finished,
- * 0 busy, < 0 = -status; grv_image_read = _read_async + _wait */
+/* D2H of the first `elems` floats behind the image's last producer, on the image's own copy stream
+ * (page-locked `host` memory: one DMA at the PCIe rate).
+ *   grv_image_read        blocking: waits for the producers on the host, queues the copy, waits for it.  The
+ *                         form a host runs on a worker thread (image-only call) while its main thread queues
+ *                         the next frames into OTHER images; no producer may be queued into THIS image until
+ *                         it has returned.
+ *   grv_image_read_async  queues the copy behind the producers (an event wait on the copy stream) and
+ *                         returns; a later producer of the image waits for it on the device.  With more live
+ *                         streams than the runtime has hardware queues (4 by default) that event wait can
+ *                         sit in front of another stream's kernels: prefer grv_image_read on a worker thread.
+ *   grv_image_wait        blocks until the image's last producer and last read have finished (not for later
+ *                         work of images sharing its stream); grv_image_query: 1 finished, 0 busy, < 0 = -status */
 int grv_image_read_async(grv_image *img, float *host, size_t elems);
 int grv_image_wait(grv_image *img);
 int grv_image_query(grv_image *img);

@@ -815,14 +815,14 @@ static void bulk_execute(bulk_work *w) {
              * wait: the next work queues its kernels (other image, other stream) under this frame's copy */
             grv_image *img = NULL;
             int slot = (b->async_turn ^= 1), priv = 0;
-            if (b->async_img[slot] && (grv_image_width(b->async_img[slot]) != w->p.width ||
-                                       grv_image_height(b->async_img[slot]) != w->p.height)) {
-                if (b->async_img_users[slot] == 0) {
-                    grv_image_destroy(b->async_img[slot]);
-                    b->async_img[slot] = NULL;
-                } else {
-                    priv = 1; /* another size is still in flight on this slot: an image of its own for this work */
-                }
+            if (b->async_img_users[slot] > 0 && b->async_img_users[slot ^ 1] == 0) slot ^= 1;
+            if (b->async_img_users[slot] > 0) {
+                priv = 1; /* both images still have a work between its queueing and the end of its read (more than
+                             two frames in flight): this one gets an image of its own */
+            } else if (b->async_img[slot] && (grv_image_width(b->async_img[slot]) != w->p.width ||
+                                              grv_image_height(b->async_img[slot]) != w->p.height)) {
+                grv_image_destroy(b->async_img[slot]);
+                b->async_img[slot] = NULL;
             }
             if (priv) w->rc = grv_image_create(h, w->p.width, w->p.height, &img);
             else {
@@ -833,14 +833,12 @@ static void bulk_execute(bulk_work *w) {
             }
             if (w->rc == GRV_OK) w->rc = grv_render_frame_image(h, &w->cam, &w->p, img);
             if (w->rc != GRV_OK) snprintf(w->err, sizeof w->err, "%s", grv_last_error(h));
-            if (w->rc == GRV_OK) {
-                w->rc = grv_image_read_async(img, w->rgba, (size_t)w->p.width * w->p.height * 4);
-                if (w->rc != GRV_OK) snprintf(w->err, sizeof w->err, "%s", grv_image_last_error(img));
-            }
             if (!priv && img) b->async_img_users[slot]++;
             pthread_mutex_unlock(&b->async_mu);
-            if (img) { /* (waits even after a failed read: kernels are queued on it) */
-                const int rc2 = w->rc == GRV_OK ? grv_image_frame_stats(img, &w->st) : grv_image_wait(img);
+            if (img) { /* image-only calls: the next work queues its kernels meanwhile */
+                /* waits for the frame on the host, then copies (even after a failed render: kernels may be queued) */
+                int rc2 = w->rc == GRV_OK ? grv_image_read(img, w->rgba, (size_t)w->p.width * w->p.height * 4) : grv_image_wait(img);
+                if (rc2 == GRV_OK && w->rc == GRV_OK) rc2 = grv_image_frame_stats(img, &w->st);
                 if (w->rc == GRV_OK && rc2 != GRV_OK) {
                     w->rc = rc2;
                     snprintf(w->err, sizeof w->err, "%s", grv_image_last_error(img));
@@ -1331,6 +1329,11 @@ static image_box *target_image(napi_env env, engine_box *b, napi_value opts, uin
             napi_throw_type_error(env, NULL, msg);
             return NULL;
         }
+        if (ib->pending > 0) {
+            snprintf(msg, sizeof msg, "%s: a readAsync of this image is still pending (await it first)", who);
+            napi_throw_error(env, NULL, msg);
+            return NULL;
+        }
         if (ib->w != w || ib->h != h) {
             snprintf(msg, sizeof msg, "%s: a %u x %u frame into an image of %u x %u", who, w, h, ib->w, ib->h);
             napi_throw_range_error(env, NULL, msg);
@@ -1439,6 +1442,10 @@ static napi_value read_target(napi_env env, napi_value v, int given, size_t n, f
 }
 static napi_value image_read_into(napi_env env, image_box *ib, napi_value out, int given) {
     const size_t n = (size_t)ib->w * ib->h * 4;
+    if (ib->pending > 0) {
+        napi_throw_error(env, NULL, "DeviceImage.read: a readAsync of this image is still pending (await it first)");
+        return NULL;
+    }
     float *dst = NULL;
     napi_value ta = read_target(env, out, given, n, &dst, "DeviceImage.read");
     if (!ta) return NULL;
@@ -1476,6 +1483,7 @@ static napi_value m_read_image(napi_env env, napi_callback_info info) {
 typedef struct {
     image_box *ib;
     pinned_block *pin;
+    float *dst;
     size_t n;
     int rc;
     char err[256];
@@ -1486,7 +1494,8 @@ typedef struct {
 static void read_async_execute(napi_env env, void *data) {
     (void)env;
     read_work *w = (read_work *)data;
-    w->rc = grv_image_wait(w->ib->img); /* the copy was queued on the JS thread: this only waits (image-only call) */
+    /* image-only call: waits for the image's producers on this thread, then copies */
+    w->rc = grv_image_read(w->ib->img, w->dst, w->n);
     if (w->rc != GRV_OK) snprintf(w->err, sizeof w->err, "%s", grv_image_last_error(w->ib->img));
 }
 static void read_async_complete(napi_env env, napi_status status, void *data) {
@@ -1511,8 +1520,9 @@ static void read_async_complete(napi_env env, napi_status status, void *data) {
     napi_delete_reference(env, w->out_ref);
     free(w);
 }
-/* img.readAsync(out) -> Promise<out>: the D2H is queued behind the image's producers at once; the promise
- * settles when it has landed.  `out` must live in allocPinned() memory: the DMA writes it while JS runs. */
+/* img.readAsync(out) -> Promise<out>: a pool thread waits for the image's producers, copies, and the promise
+ * settles when the pixels have landed.  `out` must live in allocPinned() memory: the DMA writes it while JS runs.
+ * Until then the image is busy: rendering into it (or reading it again) throws. */
 static napi_value im_read_async(napi_env env, napi_callback_info info) {
     size_t argc = 1;
     napi_value argv[1], self, promise, name;
@@ -1520,6 +1530,10 @@ static napi_value im_read_async(napi_env env, napi_callback_info info) {
     if (!ib) return NULL;
     const size_t n = (size_t)ib->w * ib->h * 4;
     float *dst = NULL;
+    if (ib->pending > 0) {
+        napi_throw_error(env, NULL, "DeviceImage.readAsync: a readAsync of this image is still pending (await it first)");
+        return NULL;
+    }
     if (argc < 1 || !read_target(env, argv[0], 1, n, &dst, "DeviceImage.readAsync")) {
         if (argc < 1) napi_throw_type_error(env, NULL, "DeviceImage.readAsync(out): out is required");
         return NULL;
@@ -1537,20 +1551,14 @@ static napi_value im_read_async(napi_env env, napi_callback_info info) {
     }
     w->ib = ib;
     w->pin = pin;
+    w->dst = dst;
     w->n = n;
-    if (grv_image_read_async(ib->img, dst, n) != GRV_OK) {
-        napi_throw_error(env, NULL, grv_image_last_error(ib->img));
-        pinned_release(pin);
-        free(w);
-        return NULL;
-    }
     if (napi_create_promise(env, &w->deferred, &promise) != napi_ok ||
         napi_create_reference(env, self, 1, &w->self_ref) != napi_ok ||
         napi_create_reference(env, argv[0], 1, &w->out_ref) != napi_ok ||
         napi_create_string_utf8(env, "gravitas.read", NAPI_AUTO_LENGTH, &name) != napi_ok ||
         napi_create_async_work(env, NULL, name, read_async_execute, read_async_complete, w, &w->work) != napi_ok ||
         napi_queue_async_work(env, w->work) != napi_ok) {
-        grv_image_wait(ib->img); /* the copy is queued: let it land before the block may go */
         pinned_release(pin);
         if (w->self_ref) napi_delete_reference(env, w->self_ref);
         if (w->out_ref) napi_delete_reference(env, w->out_ref);
@@ -1592,6 +1600,10 @@ static napi_value im_wait(napi_env env, napi_callback_info info) {
     napi_value self;
     image_box *ib = this_image(env, info, &argc, NULL, &self);
     if (!ib) return NULL;
+    if (ib->pending > 0) {
+        napi_throw_error(env, NULL, "DeviceImage.wait: a readAsync of this image is pending -- await its promise instead");
+        return NULL;
+    }
     if (grv_image_wait(ib->img) != GRV_OK) {
         napi_throw_error(env, NULL, grv_image_last_error(ib->img));
         return NULL;
@@ -1603,7 +1615,7 @@ static napi_value im_ready(napi_env env, napi_callback_info info) {
     napi_value self, v;
     image_box *ib = this_image(env, info, &argc, NULL, &self);
     if (!ib) return NULL;
-    const int q = grv_image_query(ib->img);
+    const int q = ib->pending > 0 ? 0 : grv_image_query(ib->img);
     if (q < 0) {
         napi_throw_error(env, NULL, grv_image_last_error(ib->img));
         return NULL;
@@ -1758,6 +1770,10 @@ static napi_value m_post_bloom(napi_env env, napi_callback_info info) {
         napi_throw_type_error(env, NULL, "postBloom(scene, out, opts?): scene and out must be live DeviceImages");
         return NULL;
     }
+    if (dst->pending > 0) {
+        napi_throw_error(env, NULL, "postBloom: a readAsync of `out` is still pending (await it first)");
+        return NULL;
+    }
     GrvBloomParams p;
     grv_bloom_params_default(src->w, src->h, &p);
     napi_valuetype t;
@@ -1785,6 +1801,10 @@ static napi_value m_post_taa(napi_env env, napi_callback_info info) {
               *dst = argc > 2 ? image_of(env, argv[2]) : NULL;
     if (!cur || !hist || !dst) {
         napi_throw_type_error(env, NULL, "postTaa(current, history, out, opts?): three live DeviceImages");
+        return NULL;
+    }
+    if (dst->pending > 0) {
+        napi_throw_error(env, NULL, "postTaa: a readAsync of `out` is still pending (await it first)");
         return NULL;
     }
     GrvTaaParams p;
