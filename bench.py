@@ -340,6 +340,7 @@ def spawn_ranks(n):
 TOL = 1e-8                # RKF45 tolerance of the f64 frame (--config c5 / --tolerance change it)
 BASELINE_LABEL = {"c2": "configs[1]", "c3": "configs[2]", "c4": "configs[3]", "c5": "configs[4]"}
 KERNEL = "glsl"           # --kernel of --config c2
+EYE = (60.0, 97.0)        # --eye: camera distance (M) and polar angle (deg); BASELINE's frames use the default
 
 
 def workload_text(cfg, W, H, split):
@@ -347,20 +348,20 @@ def workload_text(cfg, W, H, split):
         return ("%dx%d frame%s, a=0.999, f32 Cartesian Velocity-Verlet march of the WebGL fragment shader "
                 "(fragment.glsl.ts:129-221, chunks/metric.ts:96-149) at u_maxRaySteps=512 (the shader clamps "
                 "to 500), default high-quality preset (lensing, volumetric disk + Doppler, jets, stars, photon "
-                "glow, blue-noise dither; seeded noise textures), mouse camera zoom=60 theta=97deg" % (W, H, split))
+                "glow, blue-noise dither; seeded noise textures), mouse camera zoom=%g theta=%gdeg" % (W, H, split, EYE[0], EYE[1]))
     if cfg == "c2":
         return ("%dx%d frame%s, a=0.999, f32 compute march (Kerr-Schild implicit-midpoint, compute.wgsl.ts) "
-                "at a 512-step budget, disk g-factor shading + star field, camera r0=60M theta=97deg "
-                "fov=60deg" % (W, H, split))
+                "at a 512-step budget, disk g-factor shading + star field, camera r0=%gM theta=%gdeg "
+                "fov=60deg" % (W, H, split, EYE[0], EYE[1]))
     if cfg == "c3":
         return ("%dx%d frame%s, a=0.999 Kerr-Schild, adaptive RKF45 tol=%g h0=0.01 escape=1000 "
                 "renorm=10 max_steps=2048, Planck LUT 512x64 Tmax=1e5 redshift shading, camera "
-                "r0=60M theta=97deg fov=60deg" % (W, H, split, TOL))
+                "r0=%gM theta=%gdeg fov=60deg" % (W, H, split, TOL, EYE[0], EYE[1]))
     return ("%dx%d frame%s, a=0.999, f32 compute march (Kerr-Schild implicit-midpoint, "
             "compute.wgsl.ts) at a fixed 1024-step budget, disk g-factor shading + star field "
             "(packed / fast arithmetic: the star hash takes a FAST-contract sin, so individual stars "
             "differ from the shader-order sky; parity tests compare with stars off), "
-            "camera r0=60M theta=97deg fov=60deg" % (W, H, split))
+            "camera r0=%gM theta=%gdeg fov=60deg" % (W, H, split, EYE[0], EYE[1]))
 
 
 def main_native(args, cfg, base_w, base_h):
@@ -400,8 +401,8 @@ def main_native(args, cfg, base_w, base_h):
         m.set_exchange_format(bh.EXCHANGE_RGBA16F)
     torch.cuda.set_device(0)
     W, H = base_w, base_h
-    th = np.deg2rad(97.0)
-    eye = (60.0 * np.sin(th), 60.0 * np.cos(th), 0.0)
+    th = np.deg2rad(EYE[1])
+    eye = (EYE[0] * np.sin(th), EYE[0] * np.cos(th), 0.0)
     arith = {"fast": bh.ARITH_FAST, "strict": bh.ARITH_STRICT, "packed": bh.ARITH_FAST_PACKED}[args.arith]
     cam = bh.camera_look_at(eye, aspect=W / H)
     params = bh.render_params(W, H, arith=arith if cfg == "c3" else bh.ARITH_FAST, segment_tries=args.segment_tries,
@@ -512,6 +513,10 @@ def main():
                     help="arithmetic contract (default: fast for c3; packed = the FAST contract with two rays per "
                          "lane on the packed-f32 ops for c4)")
     ap.add_argument("--segment-tries", type=int, default=0)
+    ap.add_argument("--eye", default=None, metavar="R0,THETA",
+                    help="camera distance in M and polar angle in degrees (default 60,97: BASELINE's frames).  The "
+                         "reference's observer ranges over 1.5-100 R_s and 0.1-179.9 deg (simulation.config.ts:106-121); a "
+                         "line taken with another camera is a secondary record (config.eye), never the headline")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
@@ -542,8 +547,13 @@ def main():
         args.steps = 300 if cfg == "c2" else 20
     if args.warmup is None:
         args.warmup = 60 if cfg == "c2" else 3
-    global TOL, KERNEL
+    global TOL, KERNEL, EYE
     KERNEL = args.kernel
+    if args.eye:
+        r0, thd = (float(x) for x in args.eye.split(","))
+        if not (r0 > 0.0 and 0.0 < thd < 180.0):
+            raise SystemExit("--eye R0,THETA: R0 > 0 M, 0 < THETA < 180 deg")
+        EYE = (r0, thd)
     label = BASELINE_LABEL[cfg]
     if cfg == "c5":  # the c3 code path with the parity run's tolerance and arithmetic
         cfg = "c3"
@@ -642,8 +652,8 @@ def main():
 
     gx, gy = GRID.get(world, (world, 1)) if args.scaling == "weak" else (1, 1)
     W, H = base_w * gx, base_h * gy
-    th = np.deg2rad(97.0)
-    eye = (60.0 * np.sin(th), 60.0 * np.cos(th), 0.0)
+    th = np.deg2rad(EYE[1])
+    eye = (EYE[0] * np.sin(th), EYE[0] * np.cos(th), 0.0)
     arith = {"fast": bh.ARITH_FAST, "strict": bh.ARITH_STRICT, "packed": bh.ARITH_FAST_PACKED}[args.arith]
 
     eng = bh.PhysicsEngine(1.0, 0.999, device=local_rank)
@@ -663,6 +673,9 @@ def main():
         # the uniforms WebGLRenderer uploads at the default preset (grv_glsl_params_default), with the
         # config's step budget; linear output (the post chain owns tone mapping upstream)
         gp = bh.glsl_params(W, H, 1.0, 0.999, max_ray_steps=512, arith=arith, tile_world=world, tile_rank=rank)
+        if args.eye:  # the shader's mouse camera: u_zoom = distance, u_mouse.y = polar angle / 180 deg
+            gp.zoom = EYE[0]
+            gp.mouse[1] = EYE[1] / 180.0
     # two frames in flight: even and odd frames go to two streams (the engine alternates two ray
     # workspaces and orders each behind its previous user), so the tail of one frame's integrate
     # launch -- too few waves left to fill 256 CUs -- runs under the head of the next frame
@@ -825,6 +838,7 @@ def main():
                        "partition": ("64x64 tiles round-robin, one RCCL gather to rank 0 per frame%s"
                                      % (", overlapped with the next frame" if overlap else ""))
                        if world > 1 else "single GPU",
+                       "eye": {"r0_M": EYE[0], "theta_deg": EYE[1], "default": args.eye is None},
                        "rays": total_rays, "accepted_steps_per_frame": int(total_steps / args.steps),
                        "host_waits_in_frame_loop": 0 if not args.segment_tries else "one per segment",
                        "frames_in_flight": 2 if two else 1,

@@ -383,7 +383,7 @@ int resolve_frame_events(grv_engine *e) {
     return GRV_OK;
 }
 
-int begin_march_order(grv_engine *e, int kind, uint32_t n_blocks, uint64_t key, hipStream_t s, MarchSched *out,
+int begin_march_order(grv_engine *e, int kind, uint32_t n_blocks, const uint32_t geom[4], hipStream_t s, MarchSched *out,
                       int *parity) {
     const int b = (int)(e->march_frames[kind]++ & 1u);
     grv_engine::MarchOrder &M = e->march_order[kind][b];
@@ -392,18 +392,25 @@ int begin_march_order(grv_engine *e, int kind, uint32_t n_blocks, uint64_t key, 
     if (M.ready_rec) GRV_HIP(e, hipStreamWaitEvent(s, M.ready, 0));
     if (M.n_blocks < n_blocks) {
         if (M.mem) {
-            GRV_HIP(e, hipEventSynchronize(M.ready)); // its last user has finished before it is freed
+            if (M.ready_rec) GRV_HIP(e, hipEventSynchronize(M.ready)); // its last user has finished before it is freed
             (void)hipFree(M.mem);
         }
         M.mem = nullptr;
         M.n_blocks = 0;
-        M.key = 0;
+        M.has_order = false;
         GRV_HIP(e, hipMalloc(reinterpret_cast<void **>(&M.mem), (size_t)2 * n_blocks * sizeof(uint32_t)));
         M.n_blocks = n_blocks;
     }
-    if (M.key != key) { // first frame of this geometry: natural order, no forecast yet
+    const uint32_t want[5] = {geom[0], geom[1], geom[2], geom[3], n_blocks};
+    if (!M.has_order || std::memcmp(M.geom, want, sizeof want) != 0) {
+        // first frame of exactly this geometry: natural order, no forecast yet
+        M.has_order = false;
         GRV_HIP(e, launch_march_order_identity(M.mem + M.n_blocks, M.mem, n_blocks, s));
-        M.key = key;
+        // the table is in use on `s` from here on, whatever happens next: a later grow / free waits for it
+        GRV_HIP(e, hipEventRecord(M.ready, s));
+        M.ready_rec = true;
+        std::memcpy(M.geom, want, sizeof want);
+        M.has_order = true;
     }
     M.cur = n_blocks;
     out->cost = M.mem;
@@ -964,7 +971,7 @@ void grv_render_params_default(uint32_t width, uint32_t height, GrvRenderParams 
     p->segment_tries = 0;
     p->profile = 0;
     p->disk_profile = GRV_DISK_PROFILE_SHORTCUT;
-    p->reserved1 = 0;
+    p->schedule = GRV_SCHEDULE_DEFAULT;
 }
 
 int grv_render_frame_device(grv_engine *e, const GrvCamera *cam, const GrvRenderParams *p,
@@ -973,7 +980,8 @@ int grv_render_frame_device(grv_engine *e, const GrvCamera *cam, const GrvRender
     if (!cam || !p || !out) return fail(e, GRV_ERR_INVALID, "null argument");
     if (!options_valid(p->opt)) return fail(e, GRV_ERR_INVALID, "invalid GrvOptions");
     if (p->width == 0 || p->height == 0) return fail(e, GRV_ERR_INVALID, "empty frame");
-    if (p->reserved0 != 0 || p->reserved1 != 0) return fail(e, GRV_ERR_INVALID, "reserved field must be 0");
+    if (p->reserved0 != 0) return fail(e, GRV_ERR_INVALID, "reserved field must be 0");
+    if (p->schedule > GRV_SCHEDULE_SLOT_ORDER) return fail(e, GRV_ERR_INVALID, "unknown schedule %u", p->schedule);
     if (p->tile_world >= 1 && p->tile_rank >= p->tile_world) return fail(e, GRV_ERR_INVALID, "tile_rank >= tile_world"); // 0 = whole frame
     if (p->disk_profile > GRV_DISK_PROFILE_PAGE_THORNE) return fail(e, GRV_ERR_INVALID, "unknown disk_profile");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1048,6 +1056,16 @@ int grv_render_frame_device(grv_engine *e, const GrvCamera *cam, const GrvRender
         if (rc != GRV_OK) return rc;
         GRV_HIP(e, hipEventRecord(ev4[0], s));
     }
+    // one-launch schedule of a whole frame in one-wave blocks: dispatched longest-first by the previous frame's
+    // per-wave tries (costs written by this frame's finalize kernel, sorted behind it for the next frame)
+    MarchSched sched{nullptr, nullptr};
+    int order_parity = -1;
+    if (p->schedule == GRV_SCHEDULE_DEFAULT && p->segment_tries == 0 && P.block_order == 0 && slots >= kSegOneWaveMinRays) {
+        const uint32_t geom[4] = {p->width, p->height, G.tile_world, G.tile_rank};
+        rc = begin_march_order(e, 2, (uint32_t)(slots / 64u), geom, s, &sched, &order_parity);
+        if (rc != GRV_OK) return rc;
+        P.order = sched.order;
+    }
     GRV_HIP(e, launch_init_pixels(p->opt.metric_kind, e->ws, P, G, cd, p->opt.initial_step,
                                   p->opt.method == GRV_METHOD_RKF45, s));
     if (profile) GRV_HIP(e, hipEventRecord(ev4[1], s));
@@ -1086,7 +1104,11 @@ int grv_render_frame_device(grv_engine *e, const GrvCamera *cam, const GrvRender
                                      p->disk_profile == GRV_DISK_PROFILE_PAGE_THORNE ? e->d_disk_lut : nullptr,
                                      out->rgba,
                                      out->final_state, out->steps, out->termination, out->drift,
-                                     e->d_stats, e->n_cu, s));
+                                     e->d_stats, e->n_cu, s, sched.cost));
+    if (order_parity >= 0) {
+        rc = finish_march_order(e, 2, order_parity, s);
+        if (rc != GRV_OK) return rc;
+    }
     if (profile) {
         GRV_HIP(e, hipEventRecord(ev4[3], s));
         // the segment-loop schedule timed its launches one by one (it synchronises anyway): the

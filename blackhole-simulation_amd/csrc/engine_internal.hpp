@@ -126,15 +126,21 @@ struct grv_engine {
     // measured-cost dispatch order of the FAST marches (engine_types.hpp MarchSched): per march kind (0 GLSL,
     // 1 packed WGSL) and frame parity one {cost, order} pair; a frame reads the order its parity's previous
     // frame produced.  `ready` orders a user on another stream behind the sort that wrote the order.
+    // (kind 2: the f64 segment kernel's one-launch schedule -- costs are the waves' tries, written by the
+    // finalize kernel)
     struct MarchOrder {
         uint32_t *mem = nullptr; // [2][n_blocks]: cost, order
         uint32_t n_blocks = 0;   // allocated entries per array
         uint32_t cur = 0;        // blocks of the frame in flight
-        uint64_t key = 0;        // frame geometry the order was measured on
+        // the exact frame geometry the order is a permutation for: {width, height, tile_world, tile_rank, blocks};
+        // anything else starts from the identity again (a permutation of another block count would leave
+        // blocks undispatched)
+        uint32_t geom[5] = {0, 0, 0, 0, 0};
+        bool has_order = false;
         hipEvent_t ready = nullptr;
         bool ready_rec = false;
-    } march_order[2][2];
-    uint32_t march_frames[2] = {0, 0};
+    } march_order[3][2];
+    uint32_t march_frames[3] = {0, 0, 0};
     uint8_t *d_noise = nullptr; // [2][256*256] R planes: u_noiseTex, u_blueNoiseTex
     std::vector<float> disk_lut = std::vector<float>(512, 0.0f); // lut_buffer (lib.rs:50, 65-66)
     std::vector<float> sab;
@@ -203,7 +209,7 @@ constexpr size_t kOffControl = 0, kOffCamera = 64, kOffPhysics = 128, kOffTeleme
 
 // {order, cost} of the next frame of march `kind` (0 GLSL, 1 packed WGSL) with n_blocks blocks on stream s
 // (n_blocks == 0: no measured order for this form); finish_march_order queues the sort behind the march
-int begin_march_order(grv_engine *e, int kind, uint32_t n_blocks, uint64_t key, hipStream_t s, grvhip::MarchSched *out, int *parity);
+int begin_march_order(grv_engine *e, int kind, uint32_t n_blocks, const uint32_t geom[4], hipStream_t s, grvhip::MarchSched *out, int *parity);
 int finish_march_order(grv_engine *e, int kind, int parity, hipStream_t s);
 
 template <typename Launch>
@@ -240,8 +246,8 @@ int run_shader_frame(grv_engine *e, uint32_t width, uint32_t height, uint32_t tw
     int parity = -1;
     const uint32_t sched_blocks = sched_blocks_of_slots ? sched_blocks_of_slots((uint32_t)slots, budget) : 0u;
     if (sched_blocks) {
-        const uint64_t key = ((uint64_t)width << 40) ^ ((uint64_t)height << 16) ^ ((uint64_t)tw << 8) ^ tr ^ ((uint64_t)sched_blocks << 1);
-        const int rc = begin_march_order(e, kind, sched_blocks, key, s, &sched, &parity);
+        const uint32_t geom[4] = {width, height, tw, tr};
+        const int rc = begin_march_order(e, kind, sched_blocks, geom, s, &sched, &parity);
         if (rc != GRV_OK) return rc;
     }
     GRV_HIP(e, launch(G, (uint32_t)slots, &e->d_stats->accepted_steps, sched));

@@ -117,7 +117,16 @@ struct SegmentParams {
     double disk_inner, disk_outer;
     uint32_t max_crossings;
     uint32_t block_order; // segment kernel: 0 = blocks in slot order, 1 = centre-out (a rank's share of a split frame)
+    // segment kernel, one-launch schedule of whole frames: the block a workgroup takes (a permutation of the
+    // launch's one-wave blocks, longest first by LAST frame's per-wave tries -- finalize_frame_kernel writes the
+    // costs, march_rank_kernel sorts them); null = block_order decides.  Any permutation gives the same frame.
+    const uint32_t *order;
 };
+// one-launch frames of at least this many rays start one-wave blocks (geodesic_kernels.hpp segment_block_threads);
+// only those take a measured dispatch order (its entries are one-wave blocks)
+constexpr uint32_t kSegOneWaveMinRays = 3u << 19; // 1 572 864
+// cost entry of a wave whose slowest ray took `tries` integrator tries (march_rank_kernel buckets by cost >> 7)
+constexpr uint32_t kWaveCostShift = 6;
 
 struct FrameGeom {
     uint32_t width, height;
@@ -221,7 +230,7 @@ hipError_t launch_finalize_frame(const RayWorkspace &ws, const FrameGeom &G, con
                                  int shading, const float *lut, const float *disk_lut, float *out_rgba,
                                  double *out_states, uint32_t *out_steps, uint8_t *out_term,
                                  double *out_drift, FrameStatsDev *st, int n_blocks,
-                                 hipStream_t s);
+                                 hipStream_t s, uint32_t *wave_cost = nullptr);
 hipError_t launch_pack_half(const float *rgba, void *half4, size_t n_px, hipStream_t s);
 hipError_t launch_widen_half(const void *half4, float *rgba, size_t n_px, hipStream_t s);
 hipError_t launch_unpack_tiles_half(const FrameGeom &G, const void *packed_half4, float *image, hipStream_t s);

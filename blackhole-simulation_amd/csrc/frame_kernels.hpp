@@ -169,7 +169,7 @@ __global__ __launch_bounds__(1024) void finalize_frame_kernel(
     RayWorkspace ws, FrameGeom G, ShadeParams S, int shading, const float4 *__restrict__ lut,
     const float *__restrict__ disk_lut, float4 *__restrict__ out_rgba, double *__restrict__ out_states,
     uint32_t *__restrict__ out_steps, uint8_t *__restrict__ out_term,
-    double *__restrict__ out_drift, FrameStatsDev *st) {
+    double *__restrict__ out_drift, FrameStatsDev *st, uint32_t *__restrict__ wave_cost) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float4 *lut_s = reinterpret_cast<float4 *>(smem_raw);
     // the Page-Thorne table (2 KB) sits behind the staged Planck rows
@@ -254,6 +254,17 @@ __global__ __launch_bounds__(1024) void finalize_frame_kernel(
         }
         if (valid)
             acc.add(steps, tries, flags & kFlagTermMask, (flags & kFlagCrossMask) >> kFlagCrossShift, drift);
+        if (wave_cost) {
+            // 64 consecutive slots = one wave of the segment kernel: it ran as long as its slowest ray.  The
+            // next frame's one-launch dispatch starts the longest waves first (SegmentParams.order).
+            uint32_t m = tries;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint32_t o = (uint32_t)__shfl_xor((int)m, off);
+                m = o > m ? o : m;
+            }
+            if ((threadIdx.x & 63u) == 0u) wave_cost[slot >> 6] = (m < 2047u ? m : 2047u) << kWaveCostShift;
+        }
     }
     if (st) flush_stats(st, acc);
 }

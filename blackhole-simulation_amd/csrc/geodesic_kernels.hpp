@@ -519,7 +519,7 @@ constexpr int kSegBlockOneLaunch = GRV_SEGMENT_BLOCK_ONE_LAUNCH;
 // the launch shape of a segment launch: no live list to append to = the one-launch schedule.  Small launches
 // (a rank's eighth of the 4K frame, 1.04 M rays, with two frames in flight: 3.56 against 3.64 ms) still prefer
 // four-wave blocks; from 2 M rays on one-wave blocks are level or ahead (profiles/r05_rank_share_segment_block.txt)
-constexpr uint32_t kSegOneWaveMinRays = 3u << 19; // 1 572 864
+// (kSegOneWaveMinRays: engine_types.hpp)
 __host__ inline uint32_t segment_block_threads(const uint32_t *live_out, uint32_t n_live) {
     return (live_out || n_live < kSegOneWaveMinRays) ? (uint32_t)kSegBlock : (uint32_t)kSegBlockOneLaunch;
 }
@@ -529,7 +529,8 @@ __global__ __launch_bounds__(kSegBlock) __attribute__((amdgpu_waves_per_eu(kSegm
 void integrate_segment_kernel(
     RayWorkspace ws, SegmentParams P, const uint32_t *__restrict__ live_in, uint32_t n_live,
     uint32_t *__restrict__ live_out, uint32_t *__restrict__ live_out_count) {
-    const uint32_t k = dispatch_block_f64(blockIdx.x, gridDim.x, P.block_order) * blockDim.x + threadIdx.x;
+    const uint32_t blk = P.order ? P.order[blockIdx.x] : dispatch_block_f64(blockIdx.x, gridDim.x, P.block_order);
+    const uint32_t k = blk * blockDim.x + threadIdx.x;
     const bool have = k < n_live;
     const uint32_t slot = have ? (live_in ? live_in[k] : k) : 0u;
 

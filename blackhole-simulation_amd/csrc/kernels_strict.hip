@@ -128,7 +128,7 @@ hipError_t launch_finalize_frame(const RayWorkspace &ws, const FrameGeom &G, con
                                  int shading, const float *lut, const float *disk_lut, float *out_rgba,
                                  double *out_states, uint32_t *out_steps, uint8_t *out_term,
                                  double *out_drift, FrameStatsDev *st, int n_blocks,
-                                 hipStream_t s) {
+                                 hipStream_t s, uint32_t *wave_cost) {
     if (ws.n == 0) return hipSuccess;
     const size_t lds = (shading && lut)
                            ? (size_t)S.lds_rows * S.lut_w * sizeof(float4) + kDiskLutWidth * sizeof(float)
@@ -151,7 +151,7 @@ hipError_t launch_finalize_frame(const RayWorkspace &ws, const FrameGeom &G, con
     if (grid == 0) grid = 1;
     hipLaunchKernelGGL(finalize_frame_kernel, dim3(grid), dim3(1024), lds, s, ws, G, S, shading,
                        reinterpret_cast<const float4 *>(lut), disk_lut, reinterpret_cast<float4 *>(out_rgba),
-                       out_states, out_steps, out_term, out_drift, st);
+                       out_states, out_steps, out_term, out_drift, st, wave_cost);
     return hipGetLastError();
 }
 

@@ -18,6 +18,7 @@ _LIB = os.path.join(_HERE, "libgravitas_hip.so")
 KERR_BL, KERR_KS, SCHWARZSCHILD = 0, 1, 2
 METHOD_RKF45, METHOD_RK4, METHOD_SYMPLECTIC = 0, 1, 2
 ARITH_STRICT, ARITH_FAST, ARITH_FAST_PACKED = 0, 1, 2
+SCHEDULE_DEFAULT, SCHEDULE_SLOT_ORDER = 0, 1  # GrvRenderParams.schedule
 DISK_PROFILE_SHORTCUT, DISK_PROFILE_PAGE_THORNE = 0, 1
 MATH_SINCOS_SIN, MATH_SINCOS_COS, MATH_SIN, MATH_COS, MATH_POW, MATH_EXP, MATH_ATAN = 0, 1, 2, 3, 4, 5, 6
 MATH_LOG, MATH_ACOS, MATH_ATAN2, MATH_F32 = 7, 8, 9, 16
@@ -53,7 +54,7 @@ class RenderParams(C.Structure):
                 ("lut_width", C.c_uint32), ("lut_height", C.c_uint32),
                 ("lut_max_temp", C.c_double), ("tile_world", C.c_uint32),
                 ("tile_rank", C.c_uint32), ("segment_tries", C.c_uint32),
-                ("profile", C.c_uint32), ("disk_profile", C.c_uint32), ("reserved1", C.c_uint32)]
+                ("profile", C.c_uint32), ("disk_profile", C.c_uint32), ("schedule", C.c_uint32)]
 
 
 class FrameStats(C.Structure):

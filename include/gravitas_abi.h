@@ -122,8 +122,16 @@ typedef struct {
                                elapsed times are resolved by grv_frame_stats (GrvFrameStats.*_ms),
                                the frame call itself never waits */
     uint32_t disk_profile;  /* GRV_DISK_PROFILE_*: radial temperature profile of the disk shading */
-    uint32_t reserved1;     /* must be 0 */
+    uint32_t schedule;      /* GRV_SCHEDULE_*: how the integrate launch(es) are ordered.  Results do not depend on it. */
 } GrvRenderParams;
+
+/* GRV_SCHEDULE_DEFAULT: the engine's choice -- with segment_tries == 0, one launch whose waves start
+ *   longest-first by the PREVIOUS frame's per-wave try counts (a renderer's frames resemble their
+ *   predecessors; whole frames of >= 1.5 M rays; the first frame of a geometry runs in slot order):
+ *   the few waves that graze the photon ring no longer start in the middle of the launch and keep the
+ *   chip waiting at its end;
+ * GRV_SCHEDULE_SLOT_ORDER: waves start in slot (tile) order, as every launch did before ABI 8. */
+enum { GRV_SCHEDULE_DEFAULT = 0, GRV_SCHEDULE_SLOT_ORDER = 1 };
 
 /* radial temperature profile T(r)/T_max of the thin-disk shading:
  *  SHORTCUT    : (isco/r)^3/4 (1 - sqrt(isco/r))^1/4, the shader's closed form
