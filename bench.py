@@ -478,7 +478,7 @@ def main_native(args, cfg, base_w, base_h):
                    "virtual_ranks_on_one_device": bool(one_device),
                    "exchange": args.exchange, "exchange_bytes_per_frame": m.exchange_bytes_per_frame(W, H),
                    "rays": W * H, "accepted_steps_per_frame": int(total_steps / args.steps),
-                   "host_waits_in_frame_loop": 0 if not args.segment_tries else "one per segment",
+                   "host_waits_in_frame_loop": 0,
                    "frames_in_flight": 2},
         "roofline": roofline,
     }
@@ -840,7 +840,7 @@ def main():
                        if world > 1 else "single GPU",
                        "eye": {"r0_M": EYE[0], "theta_deg": EYE[1], "default": args.eye is None},
                        "rays": total_rays, "accepted_steps_per_frame": int(total_steps / args.steps),
-                       "host_waits_in_frame_loop": 0 if not args.segment_tries else "one per segment",
+                       "host_waits_in_frame_loop": 0,
                        "frames_in_flight": 2 if two else 1,
                        **({"exchange": args.exchange} if world > 1 else {}),
                        **({"exchange_backend": backend} if backend != "nccl" else {})},

@@ -258,14 +258,22 @@ uint32_t try_bound(const grv_engine *e, uint64_t max_steps) {
 }
 
 // One integrate pass over the initialised workspace.
-//   seg_tries == 0 (default): ONE launch that runs every ray to its end (or to try_bound): no live
-//     list, no counter read-back -- and the host does not wait for it: the call returns with the
-//     work queued on `s`.
-//   seg_tries  > 0: the compacting wavefront schedule.  Every launch appends its survivors to the
-//     next live list; the host reads the count back (one stream synchronise per launch) to size
-//     the next launch.  Results are bitwise those of the single launch.
+//   seg_tries == 0 (default): ONE launch that runs every ray to its end (or to try_bound): no live list.
+//   seg_tries  > 0: the compacting wavefront schedule.  Every launch appends its survivors to the next live
+//     list; the NEXT launch reads the list's length from device memory (integrate_compact_kernel), so the whole
+//     pass -- L launches of seg_tries tries and a last one that runs whatever is left to its end -- is queued
+//     at once.  L and the grids come from a forecast: the live counts the launches of the last completed pass
+//     reported into pinned host memory (fire-and-forget stores; never waited for).  A wrong forecast costs time,
+//     not correctness: grids stride over any count, and the last launch is unbounded.
+//   Either way the host does not wait: the call returns with the work queued on `s`, and the results are
+//   bitwise those of the single launch.
+constexpr uint32_t kCompactMaxLaunches = 192;    // bounded launches of one pass (the last, unbounded one comes on top)
+constexpr uint32_t kCompactUnknown = 0xFFFFFFFFu;
+constexpr uint32_t kCompactTailRays = 4096u;     // fewer live rays than this: leave them to the last launch
+
 int run_segments(grv_engine *e, const GrvOptions &o, SegmentParams P, uint32_t seg_tries,
                  hipStream_t s, bool profile) {
+    (void)profile; // the frame's ring events bracket the pass; nothing in here waits, so there are no host gaps in it
     const uint32_t bound = try_bound(e, o.max_steps);
     if (seg_tries == 0) {
         P.max_tries = bound;
@@ -275,39 +283,56 @@ int run_segments(grv_engine *e, const GrvOptions &o, SegmentParams P, uint32_t s
         e->last_launches += 1;
         return GRV_OK;
     }
+    const uint32_t n = e->ws.n;
+    if (!e->compact_fb) {
+        GRV_HIP(e, hipHostMalloc(reinterpret_cast<void **>(&e->compact_fb), (kCompactMaxLaunches + 2) * sizeof(uint32_t),
+                                 hipHostMallocCoherent | hipHostMallocMapped));
+        for (uint32_t j = 0; j < kCompactMaxLaunches + 2; ++j) e->compact_fb[j] = kCompactUnknown;
+    }
+    // forecast from what the launches of an earlier pass reported (entry j: live rays launch j started with)
+    volatile const uint32_t *fb = e->compact_fb;
+    uint32_t L = 0;
+    for (uint32_t j = 1; j <= kCompactMaxLaunches; ++j) {
+        const uint32_t v = fb[j];
+        if (v == kCompactUnknown) { // nothing known from here on: a first pass, or rays outlived the last forecast
+            const uint32_t guess = j == 1 ? (512u + seg_tries - 1u) / seg_tries : j + 7u;
+            L = guess < kCompactMaxLaunches ? guess : kCompactMaxLaunches;
+            break;
+        }
+        if (v < kCompactTailRays) {
+            L = j;
+            break;
+        }
+    }
+    if (L == 0) L = kCompactMaxLaunches;
+    auto blocks_for = [&](uint32_t j) {
+        const uint32_t v = fb[j];
+        uint64_t rays = n;
+        if (v != kCompactUnknown) {
+            rays = (uint64_t)v + v / 4u + 16384u; // headroom for a moving camera; the grid strides anyway
+            if (rays > n) rays = n;
+        }
+        return (uint32_t)((rays + 255u) / 256u);
+    };
+    uint32_t *c = e->d_counters + 4; // three rotating live counters (d_counters[0..3]: refill cursor and spares)
+    GRV_HIP(e, hipMemsetAsync(c, 0, 3 * sizeof(uint32_t), s));
     P.max_tries = seg_tries;
     P.final_launch = 0;
-    uint32_t n_live = e->ws.n;
-    const uint32_t *live_in = nullptr;
-    int cur = 0;
-    float integ_ms = 0.f;
-    const uint64_t hard_cap = (uint64_t)bound / seg_tries + 2u; // launches a correct kernel can need
-    uint64_t launches = 0;
-    GRV_HIP(e, hipMemsetAsync(e->d_counters, 0, 4 * sizeof(uint32_t), s));
-    while (n_live > 0) {
-        if (++launches > hard_cap)
-            return fail(e, GRV_ERR_HIP, "integrate: %u rays still live after %llu launches of %u tries "
-                        "(bound %u tries per ray)", n_live, (unsigned long long)hard_cap, seg_tries, bound);
-        const int nxt = cur ^ 1;
-        GRV_HIP(e, hipMemsetAsync(e->d_counters + nxt, 0, sizeof(uint32_t), s));
-        if (profile) GRV_HIP(e, hipEventRecord(e->ev[2], s));
-        GRV_HIP(e, launch_segment(o.arith, o.metric_kind, o.method, e->ws, P, live_in, n_live,
-                                  e->live[nxt], e->d_counters + nxt, s));
-        if (profile) GRV_HIP(e, hipEventRecord(e->ev[3], s));
-        GRV_HIP(e, hipMemcpyAsync(e->h_counters + nxt, e->d_counters + nxt, sizeof(uint32_t),
-                                  hipMemcpyDeviceToHost, s));
-        GRV_HIP(e, hipStreamSynchronize(s));
-        if (profile) {
-            float ms = 0.f;
-            GRV_HIP(e, hipEventElapsedTime(&ms, e->ev[2], e->ev[3]));
-            integ_ms += ms;
+    // launch 0: every slot, appends to live[1] / c[1]
+    GRV_HIP(e, launch_segment(o.arith, o.metric_kind, o.method, e->ws, P, nullptr, n, e->live[1], c + 1, s));
+    for (uint32_t j = 1; j <= L; ++j) {
+        const bool last = j == L;
+        if (last) {
+            P.max_tries = bound;
+            P.final_launch = 1;
         }
-        n_live = e->h_counters[nxt];
-        live_in = e->live[nxt];
-        cur = nxt;
-        e->last_launches++;
+        uint32_t *out = last ? nullptr : e->live[(j + 1u) & 1u];
+        const auto fn = o.arith == GRV_ARITH_FAST ? launch_compact_fast : launch_compact_strict;
+        GRV_HIP(e, fn(o.metric_kind, o.method, e->ws, P, e->live[j & 1u], c + (j % 3u), out, c + ((j + 1u) % 3u),
+                      c + ((j + 2u) % 3u), e->compact_fb + j, blocks_for(j), s));
     }
-    e->last_ms[1] += integ_ms;
+    // (entries beyond L keep what older passes reported; the scan above stops at the first small or unknown one)
+    e->last_launches += L + 1u;
     return GRV_OK;
 }
 
@@ -422,8 +447,16 @@ int begin_march_order(grv_engine *e, int kind, uint32_t n_blocks, const uint32_t
 int finish_march_order(grv_engine *e, int kind, int parity, hipStream_t s) {
     grv_engine::MarchOrder &M = e->march_order[kind][parity];
     // the next frame of this parity starts its longest blocks first
-    GRV_HIP(e, launch_march_rank(M.mem, M.mem + M.n_blocks, M.cur, s));
-    GRV_HIP(e, hipEventRecord(M.ready, s));
+    hipStream_t q = s;
+    if (kind == 2) { // beside the frame loop (the next frame reads the OTHER parity's order)
+        if (!e->sort_stream) GRV_HIP(e, hipStreamCreateWithFlags(&e->sort_stream, hipStreamNonBlocking));
+        if (!e->sort_from) GRV_HIP(e, hipEventCreateWithFlags(&e->sort_from, hipEventDisableTiming));
+        GRV_HIP(e, hipEventRecord(e->sort_from, s));
+        GRV_HIP(e, hipStreamWaitEvent(e->sort_stream, e->sort_from, 0));
+        q = e->sort_stream;
+    }
+    GRV_HIP(e, launch_march_rank(M.mem, M.mem + M.n_blocks, M.cur, q));
+    GRV_HIP(e, hipEventRecord(M.ready, q));
     M.ready_rec = true;
     return GRV_OK;
 }
@@ -600,7 +633,13 @@ void grv_engine_destroy(grv_engine *e) {
     if (e->stats_cleared) (void)hipEventDestroy(e->stats_cleared);
     if (e->disk_lut_ready) (void)hipEventDestroy(e->disk_lut_ready);
     if (e->chain_done) (void)hipEventDestroy(e->chain_done);
+    if (e->sort_stream) {
+        (void)hipStreamSynchronize(e->sort_stream);
+        (void)hipStreamDestroy(e->sort_stream);
+    }
+    if (e->sort_from) (void)hipEventDestroy(e->sort_from);
     if (e->h_counters) (void)hipHostFree(e->h_counters);
+    if (e->compact_fb) (void)hipHostFree(e->compact_fb);
     if (e->h_stats) (void)hipHostFree(e->h_stats);
     if (e->ray_stream) {
         (void)hipStreamSynchronize(e->ray_stream);
@@ -1111,10 +1150,10 @@ int grv_render_frame_device(grv_engine *e, const GrvCamera *cam, const GrvRender
     }
     if (profile) {
         GRV_HIP(e, hipEventRecord(ev4[3], s));
-        // the segment-loop schedule timed its launches one by one (it synchronises anyway): the
-        // ring's before-integrate..before-shade interval would count its host gaps as well
+        // (no schedule waits for the host any more: the ring's before-integrate..before-shade interval is the
+        // integrate pass for every one of them)
         e->ev_loop.resize(e->ev_frames + 1);
-        e->ev_loop[e->ev_frames] = p->segment_tries != 0;
+        e->ev_loop[e->ev_frames] = 0;
         e->ev_frames += 1;
     }
     return GRV_OK;

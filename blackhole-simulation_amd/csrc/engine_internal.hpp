@@ -45,7 +45,7 @@ struct grv_engine {
         size_t slots = 0, bytes = 0;
         grvhip::RayWorkspace ws{};
         uint32_t *live[2] = {nullptr, nullptr};
-        uint32_t *d_counters = nullptr; // [0],[1] live counts (ping-pong), [2] refill cursor
+        uint32_t *d_counters = nullptr; // [2] refill cursor, [4..6] live counts of the compacting schedule (rotating)
         hipEvent_t done = nullptr;
         hipStream_t last_stream = nullptr;
         bool used = false;
@@ -68,6 +68,9 @@ struct grv_engine {
     bool stats_open = false;           // a call holds d_stats (begin_frame_stats .. end_frame_stats)
     grvhip::FrameStatsDev *d_stats = nullptr;
     uint32_t *h_counters = nullptr; // pinned
+    // compacting schedule: live rays each launch of the last completed pass started with, written by the launches
+    // themselves into pinned host memory (engine.hip run_segments: the next pass's forecast; never waited for)
+    uint32_t *compact_fb = nullptr;
     grvhip::FrameStatsDev *h_stats = nullptr; // pinned
 
     // single-ray entry (grv_integrate_ray_relativistic): its own non-blocking stream and a pinned
@@ -141,6 +144,10 @@ struct grv_engine {
         bool ready_rec = false;
     } march_order[3][2];
     uint32_t march_frames[3] = {0, 0, 0};
+    // the f64 order's sort runs beside the frame loop, not in it (a 130 000-entry counting sort in one workgroup is
+    // 2 % of a 4 ms close-up frame): queued on a stream of its own behind the finalize kernel that wrote the costs
+    hipStream_t sort_stream = nullptr;
+    hipEvent_t sort_from = nullptr;
     uint8_t *d_noise = nullptr; // [2][256*256] R planes: u_noiseTex, u_blueNoiseTex
     std::vector<float> disk_lut = std::vector<float>(512, 0.0f); // lut_buffer (lib.rs:50, 65-66)
     std::vector<float> sab;

@@ -335,6 +335,16 @@ hipError_t launch_segment_fast(int kind, int method, const RayWorkspace &ws,
                                uint32_t *live_out, uint32_t *live_out_count, hipStream_t s);
 hipError_t launch_refill_fast(int kind, int method, const RayWorkspace &ws, const SegmentParams &P,
                               uint32_t *cursor, int n_cu, hipStream_t s);
+// launches 2.. of the compacting schedule: the live list's length comes from device memory (geodesic_kernels.hpp
+// integrate_compact_kernel); `blocks` four-wave blocks stride over it
+hipError_t launch_compact_fast(int kind, int method, const RayWorkspace &ws, const SegmentParams &P,
+                               const uint32_t *live_in, const uint32_t *live_in_count, uint32_t *live_out,
+                               uint32_t *live_out_count, uint32_t *clear_count, uint32_t *feedback, uint32_t blocks,
+                               hipStream_t s);
+hipError_t launch_compact_strict(int kind, int method, const RayWorkspace &ws, const SegmentParams &P,
+                                 const uint32_t *live_in, const uint32_t *live_in_count, uint32_t *live_out,
+                                 uint32_t *live_out_count, uint32_t *clear_count, uint32_t *feedback, uint32_t blocks,
+                                 hipStream_t s);
 hipError_t launch_path_fast(int kind, int method, const RayWorkspace &ws, const SegmentParams &P,
                             const double *states_in, double *paths, uint32_t *counts, uint32_t max_points,
                             hipStream_t s);

@@ -598,6 +598,71 @@ void integrate_segment_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// The compacting schedule's launches 2..: the segment kernel's body over a live list whose LENGTH is read from
+// device memory (the previous launch's append counter), so the host never waits between launches -- the whole
+// frame is queued at once.  The grid is sized by the host from a forecast (the live counts the previous frame's
+// launches reported, CompactFeedback) and strides over the list, so any grid is correct for any count; surplus
+// blocks find nothing and exit.  Three counters rotate: launch j reads c[j % 3], appends to c[(j + 1) % 3] and
+// clears c[(j + 2) % 3] (which launch j - 1 read and nobody touches during launch j) for launch j + 1 to append to.
+// Same advance_one as every other schedule: results are bitwise those of the one-launch frame.
+// ---------------------------------------------------------------------------
+template <int KIND, int ARITH, int METHOD>
+__global__ __launch_bounds__(kSegBlock) __attribute__((amdgpu_waves_per_eu(kSegmentWavesMin<KIND, METHOD>)))
+void integrate_compact_kernel(
+    RayWorkspace ws, SegmentParams P, const uint32_t *__restrict__ live_in, const uint32_t *__restrict__ live_in_count,
+    uint32_t *__restrict__ live_out, uint32_t *__restrict__ live_out_count, uint32_t *__restrict__ clear_count,
+    uint32_t *__restrict__ feedback) {
+    const uint32_t n_live = *live_in_count;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *clear_count = 0u;
+        if (feedback) __hip_atomic_store(feedback, n_live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // pinned host word
+    }
+    const Hole<double> bh = make_hole(P);
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n_live; base += gridDim.x * blockDim.x) {
+        const uint32_t k = base + threadIdx.x;
+        const bool have = k < n_live;
+        const uint32_t slot = have ? live_in[k] : 0u;
+        RayRegs y;
+        y.flags = 0;
+        y.nf_ok = false;
+        y.pt = y.pph = 0.0;
+        if (have) load_ray(ws, slot, y);
+        bool live = have && ray_live(y);
+        KsRayConsts rc;
+        ray_resume<KIND, ARITH>(bh, y, P, live, rc);
+        for (uint32_t it = 0; it < P.max_tries; ++it) {
+            if (__ballot(live) == 0ull) break;
+            if (live) live = advance_one<KIND, ARITH, METHOD>(bh, y, P, ws, slot, rc);
+        }
+        if (P.final_launch && live) { // max_tries is then the hard bound no ray of a correct kernel reaches
+            y.flags = (y.flags & ~kFlagTermMask) | GRV_TERM_MAXSTEPS;
+            live = false;
+        }
+        if (have) store_ray(ws, slot, y);
+        if (live_out) { // block-aggregated append of the survivors, as in the segment kernel
+            __shared__ uint32_t s_wave_cnt[kSegBlock / 64];
+            __shared__ uint32_t s_base;
+            const unsigned long long mask = __ballot(live);
+            const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+            if (lane == 0) s_wave_cnt[wave] = (uint32_t)__popcll(mask);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t total = 0;
+                for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) total += s_wave_cnt[w];
+                s_base = total ? atomicAdd(live_out_count, total) : 0u;
+            }
+            __syncthreads();
+            if (live) {
+                uint32_t off = s_base;
+                for (uint32_t w = 0; w < wave; ++w) off += s_wave_cnt[w];
+                live_out[off + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = slot;
+            }
+            __syncthreads(); // s_wave_cnt / s_base are reused by the next stride
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // The path kernel: integrate() with IntegrationOptions.record_path (integrator.rs:32), i.e.
 // Trajectory.path (mod.rs:160).  One launch runs every ray of a (small) batch to its end and
 // appends the state after every completed loop body (mod.rs:241-243: after the step, the periodic

@@ -44,4 +44,10 @@ hipError_t launch_segment_fast(int kind, int method, const RayWorkspace &ws,
     }
 }
 
+#define GRV_COMPACT_ARITH GRV_ARITH_FAST
+#define GRV_COMPACT_FN launch_compact_fast
+#include "compact_launch.inc"
+#undef GRV_COMPACT_ARITH
+#undef GRV_COMPACT_FN
+
 } // namespace grvhip

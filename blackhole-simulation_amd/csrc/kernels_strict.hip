@@ -51,6 +51,12 @@ hipError_t launch_segment_strict(int kind, int method, const RayWorkspace &ws,
 #undef GRV_REFILL_ARITH
 #undef GRV_REFILL_FN
 
+#define GRV_COMPACT_ARITH GRV_ARITH_STRICT
+#define GRV_COMPACT_FN launch_compact_strict
+#include "compact_launch.inc"
+#undef GRV_COMPACT_ARITH
+#undef GRV_COMPACT_FN
+
 #define GRV_PATH_ARITH GRV_ARITH_STRICT
 #define GRV_PATH_FN launch_path_strict
 #include "path_launch.inc"

@@ -75,7 +75,8 @@ typedef struct {
                                            finished lanes from a device-side cursor every 8 tries;
                                       <0 = the same with a refill check every -segment_tries tries;
                                       >0 = relaunch with live-ray compaction every segment_tries
-                                           tries (one host read-back per launch).
+                                           tries (the next launch reads the live count from device
+                                           memory: the whole pass is queued without a host wait).
                                       Results do not depend on this field. */
     int32_t record_path;           /* integrator.rs:32 IntegrationOptions.record_path: read by
                                       grv_integrate_paths only (the other entry points have no path
@@ -116,7 +117,10 @@ typedef struct {
     uint32_t segment_tries; /* 0 = engine default: ONE integrate launch that runs every ray to its
                                end, queued on the stream without any host wait;
                                K > 0: the compacting wavefront schedule, K tries per launch, live
-                               rays re-listed between launches (one host read-back per launch).
+                               rays re-listed between launches; every launch after the first takes
+                               the list's length from device memory, so this pass too is queued at
+                               once (launch count and grids follow the live counts the previous
+                               pass's launches reported; a last launch runs what is left to its end).
                                Results do not depend on this field. */
     uint32_t profile;       /* 1: record HIP events around the frame's kernels on the stream; their
                                elapsed times are resolved by grv_frame_stats (GrvFrameStats.*_ms),

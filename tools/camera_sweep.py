@@ -30,14 +30,12 @@ def eye_of(r0, th_deg):
 
 def sched_params(name):
     """schedule name -> GrvRenderParams fields"""
-    if name == "one":
+    if name == "one":   # the engine default: one launch, waves longest-first by the previous frame's tries
         return dict(segment_tries=0)
-    if name == "auto":
-        return dict(segment_tries=0, schedule=bh.SCHEDULE_AUTO)
+    if name == "slot":  # one launch in slot order (every launch before ABI 8)
+        return dict(segment_tries=0, schedule=bh.SCHEDULE_SLOT_ORDER)
     if name.startswith("k"):
         return dict(segment_tries=int(name[1:]))
-    if name.startswith("h"):  # h<T>: one launch bounded at T tries, then the survivors compacted and run to their end
-        return dict(segment_tries=int(name[1:]), schedule=bh.SCHEDULE_HEAD_TAIL)
     raise SystemExit("unknown schedule " + name)
 
 
