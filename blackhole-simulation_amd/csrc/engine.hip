@@ -269,7 +269,7 @@ uint32_t try_bound(const grv_engine *e, uint64_t max_steps) {
 //   bitwise those of the single launch.
 constexpr uint32_t kCompactMaxLaunches = 192;    // bounded launches of one pass (the last, unbounded one comes on top)
 constexpr uint32_t kCompactUnknown = 0xFFFFFFFFu;
-constexpr uint32_t kCompactTailRays = 4096u;     // fewer live rays than this: leave them to the last launch
+constexpr uint32_t kCompactTailRays = 65536u;    // fewer live rays than one wave per SIMD: compaction has nothing left to fill, the last launch takes them
 
 int run_segments(grv_engine *e, const GrvOptions &o, SegmentParams P, uint32_t seg_tries,
                  hipStream_t s, bool profile) {
@@ -289,8 +289,14 @@ int run_segments(grv_engine *e, const GrvOptions &o, SegmentParams P, uint32_t s
                                  hipHostMallocCoherent | hipHostMallocMapped));
         for (uint32_t j = 0; j < kCompactMaxLaunches + 2; ++j) e->compact_fb[j] = kCompactUnknown;
     }
-    // forecast from what the launches of an earlier pass reported (entry j: live rays launch j started with)
-    volatile const uint32_t *fb = e->compact_fb;
+    // forecast from what the launches of an earlier pass reported (entry j: live rays launch j started with); a pass
+    // of another shape (ray count, tries per launch) says nothing about this one
+    if (e->compact_fb_n != n || e->compact_fb_tries != seg_tries) {
+        for (uint32_t j = 0; j < kCompactMaxLaunches + 2; ++j) e->compact_fb[j] = kCompactUnknown;
+        e->compact_fb_n = n;
+        e->compact_fb_tries = seg_tries;
+    }
+    volatile uint32_t *fb = e->compact_fb;
     uint32_t L = 0;
     for (uint32_t j = 1; j <= kCompactMaxLaunches; ++j) {
         const uint32_t v = fb[j];
@@ -309,18 +315,21 @@ int run_segments(grv_engine *e, const GrvOptions &o, SegmentParams P, uint32_t s
         const uint32_t v = fb[j];
         uint64_t rays = n;
         if (v != kCompactUnknown) {
-            rays = (uint64_t)v + v / 4u + 16384u; // headroom for a moving camera; the grid strides anyway
+            // generous: surplus blocks cost microseconds, a grid that is too small serialises the launch
+            rays = 2ull * v + 16384u;
+            if (rays < 262144u) rays = 262144u;
             if (rays > n) rays = n;
         }
+        // (one chunk per block when the forecast holds: a resident grid striding over the list measured 10 % slower,
+        // as it did for the f32 marches -- the dispatcher refills a slot faster than a block turns around)
         return (uint32_t)((rays + 255u) / 256u);
     };
     uint32_t *c = e->d_counters + 4; // three rotating live counters (d_counters[0..3]: refill cursor and spares)
     GRV_HIP(e, hipMemsetAsync(c, 0, 3 * sizeof(uint32_t), s));
+    GRV_HIP(e, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c), (int)n, 1, s)); // launch 0 "reads" c[0] = every slot
     P.max_tries = seg_tries;
     P.final_launch = 0;
-    // launch 0: every slot, appends to live[1] / c[1]
-    GRV_HIP(e, launch_segment(o.arith, o.metric_kind, o.method, e->ws, P, nullptr, n, e->live[1], c + 1, s));
-    for (uint32_t j = 1; j <= L; ++j) {
+    for (uint32_t j = 0; j <= L; ++j) { // launch 0: the identity list (null), appends to live[1] / c[1]
         const bool last = j == L;
         if (last) {
             P.max_tries = bound;
@@ -328,10 +337,12 @@ int run_segments(grv_engine *e, const GrvOptions &o, SegmentParams P, uint32_t s
         }
         uint32_t *out = last ? nullptr : e->live[(j + 1u) & 1u];
         const auto fn = o.arith == GRV_ARITH_FAST ? launch_compact_fast : launch_compact_strict;
-        GRV_HIP(e, fn(o.metric_kind, o.method, e->ws, P, e->live[j & 1u], c + (j % 3u), out, c + ((j + 1u) % 3u),
-                      c + ((j + 2u) % 3u), e->compact_fb + j, blocks_for(j), s));
+        GRV_HIP(e, fn(o.metric_kind, o.method, e->ws, P, j == 0 ? nullptr : e->live[j & 1u], c + (j % 3u), out,
+                      c + ((j + 1u) % 3u), c + ((j + 2u) % 3u), e->compact_fb + j, blocks_for(j), s));
     }
-    // (entries beyond L keep what older passes reported; the scan above stops at the first small or unknown one)
+    // what older passes reported beyond this pass's last launch is forgotten (if rays outlive the forecast, the next
+    // pass finds "unknown" there and adds launches)
+    for (uint32_t j = L + 1u; j <= kCompactMaxLaunches; ++j) fb[j] = kCompactUnknown;
     e->last_launches += L + 1u;
     return GRV_OK;
 }

@@ -71,6 +71,7 @@ struct grv_engine {
     // compacting schedule: live rays each launch of the last completed pass started with, written by the launches
     // themselves into pinned host memory (engine.hip run_segments: the next pass's forecast; never waited for)
     uint32_t *compact_fb = nullptr;
+    uint32_t compact_fb_n = 0, compact_fb_tries = 0; // shape of the pass the entries describe
     grvhip::FrameStatsDev *h_stats = nullptr; // pinned
 
     // single-ray entry (grv_integrate_ray_relativistic): its own non-blocking stream and a pinned

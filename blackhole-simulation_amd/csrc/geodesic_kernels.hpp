@@ -621,7 +621,7 @@ void integrate_compact_kernel(
     for (uint32_t base = blockIdx.x * blockDim.x; base < n_live; base += gridDim.x * blockDim.x) {
         const uint32_t k = base + threadIdx.x;
         const bool have = k < n_live;
-        const uint32_t slot = have ? live_in[k] : 0u;
+        const uint32_t slot = have ? (live_in ? live_in[k] : k) : 0u;
         RayRegs y;
         y.flags = 0;
         y.nf_ok = false;
