@@ -17,6 +17,10 @@ sys.path.insert(0, os.path.join(ROOT, "tools", "ref_vectors"))
 import export_inputs  # noqa: E402
 
 REF = os.path.join(GOLD, "ref_rays_v1.json")
+# the same pipeline over the controller ray list that tests/test_oracle_independent.py holds the oracle to
+# (tests/golden/make_golden_controller.py): one run of tools/ref_vectors on a machine with cargo pins the oracle,
+# the independent Python implementation and the reference to each other
+SETS = [("rays_v1.npz", "ref_rays_v1.json"), ("rays_v2.npz", "ref_rays_v2.json")]
 TOL_REL = 3e-7  # the reference's own libm uncertainty on end states
 
 
@@ -57,10 +61,11 @@ def compare(ref, z):
     return worst
 
 
-def test_harness_inputs_round_trip_the_golden_inputs(tmp_path):
-    z = np.load(os.path.join(GOLD, "rays_v1.npz"))
+@pytest.mark.parametrize("npz", [s[0] for s in SETS])
+def test_harness_inputs_round_trip_the_golden_inputs(tmp_path, npz):
+    z = np.load(os.path.join(GOLD, npz))
     p = tmp_path / "inputs.txt"
-    export_inputs.export(os.path.join(GOLD, "rays_v1.npz"), str(p))
+    export_inputs.export(os.path.join(GOLD, npz), str(p))
     cases = export_inputs.parse(str(p))
     assert list(cases) == [str(c) for c in z["cases"]]
     for key, c in cases.items():
@@ -93,10 +98,12 @@ def test_comparator_on_the_oracles_own_outputs(oracle):
         compare(bad, z)
 
 
-@pytest.mark.skipif(not os.path.exists(REF), reason="tests/golden/ref_rays_v1.json not generated (needs cargo: tools/ref_vectors)")
-def test_oracle_matches_the_reference_endpoints():
-    z = np.load(os.path.join(GOLD, "rays_v1.npz"))
-    with open(REF) as f:
+@pytest.mark.parametrize("npz,ref_json", SETS)
+def test_oracle_matches_the_reference_endpoints(npz, ref_json):
+    if not os.path.exists(os.path.join(GOLD, ref_json)):
+        pytest.skip("tests/golden/%s not generated (needs cargo: tools/ref_vectors)" % ref_json)
+    z = np.load(os.path.join(GOLD, npz))
+    with open(os.path.join(GOLD, ref_json)) as f:
         ref = json.load(f)
     worst = compare(ref, z)
     print("worst relative endpoint difference oracle vs gravitas-core:", worst)
