@@ -753,6 +753,8 @@ def main():
 
     in_loop_profile = world == 1 and not two  # no events in a multi-rank / two-stream timed loop
     if tg is not None:
+        tg.enable_wait_timing()  # two events around each wait point of the exchange: where a rank's stream stood still
+    if tg is not None:
         # communicator set-up (RCCL opens its xGMI peer connections on first use) belongs to
         # initialisation, not to a frame: one exchange of the still empty buffers, whatever --warmup is
         tg.run(dev_unpack, force_collective=True)
@@ -762,11 +764,14 @@ def main():
     fence()
     eng.frame_stats_reset(stream)
     torch.cuda.synchronize()
+    if tg is not None:
+        tg.exchange_wait_ms()  # drop the warm-up's wait events
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_frame(args.warmup + i, in_loop_profile)
     fence()
     elapsed = time.perf_counter() - t0
+    my_wait_ms = tg.exchange_wait_ms() / max(args.steps, 1) if tg is not None else 0.0
     st, integ_ms, launches = read_stats()
     steps_local = st.accepted_steps
     rays_local = st.rays // max(args.steps, 1) if cfg == "c3" else min(n_local, W * H)
@@ -789,9 +794,12 @@ def main():
     # per-rank mean integrate-launch time (every rank's own HIP events), gathered for the JSON line
     my_ms = integ_ms / max(launches, 1)
     rank_ms = [my_ms]
+    rank_wait_ms = [my_wait_ms]
     if use_dist:
         rank_ms = [None] * world
         dist.all_gather_object(rank_ms, my_ms)
+        rank_wait_ms = [None] * world
+        dist.all_gather_object(rank_wait_ms, my_wait_ms)
     agg = torch.tensor([elapsed, float(steps_local), float(rays_local)], dtype=torch.float64, device="cuda")
     if use_dist:
         tmax = agg[:1].clone()
@@ -829,6 +837,11 @@ def main():
             "rank_integrate_ms": {"min": round(min(rank_ms), 4), "max": round(max(rank_ms), 4),
                                   "per_rank": [round(x, 4) for x in rank_ms],
                                   "source": "mean HIP-event time of a rank's march / integrate launch (%s)" % prof_note},
+            # per rank and frame: how long the rank's streams stood at the exchange's wait points (the gather of the
+            # previous frame, the reader of a send buffer) -- with rank_integrate_ms, where a scaling point's time went
+            "exchange_wait_ms": ({"per_rank": [round(x, 4) for x in rank_wait_ms], "max": round(max(rank_wait_ms), 4),
+                                  "source": "HIP events around TileGather's wait points on the rank's stream, mean per timed frame"}
+                                 if use_dist else None),
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None,

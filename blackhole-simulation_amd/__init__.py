@@ -14,5 +14,5 @@ from .engine import (  # noqa: F401
     GLSL_LENSING, GLSL_DISK, GLSL_DOPPLER, GLSL_STARS, GLSL_PHOTON_GLOW, GLSL_JETS, GLSL_REDSHIFT,
     GLSL_DITHER, GLSL_FEATURES_DEFAULT, AtaaParams, BloomParams, TaaParams,
     MultiEngine, TRANSPORT_AUTO, TRANSPORT_PEER_COPY, TRANSPORT_RCCL, rccl_probe,
-    EXCHANGE_RGBA16F, EXCHANGE_RGBA32F, unlock_test_hooks, DeviceImage, SCHEDULE_DEFAULT, SCHEDULE_SLOT_ORDER,
+    EXCHANGE_RGBA16F, EXCHANGE_RGBA32F, unlock_test_hooks, DeviceImage, SCHEDULE_DEFAULT, SCHEDULE_SLOT_ORDER, FAULT_NONE, FAULT_RENDER, FAULT_SEND, FAULT_PEER_COPY,
 )

@@ -21,10 +21,10 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
-#include <condition_variable>
 #include <functional>
 #include <mutex>
-#include <thread>
+
+#include "multi_core.hpp"
 
 using namespace grvhost;
 
@@ -113,101 +113,88 @@ int cfail(int code, const char *fmt, ...) {
     return code;
 }
 
-// One worker thread per rank.  run(job) hands `job(rank)` to every worker and returns when all of
-// them have finished QUEUEING (the device work stays asynchronous); the first non-zero status wins.
-class RankThreads {
-  public:
-    explicit RankThreads(int n) : n_(n), rc_(n, 0) {
-        for (int r = 0; r < n; ++r) th_.emplace_back([this, r] { loop(r); });
+// The HIP / RCCL side of grvmulti::Core (multi_core.hpp lists what an Api provides).
+struct HipApi {
+    using Stream = hipStream_t;
+    using Event = hipEvent_t;
+    std::vector<ncclComm_t> comm;
+    const char *error_text() const { return msg().c_str(); }
+    static std::string &msg() {
+        static thread_local std::string m;
+        return m;
     }
-    ~RankThreads() {
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            stop_ = true;
-            ++gen_;
-        }
-        cv_.notify_all();
-        for (auto &t : th_) t.join();
+    static int hip(hipError_t st) {
+        if (st == hipSuccess) return GRV_OK;
+        msg() = hipGetErrorString(st);
+        (void)hipGetLastError();
+        return st == hipErrorOutOfMemory ? GRV_ERR_OOM : GRV_ERR_HIP;
     }
-    int run(const std::function<int(int)> &job) {
-        std::unique_lock<std::mutex> lk(mu_);
-        job_ = &job;
-        pending_ = n_;
-        ++gen_;
-        cv_.notify_all();
-        done_.wait(lk, [this] { return pending_ == 0; });
-        job_ = nullptr;
-        for (int rc : rc_)
-            if (rc != 0) return rc;
-        return 0;
+    static int nccl(ncclResult_t st) {
+        if (st == ncclSuccess) return GRV_OK;
+        msg() = g_rccl.GetErrorString(st);
+        return GRV_ERR_HIP;
     }
-
-  private:
-    void loop(int r) {
-        uint64_t seen = 0;
-        for (;;) {
-            const std::function<int(int)> *job;
-            {
-                std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [&] { return gen_ != seen; });
-                seen = gen_;
-                if (stop_) return;
-                job = job_;
-            }
-            const int rc = (*job)(r);
-            {
-                std::lock_guard<std::mutex> lk(mu_);
-                rc_[r] = rc;
-                if (--pending_ == 0) done_.notify_all();
-            }
-        }
+    int set_device(int d) { return hip(hipSetDevice(d)); }
+    int device_synchronize() { return hip(hipDeviceSynchronize()); }
+    int malloc(void **p, size_t bytes) { return hip(hipMalloc(p, bytes)); }
+    void free(void *p) { (void)hipFree(p); }
+    int stream_wait_event(Stream s, Event e) { return hip(hipStreamWaitEvent(s, e, 0)); }
+    int event_record(Event e, Stream s) { return hip(hipEventRecord(e, s)); }
+    int copy_to_rank0(void *dst, int dst_dev, const void *src, int src_dev, size_t bytes, Stream s) {
+        return hip(dst_dev == src_dev ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s)
+                                      : hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, s));
     }
-    int n_;
-    std::vector<std::thread> th_;
-    std::vector<int> rc_;
-    std::mutex mu_;
-    std::condition_variable cv_, done_;
-    const std::function<int(int)> *job_ = nullptr;
-    int pending_ = 0;
-    uint64_t gen_ = 0;
-    bool stop_ = false;
+    int copy_on_device(void *dst, const void *src, size_t bytes, Stream s) {
+        return hip(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
+    }
+    int pack_half(const float *src, void *dst, size_t n_px, Stream s) { return hip(launch_pack_half(src, dst, n_px, s)); }
+    int widen_half(const void *src, float *dst, size_t n_px, Stream s) { return hip(launch_widen_half(src, dst, n_px, s)); }
+    int quantize(float *img, size_t n_px, Stream s) { return hip(launch_post_quantize(img, (uint32_t)n_px, s)); }
+    static GrvRenderParams geom_of(uint32_t width, uint32_t height, int G, int r) {
+        GrvRenderParams geom{};
+        geom.width = width;
+        geom.height = height;
+        geom.tile_world = (uint32_t)G;
+        geom.tile_rank = (uint32_t)r;
+        return geom;
+    }
+    int unpack_tiles(uint32_t width, uint32_t height, int G, int r, const void *slot, float *image, bool half, Stream s) {
+        FrameGeom FG;
+        frame_geometry(geom_of(width, height, G, r), FG);
+        return hip(half ? launch_unpack_tiles_half(FG, slot, image, s) : launch_unpack_tiles(FG, slot, image, 4u, s));
+    }
+    size_t share_pixels(uint32_t width, uint32_t height, int G, int r) {
+        const GrvRenderParams geom = geom_of(width, height, G, r);
+        return grv_frame_ray_count(&geom);
+    }
+    size_t slot_pixels(uint32_t width, uint32_t height, int G) {
+        const size_t total = (size_t)tile_pitch(width, (uint32_t)G) * ((height + 63u) / 64u);
+        return (total + (size_t)G - 1) / (size_t)G * 4096u;
+    }
+    int group_start() { return nccl(g_rccl.GroupStart()); }
+    int group_end() { return nccl(g_rccl.GroupEnd()); }
+    int send(const void *src, size_t n, bool half, int r, Stream s) {
+        return nccl(g_rccl.Send(src, n, half ? ncclHalf : ncclFloat, 0, comm[r], s));
+    }
+    int recv(void *dst, size_t n, bool half, int from, Stream s) {
+        return nccl(g_rccl.Recv(dst, n, half ? ncclHalf : ncclFloat, from, comm[0], s));
+    }
 };
 
 } // namespace
 
+static_assert(grvmulti::OK == GRV_OK && grvmulti::ERR_INVALID == GRV_ERR_INVALID && grvmulti::ERR_HIP == GRV_ERR_HIP, "status codes");
+static_assert(grvmulti::TRANSPORT_RCCL == GRV_TRANSPORT_RCCL && grvmulti::TRANSPORT_PEER_COPY == GRV_TRANSPORT_PEER_COPY, "transports");
+static_assert(grvmulti::FORMAT_RGBA32F == GRV_EXCHANGE_RGBA32F && grvmulti::FORMAT_RGBA16F == GRV_EXCHANGE_RGBA16F, "formats");
+static_assert(grvmulti::FAULT_RENDER == GRV_FAULT_RENDER && grvmulti::FAULT_SEND == GRV_FAULT_SEND &&
+              grvmulti::FAULT_PEER_COPY == GRV_FAULT_PEER_COPY, "fault kinds");
+
 struct grv_multi {
-    int G = 0;
-    int transport = GRV_TRANSPORT_PEER_COPY;
+    grvmulti::Core<HipApi> c; // rank threads, exchange buffers, the frame skeleton (multi_core.hpp)
     bool virtual_ranks = false;
-    bool self_exchange = false; // test hook: rank 0's own share travels through the transport too
-    std::vector<int> dev;
     std::vector<grv_engine *> eng;
-    std::string err;
-
-    int format = GRV_EXCHANGE_RGBA32F; // what travels: RGBA f32 (16 B / pixel) or RGBA binary16 (8 B / pixel)
-
-    struct Rank {
-        hipStream_t s[2] = {nullptr, nullptr};
-        float *send[2] = {nullptr, nullptr}; // packed tile-order RGBA f32 (ranks >= 1; rank 0 under self_exchange
-                                             // and, RGBA16F, as its f32 render target)
-        void *send16[2] = {nullptr, nullptr}; // RGBA16F: the share as it travels (ranks that exchange)
-        hipEvent_t arrived[2] = {nullptr, nullptr}; // this rank's tiles of frame parity b sit in rank 0's slot
-    };
-    std::vector<Rank> rank;
-    size_t slot_px = 0; // pixels per receive slot / send buffer (max tiles of a rank * 4096)
-
-    // rank 0 side
-    float *recv[2] = {nullptr, nullptr}; // [G][slot_px][4] per parity (RGBA16F: [G][slot_px] x 8 B in the same allocation)
-    hipStream_t rs[2] = {nullptr, nullptr}; // exchange + unpack streams
-    hipEvent_t unpacked[2] = {nullptr, nullptr};
-    bool unpacked_rec[2] = {false, false};
-    hipEvent_t caller_ready = nullptr;
     float *image = nullptr; // host-pointer entry: assembled image on rank 0's device
     size_t image_px = 0;
-
-    std::vector<ncclComm_t> comm;
-    RankThreads *threads = nullptr;
-    uint64_t frame = 0;
 };
 
 namespace {
@@ -218,7 +205,7 @@ int mfail(grv_multi *m, int code, const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (m) m->err = buf;
+    if (m) m->c.err = buf;
     return code;
 }
 
@@ -229,185 +216,12 @@ int mfail(grv_multi *m, int code, const char *fmt, ...) {
             return mfail((m), _st == hipErrorOutOfMemory ? GRV_ERR_OOM : GRV_ERR_HIP,         \
                          "%s failed: %s", #call, hipGetErrorString(_st));                    \
     } while (0)
-#define GRVM_NCCL(m, call)                                                                   \
-    do {                                                                                     \
-        ncclResult_t _st = (call);                                                           \
-        if (_st != ncclSuccess)                                                              \
-            return mfail((m), GRV_ERR_HIP, "%s failed: %s", #call, g_rccl.GetErrorString(_st)); \
-    } while (0)
 
-size_t max_tiles_per_rank(uint32_t width, uint32_t height, uint32_t world) {
-    const size_t total = (size_t)tile_pitch(width, world) * ((height + 63u) / 64u);
-    return (total + world - 1) / world;
-}
-
-// Waits for the devices and frees every exchange buffer (the next frame allocates for the mode /
-// size then in force).
-int drop_buffers(grv_multi *m) {
-    for (int r = 0; r < m->G; ++r) {
-        GRVM_HIP(m, hipSetDevice(m->dev[r]));
-        GRVM_HIP(m, hipDeviceSynchronize());
-        for (int b = 0; b < 2; ++b) {
-            if (m->rank[r].send[b]) (void)hipFree(m->rank[r].send[b]);
-            if (m->rank[r].send16[b]) (void)hipFree(m->rank[r].send16[b]);
-            m->rank[r].send[b] = nullptr;
-            m->rank[r].send16[b] = nullptr;
-        }
-    }
-    GRVM_HIP(m, hipSetDevice(m->dev[0]));
-    for (int b = 0; b < 2; ++b) {
-        if (m->recv[b]) (void)hipFree(m->recv[b]);
-        m->recv[b] = nullptr;
-        m->unpacked_rec[b] = false;
-    }
-    m->slot_px = 0;
-    return GRV_OK;
-}
-
-// Buffers sized for a width x height frame split over G ranks (grown on demand; growing waits for
-// the device -- frames of a fixed size never do).
-int ensure_buffers(grv_multi *m, uint32_t width, uint32_t height) {
-    const size_t need = max_tiles_per_rank(width, height, (uint32_t)m->G) * 4096u;
-    if (need <= m->slot_px) return GRV_OK;
-    int rc = drop_buffers(m);
-    if (rc != GRV_OK) return rc;
-    const bool half = m->format == GRV_EXCHANGE_RGBA16F;
-    const size_t wire = half ? 8u : 16u; // bytes per pixel as exchanged
-    for (int b = 0; b < 2; ++b)
-        GRVM_HIP(m, hipMalloc(reinterpret_cast<void **>(&m->recv[b]), (size_t)m->G * need * wire));
-    for (int r = 0; r < m->G; ++r) {
-        const bool direct = (r == 0 && !m->self_exchange); // rank 0's share needs no transport
-        if (direct && !half) continue;                     // ... and, RGBA f32, is rendered into its receive slot
-        GRVM_HIP(m, hipSetDevice(m->dev[r]));
-        for (int b = 0; b < 2; ++b) {
-            GRVM_HIP(m, hipMalloc(reinterpret_cast<void **>(&m->rank[r].send[b]), need * 16u));
-            if (half && !direct) GRVM_HIP(m, hipMalloc(&m->rank[r].send16[b], need * 8u));
-        }
-    }
-    m->slot_px = need;
-    return GRV_OK;
-}
-
-// The frame skeleton shared by the f64 frame and the f32 compute march.
-//   render(rank, engine, target, stream): queue this rank's tile share into `target` (packed tile
-//   order, RGBA f32) on `stream`; n_px(rank): pixels of that share.
 int run_frame(grv_multi *m, uint32_t width, uint32_t height, float *d_rgba, hipStream_t caller,
               const std::function<int(int, grv_engine *, float *, hipStream_t)> &render) {
-    if (!d_rgba) return mfail(m, GRV_ERR_INVALID, "null image");
-    if (width == 0 || height == 0) return mfail(m, GRV_ERR_INVALID, "empty frame");
-    const int G = m->G;
-    const bool half = m->format == GRV_EXCHANGE_RGBA16F;
-    if (G == 1 && !m->self_exchange) {
-        // one rank: the whole frame is already row-major (GrvFrameBuffers), nothing to exchange
-        GRVM_HIP(m, hipSetDevice(m->dev[0]));
-        const int rc = render(0, m->eng[0], d_rgba, caller);
-        if (rc != GRV_OK) return mfail(m, rc, "rank 0: %s", grv_last_error(m->eng[0]));
-        // RGBA16F: the image a G-rank handle assembles is the half-rounded frame; so is this one
-        if (half) GRVM_HIP(m, launch_post_quantize(d_rgba, width * height, caller));
-        m->frame++;
-        return GRV_OK;
-    }
-    int rc = ensure_buffers(m, width, height);
-    if (rc != GRV_OK) return rc;
-    const int b = (int)(m->frame & 1u);
-    GrvRenderParams geom{};
-    geom.width = width;
-    geom.height = height;
-    geom.tile_world = (uint32_t)G;
-    std::vector<size_t> n_px(G);
-    for (int r = 0; r < G; ++r) {
-        geom.tile_rank = (uint32_t)r;
-        n_px[r] = grv_frame_ray_count(&geom);
-    }
-    const bool rccl = m->transport == GRV_TRANSPORT_RCCL;
-    const size_t wire = half ? 8u : 16u;
-
-    // every rank: render its share (and, peer-copy transport, push it to rank 0) on its own thread
-    rc = m->threads->run([&](int r) -> int {
-        grv_multi::Rank &R = m->rank[r];
-        if (hipSetDevice(m->dev[r]) != hipSuccess) return GRV_ERR_HIP;
-        hipStream_t s = R.s[b];
-        // the receive slot of this parity is free once frame - 2 has been unpacked
-        if (m->unpacked_rec[b] && hipStreamWaitEvent(s, m->unpacked[b], 0) != hipSuccess) return GRV_ERR_HIP;
-        // receive slot of rank r: f32 pixels, or (RGBA16F) 8-byte pixels in the same allocation
-        char *slot = reinterpret_cast<char *>(m->recv[b]) + (size_t)r * m->slot_px * wire;
-        const bool direct = (r == 0 && !m->self_exchange);
-        float *target = (direct && !half) ? reinterpret_cast<float *>(slot) : R.send[b];
-        if (n_px[r] > 0) {
-            const int st = render(r, m->eng[r], target, s);
-            if (st != GRV_OK) return st;
-        }
-        const void *wire_src = target;
-        if (half && n_px[r] > 0) {
-            // narrow the share to binary16 where it was rendered: rank 0's straight into its slot
-            void *dst = direct ? static_cast<void *>(slot) : R.send16[b];
-            if (launch_pack_half(target, dst, n_px[r], s) != hipSuccess) return GRV_ERR_HIP;
-            wire_src = dst;
-        }
-        if (!direct && !rccl && n_px[r] > 0) {
-            const hipError_t st = (m->dev[r] == m->dev[0])
-                                      ? hipMemcpyAsync(slot, wire_src, n_px[r] * wire, hipMemcpyDeviceToDevice, s)
-                                      : hipMemcpyPeerAsync(slot, m->dev[0], wire_src, m->dev[r], n_px[r] * wire, s);
-            if (st != hipSuccess) return GRV_ERR_HIP;
-        }
-        // RCCL: the event marks "rendered"; the transfer itself is ordered by ncclRecv on rank 0's stream
-        if (hipEventRecord(R.arrived[b], s) != hipSuccess) return GRV_ERR_HIP;
-        return GRV_OK;
-    });
-    if (rc != GRV_OK) {
-        for (int r = 0; r < G; ++r)
-            if (m->eng[r] && *grv_last_error(m->eng[r])) return mfail(m, rc, "rank %d: %s", r, grv_last_error(m->eng[r]));
-        return mfail(m, rc, "a rank failed to queue its share: %s", hipGetErrorString(hipGetLastError()));
-    }
-
-    // rank 0: the one exchange, then the de-interleave into the caller's image
-    GRVM_HIP(m, hipSetDevice(m->dev[0]));
-    hipStream_t rs = m->rs[b];
-    if (rccl) {
-        // one group: G-1 sends on the ranks' render streams (behind their kernels), G-1 receives
-        // on rank 0's exchange stream -- concurrent point-to-point transfers, one xGMI link each
-        GRVM_NCCL(m, g_rccl.GroupStart());
-        ncclResult_t gst = ncclSuccess; // a failed call must not leave the group open: always reach GroupEnd
-        for (int r = (m->self_exchange ? 0 : 1); r < G && gst == ncclSuccess; ++r) {
-            if (n_px[r] == 0) continue;
-            // four channels per pixel either way: ncclFloat or ncclHalf elements
-            const ncclDataType_t ty = half ? ncclHalf : ncclFloat;
-            const void *src = half ? m->rank[r].send16[b] : static_cast<const void *>(m->rank[r].send[b]);
-            gst = g_rccl.Send(src, n_px[r] * 4u, ty, 0, m->comm[r], m->rank[r].s[b]);
-            if (gst == ncclSuccess)
-                gst = g_rccl.Recv(reinterpret_cast<char *>(m->recv[b]) + (size_t)r * m->slot_px * wire, n_px[r] * 4u, ty, r,
-                                  m->comm[0], rs);
-        }
-        const ncclResult_t gend = g_rccl.GroupEnd();
-        if (gst != ncclSuccess) return mfail(m, GRV_ERR_HIP, "ncclSend / ncclRecv failed: %s", g_rccl.GetErrorString(gst));
-        GRVM_NCCL(m, gend);
-        if (!m->self_exchange) GRVM_HIP(m, hipStreamWaitEvent(rs, m->rank[0].arrived[b], 0));
-    } else {
-        for (int r = 0; r < G; ++r) GRVM_HIP(m, hipStreamWaitEvent(rs, m->rank[r].arrived[b], 0));
-    }
-    // the caller's image may still be read by work the caller queued earlier
-    GRVM_HIP(m, hipEventRecord(m->caller_ready, caller));
-    GRVM_HIP(m, hipStreamWaitEvent(rs, m->caller_ready, 0));
-    if (G == 1) {
-        // (self-exchange walk) one rank's share is the whole frame, already row-major
-        if (half) GRVM_HIP(m, launch_widen_half(m->recv[b], d_rgba, n_px[0], rs));
-        else GRVM_HIP(m, hipMemcpyAsync(d_rgba, m->recv[b], n_px[0] * 16u, hipMemcpyDeviceToDevice, rs));
-    } else {
-        for (int r = 0; r < G; ++r) {
-            if (n_px[r] == 0) continue;
-            geom.tile_rank = (uint32_t)r;
-            FrameGeom FG;
-            frame_geometry(geom, FG);
-            const char *slot = reinterpret_cast<const char *>(m->recv[b]) + (size_t)r * m->slot_px * wire;
-            if (half) GRVM_HIP(m, launch_unpack_tiles_half(FG, slot, d_rgba, rs));
-            else GRVM_HIP(m, launch_unpack_tiles(FG, slot, d_rgba, 4u, rs));
-        }
-    }
-    GRVM_HIP(m, hipEventRecord(m->unpacked[b], rs));
-    m->unpacked_rec[b] = true;
-    GRVM_HIP(m, hipStreamWaitEvent(caller, m->unpacked[b], 0)); // the image is complete in the caller's stream order
-    m->frame++;
-    return GRV_OK;
+    return m->c.run_frame(
+        width, height, d_rgba, caller, [&](int r, float *target, hipStream_t s) { return render(r, m->eng[r], target, s); },
+        [&](int r) { return std::string(grv_last_error(m->eng[r])); });
 }
 
 int create_common(double mass, double spin, const std::vector<int> &devs, bool virt, int transport,
@@ -432,12 +246,12 @@ int create_common(double mass, double spin, const std::vector<int> &devs, bool v
         return cfail(GRV_ERR_INVALID, "multi-GPU handle: RCCL takes one rank per device");
     grv_multi *m = new (std::nothrow) grv_multi();
     if (!m) return cfail(GRV_ERR_OOM, "multi-GPU handle: out of host memory");
-    m->G = G;
-    m->dev = devs;
+    m->c.G = G;
+    m->c.dev = devs;
     m->virtual_ranks = virt;
-    m->transport = transport;
+    m->c.transport = transport;
     m->eng.assign(G, nullptr);
-    m->rank.resize(G);
+    m->c.rank.resize(G);
     auto bail = [&](int code) {
         grv_multi_destroy(m);
         return code;
@@ -462,8 +276,8 @@ int create_common(double mass, double spin, const std::vector<int> &devs, bool v
                               devs[r], r, rc, rc == GRV_ERR_NO_DEVICE ? " (no usable HIP device)" : ""));
         GRVC_HIP(hipSetDevice(devs[r]), "hipSetDevice", r);
         for (int b = 0; b < 2; ++b) {
-            GRVC_HIP(hipStreamCreateWithFlags(&m->rank[r].s[b], hipStreamNonBlocking), "hipStreamCreate", r);
-            GRVC_HIP(hipEventCreateWithFlags(&m->rank[r].arrived[b], hipEventDisableTiming), "hipEventCreate", r);
+            GRVC_HIP(hipStreamCreateWithFlags(&m->c.rank[r].s[b], hipStreamNonBlocking), "hipStreamCreate", r);
+            GRVC_HIP(hipEventCreateWithFlags(&m->c.rank[r].arrived[b], hipEventDisableTiming), "hipEventCreate", r);
         }
         // peer access rank r -> rank 0 for the push copies (RCCL sets up its own mappings)
         if (r > 0 && devs[r] != devs[0]) {
@@ -477,10 +291,10 @@ int create_common(double mass, double spin, const std::vector<int> &devs, bool v
     }
     GRVC_HIP(hipSetDevice(devs[0]), "hipSetDevice", 0);
     for (int b = 0; b < 2; ++b) {
-        GRVC_HIP(hipStreamCreateWithFlags(&m->rs[b], hipStreamNonBlocking), "hipStreamCreate (exchange)", 0);
-        GRVC_HIP(hipEventCreateWithFlags(&m->unpacked[b], hipEventDisableTiming), "hipEventCreate (exchange)", 0);
+        GRVC_HIP(hipStreamCreateWithFlags(&m->c.rs[b], hipStreamNonBlocking), "hipStreamCreate (exchange)", 0);
+        GRVC_HIP(hipEventCreateWithFlags(&m->c.unpacked[b], hipEventDisableTiming), "hipEventCreate (exchange)", 0);
     }
-    GRVC_HIP(hipEventCreateWithFlags(&m->caller_ready, hipEventDisableTiming), "hipEventCreate (caller)", 0);
+    GRVC_HIP(hipEventCreateWithFlags(&m->c.caller_ready, hipEventDisableTiming), "hipEventCreate (caller)", 0);
 #undef GRVC_HIP
     if (transport == GRV_TRANSPORT_RCCL) {
         std::lock_guard<std::mutex> lk(g_rccl_mu);
@@ -488,15 +302,15 @@ int create_common(double mass, double spin, const std::vector<int> &devs, bool v
         // devices included) and cannot have it is refused, with the reason
         if (!g_rccl.load())
             return bail(cfail(GRV_ERR_NO_DEVICE, "RCCL transport unavailable: %s", g_rccl.err.c_str()));
-        m->comm.assign(G, nullptr);
-        const ncclResult_t st = g_rccl.CommInitAll(m->comm.data(), G, devs.data());
+        m->c.api.comm.assign(G, nullptr);
+        const ncclResult_t st = g_rccl.CommInitAll(m->c.api.comm.data(), G, devs.data());
         if (st != ncclSuccess) {
-            m->comm.clear();
+            m->c.api.comm.clear();
             return bail(cfail(GRV_ERR_HIP, "ncclCommInitAll over %d devices failed: %s", G, g_rccl.GetErrorString(st)));
         }
     }
-    m->threads = new (std::nothrow) RankThreads(G);
-    if (!m->threads) return bail(cfail(GRV_ERR_OOM, "multi-GPU handle: out of host memory (rank threads)"));
+    m->c.threads = new (std::nothrow) grvmulti::RankThreads(G);
+    if (!m->c.threads) return bail(cfail(GRV_ERR_OOM, "multi-GPU handle: out of host memory (rank threads)"));
     *out = m;
     return GRV_OK;
 }
@@ -520,42 +334,42 @@ int grv_engine_create_multi_virtual(double mass, double spin, int device, int ra
 
 void grv_multi_destroy(grv_multi *m) {
     if (!m) return;
-    delete m->threads; // joins the workers
-    m->threads = nullptr;
-    for (int r = 0; r < m->G; ++r) {
-        if (hipSetDevice(m->dev[r]) != hipSuccess) continue;
+    delete m->c.threads; // joins the workers
+    m->c.threads = nullptr;
+    for (int r = 0; r < m->c.G; ++r) {
+        if (hipSetDevice(m->c.dev[r]) != hipSuccess) continue;
         (void)hipDeviceSynchronize();
     }
-    if (!m->comm.empty())
-        for (auto c : m->comm)
+    if (!m->c.api.comm.empty())
+        for (auto c : m->c.api.comm)
             if (c) (void)g_rccl.CommDestroy(c);
-    for (int r = 0; r < m->G; ++r) {
-        (void)hipSetDevice(m->dev[r]);
+    for (int r = 0; r < m->c.G; ++r) {
+        (void)hipSetDevice(m->c.dev[r]);
         for (int b = 0; b < 2; ++b) {
-            if (m->rank[r].send[b]) (void)hipFree(m->rank[r].send[b]);
-            if (m->rank[r].send16[b]) (void)hipFree(m->rank[r].send16[b]);
-            if (m->rank[r].s[b]) (void)hipStreamDestroy(m->rank[r].s[b]);
-            if (m->rank[r].arrived[b]) (void)hipEventDestroy(m->rank[r].arrived[b]);
+            if (m->c.rank[r].send[b]) (void)hipFree(m->c.rank[r].send[b]);
+            if (m->c.rank[r].send16[b]) (void)hipFree(m->c.rank[r].send16[b]);
+            if (m->c.rank[r].s[b]) (void)hipStreamDestroy(m->c.rank[r].s[b]);
+            if (m->c.rank[r].arrived[b]) (void)hipEventDestroy(m->c.rank[r].arrived[b]);
         }
         if (m->eng[r]) grv_engine_destroy(m->eng[r]);
     }
-    (void)hipSetDevice(m->dev[0]);
+    (void)hipSetDevice(m->c.dev[0]);
     for (int b = 0; b < 2; ++b) {
-        if (m->recv[b]) (void)hipFree(m->recv[b]);
-        if (m->rs[b]) (void)hipStreamDestroy(m->rs[b]);
-        if (m->unpacked[b]) (void)hipEventDestroy(m->unpacked[b]);
+        if (m->c.recv[b]) (void)hipFree(m->c.recv[b]);
+        if (m->c.rs[b]) (void)hipStreamDestroy(m->c.rs[b]);
+        if (m->c.unpacked[b]) (void)hipEventDestroy(m->c.unpacked[b]);
     }
-    if (m->caller_ready) (void)hipEventDestroy(m->caller_ready);
+    if (m->c.caller_ready) (void)hipEventDestroy(m->c.caller_ready);
     if (m->image) (void)hipFree(m->image);
     delete m;
 }
 
-const char *grv_multi_last_error(const grv_multi *m) { return m ? m->err.c_str() : "null handle"; }
-int grv_multi_rank_count(const grv_multi *m) { return m ? m->G : 0; }
+const char *grv_multi_last_error(const grv_multi *m) { return m ? m->c.err.c_str() : "null handle"; }
+int grv_multi_rank_count(const grv_multi *m) { return m ? m->c.G : 0; }
 int grv_multi_rank_device(const grv_multi *m, int rank) {
-    return (m && rank >= 0 && rank < m->G) ? m->dev[rank] : -1;
+    return (m && rank >= 0 && rank < m->c.G) ? m->c.dev[rank] : -1;
 }
-int grv_multi_transport(const grv_multi *m) { return m ? m->transport : -1; }
+int grv_multi_transport(const grv_multi *m) { return m ? m->c.transport : -1; }
 
 const char *grv_multi_create_error(void) { return g_create_err.c_str(); }
 
@@ -584,9 +398,20 @@ int grv_multi_test_self_exchange(grv_multi *m, int enable) {
     int rc = grv_multi_synchronize(m);
     if (rc != GRV_OK) return rc;
     // the buffers are laid out for the other mode: drop them, the next frame allocates afresh
-    rc = drop_buffers(m);
+    rc = m->c.drop_buffers();
     if (rc != GRV_OK) return rc;
-    m->self_exchange = enable != 0;
+    m->c.self_exchange = enable != 0;
+    return GRV_OK;
+}
+
+int grv_multi_test_inject_fault(grv_multi *m, int kind, int rank) {
+    if (!m) return GRV_ERR_INVALID;
+    if (!grv_test_hooks_unlocked())
+        return mfail(m, GRV_ERR_INVALID, "grv_multi_test_inject_fault: verification hooks are locked (grv_test_hooks_unlock)");
+    if (kind < GRV_FAULT_NONE || kind > GRV_FAULT_PEER_COPY || rank < 0 || rank >= m->c.G)
+        return mfail(m, GRV_ERR_INVALID, "grv_multi_test_inject_fault: kind %d / rank %d out of range", kind, rank);
+    m->c.fault_kind = kind;
+    m->c.fault_rank = rank;
     return GRV_OK;
 }
 
@@ -594,40 +419,40 @@ int grv_multi_set_exchange_format(grv_multi *m, int format) {
     if (!m) return GRV_ERR_INVALID;
     if (format != GRV_EXCHANGE_RGBA32F && format != GRV_EXCHANGE_RGBA16F)
         return mfail(m, GRV_ERR_INVALID, "unknown exchange format %d", format);
-    if (format == m->format) return GRV_OK;
+    if (format == m->c.format) return GRV_OK;
     int rc = grv_multi_synchronize(m);
     if (rc != GRV_OK) return rc;
-    rc = drop_buffers(m); // sized for the other pixel width
+    rc = m->c.drop_buffers(); // sized for the other pixel width
     if (rc != GRV_OK) return rc;
-    m->format = format;
+    m->c.format = format;
     return GRV_OK;
 }
-int grv_multi_exchange_format(const grv_multi *m) { return m ? m->format : -1; }
+int grv_multi_exchange_format(const grv_multi *m) { return m ? m->c.format : -1; }
 size_t grv_multi_exchange_bytes_per_frame(const grv_multi *m, uint32_t width, uint32_t height) {
     if (!m) return 0;
     GrvRenderParams geom{};
     geom.width = width;
     geom.height = height;
-    geom.tile_world = (uint32_t)m->G;
+    geom.tile_world = (uint32_t)m->c.G;
     size_t px = 0;
-    for (int r = (m->self_exchange ? 0 : 1); r < m->G; ++r) {
+    for (int r = (m->c.self_exchange ? 0 : 1); r < m->c.G; ++r) {
         geom.tile_rank = (uint32_t)r;
         px += grv_frame_ray_count(&geom);
     }
-    if (m->G == 1 && !m->self_exchange) px = 0;
-    return px * (m->format == GRV_EXCHANGE_RGBA16F ? 8u : 16u);
+    if (m->c.G == 1 && !m->c.self_exchange) px = 0;
+    return px * (m->c.format == GRV_EXCHANGE_RGBA16F ? 8u : 16u);
 }
 
 int grv_multi_rank_frame_stats(grv_multi *m, int rank, GrvFrameStats *out) {
-    if (!m || !out || rank < 0 || rank >= m->G) return GRV_ERR_INVALID;
+    if (!m || !out || rank < 0 || rank >= m->c.G) return GRV_ERR_INVALID;
     int rc = grv_multi_synchronize(m);
     if (rc != GRV_OK) return rc;
-    rc = grv_frame_stats(m->eng[rank], m->rank[rank].s[0], out);
+    rc = grv_frame_stats(m->eng[rank], m->c.rank[rank].s[0], out);
     if (rc != GRV_OK) return mfail(m, rc, "rank %d: %s", rank, grv_last_error(m->eng[rank]));
     return GRV_OK;
 }
 grv_engine *grv_multi_engine(grv_multi *m, int rank) {
-    return (m && rank >= 0 && rank < m->G) ? m->eng[rank] : nullptr;
+    return (m && rank >= 0 && rank < m->c.G) ? m->eng[rank] : nullptr;
 }
 
 int grv_multi_update_params(grv_multi *m, double mass, double spin) {
@@ -646,11 +471,11 @@ int grv_render_frame_multi_device(grv_multi *m, const GrvCamera *cam, const GrvR
     if (p->tile_world > 1) return mfail(m, GRV_ERR_INVALID, "the multi-GPU entry deals the tiles itself: tile_world must be 0 or 1");
     const GrvRenderParams base = *p;
     const GrvCamera camera = *cam;
-    const int G = m->G;
+    const int G = m->c.G;
     return run_frame(m, p->width, p->height, d_rgba, static_cast<hipStream_t>(root_stream),
                      [&](int r, grv_engine *e, float *target, hipStream_t s) -> int {
                          GrvRenderParams rp = base;
-                         if (G > 1 || m->self_exchange) {
+                         if (G > 1 || m->c.self_exchange) {
                              rp.tile_world = (uint32_t)G;
                              rp.tile_rank = (uint32_t)r;
                          }
@@ -665,11 +490,11 @@ int grv_render_frame_wgsl_multi_device(grv_multi *m, const GrvWgslParams *p, flo
     if (!p) return mfail(m, GRV_ERR_INVALID, "null argument");
     if (p->tile_world > 1) return mfail(m, GRV_ERR_INVALID, "the multi-GPU entry deals the tiles itself: tile_world must be 0 or 1");
     const GrvWgslParams base = *p;
-    const int G = m->G;
+    const int G = m->c.G;
     return run_frame(m, p->width, p->height, d_rgba, static_cast<hipStream_t>(root_stream),
                      [&](int r, grv_engine *e, float *target, hipStream_t s) -> int {
                          GrvWgslParams rp = base;
-                         if (G > 1 || m->self_exchange) {
+                         if (G > 1 || m->c.self_exchange) {
                              rp.tile_world = (uint32_t)G;
                              rp.tile_rank = (uint32_t)r;
                          }
@@ -679,12 +504,12 @@ int grv_render_frame_wgsl_multi_device(grv_multi *m, const GrvWgslParams *p, flo
 
 int grv_multi_synchronize(grv_multi *m) {
     if (!m) return GRV_ERR_INVALID;
-    for (int r = 0; r < m->G; ++r) {
-        GRVM_HIP(m, hipSetDevice(m->dev[r]));
-        for (int b = 0; b < 2; ++b) GRVM_HIP(m, hipStreamSynchronize(m->rank[r].s[b]));
+    for (int r = 0; r < m->c.G; ++r) {
+        GRVM_HIP(m, hipSetDevice(m->c.dev[r]));
+        for (int b = 0; b < 2; ++b) GRVM_HIP(m, hipStreamSynchronize(m->c.rank[r].s[b]));
     }
-    GRVM_HIP(m, hipSetDevice(m->dev[0]));
-    for (int b = 0; b < 2; ++b) GRVM_HIP(m, hipStreamSynchronize(m->rs[b]));
+    GRVM_HIP(m, hipSetDevice(m->c.dev[0]));
+    for (int b = 0; b < 2; ++b) GRVM_HIP(m, hipStreamSynchronize(m->c.rs[b]));
     return GRV_OK;
 }
 
@@ -698,8 +523,8 @@ int grv_multi_frame_stats_reset(grv_multi *m) {
     if (!m) return GRV_ERR_INVALID;
     int rc = grv_multi_synchronize(m);
     if (rc != GRV_OK) return rc;
-    for (int r = 0; r < m->G; ++r) {
-        rc = grv_frame_stats_reset(m->eng[r], m->rank[r].s[0]);
+    for (int r = 0; r < m->c.G; ++r) {
+        rc = grv_frame_stats_reset(m->eng[r], m->c.rank[r].s[0]);
         if (rc != GRV_OK) return mfail(m, rc, "rank %d: %s", r, grv_last_error(m->eng[r]));
     }
     return grv_multi_synchronize(m);
@@ -711,9 +536,9 @@ int grv_multi_frame_stats(grv_multi *m, GrvFrameStats *out) {
     int rc = grv_multi_synchronize(m);
     if (rc != GRV_OK) return rc;
     std::memset(out, 0, sizeof *out);
-    for (int r = 0; r < m->G; ++r) {
+    for (int r = 0; r < m->c.G; ++r) {
         GrvFrameStats st;
-        rc = grv_frame_stats(m->eng[r], m->rank[r].s[0], &st);
+        rc = grv_frame_stats(m->eng[r], m->c.rank[r].s[0], &st);
         if (rc != GRV_OK) return mfail(m, rc, "rank %d: %s", r, grv_last_error(m->eng[r]));
         out->rays += st.rays;
         out->accepted_steps += st.accepted_steps;
@@ -736,7 +561,7 @@ int grv_render_frame_multi(grv_multi *m, const GrvCamera *cam, const GrvRenderPa
     if (!m) return GRV_ERR_INVALID;
     if (!p || !rgba_host) return mfail(m, GRV_ERR_INVALID, "null argument");
     const size_t px = (size_t)p->width * p->height;
-    GRVM_HIP(m, hipSetDevice(m->dev[0]));
+    GRVM_HIP(m, hipSetDevice(m->c.dev[0]));
     if (px > m->image_px) {
         if (m->image) (void)hipFree(m->image);
         m->image = nullptr;
@@ -744,10 +569,10 @@ int grv_render_frame_multi(grv_multi *m, const GrvCamera *cam, const GrvRenderPa
         GRVM_HIP(m, hipMalloc(reinterpret_cast<void **>(&m->image), px * 16u));
         m->image_px = px;
     }
-    hipStream_t s = m->rs[0];
+    hipStream_t s = m->c.rs[0];
     int rc = grv_render_frame_multi_device(m, cam, p, m->image, s);
     if (rc != GRV_OK) return rc;
-    GRVM_HIP(m, hipSetDevice(m->dev[0]));
+    GRVM_HIP(m, hipSetDevice(m->c.dev[0]));
     GRVM_HIP(m, hipMemcpyAsync(rgba_host, m->image, px * 16u, hipMemcpyDeviceToHost, s));
     GRVM_HIP(m, hipStreamSynchronize(s));
     if (stats) return grv_multi_frame_stats(m, stats);

@@ -72,13 +72,43 @@ class TileGather:
             self.image = torch.zeros((params.height, params.width, channels), dtype=dtype, device=device)
         self.rparams = [rank_params(params, world, r) for r in range(world)]
 
+    # ---- where a rank's time goes when it is not computing: every point at which the rank's stream is made to
+    # wait for the exchange (the gather of the previous frame, the reader of a send buffer) can be bracketed by
+    # two events on that stream; exchange_wait_ms() resolves them after the loop.  Off unless asked for. ----
+    def enable_wait_timing(self, enable=True):
+        self._wait_events = [] if enable else None
+        return self
+
+    def _timed_wait(self, wait):
+        ev = getattr(self, "_wait_events", None)
+        if ev is None:
+            return wait()
+        import torch
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        out = wait()
+        b.record()
+        ev.append((a, b))
+        return out
+
+    def exchange_wait_ms(self, reset=True):
+        """Total time (ms) this rank's streams were held at the exchange's wait points since the last reset
+        (call after a device synchronise); 0.0 when timing is off or nothing was waited for."""
+        ev = getattr(self, "_wait_events", None)
+        if not ev:
+            return 0.0
+        total = sum(a.elapsed_time(b) for a, b in ev)
+        if reset:
+            del ev[:]
+        return float(total)
+
     def local_view(self, n_local):
         """Render directly into the (padded) send buffer: no staging copy."""
         return self.send[:n_local]
 
     def run(self, unpack, force_collective=False):
         """Synchronous form: gather this frame's tiles now, de-interleave on rank 0."""
-        return self._unpack(unpack, self._gather(self.send, force_collective, False), self.send)
+        return self._unpack(unpack, self._timed_wait(lambda: self._gather(self.send, force_collective, False)), self.send)
 
     # ---- pipelined form: the gather of frame i runs while frame i+1 is integrated ----------
     # Two send buffers alternate; the exchange is issued asynchronously (RCCL runs it on its own
@@ -100,7 +130,7 @@ class TileGather:
         the gather of frame_index - 2, which read the same buffer."""
         b = frame_index % 2
         if self._reader[b] is not None:
-            self._reader[b].wait()
+            self._timed_wait(self._reader[b].wait)
             self._reader[b] = None
         return self.sends[b][:n_local]
 
@@ -122,7 +152,7 @@ class TileGather:
         (work, collective), buf = self._pending
         self._pending = None
         if work is not None:
-            work.wait()
+            self._timed_wait(work.wait)
         return self._unpack(unpack, (None, collective), buf)
 
     def _gather(self, buf, force_collective, async_op):

@@ -19,6 +19,7 @@ KERR_BL, KERR_KS, SCHWARZSCHILD = 0, 1, 2
 METHOD_RKF45, METHOD_RK4, METHOD_SYMPLECTIC = 0, 1, 2
 ARITH_STRICT, ARITH_FAST, ARITH_FAST_PACKED = 0, 1, 2
 SCHEDULE_DEFAULT, SCHEDULE_SLOT_ORDER = 0, 1  # GrvRenderParams.schedule
+FAULT_NONE, FAULT_RENDER, FAULT_SEND, FAULT_PEER_COPY = 0, 1, 2, 3  # grv_multi_test_inject_fault
 DISK_PROFILE_SHORTCUT, DISK_PROFILE_PAGE_THORNE = 0, 1
 MATH_SINCOS_SIN, MATH_SINCOS_COS, MATH_SIN, MATH_COS, MATH_POW, MATH_EXP, MATH_ATAN = 0, 1, 2, 3, 4, 5, 6
 MATH_LOG, MATH_ACOS, MATH_ATAN2, MATH_F32 = 7, 8, 9, 16
@@ -196,6 +197,8 @@ def load_library():
     L.grv_test_hooks_unlocked.argtypes = []
     L.grv_test_try_bound.restype = C.c_uint32
     L.grv_test_try_bound.argtypes = [p]
+    L.grv_multi_test_inject_fault.restype = i
+    L.grv_multi_test_inject_fault.argtypes = [p, i, i]
     L.grv_multi_set_exchange_format.restype = i
     L.grv_multi_set_exchange_format.argtypes = [p, i]
     L.grv_multi_exchange_format.restype = i
@@ -1101,6 +1104,11 @@ class MultiEngine:
         return self._lib.grv_multi_exchange_bytes_per_frame(self._h, int(width), int(height))
 
     def test_self_exchange(self, enable=True):
-        """Verification hook: rank 0's own share goes through the transport too."""
-        unlock_test_hooks()
+        """Verification hook: rank 0's own share goes through the transport too.  Locked until the process has
+        called unlock_test_hooks() (tests do, explicitly; this wrapper never unlocks on a caller's behalf)."""
         self._check(self._lib.grv_multi_test_self_exchange(self._h, 1 if enable else 0), "multi_test_self_exchange")
+
+    def test_inject_fault(self, kind, rank):
+        """Verification hook (locked like test_self_exchange): the next frame fails on `rank` at FAULT_RENDER /
+        FAULT_SEND (RCCL) / FAULT_PEER_COPY."""
+        self._check(self._lib.grv_multi_test_inject_fault(self._h, int(kind), int(rank)), "multi_test_inject_fault")

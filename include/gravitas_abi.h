@@ -370,6 +370,13 @@ int grv_test_hooks_unlocked(void);
 int grv_test_set_try_bound(grv_engine *e, uint32_t tries);
 uint32_t grv_test_try_bound(const grv_engine *e);
 int grv_multi_test_self_exchange(grv_multi *m, int enable);
+/* grv_multi_test_inject_fault (locked like the hooks above): the NEXT frame of the handle fails where `kind`
+ * says, on rank `rank` -- GRV_FAULT_RENDER: the rank's render call; GRV_FAULT_PEER_COPY: its push to rank 0
+ * (peer-copy transport); GRV_FAULT_SEND: its ncclSend inside the group (RCCL transport).  The frame call then
+ * returns GRV_ERR_HIP with the rank and the cause in grv_multi_last_error, no group is left open, and the
+ * handle renders the following frame as if nothing had happened (tests/test_gpu_multi_native.py). */
+enum { GRV_FAULT_NONE = 0, GRV_FAULT_RENDER = 1, GRV_FAULT_SEND = 2, GRV_FAULT_PEER_COPY = 3 };
+int grv_multi_test_inject_fault(grv_multi *m, int kind, int rank);
 
 /* ---- f32 march loops of the reference's GPU shaders ----
  * Uniform blocks as the shaders receive them.  Outputs are device pointers: RGBA f32

@@ -1,7 +1,8 @@
 #!/bin/bash
 # ASan + UBSan pass over the PRODUCT's host code on the CPU box (GPU ASan is not available on this
 # pool): the host side of libgravitas_hip.so -- every engine*.hip entry point (engine_multi.hip included), control_plane.hip's
-# host twins, grv_strict_math_host, the tile (un)pack helpers -- and napi/gravitas_napi.c.
+# host twins, grv_strict_math_host, the tile (un)pack helpers -- and napi/gravitas_napi.c; then the multi-GPU host logic
+# (csrc/multi_core.hpp) under ThreadSanitizer over a mock stream / transport Api (tests/host/multi_tsan.cpp).
 #   device code : compiled for gfx950 as shipped (-Xarch_host keeps the sanitizers off it)
 #   host code   : -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=undefined
 # The sanitized library takes the in-tree library's place for the run (restored on exit); the tests
@@ -32,7 +33,7 @@ restore() {
 }
 trap restore EXIT
 
-for tu in kernels_strict kernels_fast kernels_fast_f64 control_plane spacetime_viz engine engine_shaders engine_control engine_multi; do
+for tu in kernels_strict kernels_fast kernels_fast_f64 control_plane spacetime_viz engine engine_shaders engine_control engine_images engine_multi; do
   fp="-ffp-contract=off"
   [ $tu = kernels_fast ] && fp="-ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt"
   [ $tu = kernels_fast_f64 ] && fp="-ffp-contract=fast"
@@ -41,7 +42,7 @@ for tu in kernels_strict kernels_fast kernels_fast_f64 control_plane spacetime_v
 done
 wait
 $HIPCC --offload-arch=gfx950 -shared -fPIC $SAN -shared-libsan -o "$LIB" $B/kernels_strict.o $B/kernels_fast.o $B/kernels_fast_f64.o \
-    $B/control_plane.o $B/spacetime_viz.o $B/engine.o $B/engine_shaders.o $B/engine_control.o $B/engine_multi.o -ldl -lpthread
+    $B/control_plane.o $B/spacetime_viz.o $B/engine.o $B/engine_shaders.o $B/engine_control.o $B/engine_images.o $B/engine_multi.o -ldl -lpthread
 # -asan-globals=0 on the addon only: its merged string literals land on odd addresses, which ASan's
 # global registration refuses under node; stack and heap checking (the argument buffers, the arena)
 # stay on
@@ -50,6 +51,19 @@ if [ -f /usr/include/node/node_api.h ]; then
       "$R/napi/gravitas_napi.c" -o "$ADDON" -L"$R/blackhole-simulation_amd" -lgravitas_hip \
       -Wl,-rpath,'$ORIGIN/../blackhole-simulation_amd'
 fi
+# ---- ThreadSanitizer leg: the multi-GPU host logic (csrc/multi_core.hpp: rank threads, per-parity slots and events,
+# the frame skeleton) over a mock Api whose streams are threads and whose copies touch memory -- 1000 frames x
+# G = 2, 4, 8 x both transports x both exchange formats with frames of both parities in flight and injected faults;
+# the two mutants (an event wait removed) must be caught.  SAN_TSAN_FRAMES overrides the frame count.
+echo "== multi-GPU host logic under ThreadSanitizer (tests/host/multi_tsan.cpp)"
+TS="$R/tests/host/multi_tsan.cpp"
+$CLANG++ -O1 -g -std=c++17 -pthread -fsanitize=thread "$TS" -o $B/multi_tsan
+TSAN_OPTIONS=halt_on_error=1:second_deadlock_stack=1 $B/multi_tsan ${SAN_TSAN_FRAMES:-1000} | tail -1
+for mut in GRVMULTI_MUTANT_NO_SLOT_WAIT GRVMULTI_MUTANT_NO_ARRIVED_WAIT; do
+  $CLANG++ -O1 -g -std=c++17 -pthread -fsanitize=thread -D$mut "$TS" -o $B/multi_tsan_mut
+  if TSAN_OPTIONS=halt_on_error=1 $B/multi_tsan_mut 60 > $B/mut.log 2>&1; then echo "mutant $mut went UNNOTICED"; exit 1
+  else echo "mutant $mut: caught ($(grep -c 'ThreadSanitizer: data race' $B/mut.log) race report(s))"; fi
+done
 echo "== host code of libgravitas_hip.so + N-API addon under ASan + UBSan"
 cd "$R"
 ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1 \

@@ -214,6 +214,12 @@ with bh.PhysicsEngine(1.0, 0.999) as e:
     torch.cuda.synchronize()
 with bh.MultiEngine(1.0, 0.999, devices=[0], transport=bh.TRANSPORT_RCCL) as m:
     assert m.transport == bh.TRANSPORT_RCCL
+    try:
+        m.test_self_exchange(True)
+        raise SystemExit("the hook answered while locked")
+    except bh.GravitasError as e:
+        assert "locked" in str(e)
+    bh.unlock_test_hooks()
     m.test_self_exchange(True)
     for k in range(3):
         got = torch.zeros(h, w, 4, dtype=torch.float32, device="cuda:0")
@@ -228,6 +234,20 @@ with bh.MultiEngine(1.0, 0.999, devices=[0], transport=bh.TRANSPORT_RCCL) as m:
         m.render_frame_device(cam, p, got)
         m.synchronize()
         assert torch.equal(got.view(torch.int32), want16.view(torch.int32)), ("rgba16f", k)
+    # an ncclSend that fails inside the group: the call reports it, the group is closed, the next frame is whole
+    m.set_exchange_format(bh.EXCHANGE_RGBA32F)
+    m.test_inject_fault(bh.FAULT_SEND, 0)
+    got = torch.zeros(h, w, 4, dtype=torch.float32, device="cuda:0")
+    try:
+        m.render_frame_device(cam, p, got)
+        raise SystemExit("the injected ncclSend failure went unnoticed")
+    except bh.GravitasError as e:
+        assert "injected ncclSend failure" in str(e) and "group closed" in str(e), str(e)
+    for k in range(2):
+        got = torch.zeros(h, w, 4, dtype=torch.float32, device="cuda:0")
+        m.render_frame_device(cam, p, got)
+        m.synchronize()
+        assert torch.equal(got.view(torch.int32), want.view(torch.int32)), ("after the fault", k)
 print("RCCL_WALK_OK")
 """
 
@@ -281,3 +301,47 @@ def test_bench_native_drives_the_c_abi_multi_handle():
         assert rf["bound"] in ("fp64_valu", "fp32_valu") and rf["unit"] == "TFLOP/s"
         assert isinstance(rf["frac"], float) and 0 < rf["frac"] <= 1.0, rf
         assert rf["flops_source"] in ("counted", "algorithmic") and "hbm_nominal" in rf
+
+
+def test_injected_faults_are_reported_and_the_next_frame_is_whole(bh):
+    """grv_multi_test_inject_fault: a rank whose render call fails on frame k, and a rank whose
+    push to rank 0 fails -- the frame call returns an error that names the rank and the cause, other ranks'
+    queued work is harmless, and the SAME handle renders the following frames bit-equal to one device, with frames
+    in flight on two streams.  (The ncclSend fault runs in test_rccl_transport_walk_on_one_device: RCCL needs a
+    process of its own on this pool.)"""
+    import torch
+    bh.unlock_test_hooks()
+    w, h = 640, 360
+    cam = bh.camera_look_at(EYE, aspect=w / h)
+    p = bh.render_params(w, h, arith=bh.ARITH_FAST)
+    with bh.PhysicsEngine(1.0, 0.999) as e:
+        want = torch.zeros(h, w, 4, dtype=torch.float32, device="cuda:0")
+        e.render_frame_device(cam, p, rgba=want)
+        torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for G in (2, 4, 8):
+        with bh.MultiEngine(1.0, 0.999, virtual_ranks=G) as m:
+            outs = [torch.zeros(h, w, 4, dtype=torch.float32, device="cuda:0") for _ in range(2)]
+            frame = 0
+            for kind, rank, text in ((bh.FAULT_RENDER, G - 1, "injected render failure"),
+                                     (bh.FAULT_PEER_COPY, 1, "injected peer-copy failure"),
+                                     (bh.FAULT_RENDER, 0, "injected render failure")):
+                for _ in range(3):  # healthy frames in flight first
+                    with torch.cuda.stream(streams[frame % 2]):
+                        m.render_frame_device(cam, p, outs[frame % 2], stream=streams[frame % 2].cuda_stream)
+                    frame += 1
+                m.test_inject_fault(kind, rank)
+                with pytest.raises(bh.GravitasError) as ei:
+                    with torch.cuda.stream(streams[frame % 2]):
+                        m.render_frame_device(cam, p, outs[frame % 2], stream=streams[frame % 2].cuda_stream)
+                assert text in str(ei.value) and ("rank %d" % rank) in str(ei.value), str(ei.value)
+                for _ in range(3):  # ... and whole frames after it, both parities
+                    outs[frame % 2].fill_(-1.0)
+                    with torch.cuda.stream(streams[frame % 2]):
+                        m.render_frame_device(cam, p, outs[frame % 2], stream=streams[frame % 2].cuda_stream)
+                    m.synchronize()
+                    torch.cuda.synchronize()
+                    assert torch.equal(outs[frame % 2].view(torch.int32), want.view(torch.int32)), (G, kind, frame)
+                    frame += 1
+            with pytest.raises(bh.GravitasError, match="out of range"):
+                m.test_inject_fault(bh.FAULT_RENDER, G)
