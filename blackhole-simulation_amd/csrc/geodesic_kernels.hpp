@@ -496,7 +496,8 @@ __device__ __forceinline__ void ray_resume(const Hole<double> &bh, RayRegs &y,
 // The segment kernel.
 // ---------------------------------------------------------------------------
 // waves per SIMD the segment kernel is compiled for at least: the Kerr-Schild RKF45 forms sit at the
-// three-wave boundary (FAST 167 VGPRs; STRICT would take 171 and run two)
+// three-wave boundary (code objects of this tree: FAST 152 VGPRs, STRICT 168 -- the attribute keeps both at three
+// waves; tools/kernel_resources.py, tests/test_code_objects.py)
 template <int KIND, int METHOD>
 constexpr int kSegmentWavesMin = (KIND == GRV_METRIC_KERR_KS && METHOD == GRV_METHOD_RKF45) ? 3 : 1;
 
