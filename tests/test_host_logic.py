@@ -257,8 +257,11 @@ def test_bench_helpers():
         assert src.startswith("stale"), src  # the kernel changed since the committed pass: dropped
     else:
         assert t["hbm_bytes_per_launch"] > 1e9 and 0.5 < t["valu"]["issue_frac"] <= 1.0
-        # measured HBM bytes agree with the layout's 92 B read + 76 B written per slot to 2 %
-        assert abs(t["hbm_bytes_per_launch"] / t["expected_from_layout_bytes"] - 1.0) < 0.02
+        # measured HBM bytes against the layout's 92 B read + 76 B written per slot: within 2 % when the waves
+        # start in slot order (rounds 2-5); with the longest-first order of round 6 neighbouring waves no longer
+        # run side by side and L2 merges fewer of the partial-line stores (crossing records, 4-byte arrays):
+        # +13 % written, +7 % fetched -- 1.54 GB per 27 ms launch, 0.7 % of the HBM peak either way
+        assert -0.02 < t["hbm_bytes_per_launch"] / t["expected_from_layout_bytes"] - 1.0 < 0.15
     none, why = b.committed_pmc("no_such_kernel", bh.library_path())
     assert none is None and "no committed" in why
 

@@ -157,7 +157,9 @@ for pretty, needle, sfx, frame, layout in CASES:
     if layout:
         ent["expected_from_layout_bytes"] = layout
     if sfx == "":
-        f2, w2 = _avg("pmc_fetch_k16", "FETCH_SIZE", needle), _avg("pmc_write_k16", "WRITE_SIZE", needle)
+        # (since round 6 every launch of the compacting schedule is the compact kernel: the live count comes from device memory)
+        k16 = needle.replace("integrate_segment_kernel", "integrate_compact_kernel")
+        f2, w2 = _avg("pmc_fetch_k16", "FETCH_SIZE", k16), _avg("pmc_write_k16", "WRITE_SIZE", k16)
         if f2 is not None and w2 is not None:
             ent["segment_tries_16"] = {"fetch_size_kib_raw_avg_per_launch": f2,
                                        "write_size_kib_avg_per_launch": w2,
