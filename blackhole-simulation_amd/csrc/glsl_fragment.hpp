@@ -389,29 +389,14 @@ __device__ void glsl_starfield(const GlslParams &U, F3 dir, float stars[3]) {
     stars[2] += nebula * 0.5f + 0.05f * ln;
 }
 
-// FAST march: the loop-invariant, wave-uniform values that only the disk / jet sampling bodies read -- products of
-// the uniforms the optimiser hoists out of the march loop and, at eight waves per SIMD (64 VGPRs), spills: 11 of
-// the kernel's 17 scratch dwords per lane, written by every lane in the prologue (2 M lanes x 44 B per frame) and
-// read back where a wave samples.  GRV_GLSL_LDS_UNIFORMS keeps ONE copy per wave in LDS instead (64 B; a sampling
-// body reads what it needs behind its `asm volatile` fence, so nothing is hoisted back into registers).  The values
-// are the very subexpressions of the shader-order code below, formed by the same operations: pixels and step
-// counts bit for bit (tools/ab_glsl_identical.py).
-#ifndef GRV_GLSL_LDS_UNIFORMS
-#define GRV_GLSL_LDS_UNIFORMS 1
-#endif
-enum { kUniEffH = 0, kUniDiskOuter, kUniSqrtM, kUniSgnSqrtM, kUniASqrtM, kUniInvInOut, kUniIsco, kUniTwoM, kUniM2Ma,
-       kUniA2, kUniTwoMaa, kUniJetMin, kUniTime8, kUniCount };
-
 // chunks/disk.ts:16-115
 // (r_p = |p|, which the march has already: the FAST contract takes the sample radius from it when
 // the step did not cross the plane and the sample point is p itself)
 template <int ARITH>
 __device__ __forceinline__ void glsl_sample_disk(const GlslParams &U, F3 p, F3 p_prev, F3 v,
                                                  float isco, float M, float a, float dt,
-                                                 float col[3], float &alpha, float r_p, const float *uni = nullptr) {
+                                                 float col[3], float &alpha, float r_p) {
     if (!(U.show_redshift < 0.5f)) return;
-    constexpr bool kUni = ARITH == GRV_ARITH_FAST && GRV_GLSL_RAW_DIV && GRV_GLSL_LDS_UNIFORMS;
-    if constexpr (kUni) isco = uni[kUniIsco];
     const bool crossed = (p_prev.y * p.y < 0.0f);
     F3 sp = p;
     float sampleR = r_p;
@@ -423,21 +408,16 @@ __device__ __forceinline__ void glsl_sample_disk(const GlslParams &U, F3 p, F3 p
         if constexpr (ARITH == GRV_ARITH_FAST) sampleR = length_t<ARITH>(sp);
     }
     if constexpr (ARITH != GRV_ARITH_FAST) sampleR = length_t<ARITH>(sp);
-    const float effH = kUni ? uni[kUniEffH] : fminf(U.disk_scale_height, 0.45f);
+    const float effH = fminf(U.disk_scale_height, 0.45f);
     const float diskHeight = sampleR * effH;
     const float diskInner = isco;
-    const float diskOuter = kUni ? uni[kUniDiskOuter] : fmaxf(M * U.disk_size, diskInner * 1.1f);
+    const float diskOuter = fmaxf(M * U.disk_size, diskInner * 1.1f);
     if (!((fabsf(sp.y) < diskHeight || crossed) && sampleR > diskInner && sampleR < diskOuter)) return;
     float turbulence = U.turbulence;
     if (turbulence < 0.0f) { // disk.ts:43-55: Keplerian phase rotation of the noise field
-        float OmegaPhase;
-        if constexpr (kUni) {
-            OmegaPhase = uni[kUniSgnSqrtM] * __builtin_amdgcn_rcpf(sampleR * sqrt_t<ARITH>(sampleR) + uni[kUniASqrtM]);
-        } else {
-            const float sqrt_Mp = sqrt_t<ARITH>(M);
-            const float signSpinPhase = sign_d(U.spin + 1e-8f);
-            OmegaPhase = div_t<ARITH>(signSpinPhase * sqrt_Mp, sampleR * sqrt_t<ARITH>(sampleR) + a * sqrt_Mp);
-        }
+        const float sqrt_Mp = sqrt_t<ARITH>(M);
+        const float signSpinPhase = sign_d(U.spin + 1e-8f);
+        const float OmegaPhase = div_t<ARITH>(signSpinPhase * sqrt_Mp, sampleR * sqrt_t<ARITH>(sampleR) + a * sqrt_Mp);
         const float rotAngle = OmegaPhase * U.time * 0.12f * 10.0f;
         float cs, sn;
         if constexpr (ARITH == GRV_ARITH_FAST) {
@@ -453,8 +433,7 @@ __device__ __forceinline__ void glsl_sample_disk(const GlslParams &U, F3 p, F3 p
     const float heightFalloff = exp_d<ARITH>(div_t<ARITH>(-fabsf(sp.y), fmaxf(0.001f, (sampleR * effH) * 0.25f)));
     float radialFalloff;
     if constexpr (ARITH == GRV_ARITH_FAST && GRV_GLSL_RAW_DIV) {
-        const float inv_io = kUni ? uni[kUniInvInOut] : __builtin_amdgcn_rcpf(diskInner - diskOuter);
-        const float ts = clampf_d((sampleR - diskOuter) * inv_io, 0.0f, 1.0f);
+        const float ts = clampf_d((sampleR - diskOuter) * __builtin_amdgcn_rcpf(diskInner - diskOuter), 0.0f, 1.0f);
         radialFalloff = ts * ts * (3.0f - 2.0f * ts);
     } else {
         radialFalloff = smoothstep_d(diskOuter, diskInner, sampleR);
@@ -463,22 +442,11 @@ __device__ __forceinline__ void glsl_sample_disk(const GlslParams &U, F3 p, F3 p
     if (!(baseDensity > 0.001f)) return;
 
     const float r2 = sampleR * sampleR;
-    float Omega;
-    if constexpr (kUni) {
-        Omega = uni[kUniSgnSqrtM] * __builtin_amdgcn_rcpf(sampleR * sqrt_t<ARITH>(sampleR) + uni[kUniASqrtM]);
-    } else {
-        const float sqrt_M = sqrt_t<ARITH>(M);
-        const float signSpin = sign_d(U.spin + 1e-8f);
-        Omega = div_t<ARITH>(signSpin * sqrt_M, sampleR * sqrt_t<ARITH>(sampleR) + a * sqrt_M);
-    }
+    const float sqrt_M = sqrt_t<ARITH>(M);
+    const float signSpin = sign_d(U.spin + 1e-8f);
+    const float Omega = div_t<ARITH>(signSpin * sqrt_M, sampleR * sqrt_t<ARITH>(sampleR) + a * sqrt_M);
     float g_tt, g_tphi, g_phiphi, isco_r;
-    if constexpr (kUni) { // the same products, their wave-uniform factors from LDS
-        const float inv_r = __builtin_amdgcn_rcpf(sampleR);
-        g_tt = -(1.0f - uni[kUniTwoM] * inv_r);
-        g_tphi = uni[kUniM2Ma] * inv_r;
-        g_phiphi = r2 + uni[kUniA2] + uni[kUniTwoMaa] * inv_r;
-        isco_r = clampf_d(isco * inv_r, 0.0f, 1.0f);
-    } else if constexpr (ARITH == GRV_ARITH_FAST && GRV_GLSL_RAW_DIV) { // the four quotients by sampleR share one v_rcp_f32
+    if constexpr (ARITH == GRV_ARITH_FAST && GRV_GLSL_RAW_DIV) { // the four quotients by sampleR share one v_rcp_f32
         const float inv_r = __builtin_amdgcn_rcpf(sampleR);
         g_tt = -(1.0f - 2.0f * M * inv_r);
         g_tphi = -2.0f * M * a * inv_r;
@@ -509,18 +477,16 @@ __device__ __forceinline__ void glsl_sample_disk(const GlslParams &U, F3 p, F3 p
 // chunks/disk.ts:117-155
 template <int ARITH>
 __device__ __forceinline__ void glsl_sample_jets(const GlslParams &U, F3 p, F3 v, float rh, float dt,
-                                                 float col[3], float &alpha, float r_p = 0.0f, const float *uni = nullptr) {
+                                                 float col[3], float &alpha, float r_p = 0.0f) {
     const float jetVerticalPos = fabsf(p.y);
-    constexpr bool kUni = ARITH == GRV_ARITH_FAST && GRV_GLSL_RAW_DIV && GRV_GLSL_LDS_UNIFORMS;
     if constexpr (ARITH == GRV_ARITH_FAST) {
         // a ray is inside the jets only within 2 (1 + 0.15 |y|) of the axis, and its axial distance
         // sqrt(|p|^2 - y^2) is at least |p| - |y|: beyond |p| = 2.01 + 1.31 |y| (the shader's bound with a
         // margin of 0.01 (1 + |y|), a thousand times the rounding of |p|) nothing below can pass, and one
         // fma and one compare replace the nine operations of the tests -- which stay as they are
         if (!(r_p < fmaf(jetVerticalPos, 1.31f, 2.01f))) return;
-        if constexpr (kUni) asm volatile("" ::: "memory"); // the LDS reads below stay behind the prefilter
     }
-    if (!(jetVerticalPos > (kUni ? uni[kUniJetMin] : rh * 1.8f) && jetVerticalPos < 10000.0f * 0.8f)) return;
+    if (!(jetVerticalPos > rh * 1.8f && jetVerticalPos < 10000.0f * 0.8f)) return;
     const float jetWidth = 1.0f + jetVerticalPos * 0.15f;
     float radialFalloff;
     if constexpr (ARITH == GRV_ARITH_FAST) {
@@ -535,7 +501,7 @@ __device__ __forceinline__ void glsl_sample_jets(const GlslParams &U, F3 p, F3 v
         radialFalloff = exp_d<ARITH>(div_t<ARITH>(-(jetRadialDist * jetRadialDist), jetWidth * 0.5f));
     }
     const float lengthFalloff = exp_d<ARITH>(-jetVerticalPos * 0.05f);
-    const float flow = p.y * 2.0f - (kUni ? uni[kUniTime8] : U.time * 8.0f);
+    const float flow = p.y * 2.0f - U.time * 8.0f;
     const F3 uvJet{p.x, flow, p.z};
     const float noiseVal = glsl_noise_t<ARITH>(U, scale_f3(uvJet, 0.5f)) * 0.6f +
                            glsl_noise_t<ARITH>(U, scale_f3(uvJet, 1.5f)) * 0.4f;
@@ -575,7 +541,7 @@ __device__ __forceinline__ float glsl_seg_dist(float px, float py, float ax, flo
 // fragment.glsl.ts:40-334 -- the whole main().  Returns the march steps taken.
 template <int ARITH>
 __device__ uint32_t glsl_fragment(const GlslParams &U, uint32_t width, uint32_t height, uint32_t X,
-                                  uint32_t Y, float o[3], float *uni = nullptr) {
+                                  uint32_t Y, float o[3]) {
     const uint32_t F = U.features;
     const float PI = 3.14159265359f;
     const float resx = (float)width, resy = (float)height;
@@ -676,25 +642,6 @@ __device__ uint32_t glsl_fragment(const GlslParams &U, uint32_t width, uint32_t 
     // operations per iteration on merging them.  Here the three conditions are evaluated where the shader
     // evaluates them and tested together at the top of the next iteration; nothing else runs in between
     // (the jets of an iteration whose disk sample went opaque are skipped, as the shader's break skips them).
-    if constexpr (ARITH == GRV_ARITH_FAST && GRV_GLSL_RAW_DIV && GRV_GLSL_LDS_UNIFORMS) {
-        // the sampling bodies' wave-uniform factors: one copy per wave in LDS (every lane writes the same values)
-        const float sqrt_M = sqrt_t<ARITH>(M);
-        const float dOuter = fmaxf(M * U.disk_size, isco * 1.1f);
-        uni[kUniEffH] = fminf(U.disk_scale_height, 0.45f);
-        uni[kUniDiskOuter] = dOuter;
-        uni[kUniSqrtM] = sqrt_M;
-        uni[kUniSgnSqrtM] = sign_d(U.spin + 1e-8f) * sqrt_M;
-        uni[kUniASqrtM] = a * sqrt_M;
-        uni[kUniInvInOut] = __builtin_amdgcn_rcpf(isco - dOuter);
-        uni[kUniIsco] = isco;
-        uni[kUniTwoM] = 2.0f * M;
-        uni[kUniM2Ma] = -2.0f * M * a;
-        uni[kUniA2] = a * a;
-        uni[kUniTwoMaa] = 2.0f * M * a * a;
-        uni[kUniJetMin] = rh * 1.8f;
-        uni[kUniTime8] = U.time * 8.0f;
-        asm volatile("" ::: "memory");
-    }
     if constexpr (ARITH == GRV_ARITH_FAST) {
         int i = 0;
         bool opaque = false, hz = false;
@@ -783,10 +730,10 @@ __device__ uint32_t glsl_fragment(const GlslParams &U, uint32_t width, uint32_t 
                 asm volatile("" ::: "memory");
                 if (crossed && r_new < rph * 2.0f && r_new > rh)
                     photonCrossings = photonCrossings + 1 < 3 ? photonCrossings + 1 : 3;
-                if (disk) glsl_sample_disk<ARITH>(U, pn, pc, v, isco, M, a, cdt, col, alpha, r_new, uni);
+                if (disk) glsl_sample_disk<ARITH>(U, pn, pc, v, isco, M, a, cdt, col, alpha, r_new);
             }
             if (disk) opaque = alpha > 0.99f;
-            if (jets && !opaque) glsl_sample_jets<ARITH>(U, pn, v, rh, dt, col, alpha, r_new, uni); // un-refined dt (fragment.glsl.ts:219)
+            if (jets && !opaque) glsl_sample_jets<ARITH>(U, pn, v, rh, dt, col, alpha, r_new); // un-refined dt (fragment.glsl.ts:219)
         };
         for (;;) {
             hz = r_cur < rh * 1.15f;
@@ -961,10 +908,9 @@ void glsl_fragment_kernel(FrameGeom G, GlslParams U,
     uint32_t X = 0, Y = 0, oi = 0;
     const bool valid = slot < n_slots && slot_to_pixel(G, slot, X, Y, oi);
     uint32_t steps = 0;
-    __shared__ float s_uni[kMarchBlock / 64][16]; // FAST: the sampling bodies' wave-uniform factors (GRV_GLSL_LDS_UNIFORMS)
     if (valid) {
         float o[3];
-        steps = glsl_fragment<ARITH>(U, G.width, G.height, X, Y, o, s_uni[threadIdx.x >> 6]);
+        steps = glsl_fragment<ARITH>(U, G.width, G.height, X, Y, o);
         if (out_rgba) out_rgba[oi] = make_float4(o[0], o[1], o[2], 1.0f);
         if (out_steps) out_steps[oi] = steps;
     }
