@@ -823,6 +823,12 @@ def main():
         same_frame = bool(pmc and world == 1 and (W, H) == tuple(pmc.get("frame", (W, H))))
         roofline = roofline_block(cfg, glsl, kernel_pretty, avg_launch_ms, launches_per_frame, prof_steps_per_frame,
                                   rays_local, pmc, pmc_src, same_workload, args.segment_tries, prof_note, same_frame)
+        if args.segment_tries and cfg == "c3":
+            # every launch of the compacting schedule is the compact kernel (same body, live count from device memory);
+            # the flops per ACCEPTED ray-step are the one-launch kernel's count: useful flops -- the schedule's extra
+            # instructions (re-establishing a ray every K tries) are what lowers the line, not what it is credited with
+            roofline["kernel"] = kernel_pretty.replace("integrate_segment_kernel", "integrate_compact_kernel")
+            roofline["flops_note"] = "useful flops: per accepted ray-step as counted on the one-launch kernel"
         split = "" if world == 1 else (" split over %d GPUs" % world if args.scaling == "strong"
                                          else " (%dx%d per GPU x %d)" % (base_w, base_h, world))
         workload = workload_text(cfg, W, H, split)
