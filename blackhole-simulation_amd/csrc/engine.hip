@@ -269,7 +269,7 @@ uint32_t try_bound(const grv_engine *e, uint64_t max_steps) {
 //   bitwise those of the single launch.
 constexpr uint32_t kCompactMaxLaunches = 192;    // bounded launches of one pass (the last, unbounded one comes on top)
 constexpr uint32_t kCompactUnknown = 0xFFFFFFFFu;
-constexpr uint32_t kCompactTailRays = 65536u;    // fewer live rays than one wave per SIMD: compaction has nothing left to fill, the last launch takes them
+constexpr uint32_t kCompactTailRays = 196608u;   // fewer live rays than the chip holds at three waves per SIMD (3 072 waves): compaction has nothing left to fill, the last launch takes them
 
 int run_segments(grv_engine *e, const GrvOptions &o, SegmentParams P, uint32_t seg_tries,
                  hipStream_t s, bool profile) {

@@ -627,7 +627,23 @@ void integrate_compact_kernel(
         y.flags = 0;
         y.nf_ok = false;
         y.pt = y.pph = 0.0;
+#if GRV_WS_RELOAD && defined(__HIP_DEVICE_COMPILE__)
+        // FAST forms: the thirteen array pointers of the load and of the store come from the kernel-argument
+        // segment again (`ws` is the first argument: offset 0) through a pointer the optimiser cannot see through,
+        // right where they are needed, instead of living in SGPRs across the try loop and the stride loop (this
+        // kernel parked ~60 scalars in VGPR lanes otherwise: 129 v_readlane / v_writelane per chunk)
+        if constexpr (ARITH == GRV_ARITH_FAST) {
+            if (have) {
+                const RayWorkspace *w1 = reinterpret_cast<const RayWorkspace *>(__builtin_amdgcn_kernarg_segment_ptr());
+                asm volatile("" : "+s"(w1));
+                load_ray(*w1, slot, y);
+            }
+        } else {
+            if (have) load_ray(ws, slot, y);
+        }
+#else
         if (have) load_ray(ws, slot, y);
+#endif
         bool live = have && ray_live(y);
         KsRayConsts rc;
         ray_resume<KIND, ARITH>(bh, y, P, live, rc);
@@ -639,7 +655,19 @@ void integrate_compact_kernel(
             y.flags = (y.flags & ~kFlagTermMask) | GRV_TERM_MAXSTEPS;
             live = false;
         }
+#if GRV_WS_RELOAD && defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (ARITH == GRV_ARITH_FAST) {
+            if (have) {
+                const RayWorkspace *w2 = reinterpret_cast<const RayWorkspace *>(__builtin_amdgcn_kernarg_segment_ptr());
+                asm volatile("" : "+s"(w2));
+                store_ray(*w2, slot, y);
+            }
+        } else {
+            if (have) store_ray(ws, slot, y);
+        }
+#else
         if (have) store_ray(ws, slot, y);
+#endif
         if (live_out) { // block-aggregated append of the survivors, as in the segment kernel
             __shared__ uint32_t s_wave_cnt[kSegBlock / 64];
             __shared__ uint32_t s_base;

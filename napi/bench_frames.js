@@ -1,6 +1,6 @@
 // BASELINE's frame loops driven from the host north_star names: JavaScript through the N-API addon.
 //
-//   node napi/bench_frames.js [--config c3|c2] [--form device|read|async|host|all] [--steps K] [--warmup W]
+//   node napi/bench_frames.js [--config c3|c2|c4|c5] [--form device|read|async|host|all] [--steps K] [--warmup W]
 //                             [--in-flight 1|2] [--eye R0,THETA_DEG] [--out file.jsonl]
 //
 // Same workloads, cameras, warm-up and timed window as bench.py (which calls the same C ABI through
@@ -37,7 +37,7 @@ function parseArgs(argv) {
     else if (k === "--height") { a.height = parseInt(v, 10); i++; }
     else throw new Error("unknown argument " + k);
   }
-  if (a.config !== "c3" && a.config !== "c2") throw new Error("--config c3|c2");
+  if (["c2", "c3", "c4", "c5"].indexOf(a.config) < 0) throw new Error("--config c2|c3|c4|c5");
   if (a.steps === null) a.steps = a.config === "c2" ? 300 : 20;
   if (a.warmup === null) a.warmup = a.config === "c2" ? 60 : 3;
   if (a.inFlight === null) a.inFlight = a.config === "c2" ? 2 : 1;  // bench.py's defaults
@@ -48,18 +48,23 @@ const nowMs = () => Number(process.hrtime.bigint()) / 1e6;
 async function main() {
   const args = parseArgs(process.argv);
   await wasm.default();
-  const c3 = args.config === "c3";
-  const W = args.width || (c3 ? 3840 : 1920), H = args.height || (c3 ? 2160 : 1080);
+  const cfg = args.config;
+  const c3 = cfg === "c3" || cfg === "c5";   // the f64 frame (c5: tol 1e-9 under the reference-order STRICT contract)
+  const W = args.width || { c2: 1920, c3: 3840, c4: 7680, c5: 3840 }[cfg], H = args.height || { c2: 1080, c3: 2160, c4: 4320, c5: 2160 }[cfg];
   const r0 = args.eye ? args.eye[0] : 60.0, thDeg = args.eye ? args.eye[1] : 97.0;
   const th = thDeg * Math.PI / 180;
   const eye = [r0 * Math.sin(th), r0 * Math.cos(th), 0.0];
   const engine = new wasm.PhysicsEngine(1.0, 0.999);
-  const frameOpts = c3 ? { width: W, height: H, eye: eye, arith: "fast", tolerance: 1e-8, maxSteps: 2048 }
-                       : { width: W, height: H, kernel: "glsl", arith: "fast", maxSteps: 512 };
+  const frameOpts = cfg === "c3" ? { width: W, height: H, eye: eye, arith: "fast", tolerance: 1e-8, maxSteps: 2048 }
+    : cfg === "c5" ? { width: W, height: H, eye: eye, arith: "strict", tolerance: 1e-9, maxSteps: 2048 }
+    : cfg === "c4" ? { width: W, height: H, kernel: "wgsl", arith: "packed", maxSteps: 1024, eye: eye }
+    : { width: W, height: H, kernel: "glsl", arith: "fast", maxSteps: 512 };
   const render = (extra) => c3 ? engine.renderFrame(Object.assign({}, frameOpts, extra))
                                : engine.renderShaderFrame(Object.assign({}, frameOpts, extra));
-  const workload = c3
+  const workload = cfg === "c3"
     ? W + "x" + H + " frame, a=0.999 Kerr-Schild, adaptive RKF45 (tol 1e-08) <= 2048 steps, f64 FAST + Planck LUT (T x g) redshift shading"
+    : cfg === "c5" ? W + "x" + H + " frame, a=0.999 Kerr-Schild, adaptive RKF45 (tol 1e-09) <= 2048 steps, f64 STRICT (reference order)"
+    : cfg === "c4" ? W + "x" + H + " frame, a=0.999, f32 WGSL compute march, fixed 1024-step budget, two rays per lane"
     : W + "x" + H + " frame, a=0.999, GLSL fragment Verlet march <= 512 steps, default preset, f32 FAST";
   const lines = [];
   const emit = (form, elapsedMs, steps, frames, extra) => {
@@ -69,7 +74,7 @@ async function main() {
       dtype: c3 ? "f64" : "f32", data: "synthetic",
       host: "node " + process.version + " through napi/blackhole_physics.node (N-API over the C ABI)",
       form: form,
-      config: { workload: workload, baseline_config: c3 ? "configs[2]" : "configs[1]", arith: "fast",
+      config: { workload: workload, baseline_config: { c2: "configs[1]", c3: "configs[2]", c4: "configs[3]", c5: "configs[4]" }[cfg], arith: frameOpts.arith,
                 eye: { r0: r0, theta_deg: thDeg }, rays: W * H, accepted_steps_per_frame: Math.round(steps / frames),
                 frames_in_flight: args.inFlight },
     }, extra || {});
@@ -136,7 +141,7 @@ async function main() {
   }
 
   // ---- (b) renderFrameAsync into two pinned `out` buffers ----
-  if (want("async") && c3) {
+  if (want("async") && cfg === "c3") {
     const outs = [new Float32Array(wasm.allocPinned(W * H * 16)), new Float32Array(wasm.allocPinned(W * H * 16))];
     const pend = [null, null];
     let steps = 0;

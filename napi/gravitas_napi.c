@@ -1261,16 +1261,27 @@ typedef struct {
     uint32_t w, h;
     int pending; /* readAsync works queued (main thread only) */
     int freed;   /* free() arrived while reads were pending: the last one destroys the image */
+    int64_t accounted; /* bytes reported to the JS heap's external-memory counter (the collector cannot see HBM:
+                          an unreachable 133 MB image should weigh on it like one) */
 } image_box;
+
+static void image_release(napi_env env, image_box *ib) {
+    if (ib->img) grv_image_destroy(ib->img);
+    ib->img = NULL;
+    if (ib->accounted) {
+        int64_t adj;
+        napi_adjust_external_memory(env, -ib->accounted, &adj);
+        ib->accounted = 0;
+    }
+}
 
 static napi_ref g_image_ctor = NULL;
 
 static void image_finalize(napi_env env, void *data, void *hint) {
-    (void)env;
     (void)hint;
     image_box *ib = (image_box *)data;
     if (ib) {
-        if (ib->img) grv_image_destroy(ib->img); /* (a pending read holds a reference to the object) */
+        image_release(env, ib); /* (a pending read holds a reference to the object) */
         free(ib);
     }
 }
@@ -1309,6 +1320,11 @@ static napi_value wrap_image(napi_env env, grv_image *img) {
         grv_image_destroy(img);
         napi_throw_error(env, NULL, "DeviceImage: cannot wrap the object");
         return NULL;
+    }
+    {
+        int64_t adj;
+        ib->accounted = (int64_t)grv_image_bytes(img);
+        napi_adjust_external_memory(env, ib->accounted, &adj);
     }
     napi_set_named_property(env, obj, "width", mk_f64(env, ib->w));
     napi_set_named_property(env, obj, "height", mk_f64(env, ib->h));
@@ -1512,10 +1528,7 @@ static void read_async_complete(napi_env env, napi_status status, void *data) {
     }
     napi_delete_async_work(env, w->work);
     pinned_release(w->pin);
-    if (--w->ib->pending == 0 && w->ib->freed && w->ib->img) {
-        grv_image_destroy(w->ib->img);
-        w->ib->img = NULL;
-    }
+    if (--w->ib->pending == 0 && w->ib->freed && w->ib->img) image_release(env, w->ib);
     napi_delete_reference(env, w->self_ref);
     napi_delete_reference(env, w->out_ref);
     free(w);
@@ -1630,10 +1643,7 @@ static napi_value im_free(napi_env env, napi_callback_info info) {
     NAPI_OK(napi_get_cb_info(env, info, &argc, NULL, &self, NULL));
     if (napi_unwrap(env, self, (void **)&ib) == napi_ok && ib && ib->img) {
         if (ib->pending > 0) ib->freed = 1; /* the last pending read destroys it */
-        else {
-            grv_image_destroy(ib->img);
-            ib->img = NULL;
-        }
+        else image_release(env, ib);
     }
     return NULL;
 }

@@ -11,7 +11,9 @@ import sys
 def main():
     d = sys.argv[1]
     out = {"session": os.path.basename(d.rstrip("/")), "configs": {}}
-    for cfg in ("c3", "c2"):
+    for cfg in ("c3", "c2", "c4", "c5"):
+        if not os.path.exists(os.path.join(d, "napi_frames_%s.jsonl" % cfg)):
+            continue
         py = json.loads(open(os.path.join(d, "frames_benchpy_%s.json" % cfg)).read().strip().splitlines()[-1])
         js = [json.loads(l) for l in open(os.path.join(d, "napi_frames_%s.jsonl" % cfg)) if l.strip()]
         rec = {"bench_py": {k: py[k] for k in ("value", "ms_per_step", "steps", "warmup")},

@@ -62,9 +62,12 @@ for stage in "$@"; do
         if [ -z "$first" ]; then first=$n; else echo "$n vs $first: $(python tools/ab_glsl_identical.py /tmp/ident_$first.npz /tmp/ident_$n.npz)" | tee -a $O/identical.txt; fi
       done; cp /tmp/lib_keep.so blackhole-simulation_amd/libgravitas_hip.so;;
     frames)
-      for cfg in c3 c2; do
-        timeout 900 python bench.py --config $cfg --no-cpu-baseline > $O/frames_benchpy_$cfg.json 2> $O/frames_benchpy_$cfg.err; echo "bench.py $cfg rc=$?"; cut -c1-120 $O/frames_benchpy_$cfg.json
-        timeout 900 node napi/bench_frames.js --config $cfg $arg --out $O/napi_frames_$cfg.jsonl > $O/napi_frames_$cfg.log 2>&1; echo "bench_frames.js $cfg rc=$?"; cut -c1-150 $O/napi_frames_$cfg.log
+      for cfg in c3 c2 c4 c5; do
+        sw=""; forms="--form all"
+        [ $cfg = c5 ] && sw="--steps 5 --warmup 1"
+        case $cfg in c4|c5) forms="--form device";; esac   # the two scaling / parity configs: the device-resident form only
+        timeout 900 python bench.py --config $cfg $sw --no-cpu-baseline > $O/frames_benchpy_$cfg.json 2> $O/frames_benchpy_$cfg.err; echo "bench.py $cfg rc=$?"; cut -c1-120 $O/frames_benchpy_$cfg.json
+        timeout 900 node napi/bench_frames.js --config $cfg $sw $forms $arg --out $O/napi_frames_$cfg.jsonl > $O/napi_frames_$cfg.log 2>&1; echo "bench_frames.js $cfg rc=$?"; cut -c1-150 $O/napi_frames_$cfg.log
       done;;
     ab) AB_CONFIGS="${arg:-c2;c2 --one-stream}" bash tools/ab_configs.sh $T/ab > $O/ab.log 2>&1; tail -40 $O/ab.log;;
     *) echo "unknown stage $stage";;
