@@ -90,9 +90,13 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // flight); a one-stream caller never allocates it.
 int ensure_workspace(grv_engine *e, size_t slots, hipStream_t s) {
     int pick = e->wlast;
-    if (e->wset[pick].used && e->wset[pick].last_stream != s) pick ^= 1;
+    if (e->ctl_stream && s == e->ctl_stream) {
+        pick = 2; // the control stream's own set: a worker-sized batch never waits for a frame's workspace
+    } else {
+        if (e->wset[pick].used && e->wset[pick].last_stream != s) pick ^= 1;
+        e->wlast = pick;
+    }
     grv_engine::WorkSet &W = e->wset[pick];
-    e->wlast = pick;
     GRV_HIP(e, hipSetDevice(e->device));
     if (!W.done) GRV_HIP(e, hipEventCreateWithFlags(&W.done, hipEventDisableTiming));
     e->cur = &W;
@@ -168,6 +172,22 @@ int release_workspace(grv_engine *e, hipStream_t s) {
     return GRV_OK;
 }
 
+int create_priority_stream(grv_engine *e, hipStream_t *out) {
+    int least = 0, greatest = 0;
+    GRV_HIP(e, hipDeviceGetStreamPriorityRange(&least, &greatest)); // numerically lower = higher priority
+    GRV_HIP(e, hipStreamCreateWithPriority(out, hipStreamNonBlocking, greatest));
+    return GRV_OK;
+}
+
+int control_stream(grv_engine *e, hipStream_t *out) {
+    if (!e->ctl_stream) {
+        const int rc = create_priority_stream(e, &e->ctl_stream);
+        if (rc != GRV_OK) return rc;
+    }
+    *out = e->ctl_stream;
+    return GRV_OK;
+}
+
 int ensure_stage(grv_engine *e, size_t bytes) {
     if (bytes <= e->stage_bytes) return GRV_OK;
     if (e->stage_mem) (void)hipFree(e->stage_mem);
@@ -235,9 +255,9 @@ hipError_t launch_path(int arith, int kind, int method, const RayWorkspace &ws, 
 }
 
 hipError_t launch_refill(int arith, int kind, int method, const RayWorkspace &ws,
-                         const SegmentParams &P, uint32_t *cursor, int n_cu, hipStream_t s) {
-    return arith == GRV_ARITH_FAST ? launch_refill_fast(kind, method, ws, P, cursor, n_cu, s)
-                                   : launch_refill_strict(kind, method, ws, P, cursor, n_cu, s);
+                         const SegmentParams &P, uint32_t *cursor, int n_cu, hipStream_t s, uint32_t block_threads = 0) {
+    return arith == GRV_ARITH_FAST ? launch_refill_fast(kind, method, ws, P, cursor, n_cu, s, block_threads)
+                                   : launch_refill_strict(kind, method, ws, P, cursor, n_cu, s, block_threads);
 }
 
 // tries between two refill checks of a wave in the refill kernel
@@ -358,8 +378,13 @@ int begin_frame_stats(grv_engine *e, hipStream_t s) {
         if (e->stats_cleared_rec) GRV_HIP(e, hipStreamWaitEvent(s, e->stats_cleared, 0));
         return GRV_OK;
     }
-    e->stats_turn ^= 1;
-    const int b = e->stats_turn;
+    int b;
+    if (e->ctl_stream && s == e->ctl_stream) {
+        b = 2; // the control stream's own block (its previous user sits on the same stream)
+    } else {
+        e->stats_turn ^= 1;
+        b = e->stats_turn;
+    }
     e->d_stats = e->stats_blocks + b;
     if (e->stats_used[b]) GRV_HIP(e, hipStreamWaitEvent(s, e->stats_done[b], 0));
     if (e->stats_cleared_rec) GRV_HIP(e, hipStreamWaitEvent(s, e->stats_cleared, 0));
@@ -595,8 +620,8 @@ int grv_engine_create(double mass, double spin, int device, grv_engine **out) {
     if (hipSetDevice(device) != hipSuccess) return bail(GRV_ERR_NO_DEVICE);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) e->n_cu = prop.multiProcessorCount;
-    if (hipMalloc(reinterpret_cast<void **>(&e->stats_blocks), 2 * sizeof(FrameStatsDev)) != hipSuccess) return bail(GRV_ERR_OOM);
-    if (hipMemset(e->stats_blocks, 0, 2 * sizeof(FrameStatsDev)) != hipSuccess) return bail(GRV_ERR_HIP);
+    if (hipMalloc(reinterpret_cast<void **>(&e->stats_blocks), 3 * sizeof(FrameStatsDev)) != hipSuccess) return bail(GRV_ERR_OOM);
+    if (hipMemset(e->stats_blocks, 0, 3 * sizeof(FrameStatsDev)) != hipSuccess) return bail(GRV_ERR_HIP);
     e->d_stats = e->stats_blocks;
     for (auto &ev : e->stats_done)
         if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return bail(GRV_ERR_HIP);
@@ -656,6 +681,10 @@ void grv_engine_destroy(grv_engine *e) {
         (void)hipStreamSynchronize(e->ray_stream);
         (void)hipStreamDestroy(e->ray_stream);
     }
+    if (e->ctl_stream) {
+        (void)hipStreamSynchronize(e->ctl_stream);
+        (void)hipStreamDestroy(e->ctl_stream);
+    }
     if (e->ray_out) (void)hipHostFree(e->ray_out);
     if (e->ev_ok)
         for (auto &ev : e->ev) (void)hipEventDestroy(ev);
@@ -705,6 +734,8 @@ int grv_integrate_batch_device(grv_engine *e, size_t n, const double *d_states,
     if (n > 0x7FFFFFFFull) return fail(e, GRV_ERR_INVALID, "batch too large");
     hipStream_t s = static_cast<hipStream_t>(stream);
     GRV_HIP(e, hipSetDevice(e->device));
+    // worker-sized batches arrive on the control stream: one-wave blocks (engine_types.hpp launch_finalize_batch)
+    const uint32_t latency_blocks = (e->ctl_stream && s == e->ctl_stream) ? 64u : 0u;
     CallScope scope(e, s); // hands the workspace set and the counter block back on every exit path
     int rc = ensure_workspace(e, n, s);
     if (rc != GRV_OK) return rc;
@@ -724,13 +755,17 @@ int grv_integrate_batch_device(grv_engine *e, size_t n, const double *d_states,
         P.max_tries = opt->segment_tries < 0 ? (uint32_t)(-(int64_t)opt->segment_tries) : kRefillPeriod;
         P.try_cap = try_bound(e, opt->max_steps);
         GRV_HIP(e, launch_refill(opt->arith, opt->metric_kind, opt->method, e->ws, P,
-                                 e->d_counters + 2, e->n_cu, s));
+                                 e->d_counters + 2, e->n_cu, s, latency_blocks));
         e->last_launches += 1;
     }
     GRV_HIP(e, launch_finalize_batch(e->ws, d_out_states, d_steps, d_termination, d_drift,
-                                     e->d_stats, s));
+                                     e->d_stats, s, latency_blocks));
     return GRV_OK;
 }
+
+// host-pointer batches up to this size take the control stream (latency), larger ones the null stream (throughput:
+// a quarter of a million rays at high priority would hold a renderer's frames back instead)
+constexpr size_t kLatencyBatchRays = 16384;
 
 int grv_integrate_batch(grv_engine *e, size_t n, const double *states, const GrvOptions *opt,
                         double *out_states, uint32_t *steps, uint8_t *termination, double *drift) {
@@ -748,6 +783,22 @@ int grv_integrate_batch(grv_engine *e, size_t n, const double *states, const Grv
     uint32_t *d_steps = reinterpret_cast<uint32_t *>(p + 2 * sb);
     uint8_t *d_term = reinterpret_cast<uint8_t *>(p + 2 * sb + ub);
     double *d_drift = reinterpret_cast<double *>(p + 2 * sb + ub + bb);
+    if (n <= kLatencyBatchRays) {
+        // a worker-sized batch: on the engine's high-priority control stream, synchronised alone -- it must not wait
+        // for the frames a renderer has queued on the same device (napi/control_latency.js)
+        hipStream_t cs;
+        rc = control_stream(e, &cs);
+        if (rc != GRV_OK) return rc;
+        GRV_HIP(e, hipMemcpyAsync(d_in, states, n * 64, hipMemcpyHostToDevice, cs));
+        rc = grv_integrate_batch_device(e, n, d_in, opt, d_out, d_steps, d_term, d_drift, cs);
+        if (rc != GRV_OK) return rc;
+        GRV_HIP(e, hipMemcpyAsync(out_states, d_out, n * 64, hipMemcpyDeviceToHost, cs));
+        if (steps) GRV_HIP(e, hipMemcpyAsync(steps, d_steps, n * 4, hipMemcpyDeviceToHost, cs));
+        if (termination) GRV_HIP(e, hipMemcpyAsync(termination, d_term, n, hipMemcpyDeviceToHost, cs));
+        if (drift) GRV_HIP(e, hipMemcpyAsync(drift, d_drift, n * 8, hipMemcpyDeviceToHost, cs));
+        GRV_HIP(e, hipStreamSynchronize(cs));
+        return GRV_OK;
+    }
     GRV_HIP(e, hipMemcpy(d_in, states, n * 64, hipMemcpyHostToDevice));
     rc = grv_integrate_batch_device(e, n, d_in, opt, d_out, d_steps, d_term, d_drift, nullptr);
     if (rc != GRV_OK) return rc;
@@ -924,9 +975,11 @@ size_t grv_integrate_ray_relativistic_ex(grv_engine *e, const double *initial_st
     const uint32_t seq = ++e->ray_seq ? e->ray_seq : ++e->ray_seq; // never 0 (the block starts zeroed)
     // the one-ray entry's own stream, created by its first call: the runtime multiplexes streams onto a few
     // hardware queues, and an engine that only renders frames should not take one of them
-    if (!e->ray_stream) {
-        st = hipStreamCreateWithFlags(&e->ray_stream, hipStreamNonBlocking);
-        if (st != hipSuccess) return nan_out("hipStreamCreate", st);
+    if (!e->ray_stream) { // highest priority: one wave must not queue behind the frames a renderer has in flight
+        if (create_priority_stream(e, &e->ray_stream) != GRV_OK) {
+            for (int i = 0; i < 8; ++i) out[i] = std::nan("");
+            return 8;
+        }
     }
     st = (o.arith == GRV_ARITH_FAST ? launch_single_ray_fast : launch_single_ray)(
         o.metric_kind, P, in, o.initial_step, e->ray_out, seq, e->ray_stream);
@@ -1191,7 +1244,7 @@ int grv_frame_stats(grv_engine *e, void *stream, GrvFrameStats *stats) {
 
 size_t grv_engine_device_bytes(const grv_engine *e) {
     if (!e) return 0;
-    size_t b = 2 * sizeof(FrameStatsDev) + e->stage_bytes + e->post_bytes;
+    size_t b = 3 * sizeof(FrameStatsDev) + e->stage_bytes + e->post_bytes;
     for (const auto &W : e->wset) b += W.bytes;
     if (e->d_lut) b += (size_t)e->lut_w * e->lut_h * 4 * sizeof(float);
     if (e->d_disk_lut) b += 4096 + kDiskLutWidth * sizeof(double);
@@ -1274,7 +1327,7 @@ int grv_frame_stats_reset(grv_engine *e, void *stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     GRV_HIP(e, hipSetDevice(e->device));
     // behind every call that may still be adding to the block (they may sit on other streams)
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < 3; ++b)
         if (e->stats_used[b]) GRV_HIP(e, hipStreamWaitEvent(s, e->stats_done[b], 0));
     for (auto &W : e->wset)
         if (W.used) GRV_HIP(e, hipStreamWaitEvent(s, W.done, 0));

@@ -21,9 +21,12 @@ int viz_grid(grv_engine *e, size_t n_a, size_t n_b, float *out, Launch &&launch)
     int rc = ensure_stage(e, bytes);
     if (rc != GRV_OK) return rc;
     float *d_out = static_cast<float *>(e->stage_mem);
-    GRV_HIP(e, launch(d_out));
-    GRV_HIP(e, hipDeviceSynchronize());
-    GRV_HIP(e, hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost));
+    hipStream_t cs;
+    rc = control_stream(e, &cs);
+    if (rc != GRV_OK) return rc;
+    GRV_HIP(e, launch(d_out, cs));
+    GRV_HIP(e, hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, cs));
+    GRV_HIP(e, hipStreamSynchronize(cs));
     return GRV_OK;
 }
 } // namespace
@@ -50,10 +53,13 @@ int grv_generate_spectrum_lut(grv_engine *e, size_t width, size_t height, double
     const size_t bytes = width * height * 4 * sizeof(float);
     int rc = ensure_stage(e, bytes);
     if (rc != GRV_OK) return rc;
-    rc = grv_generate_spectrum_lut_device(e, width, height, max_temp, static_cast<float *>(e->stage_mem), nullptr);
+    hipStream_t cs;
+    rc = control_stream(e, &cs);
     if (rc != GRV_OK) return rc;
-    GRV_HIP(e, hipDeviceSynchronize());
-    GRV_HIP(e, hipMemcpy(out_host, e->stage_mem, bytes, hipMemcpyDeviceToHost));
+    rc = grv_generate_spectrum_lut_device(e, width, height, max_temp, static_cast<float *>(e->stage_mem), cs);
+    if (rc != GRV_OK) return rc;
+    GRV_HIP(e, hipMemcpyAsync(out_host, e->stage_mem, bytes, hipMemcpyDeviceToHost, cs));
+    GRV_HIP(e, hipStreamSynchronize(cs));
     return GRV_OK;
 }
 
@@ -200,9 +206,12 @@ int grv_generate_disk_lut(grv_engine *e, float *out512) {
     if (rc != GRV_OK) return rc;
     float *d_out = static_cast<float *>(e->stage_mem);
     double *d_tmp = reinterpret_cast<double *>(static_cast<char *>(e->stage_mem) + 4096);
-    GRV_HIP(e, launch_disk_temperature_lut(d_out, d_tmp, w, e->mass, e->spin_c, nullptr));
-    GRV_HIP(e, hipDeviceSynchronize());
-    GRV_HIP(e, hipMemcpy(out512, d_out, w * sizeof(float), hipMemcpyDeviceToHost));
+    hipStream_t cs;
+    rc = control_stream(e, &cs);
+    if (rc != GRV_OK) return rc;
+    GRV_HIP(e, launch_disk_temperature_lut(d_out, d_tmp, w, e->mass, e->spin_c, cs));
+    GRV_HIP(e, hipMemcpyAsync(out512, d_out, w * sizeof(float), hipMemcpyDeviceToHost, cs));
+    GRV_HIP(e, hipStreamSynchronize(cs));
     std::memcpy(e->disk_lut.data(), out512, w * sizeof(float)); // self.lut_buffer = ... (lib.rs:108)
     return GRV_OK;
 }
@@ -231,24 +240,23 @@ int grv_generate_field(grv_engine *e, int field, double r_min, double r_max, siz
                        size_t n_polar, float *out) {
     if (e && (field < GRV_FIELD_CURVATURE || field > GRV_FIELD_FRAME_DRAG))
         return fail(e, GRV_ERR_INVALID, "unknown field %d", field);
-    return viz_grid(e, n_radial, n_polar, out, [&](float *d) {
+    return viz_grid(e, n_radial, n_polar, out, [&](float *d, hipStream_t cs) {
         return launch_viz_field(field, viz_hole(e), r_min, r_max, (uint32_t)n_radial,
-                                (uint32_t)n_polar, d, nullptr);
+                                (uint32_t)n_polar, d, cs);
     });
 }
 
 int grv_generate_embedding_mesh(grv_engine *e, double r_min, double r_max, size_t n_radial,
                                 size_t n_angular, float *out) {
-    return viz_grid(e, n_radial, n_angular, out, [&](float *d) {
+    return viz_grid(e, n_radial, n_angular, out, [&](float *d, hipStream_t cs) {
         return launch_embedding_mesh(viz_hole(e), r_min, r_max, (uint32_t)n_radial,
-                                     (uint32_t)n_angular, d, nullptr);
+                                     (uint32_t)n_angular, d, cs);
     });
 }
 
 int grv_generate_ergosphere_mesh(grv_engine *e, size_t n_polar, size_t n_azimuthal, float *out) {
-    return viz_grid(e, n_polar, n_azimuthal, out, [&](float *d) {
-        return launch_ergosphere_mesh(viz_hole(e), (uint32_t)n_polar, (uint32_t)n_azimuthal, d,
-                                      nullptr);
+    return viz_grid(e, n_polar, n_azimuthal, out, [&](float *d, hipStream_t cs) {
+        return launch_ergosphere_mesh(viz_hole(e), (uint32_t)n_polar, (uint32_t)n_azimuthal, d, cs);
     });
 }
 

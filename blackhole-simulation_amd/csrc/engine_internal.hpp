@@ -49,7 +49,7 @@ struct grv_engine {
         hipEvent_t done = nullptr;
         hipStream_t last_stream = nullptr;
         bool used = false;
-    } wset[2];
+    } wset[3]; // [2]: calls on the control stream (worker-sized batches) -- never behind a frame's workspace
     int wlast = 0;                     // the set the previous call used
     WorkSet *cur = nullptr;            // the set of the call in progress
     grvhip::RayWorkspace ws{};         // == cur->ws
@@ -59,9 +59,9 @@ struct grv_engine {
     // them (a call clears its block behind the block's previous user, so the clear never lands under
     // another stream's still-running finalize kernel); with it every call adds to the current block.
     // d_stats is the block of the call in progress / the last call: what grv_frame_stats reads.
-    grvhip::FrameStatsDev *stats_blocks = nullptr; // [2]
-    hipEvent_t stats_done[2] = {nullptr, nullptr};
-    bool stats_used[2] = {false, false};
+    grvhip::FrameStatsDev *stats_blocks = nullptr; // [3]: two alternating + one for calls on the control stream
+    hipEvent_t stats_done[3] = {nullptr, nullptr, nullptr};
+    bool stats_used[3] = {false, false, false};
     hipEvent_t stats_cleared = nullptr; // end of the last grv_frame_stats_reset
     bool stats_cleared_rec = false;
     int stats_turn = 0;
@@ -76,7 +76,11 @@ struct grv_engine {
 
     // single-ray entry (grv_integrate_ray_relativistic): its own non-blocking stream and a pinned
     // result block the kernel writes and the host polls
-    hipStream_t ray_stream = nullptr;
+    hipStream_t ray_stream = nullptr;   // (created by the first one-ray call, at the device's highest stream priority)
+    // control-plane calls that need the device (LUTs, meshes, fields, the math probes): a stream of their own at the
+    // highest priority, synchronised alone -- a worker's parameter change must not wait for the frames a renderer has
+    // queued on the same device (measured: 82 ms behind three queued 4K frames on the null stream, napi/control_latency.js)
+    hipStream_t ctl_stream = nullptr;
     grvhip::SingleRayOut *ray_out = nullptr; // pinned, host-coherent
     uint32_t ray_seq = 0;
     int ray_arith = GRV_ARITH_STRICT; // contract of the one-ray entry (grv_engine_set_ray_arith)
@@ -181,6 +185,9 @@ double g_factor(double r, double mass, double spin, double lambda);
 int ensure_workspace(grv_engine *e, size_t slots, hipStream_t s);
 int release_workspace(grv_engine *e, hipStream_t s);
 int ensure_stage(grv_engine *e, size_t bytes);
+// the engine's control stream / a stream of the device's highest priority (created on first use)
+int control_stream(grv_engine *e, hipStream_t *out);
+int create_priority_stream(grv_engine *e, hipStream_t *out);
 int ensure_lut(grv_engine *e, uint32_t w, uint32_t h, double tmax, hipStream_t s);
 int ensure_disk_lut(grv_engine *e, hipStream_t s);
 size_t align_up(size_t x, size_t a);

@@ -210,7 +210,7 @@ hipError_t launch_segment_strict(int kind, int method, const RayWorkspace &ws,
                                  const SegmentParams &P, const uint32_t *live_in, uint32_t n_live,
                                  uint32_t *live_out, uint32_t *live_out_count, hipStream_t s);
 hipError_t launch_refill_strict(int kind, int method, const RayWorkspace &ws, const SegmentParams &P,
-                                uint32_t *cursor, int n_cu, hipStream_t s);
+                                uint32_t *cursor, int n_cu, hipStream_t s, uint32_t block_threads = 0);
 hipError_t launch_path_strict(int kind, int method, const RayWorkspace &ws, const SegmentParams &P,
                               const double *states_in, double *paths, uint32_t *counts, uint32_t max_points,
                               hipStream_t s);
@@ -223,9 +223,13 @@ hipError_t launch_init_states(int kind, const RayWorkspace &ws, const SegmentPar
 hipError_t launch_init_pixels(int kind, const RayWorkspace &ws, const SegmentParams &P,
                               const FrameGeom &G, const CameraDev &cam, double h0, int adaptive,
                               hipStream_t s);
+// block_threads (0 = the default four-wave blocks): worker-sized batches on the control stream start ONE-wave blocks --
+// beside a frame kernel at full occupancy a block is dispatched when its waves fit, and a single wave fits as soon as
+// one frame wave leaves a SIMD, a four-wave block only when one leaves on all four SIMDs of a CU at once (i.e. at the
+// frame's drain: such a batch waited for two of three queued 4K frames)
 hipError_t launch_finalize_batch(const RayWorkspace &ws, double *out_states, uint32_t *out_steps,
                                  uint8_t *out_term, double *out_drift, FrameStatsDev *st,
-                                 hipStream_t s);
+                                 hipStream_t s, uint32_t block_threads = 0);
 hipError_t launch_finalize_frame(const RayWorkspace &ws, const FrameGeom &G, const ShadeParams &S,
                                  int shading, const float *lut, const float *disk_lut, float *out_rgba,
                                  double *out_states, uint32_t *out_steps, uint8_t *out_term,
@@ -334,7 +338,7 @@ hipError_t launch_segment_fast(int kind, int method, const RayWorkspace &ws,
                                const SegmentParams &P, const uint32_t *live_in, uint32_t n_live,
                                uint32_t *live_out, uint32_t *live_out_count, hipStream_t s);
 hipError_t launch_refill_fast(int kind, int method, const RayWorkspace &ws, const SegmentParams &P,
-                              uint32_t *cursor, int n_cu, hipStream_t s);
+                              uint32_t *cursor, int n_cu, hipStream_t s, uint32_t block_threads = 0);
 // launches 2.. of the compacting schedule: the live list's length comes from device memory (geodesic_kernels.hpp
 // integrate_compact_kernel); `blocks` four-wave blocks stride over it
 hipError_t launch_compact_fast(int kind, int method, const RayWorkspace &ws, const SegmentParams &P,

@@ -89,8 +89,9 @@ __global__ __launch_bounds__(kBlock) void finalize_batch_kernel(
     RayWorkspace ws, double *__restrict__ out_states, uint32_t *__restrict__ out_steps,
     uint8_t *__restrict__ out_term, double *__restrict__ out_drift, FrameStatsDev *st) {
     StatAcc acc;
-    const uint32_t stride = gridDim.x * kBlock;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < ws.n; i += stride) {
+    // (block size is a launch property: one-wave blocks for worker-sized batches on the control stream)
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ws.n; i += stride) {
         const uint32_t steps = ws.steps[i];
         const uint32_t tries = ws.tries[i];
         const uint32_t flags = ws.flags[i];

@@ -121,11 +121,12 @@ hipError_t launch_init_pixels(int kind, const RayWorkspace &ws, const SegmentPar
 
 hipError_t launch_finalize_batch(const RayWorkspace &ws, double *out_states, uint32_t *out_steps,
                                  uint8_t *out_term, double *out_drift, FrameStatsDev *st,
-                                 hipStream_t s) {
-    uint32_t grid = (ws.n + kBlock - 1) / kBlock;
+                                 hipStream_t s, uint32_t block_threads) {
+    const uint32_t bt = block_threads ? block_threads : (uint32_t)kBlock;
+    uint32_t grid = (ws.n + bt - 1) / bt;
     if (grid == 0) return hipSuccess;
     if (grid > 2048u) grid = 2048u;
-    hipLaunchKernelGGL(finalize_batch_kernel, dim3(grid), dim3(kBlock), 0, s, ws, out_states,
+    hipLaunchKernelGGL(finalize_batch_kernel, dim3(grid), dim3(bt), 0, s, ws, out_states,
                        out_steps, out_term, out_drift, st);
     return hipGetLastError();
 }

@@ -280,3 +280,39 @@ def test_post_bloom_growing_its_scratch_leaves_the_renderer_targets_alone(engine
             eng.webgl_render(bh.glsl_params(w, h, 1.0, 0.9, arith=bh.ARITH_FAST, time=0.2 * i), scr)
             assert np.array_equal(scr.cpu().numpy().view(np.uint32), want[i].view(np.uint32)), i
         del junk
+
+
+def test_control_plane_calls_do_not_wait_for_queued_frames(engine_mod):
+    """A worker's calls (physics.worker.ts:75-176: LUTs, meshes, the one-ray FFI entry, worker-sized batches) run on
+    the engine's high-priority control / one-ray streams with workspaces and counters of their own: with ~80 ms of 4K
+    frames queued on the same handle they return before ANY of those frames has finished (before round 6:
+    82 ms each, behind the whole queue -- napi/control_latency.js, profiles/r06_control_latency.json)."""
+    bh = engine_mod
+    Wb, Hb = 3840, 2160
+    with bh.PhysicsEngine(1.0, 0.999) as eng:
+        cam = bh.camera_look_at(EYE, aspect=Wb / Hb)
+        p = bh.render_params(Wb, Hb, arith=bh.ARITH_FAST, tolerance=1e-8)
+        imgs = [eng.create_image(Wb, Hb), eng.create_image(Wb, Hb), eng.create_image(Wb, Hb)]
+        st = np.array([[0, 20.0 + 0.1 * k, 1.5, 0.0, -1, -1.0, 0.0, 3.5] for k in range(256)])
+        o = bh.engine.default_options(max_steps=2000)
+        # warm: first-use allocations, code loads
+        eng.render_frame_image(cam, p, imgs[0])
+        eng.generate_disk_lut(); eng.generate_spectrum_lut(512, 64, 1e5); eng.generate_embedding_mesh(2.0, 30.0, 64, 64)
+        ref_ray = eng.integrate_ray_relativistic([0, 20, np.pi / 2, 0, -1, -1, 0, 3.5], 2000, 1e-8, True)
+        ref_batch = eng.integrate_batch(st, o)
+        eng.synchronize()
+        calls = [lambda: eng.generate_disk_lut(), lambda: eng.generate_spectrum_lut(512, 64, 1e5),
+                 lambda: eng.generate_embedding_mesh(2.0, 30.0, 64, 64),
+                 lambda: eng.integrate_ray_relativistic([0, 20, np.pi / 2, 0, -1, -1, 0, 3.5], 2000, 1e-8, True),
+                 lambda: eng.integrate_batch(st, o)]
+        for k, call in enumerate(calls):
+            for j in range(3):                      # ~80 ms of kernels on three streams, nothing waited for
+                eng.render_frame_image(cam, p, imgs[j])
+            got = call()
+            # not even the first of the three frames (they share the chip: each needs most of the 80 ms) is finished
+            assert not any(im.ready() for im in imgs), "call %d returned only after a queued frame" % k
+            eng.synchronize()
+            if k == 3:
+                assert np.array_equal(np.asarray(got), np.asarray(ref_ray))
+            if k == 4:
+                assert np.array_equal(got["states"], ref_batch["states"]) and np.array_equal(got["steps"], ref_batch["steps"])
