@@ -218,7 +218,10 @@ int grv_render_frame_image(grv_engine *e, const GrvCamera *cam, const GrvRenderP
     GrvFrameBuffers fb{};
     fb.rgba = img->d;
     rc = grv_render_frame_device(e, cam, p, &fb, img->s);
-    if (rc != GRV_OK) return rc;
+    if (rc != GRV_OK) {
+        (void)end_write(e, img); // kernels of the failed frame may be queued: a later wait / read / destroy covers them
+        return rc;
+    }
     rc = snapshot_stats(e, img);
     if (rc != GRV_OK) return rc;
     return end_write(e, img);
@@ -234,7 +237,10 @@ int grv_render_frame_glsl_image(grv_engine *e, const GrvGlslParams *p, grv_image
     int rc = begin_write(e, img);
     if (rc != GRV_OK) return rc;
     rc = grv_render_frame_glsl(e, p, img->d, nullptr, nullptr, img->s);
-    if (rc != GRV_OK) return rc;
+    if (rc != GRV_OK) {
+        (void)end_write(e, img); // kernels of the failed frame may be queued: a later wait / read / destroy covers them
+        return rc;
+    }
     rc = snapshot_stats(e, img);
     if (rc != GRV_OK) return rc;
     return end_write(e, img);
@@ -250,7 +256,10 @@ int grv_render_frame_wgsl_image(grv_engine *e, const GrvWgslParams *p, grv_image
     int rc = begin_write(e, img);
     if (rc != GRV_OK) return rc;
     rc = grv_render_frame_wgsl(e, p, img->d, nullptr, nullptr, img->s);
-    if (rc != GRV_OK) return rc;
+    if (rc != GRV_OK) {
+        (void)end_write(e, img); // kernels of the failed frame may be queued: a later wait / read / destroy covers them
+        return rc;
+    }
     rc = snapshot_stats(e, img);
     if (rc != GRV_OK) return rc;
     return end_write(e, img);

@@ -177,11 +177,25 @@ static napi_value get_arena(napi_env env) {
     return buf;
 }
 
+static napi_ref g_engine_ctor = NULL;
+/* the engine_box behind `self`, or NULL: only for objects made by the PhysicsEngine constructor (a method borrowed
+ * onto a DeviceImage would otherwise unwrap that object's box as an engine's) */
+static engine_box *engine_of(napi_env env, napi_value self) {
+    engine_box *box = NULL;
+    napi_value ctor;
+    bool is = false;
+    if (!g_engine_ctor || napi_get_reference_value(env, g_engine_ctor, &ctor) != napi_ok ||
+        napi_instanceof(env, self, ctor, &is) != napi_ok || !is) return NULL;
+    if (napi_unwrap(env, self, (void **)&box) != napi_ok) return NULL;
+    return box;
+}
+
 static engine_box *unwrap(napi_env env, napi_callback_info info, size_t *argc, napi_value *argv) {
     napi_value self;
     engine_box *box = NULL;
     if (napi_get_cb_info(env, info, argc, argv, &self, NULL) != napi_ok) return NULL;
-    if (napi_unwrap(env, self, (void **)&box) != napi_ok || !box || !box->h) {
+    box = engine_of(env, self);
+    if (!box || !box->h) {
         napi_throw_error(env, NULL, "PhysicsEngine: invalid receiver");
         return NULL;
     }
@@ -1008,7 +1022,8 @@ static napi_value render_frame_common(napi_env env, napi_callback_info info, int
     napi_value argv[1], self;
     engine_box *b = NULL;
     if (napi_get_cb_info(env, info, &argc, argv, &self, NULL) != napi_ok) return NULL;
-    if (napi_unwrap(env, self, (void **)&b) != napi_ok || !b || !b->h) {
+    b = engine_of(env, self);
+    if (!b || !b->h) {
         napi_throw_error(env, NULL, "PhysicsEngine: invalid receiver");
         return NULL;
     }
@@ -1138,7 +1153,8 @@ static napi_value integrate_batch_common(napi_env env, napi_callback_info info, 
     napi_value argv[2], self;
     engine_box *b = NULL;
     if (napi_get_cb_info(env, info, &argc, argv, &self, NULL) != napi_ok) return NULL;
-    if (napi_unwrap(env, self, (void **)&b) != napi_ok || !b || !b->h) {
+    b = engine_of(env, self);
+    if (!b || !b->h) {
         napi_throw_error(env, NULL, "PhysicsEngine: invalid receiver");
         return NULL;
     }
@@ -1294,12 +1310,12 @@ static image_box *image_of(napi_env env, napi_value v) {
     image_box *ib = NULL;
     napi_valuetype t;
     if (napi_typeof(env, v, &t) != napi_ok || t != napi_object) return NULL;
-    if (napi_unwrap(env, v, (void **)&ib) != napi_ok || !ib || !ib->img) return NULL;
-    /* (an engine object unwraps too: tell them apart by the constructor) */
+    /* (an engine object unwraps too: tell them apart by the constructor BEFORE looking at the wrapped pointer) */
     napi_value ctor;
     bool is = false;
     if (!g_image_ctor || napi_get_reference_value(env, g_image_ctor, &ctor) != napi_ok ||
         napi_instanceof(env, v, ctor, &is) != napi_ok || !is) return NULL;
+    if (napi_unwrap(env, v, (void **)&ib) != napi_ok || !ib || !ib->img) return NULL;
     return ib;
 }
 static napi_value wrap_image(napi_env env, grv_image *img) {
@@ -1421,7 +1437,8 @@ static napi_value m_create_image(napi_env env, napi_callback_info info) {
 static image_box *this_image(napi_env env, napi_callback_info info, size_t *argc, napi_value *argv, napi_value *self) {
     image_box *ib = NULL;
     if (napi_get_cb_info(env, info, argc, argv, self, NULL) != napi_ok) return NULL;
-    if (napi_unwrap(env, *self, (void **)&ib) != napi_ok || !ib || !ib->img) {
+    ib = image_of(env, *self); /* (checks the constructor: a method borrowed onto another object is refused) */
+    if (!ib) {
         napi_throw_error(env, NULL, "DeviceImage: no device memory behind this object (freed, or not made by createImage)");
         return NULL;
     }
@@ -2051,7 +2068,8 @@ static napi_value m_free(napi_env env, napi_callback_info info) { /* wasm-bindge
     napi_value self;
     engine_box *box = NULL;
     NAPI_OK(napi_get_cb_info(env, info, &argc, NULL, &self, NULL));
-    if (napi_unwrap(env, self, (void **)&box) == napi_ok && box && box->h) {
+    box = engine_of(env, self);
+    if (box && box->h) {
         if (box->async_pending > 0) {
             /* works are queued on the pool: the synchronous handle goes now (the object is unusable
              * from here on), the async handles when the last work completes */
@@ -2160,6 +2178,7 @@ static napi_value module_init(napi_env env, napi_value exports) {
     napi_value cls, fn;
     NAPI_OK(napi_define_class(env, "PhysicsEngine", NAPI_AUTO_LENGTH, engine_new, NULL,
                               sizeof props / sizeof props[0], props, &cls));
+    NAPI_OK(napi_create_reference(env, cls, 1, &g_engine_ctor));
     NAPI_OK(napi_set_named_property(env, exports, "PhysicsEngine", cls));
     NAPI_OK(napi_create_function(env, "init", NAPI_AUTO_LENGTH, f_init, NULL, &fn));
     NAPI_OK(napi_set_named_property(env, exports, "default", fn));
