@@ -291,8 +291,19 @@ constexpr uint32_t kCompactMaxLaunches = 192;    // bounded launches of one pass
 constexpr uint32_t kCompactUnknown = 0xFFFFFFFFu;
 constexpr uint32_t kCompactTailRays = 196608u;   // fewer live rays than the chip holds at three waves per SIMD (3 072 waves): compaction has nothing left to fill, the last launch takes them
 
+// share of the waves (the longest by the previous frame's count) that the compacting schedule runs in one unbounded
+// launch beside the chain instead of through it: the chain's latency-bound tail -- a few thousand rays that outlive the
+// bulk by hundreds of tries -- was 8 % of the frame (profiles/EXPERIMENTS.md section R)
+// (A/B on one box, profiles/r06_ab_compact_head.jsonl: K = 16 at -12.0 % of the one-launch frame without a head start,
+// -9 % with 1/32 of the waves, -7.0 % with 1/8, -5.8 % with 1/4; K = 64: -8.3 / -4 / -2.4 / -2.1 %.  An eighth: seven
+// eighths of the frame still go through the chain.)
+#ifndef GRV_COMPACT_HEAD_SHARE
+#define GRV_COMPACT_HEAD_SHARE 8
+#endif
+constexpr uint32_t kCompactHeadShare = GRV_COMPACT_HEAD_SHARE;
+
 int run_segments(grv_engine *e, const GrvOptions &o, SegmentParams P, uint32_t seg_tries,
-                 hipStream_t s, bool profile) {
+                 hipStream_t s, bool profile, const uint32_t *head_order) {
     (void)profile; // the frame's ring events bracket the pass; nothing in here waits, so there are no host gaps in it
     const uint32_t bound = try_bound(e, o.max_steps);
     if (seg_tries == 0) {
@@ -346,10 +357,37 @@ int run_segments(grv_engine *e, const GrvOptions &o, SegmentParams P, uint32_t s
     };
     uint32_t *c = e->d_counters + 4; // three rotating live counters (d_counters[0..3]: refill cursor and spares)
     GRV_HIP(e, hipMemsetAsync(c, 0, 3 * sizeof(uint32_t), s));
-    GRV_HIP(e, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c), (int)n, 1, s)); // launch 0 "reads" c[0] = every slot
+    // Head start: with a forecast (the previous frame's waves sorted longest-first) the top 1 / kCompactHeadShare of the
+    // waves do not go through the chain at all -- they run to their end in ONE launch on the side stream, beside the
+    // chain from its first launch on, the way the one-launch schedule runs them beside everything else.  The chain's
+    // first list is then the rest (live[0][0 .. n_rest)); the head's list sits in the part of live[1] the chain never
+    // appends to (its counts stay <= n_rest).  A stale forecast costs time, not correctness.
+    uint32_t n_rest = n;
+    bool head = false;
+    if (head_order && kCompactHeadShare && (n & 63u) == 0u && n / 64u >= 4096u) {
+        const uint32_t n_waves = n / 64u, n_head = n_waves / kCompactHeadShare;
+        n_rest = (n_waves - n_head) * 64u;
+        if (!e->sort_stream) GRV_HIP(e, hipStreamCreateWithFlags(&e->sort_stream, hipStreamNonBlocking));
+        if (!e->head_from) GRV_HIP(e, hipEventCreateWithFlags(&e->head_from, hipEventDisableTiming));
+        if (!e->head_done) GRV_HIP(e, hipEventCreateWithFlags(&e->head_done, hipEventDisableTiming));
+        GRV_HIP(e, launch_split_order(head_order, n_waves, n_head, e->live[1] + n_rest, e->live[0], s));
+        GRV_HIP(e, hipEventRecord(e->head_from, s));
+        GRV_HIP(e, hipStreamWaitEvent(e->sort_stream, e->head_from, 0));
+        SegmentParams H = P;
+        H.max_tries = bound;
+        H.final_launch = 1;
+        H.order = nullptr;
+        GRV_HIP(e, launch_segment(o.arith, o.metric_kind, o.method, e->ws, H, e->live[1] + n_rest, n_head * 64u, nullptr, nullptr,
+                                  e->sort_stream));
+        GRV_HIP(e, hipEventRecord(e->head_done, e->sort_stream));
+        e->last_launches += 1;
+        head = true;
+    }
+    GRV_HIP(e, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c), (int)n_rest, 1, s)); // launch 0 "reads" c[0]
     P.max_tries = seg_tries;
     P.final_launch = 0;
-    for (uint32_t j = 0; j <= L; ++j) { // launch 0: the identity list (null), appends to live[1] / c[1]
+    P.order = nullptr;
+    for (uint32_t j = 0; j <= L; ++j) { // launch 0: the identity list (null) or the split's rest, appends to live[1] / c[1]
         const bool last = j == L;
         if (last) {
             P.max_tries = bound;
@@ -357,9 +395,10 @@ int run_segments(grv_engine *e, const GrvOptions &o, SegmentParams P, uint32_t s
         }
         uint32_t *out = last ? nullptr : e->live[(j + 1u) & 1u];
         const auto fn = o.arith == GRV_ARITH_FAST ? launch_compact_fast : launch_compact_strict;
-        GRV_HIP(e, fn(o.metric_kind, o.method, e->ws, P, j == 0 ? nullptr : e->live[j & 1u], c + (j % 3u), out,
+        GRV_HIP(e, fn(o.metric_kind, o.method, e->ws, P, j == 0 ? (head ? e->live[0] : nullptr) : e->live[j & 1u], c + (j % 3u), out,
                       c + ((j + 1u) % 3u), c + ((j + 2u) % 3u), e->compact_fb + j, blocks_for(j), s));
     }
+    if (head) GRV_HIP(e, hipStreamWaitEvent(s, e->head_done, 0)); // the finalize kernel reads every slot
     // what older passes reported beyond this pass's last launch is forgotten (if rays outlive the forecast, the next
     // pass finds "unknown" there and adds launches)
     for (uint32_t j = L + 1u; j <= kCompactMaxLaunches; ++j) fb[j] = kCompactUnknown;
@@ -459,6 +498,7 @@ int begin_march_order(grv_engine *e, int kind, uint32_t n_blocks, const uint32_t
         M.mem = nullptr;
         M.n_blocks = 0;
         M.has_order = false;
+        M.ranked = false;
         GRV_HIP(e, hipMalloc(reinterpret_cast<void **>(&M.mem), (size_t)2 * n_blocks * sizeof(uint32_t)));
         M.n_blocks = n_blocks;
     }
@@ -466,6 +506,7 @@ int begin_march_order(grv_engine *e, int kind, uint32_t n_blocks, const uint32_t
     if (!M.has_order || std::memcmp(M.geom, want, sizeof want) != 0) {
         // first frame of exactly this geometry: natural order, no forecast yet
         M.has_order = false;
+        M.ranked = false;
         GRV_HIP(e, launch_march_order_identity(M.mem + M.n_blocks, M.mem, n_blocks, s));
         // the table is in use on `s` from here on, whatever happens next: a later grow / free waits for it
         GRV_HIP(e, hipEventRecord(M.ready, s));
@@ -494,6 +535,7 @@ int finish_march_order(grv_engine *e, int kind, int parity, hipStream_t s) {
     GRV_HIP(e, launch_march_rank(M.mem, M.mem + M.n_blocks, M.cur, q));
     GRV_HIP(e, hipEventRecord(M.ready, q));
     M.ready_rec = true;
+    M.ranked = true;
     return GRV_OK;
 }
 
@@ -674,6 +716,8 @@ void grv_engine_destroy(grv_engine *e) {
         (void)hipStreamDestroy(e->sort_stream);
     }
     if (e->sort_from) (void)hipEventDestroy(e->sort_from);
+    if (e->head_from) (void)hipEventDestroy(e->head_from);
+    if (e->head_done) (void)hipEventDestroy(e->head_done);
     if (e->h_counters) (void)hipHostFree(e->h_counters);
     if (e->compact_fb) (void)hipHostFree(e->compact_fb);
     if (e->h_stats) (void)hipHostFree(e->h_stats);
@@ -1163,11 +1207,13 @@ int grv_render_frame_device(grv_engine *e, const GrvCamera *cam, const GrvRender
     // per-wave tries (costs written by this frame's finalize kernel, sorted behind it for the next frame)
     MarchSched sched{nullptr, nullptr};
     int order_parity = -1;
-    if (p->schedule == GRV_SCHEDULE_DEFAULT && p->segment_tries == 0 && P.block_order == 0 && slots >= kSegOneWaveMinRays) {
+    const uint32_t *head_order = nullptr;
+    if (p->schedule == GRV_SCHEDULE_DEFAULT && P.block_order == 0 && slots >= kSegOneWaveMinRays) {
         const uint32_t geom[4] = {p->width, p->height, G.tile_world, G.tile_rank};
         rc = begin_march_order(e, 2, (uint32_t)(slots / 64u), geom, s, &sched, &order_parity);
         if (rc != GRV_OK) return rc;
-        P.order = sched.order;
+        if (p->segment_tries == 0) P.order = sched.order;
+        else if (e->march_order[2][order_parity].ranked) head_order = sched.order; // the compacting schedule's head start
     }
     GRV_HIP(e, launch_init_pixels(p->opt.metric_kind, e->ws, P, G, cd, p->opt.initial_step,
                                   p->opt.method == GRV_METHOD_RKF45, s));
@@ -1175,7 +1221,7 @@ int grv_render_frame_device(grv_engine *e, const GrvCamera *cam, const GrvRender
     // neighbouring pixels take near-identical step counts (8x8-pixel waves run at >99 %
     // lane efficiency at 4K), so the frame default is one long segment; segment_tries
     // selects the compacting wavefront form
-    rc = run_segments(e, p->opt, P, p->segment_tries, s, profile);
+    rc = run_segments(e, p->opt, P, p->segment_tries, s, profile, head_order);
     if (rc != GRV_OK) return rc;
 
     ShadeParams S{};

@@ -145,6 +145,7 @@ struct grv_engine {
         // blocks undispatched)
         uint32_t geom[5] = {0, 0, 0, 0, 0};
         bool has_order = false;
+        bool ranked = false;     // the order comes from a sort of measured costs (not the identity of a first frame)
         hipEvent_t ready = nullptr;
         bool ready_rec = false;
     } march_order[3][2];
@@ -153,6 +154,7 @@ struct grv_engine {
     // 2 % of a 4 ms close-up frame): queued on a stream of its own behind the finalize kernel that wrote the costs
     hipStream_t sort_stream = nullptr;
     hipEvent_t sort_from = nullptr;
+    hipEvent_t head_from = nullptr, head_done = nullptr; // the compacting schedule's head-start launch on sort_stream
     uint8_t *d_noise = nullptr; // [2][256*256] R planes: u_noiseTex, u_blueNoiseTex
     std::vector<float> disk_lut = std::vector<float>(512, 0.0f); // lut_buffer (lib.rs:50, 65-66)
     std::vector<float> sab;
@@ -193,8 +195,10 @@ int ensure_disk_lut(grv_engine *e, hipStream_t s);
 size_t align_up(size_t x, size_t a);
 SegmentParams make_segment_params(const grv_engine *e, const GrvOptions &o);
 bool options_valid(const GrvOptions &o);
+// head_order: the previous frame's wave table sorted longest-first (device), or null -- the compacting schedule then
+// gives its first n_waves / kCompactHeadShare waves a head start (engine.hip)
 int run_segments(grv_engine *e, const GrvOptions &o, SegmentParams P, uint32_t seg_tries, hipStream_t s,
-                 bool profile);
+                 bool profile, const uint32_t *head_order = nullptr);
 int begin_frame_stats(grv_engine *e, hipStream_t s);
 int end_frame_stats(grv_engine *e, hipStream_t s);
 // Ends a frame / batch call on every exit path, early error returns included: the workspace set and

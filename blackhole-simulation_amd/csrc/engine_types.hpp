@@ -79,6 +79,9 @@ struct MarchSched {
 };
 hipError_t launch_march_order_identity(uint32_t *order, uint32_t *cost, uint32_t n, hipStream_t s);
 hipError_t launch_march_rank(const uint32_t *cost, uint32_t *order, uint32_t n, hipStream_t s);
+// slot lists of the first n_head waves of `order` (64 slots each) and of the remaining ones (kernels_strict.hip)
+hipError_t launch_split_order(const uint32_t *order, uint32_t n_waves, uint32_t n_head, uint32_t *head, uint32_t *rest,
+                              hipStream_t s);
 constexpr int kMaxCrossRec = 4;
 
 // flags word: bits 0-2 termination, bit 3 forced-min-step pending, bits 4-7 crossing

@@ -266,6 +266,28 @@ __global__ __launch_bounds__(1024) void march_rank_kernel(const uint32_t *__rest
 }
 } // namespace
 
+namespace {
+// The compacting schedule's head start (engine.hip run_segments): the sorted wave table of the previous frame, longest
+// first, cut at n_head.  Waves order[0 .. n_head) -- the forecast stragglers -- become the slot list `head` (they run in
+// ONE unbounded launch beside the chain from the start), the rest the chain's first live list `rest`.
+__global__ __launch_bounds__(kBlock) void split_order_kernel(const uint32_t *__restrict__ order, uint32_t n_waves, uint32_t n_head,
+                                                            uint32_t *__restrict__ head, uint32_t *__restrict__ rest) {
+    const uint32_t total = n_waves * 64u;
+    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < total; k += gridDim.x * kBlock) {
+        const uint32_t w = k >> 6, slot = order[w] * 64u + (k & 63u);
+        if (w < n_head) head[k] = slot;
+        else rest[k - n_head * 64u] = slot;
+    }
+}
+} // namespace
+
+hipError_t launch_split_order(const uint32_t *order, uint32_t n_waves, uint32_t n_head, uint32_t *head, uint32_t *rest, hipStream_t s) {
+    if (n_waves == 0) return hipSuccess;
+    uint32_t g = (n_waves * 64u + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(split_order_kernel, dim3(g > 4096u ? 4096u : g), dim3(kBlock), 0, s, order, n_waves, n_head, head, rest);
+    return hipGetLastError();
+}
+
 hipError_t launch_march_order_identity(uint32_t *order, uint32_t *cost, uint32_t n, hipStream_t s) {
     if (n == 0) return hipSuccess;
     uint32_t g = (n + kBlock - 1) / kBlock;
