@@ -79,3 +79,25 @@ def test_compacting_schedule_equals_the_one_launch_frame(engine_mod):
                 assert st.accepted_steps == int(want[2].sum()) and st.launches >= 1
         with pytest.raises(bh.GravitasError, match="schedule"):
             _frame(bh, eng, c, schedule=7)
+
+
+def test_compacting_schedule_with_a_stale_head_start_forecast(engine_mod):
+    """The compacting schedule gives the top eighth of the PREVIOUS frame's waves (longest first) a head start in one
+    launch beside the chain (engine.hip run_segments).  The forecast is stale by construction when the camera moves --
+    rays in the head that are short, long rays left in the chain --: the frame must not care."""
+    import torch
+    bh = engine_mod
+    cams = [_eye(20.0, 97.0), _eye(7.0, 80.0), _eye(20.0, 97.0), _eye(40.0, 30.0), _eye(7.0, 80.0), _eye(20.0, 97.0)]
+    with bh.PhysicsEngine(1.0, 0.999) as ref, bh.PhysicsEngine(1.0, 0.999) as eng:
+        want = {c: _bits(_frame(bh, ref, c, schedule=bh.SCHEDULE_SLOT_ORDER)) for c in set(cams)}
+        side = torch.cuda.Stream()
+        for k in (16, 48):
+            held = []
+            for rep, c in enumerate(cams):      # queued back to back on two streams: two frames in flight
+                st = side if rep % 2 else torch.cuda.current_stream()
+                with torch.cuda.stream(st):
+                    held.append((c, _frame(bh, eng, c, stream=st.cuda_stream, segment_tries=k)))
+            for rep, (c, out) in enumerate(held):
+                got = _bits(out)
+                for j, (g, w) in enumerate(zip(got, want[c])):
+                    assert np.array_equal(g, w), (k, rep, j)
