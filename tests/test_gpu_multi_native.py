@@ -336,12 +336,14 @@ def test_injected_faults_are_reported_and_the_next_frame_is_whole(bh):
                         m.render_frame_device(cam, p, outs[frame % 2], stream=streams[frame % 2].cuda_stream)
                 assert text in str(ei.value) and ("rank %d" % rank) in str(ei.value), str(ei.value)
                 for _ in range(3):  # ... and whole frames after it, both parities
-                    outs[frame % 2].fill_(-1.0)
-                    with torch.cuda.stream(streams[frame % 2]):
+                    with torch.cuda.stream(streams[frame % 2]):   # the fill on the frame's own stream: the null stream
+                        outs[frame % 2].fill_(-1.0)               # is not ordered with a non-blocking one
                         m.render_frame_device(cam, p, outs[frame % 2], stream=streams[frame % 2].cuda_stream)
                     m.synchronize()
                     torch.cuda.synchronize()
-                    assert torch.equal(outs[frame % 2].view(torch.int32), want.view(torch.int32)), (G, kind, frame)
+                    got = outs[frame % 2]
+                    assert torch.equal(got.view(torch.int32), want.view(torch.int32)), \
+                        (G, kind, frame, int((got != want).any(dim=2).sum()), int((got == -1.0).all(dim=2).sum()))
                     frame += 1
             with pytest.raises(bh.GravitasError, match="out of range"):
                 m.test_inject_fault(bh.FAULT_RENDER, G)
