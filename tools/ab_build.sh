@@ -35,5 +35,5 @@ else
 fi
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/ab_libs/lib_$NAME.so $STRICT_O \
   $FAST_O $FAST64_O $C/build/control_plane.o $C/build/spacetime_viz.o $ENGINE_O \
-  $C/build/engine_shaders.o $C/build/engine_control.o $C/build/engine_multi.o -ldl -lpthread
+  $C/build/engine_shaders.o $C/build/engine_control.o $C/build/engine_images.o $C/build/engine_multi.o -ldl -lpthread
 echo "ab_libs/lib_$NAME.so  ($EXTRA)"
