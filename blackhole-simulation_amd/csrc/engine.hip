@@ -688,6 +688,9 @@ int grv_engine_create(double mass, double spin, int device, grv_engine **out) {
 void grv_engine_destroy(grv_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
+    // frames may still be queued on streams this handle has never seen (a device image's, a caller's): everything on the
+    // device ends before the workspaces under it are released
+    (void)hipDeviceSynchronize();
     for (auto &W : e->wset) {
         if (W.mem) (void)hipFree(W.mem);
         if (W.done) (void)hipEventDestroy(W.done);

@@ -223,8 +223,8 @@ int grv_render_frame_image(grv_engine *e, const GrvCamera *cam, const GrvRenderP
         return rc;
     }
     rc = snapshot_stats(e, img);
-    if (rc != GRV_OK) return rc;
-    return end_write(e, img);
+    const int rc2 = end_write(e, img);
+    return rc != GRV_OK ? rc : rc2;
 }
 
 int grv_render_frame_glsl_image(grv_engine *e, const GrvGlslParams *p, grv_image *img) {
@@ -242,8 +242,8 @@ int grv_render_frame_glsl_image(grv_engine *e, const GrvGlslParams *p, grv_image
         return rc;
     }
     rc = snapshot_stats(e, img);
-    if (rc != GRV_OK) return rc;
-    return end_write(e, img);
+    const int rc2 = end_write(e, img);
+    return rc != GRV_OK ? rc : rc2;
 }
 
 int grv_render_frame_wgsl_image(grv_engine *e, const GrvWgslParams *p, grv_image *img) {
@@ -261,8 +261,8 @@ int grv_render_frame_wgsl_image(grv_engine *e, const GrvWgslParams *p, grv_image
         return rc;
     }
     rc = snapshot_stats(e, img);
-    if (rc != GRV_OK) return rc;
-    return end_write(e, img);
+    const int rc2 = end_write(e, img);
+    return rc != GRV_OK ? rc : rc2;
 }
 
 int grv_webgl_render_image(grv_engine *e, const GrvGlslParams *p, int32_t bloom_enabled, int32_t camera_moving,
@@ -278,11 +278,10 @@ int grv_webgl_render_image(grv_engine *e, const GrvGlslParams *p, int32_t bloom_
     rc = grv_webgl_render(e, p, bloom_enabled, camera_moving, screen->d, screen->s);
     // (chained even after a failure: kernels of the chain may already be queued)
     const int rc2 = chain_end(e, screen->s);
-    if (rc != GRV_OK) return rc;
-    if (rc2 != GRV_OK) return rc2;
-    rc = snapshot_stats(e, screen);
-    if (rc != GRV_OK) return rc;
-    return end_write(e, screen);
+    if (rc == GRV_OK) rc = rc2;
+    if (rc == GRV_OK) rc = snapshot_stats(e, screen);
+    const int rc3 = end_write(e, screen); // on the error paths too: a later wait / read / destroy covers what is queued
+    return rc != GRV_OK ? rc : rc3;
 }
 
 int grv_webgpu_render_image(grv_engine *e, const float camera_uniforms[88], const float physics_params[8],
@@ -298,11 +297,10 @@ int grv_webgpu_render_image(grv_engine *e, const float camera_uniforms[88], cons
     if (rc != GRV_OK) return rc;
     rc = grv_webgpu_render(e, camera_uniforms, physics_params, max_steps, arith, screen->d, screen->s);
     const int rc2 = chain_end(e, screen->s);
-    if (rc != GRV_OK) return rc;
-    if (rc2 != GRV_OK) return rc2;
-    rc = snapshot_stats(e, screen);
-    if (rc != GRV_OK) return rc;
-    return end_write(e, screen);
+    if (rc == GRV_OK) rc = rc2;
+    if (rc == GRV_OK) rc = snapshot_stats(e, screen);
+    const int rc3 = end_write(e, screen); // on the error paths too: a later wait / read / destroy covers what is queued
+    return rc != GRV_OK ? rc : rc3;
 }
 
 int grv_post_bloom_image(grv_engine *e, const GrvBloomParams *p, grv_image *scene, grv_image *out) {
@@ -319,11 +317,11 @@ int grv_post_bloom_image(grv_engine *e, const GrvBloomParams *p, grv_image *scen
     rc = grv_post_bloom(e, p, scene->d, out->d, out->s);
     const int rc2 = chain_end(e, out->s);
     const int rc3 = end_read(e, scene, out->s);
+    out->has_stats = false;
+    const int rc4 = end_write(e, out); // on the error paths too
     if (rc != GRV_OK) return rc;
     if (rc2 != GRV_OK) return rc2;
-    if (rc3 != GRV_OK) return rc3;
-    out->has_stats = false;
-    return end_write(e, out);
+    return rc3 != GRV_OK ? rc3 : rc4;
 }
 
 int grv_post_taa_resolve_image(grv_engine *e, const GrvTaaParams *p, grv_image *current, grv_image *history,
@@ -342,11 +340,11 @@ int grv_post_taa_resolve_image(grv_engine *e, const GrvTaaParams *p, grv_image *
     rc = grv_post_taa_resolve(e, p, current->d, history->d, out->d, out->s);
     const int rc2 = end_read(e, current, out->s);
     const int rc3 = end_read(e, history, out->s);
+    out->has_stats = false;
+    const int rc4 = end_write(e, out); // on the error paths too
     if (rc != GRV_OK) return rc;
     if (rc2 != GRV_OK) return rc2;
-    if (rc3 != GRV_OK) return rc3;
-    out->has_stats = false;
-    return end_write(e, out);
+    return rc3 != GRV_OK ? rc3 : rc4;
 }
 
 // ---- reads: these touch the image only (its stream, its events), never an engine: a host may

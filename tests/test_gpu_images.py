@@ -258,6 +258,26 @@ def test_image_lifetime_and_refusals(engine_mod):
     small.close()
 
 
+def test_engine_destroyed_under_a_frame_in_flight(engine_mod):
+    """free() right behind a queued 4K frame (wasm-bindgen's .free() on the engine object): the frame ends in the
+    image before the engine's workspaces go, and the image -- which holds no pointer to the engine -- still reads."""
+    bh = engine_mod
+    w, h = 3840, 2160
+    cam = bh.camera_look_at(EYE, aspect=w / h)
+    p = bh.render_params(w, h, arith=bh.ARITH_FAST, tolerance=1e-8)
+    with bh.PhysicsEngine(1.0, 0.999) as ref:
+        want, st = _ptr_frame(bh, ref, cam, p)
+    eng = bh.PhysicsEngine(1.0, 0.999)
+    img = eng.create_image(w, h)
+    eng.render_frame_image(cam, p, img)         # ~27 ms of kernels queued
+    assert not img.ready()
+    eng.close()
+    got = img.read()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert img.stats().accepted_steps == st.accepted_steps
+    img.close()
+
+
 def test_post_bloom_growing_its_scratch_leaves_the_renderer_targets_alone(engine_mod):
     """Regression: grv_post_bloom used to free the renderer's history targets when it grew the bloom
     scratch, leaving grv_webgl_render with dangling pointers on the next frame."""
