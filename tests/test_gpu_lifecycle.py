@@ -65,3 +65,53 @@ def test_engines_give_back_device_and_host_memory(engine_mod):
     # one engine holds ~10 MB of device workspace for these sizes: a leak of it would show as n x that
     assert free0 - free1 < 16 * 2 ** 20, "device memory not returned: %.1f MB over %d cycles" % ((free0 - free1) / 2 ** 20, n)
     assert rss1 - rss0 < 48 * 2 ** 20, "host memory grew by %.1f MB over %d cycles" % ((rss1 - rss0) / 2 ** 20, n)
+
+
+@pytest.mark.gpu
+def test_frame_loop_resources_are_given_back(engine_mod):
+    """The per-handle resources the frame-loop paths create lazily -- measured dispatch orders and their side stream,
+    the compacting schedule's counters, feedback block and head-start events, the control stream with its workspace
+    set, device images (own and shared compute streams, copy streams, pinned counter blocks) -- go with the handle."""
+    import psutil
+    import torch
+    bh = engine_mod
+    W, H = 1920, 1080                      # 2 073 600 rays: above the size from which one-launch frames take an order
+    th = np.deg2rad(97.0)
+    cam = bh.camera_look_at((20.0 * np.sin(th), 20.0 * np.cos(th), 0.0), aspect=W / H)
+    one = np.array([[0.0, 20.0, 1.5, 0.0, -1.0, -0.9, 0.0, 3.0]])
+    proc = psutil.Process()
+
+    def cycle():
+        with bh.PhysicsEngine(1.0, 0.999) as e:
+            imgs = [e.create_image(W, H)]
+            imgs.append(e.create_image(W, H, stream_of=imgs[0]))
+            imgs.append(e.create_image(W, H))
+            p = bh.render_params(W, H, arith=bh.ARITH_FAST, tolerance=1e-7, max_steps=400)
+            k = bh.render_params(W, H, arith=bh.ARITH_FAST, tolerance=1e-7, max_steps=400, segment_tries=16)
+            for i in range(6):
+                e.render_frame_image(cam, p if i < 3 else k, imgs[i % 3])
+                e.integrate_ray_relativistic(one[0], 50, 1e-8, True)      # the control stream beside queued frames
+            gp = bh.glsl_params(W, H, 1.0, 0.999, max_ray_steps=64, arith=bh.ARITH_FAST)
+            e.render_frame_glsl_image(gp, imgs[2])
+            got = imgs[1].read()
+            assert got.shape == (H, W, 4)
+            st = imgs[0].stats()
+            assert st.rays == W * H
+            e.synchronize()
+            for im in imgs:
+                im.close()
+
+    for _ in range(2):
+        cycle()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    rss0 = proc.memory_info().rss
+    n = 8
+    for _ in range(n):
+        cycle()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    rss1 = proc.memory_info().rss
+    # one cycle holds ~0.5 GB of device memory (three 33 MB images, two 1080p ray workspaces): a leak of any would show
+    assert free0 - free1 < 24 * 2 ** 20, "device memory not returned: %.1f MB over %d cycles" % ((free0 - free1) / 2 ** 20, n)
+    assert rss1 - rss0 < 64 * 2 ** 20, "host memory grew by %.1f MB over %d cycles" % ((rss1 - rss0) / 2 ** 20, n)
