@@ -45,7 +45,7 @@ for stage in "$@"; do
         done
       fi;;
     fuzz) ( GRV_FUZZ_SEEDS=${arg:-100} GRV_FUZZ_REPORT=$O/fuzz_fast_report.jsonl timeout 3000 python -m pytest tests/test_fuzz_parity.py -m gpu -q --timeout 900 2>&1 | tail -25 ) > $O/fuzz.log 2>&1; cat $O/fuzz.log;;
-    fuzzfast) ( GRV_FUZZ_SEEDS=${arg:-500} GRV_FUZZ_REPORT=$O/fuzz_fast_report.jsonl timeout 3000 python -m pytest tests/test_fuzz_parity.py -m gpu -q --timeout 900 -k "fast_stay or fast_hold" 2>&1 | tail -25 ) > $O/fuzzfast.log 2>&1; cat $O/fuzzfast.log;;
+    fuzzfast) ( GRV_FUZZ_SEED0=${FUZZ_SEED0:-0} GRV_FUZZ_SEEDS=${arg:-500} GRV_FUZZ_REPORT=$O/fuzz_fast_report.jsonl timeout 3000 python -m pytest tests/test_fuzz_parity.py -m gpu -q --timeout 900 -k "fast_stay or fast_hold" 2>&1 | tail -25 ) > $O/fuzzfast.log 2>&1; cat $O/fuzzfast.log;;
     timeline) for t in base lpt; do timeout 300 python tools/march_timeline.py ab_libs/tl_$t.so --frames 5 > $O/timeline_$t.json 2> $O/timeline_$t.err; echo "timeline $t rc=$?"; done;;
     parity)
       GRV_PARITY_TOL=1e-9 GRV_PARITY_JSON=$O/full_frame_parity_c5.json timeout 1200 python -m pytest tests/test_full_frame_parity.py -m gpu -q 2>&1 | tail -2
