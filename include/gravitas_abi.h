@@ -170,6 +170,8 @@ typedef struct {
 
 /* ---- lifecycle: `new PhysicsEngine(mass, spin)` lib.rs:59 ; update_params lib.rs:78 ---- */
 int grv_engine_create(double mass, double spin, int device, grv_engine **out);
+/* wasm-bindgen's .free(): waits for everything queued on the handle's device (frames may still be running on a caller's
+ * or a device image's stream) before the workspaces go; images created through the handle stay valid */
 void grv_engine_destroy(grv_engine *e);
 const char *grv_last_error(const grv_engine *e);
 int grv_abi_version(void);
