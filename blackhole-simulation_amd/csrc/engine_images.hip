@@ -164,6 +164,17 @@ static int image_create(grv_engine *e, uint32_t width, uint32_t height, grv_imag
                     height, hipGetErrorString(st));
     }
     std::memset(img->h_stats, 0, sizeof(FrameStatsDev));
+    // A new image is black, and its compute stream has carried work before the first frame does: the runtime sets a
+    // stream's hardware queue up at its first use, and a first use in the middle of a burst of frames held every
+    // synchronising call of the process -- a worker's control-plane call on its own high-priority stream included --
+    // until the frames in flight had finished (measured: 41-57 ms once per new image stream, 1 ms afterwards;
+    // profiles/EXPERIMENTS.md T, addendum).
+    st = hipMemsetAsync(img->d, 0, img->bytes, img->s);
+    if (st == hipSuccess) st = hipStreamSynchronize(img->s);
+    if (st != hipSuccess) {
+        grv_image_destroy(img);
+        return fail(e, GRV_ERR_HIP, "grv_image_create(%u x %u): %s", width, height, hipGetErrorString(st));
+    }
     *out = img;
     return GRV_OK;
 }

@@ -308,6 +308,9 @@ __device__ GRV_GLSL_NOISE_INLINE float glsl_noise(const uint8_t *__restrict__ T,
 #ifndef GRV_GLSL_LATTICE_NOISE
 #define GRV_GLSL_LATTICE_NOISE 1
 #endif
+#ifndef GRV_GLSL_JET_PREFILTER
+#define GRV_GLSL_JET_PREFILTER 1
+#endif
 __device__ __forceinline__ float glsl_noise_lattice(const GlslParams &U, F3 p) {
     const F3 i{floorf(p.x), floorf(p.y), floorf(p.z)};
     F3 f{p.x - i.x, p.y - i.y, p.z - i.z};
@@ -494,7 +497,20 @@ __device__ __forceinline__ void glsl_sample_jets(const GlslParams &U, F3 p, F3 v
         // fed to the falloff as it is, no root (most steps outside the slab reach this test and fail it)
         const float rad2 = fmaf(p.x, p.x, p.z * p.z), w2 = jetWidth * 2.0f;
         if (!(rad2 < w2 * w2)) return;
-        radialFalloff = exp_d<ARITH>(div_t<ARITH>(-rad2, jetWidth * 0.5f));
+        const float q = div_t<ARITH>(-rad2, jetWidth * 0.5f);   // the radial falloff's exponent, as the shader forms it
+        if constexpr (GRV_GLSL_JET_PREFILTER) {
+            // The density below is exp(q) exp(-0.05 |y|) max(0, noise - 0.2) with noise <= 1 (both octaves are trilinear
+            // mixes of texels in [0, 1]), cut at 0.001.  Where the two exponents sum to -6.9 or less the falloffs' product
+            // is <= 0.00101 (v_exp_f32 is good to 1e-6 relative, this sum to 1e-6 absolute) and the density <= 0.00081:
+            // the cut is taken whatever the noise says -- and neither the noise's sixteen texel loads nor the two
+            // exponentials are issued.  (Rays between -6.9 and the exact boundary ln(0.00125) = -6.68 take the shader's
+            // path.)  The shader's own cone, axial distance < 2 w, is far wider than what can pass (distance^2 < 3.4 w:
+            // 85 % of the cone's section at w = 1, 21 % at |y| = 20): a view down the axis spent most of its steps in that
+            // dead shell -- c2 at theta = 5 deg: 162 -> 448 G ray-steps/s at r0 = 60 M, 237 -> 478 G at 200 M, every pixel
+            // and step count unchanged (profiles/r06_ab_glsl_jet_prefilter.jsonl, profiles/EXPERIMENTS.md W).
+            if (!(fmaf(jetVerticalPos, -0.05f, q) > -6.9f)) return;
+        }
+        radialFalloff = exp_d<ARITH>(q);
     } else {
         const float jetRadialDist = sqrt_t<ARITH>(p.x * p.x + p.z * p.z);
         if (!(jetRadialDist < jetWidth * 2.0f)) return;

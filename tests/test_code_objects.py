@@ -138,9 +138,13 @@ def test_glsl_fast_march_keeps_its_scratch_to_the_sampling_bodies(engine_mod):
             cur += 1
     runs.append(cur)
     assert sorted(runs)[-2] >= 60, runs     # two such stretches: one per step instance
-    # no scratch access before the first conditional branch of the loop (the exit tests run on every pass)
+    # the loop head (exit tests, up to the first conditional branch: it runs on every pass) holds no scratch STORE and at
+    # most one reload -- since the jets' dead-shell prefilter (round 6) the allocator parks one loop-invariant dword there
+    # (scratch_load_dword at the join, L1-resident); measured with it in place: c2 +1.0 % two streams, +1.3 % one
+    # stream, views down the axis x 2.0 ... 2.8 (profiles/r06_ab_glsl_jet_prefilter.jsonl)
     first_br = next(i for i in range(head, latch + 1) if ins[i][1].startswith("s_cbranch"))
-    assert not [i for i in scratch if i < first_br]
+    in_head = [ins[i][1] for i in scratch if i < first_br]
+    assert len(in_head) <= 1 and all(m.startswith("scratch_load") for m in in_head), in_head
 
 
 def test_march_kernels_launch_one_wave_blocks(kernels):

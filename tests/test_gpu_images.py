@@ -321,6 +321,13 @@ def test_control_plane_calls_do_not_wait_for_queued_frames(engine_mod):
         ref_ray = eng.integrate_ray_relativistic([0, 20, np.pi / 2, 0, -1, -1, 0, 3.5], 2000, 1e-8, True)
         ref_batch = eng.integrate_batch(st, o)
         eng.synchronize()
+        # one burst of the same shape first, not judged: what a process does ONCE when three frames are in flight for the
+        # first time (the second ray workspace, per-parity order tables, the runtime's per-stream queue set-up) held the
+        # first synchronising call for 20-57 ms in some orders of the suite and 1 ms in others (profiles/EXPERIMENTS.md T)
+        for j in range(3):
+            eng.render_frame_image(cam, p, imgs[j])
+        eng.generate_disk_lut()
+        eng.synchronize()
         calls = [lambda: eng.generate_disk_lut(), lambda: eng.generate_spectrum_lut(512, 64, 1e5),
                  lambda: eng.generate_embedding_mesh(2.0, 30.0, 64, 64),
                  lambda: eng.integrate_ray_relativistic([0, 20, np.pi / 2, 0, -1, -1, 0, 3.5], 2000, 1e-8, True),
@@ -328,9 +335,13 @@ def test_control_plane_calls_do_not_wait_for_queued_frames(engine_mod):
         for k, call in enumerate(calls):
             for j in range(3):                      # ~80 ms of kernels on three streams, nothing waited for
                 eng.render_frame_image(cam, p, imgs[j])
+            import time
+            t0 = time.perf_counter()
             got = call()
+            ms = (time.perf_counter() - t0) * 1e3
             # not even the first of the three frames (they share the chip: each needs most of the 80 ms) is finished
-            assert not any(im.ready() for im in imgs), "call %d returned only after a queued frame" % k
+            flags = [im.ready() for im in imgs]
+            assert not any(flags), "call %d returned only after a queued frame (%.2f ms on the host, ready: %s)" % (k, ms, flags)
             eng.synchronize()
             if k == 3:
                 assert np.array_equal(np.asarray(got), np.asarray(ref_ray))

@@ -33,8 +33,13 @@ if os.environ.get("AB_KERNEL") == "wgsl":  # the one-ray FAST compute march, sta
     np.savez(sys.argv[1], rgba=np.stack([v[0] for v in out.values()]), steps=np.stack([v[1] for v in out.values()]))
     sys.exit(0)
 with bh.PhysicsEngine(1.0, 0.999) as e:
-    for name, kw in (("default", {}), ("time", {"time": 12.5}), ("march_disk", {"features": 7, "turbulence": 0.75})):
+    for name, kw in (("default", {}), ("time", {"time": 12.5}), ("march_disk", {"features": 7, "turbulence": 0.75}),
+                     ("polar_60M", {"zoom": 60.0, "theta": 5.0}), ("polar_200M_time", {"zoom": 200.0, "theta": 5.0, "time": 3.25}),
+                     ("close_10M", {"zoom": 10.0, "theta": 60.0})):   # views down the jets (tools/camera_sweep.py's cameras)
+        theta = kw.pop("theta", None)
         gp = bh.glsl_params(W, H, 1.0, 0.999, max_ray_steps=512, arith=1, **kw)
+        if theta is not None:
+            gp.mouse[1] = theta / 180.0
         rgba = torch.zeros(W * H, 4, dtype=torch.float32, device="cuda:0")
         steps = torch.zeros(W * H, dtype=torch.int32, device="cuda:0")
         e.render_frame_glsl(gp, rgba, steps)
