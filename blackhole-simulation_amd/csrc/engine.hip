@@ -616,7 +616,7 @@ void frame_geometry(const GrvRenderParams &p, FrameGeom &G) {
 void stats_to_abi(const grv_engine *e, const FrameStatsDev &d, GrvFrameStats *out) {
     std::memset(out, 0, sizeof *out);
     out->rays = d.rays;
-    out->accepted_steps = d.accepted_steps;
+    out->accepted_steps = stats_total_steps(d);
     out->rkf_tries = d.rkf_tries;
     for (int k = 0; k < 5; ++k) out->term_count[k] = d.term_count[k];
     out->crossings = d.crossings;

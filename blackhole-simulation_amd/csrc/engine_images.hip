@@ -426,7 +426,7 @@ int grv_image_frame_stats(grv_image *img, GrvFrameStats *stats) {
     std::memset(stats, 0, sizeof *stats);
     const FrameStatsDev &d = *img->h_stats;
     stats->rays = d.rays;
-    stats->accepted_steps = d.accepted_steps;
+    stats->accepted_steps = stats_total_steps(d);
     stats->rkf_tries = d.rkf_tries;
     for (int k = 0; k < 5; ++k) stats->term_count[k] = d.term_count[k];
     stats->crossings = d.crossings;

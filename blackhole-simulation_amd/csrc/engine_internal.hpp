@@ -269,7 +269,7 @@ int run_shader_frame(grv_engine *e, uint32_t width, uint32_t height, uint32_t tw
         const int rc = begin_march_order(e, kind, sched_blocks, geom, s, &sched, &parity);
         if (rc != GRV_OK) return rc;
     }
-    GRV_HIP(e, launch(G, (uint32_t)slots, &e->d_stats->accepted_steps, sched));
+    GRV_HIP(e, launch(G, (uint32_t)slots, e->d_stats->steps_part, sched));
     if (parity >= 0) {
         const int rc = finish_march_order(e, kind, parity, s);
         if (rc != GRV_OK) return rc;
@@ -285,7 +285,7 @@ int run_shader_frame(grv_engine *e, uint32_t width, uint32_t height, uint32_t tw
     if (total_steps) {
         GRV_HIP(e, hipMemcpyAsync(e->h_stats, e->d_stats, sizeof(FrameStatsDev), hipMemcpyDeviceToHost, s));
         GRV_HIP(e, hipStreamSynchronize(s));
-        *total_steps = e->h_stats->accepted_steps;
+        *total_steps = stats_total_steps(*e->h_stats);
     }
     return GRV_OK;
 }

@@ -4,6 +4,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "../../include/gravitas_abi.h"
@@ -202,10 +203,23 @@ struct SingleRayOut {
     unsigned long long loop_cycles, loop_ticks;
 };
 
+// The f32 marches add their step total once per one-wave block.  32 400 blocks of a 1080p frame adding to ONE address
+// retire at ~13 ns apiece: 0.43 ms when they all come at once -- which is the whole frame of a close-up view (25-50
+// steps per pixel; profiles/EXPERIMENTS.md J, X).  They add to one of kStepParts slots by block index instead (one
+// 128-byte line each: atomics on one line still queue behind each other); readers sum (stats_total_steps).
+constexpr uint32_t kStepParts = 32, kStepPartStride = 16; // 32 slots, 16 u64 = 128 B apart
 struct FrameStatsDev {
     unsigned long long accepted_steps, rkf_tries, term_count[5], crossings, rays;
     unsigned long long max_drift_bits;
+    unsigned long long pad_[6];                               // steps_part starts on a 128-byte line of the block
+    unsigned long long steps_part[kStepParts * kStepPartStride];
 };
+static_assert(offsetof(FrameStatsDev, steps_part) % 128 == 0, "FrameStatsDev: the step slots sit on lines of their own");
+inline unsigned long long stats_total_steps(const FrameStatsDev &d) {
+    unsigned long long t = d.accepted_steps;
+    for (uint32_t k = 0; k < kStepParts; ++k) t += d.steps_part[k * kStepPartStride];
+    return t;
+}
 
 
 // ---- launchers (kernels_strict.hip: -ffp-contract=off) ----

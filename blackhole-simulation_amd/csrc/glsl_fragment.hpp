@@ -930,7 +930,7 @@ void glsl_fragment_kernel(FrameGeom G, GlslParams U,
         if (out_rgba) out_rgba[oi] = make_float4(o[0], o[1], o[2], 1.0f);
         if (out_steps) out_steps[oi] = steps;
     }
-    add_steps(total_steps, steps);
+    add_steps(total_steps, steps, block);
     if (kSched && sched.cost && threadIdx.x == 0) sched.cost[block] = (uint32_t)(wall_clock64() - sched_t0);
 #ifdef GRV_MARCH_TIMELINE
     if (ARITH == GRV_ARITH_FAST && g_march_timeline) {

@@ -51,7 +51,7 @@ __device__ __forceinline__ float smoothstep_d(float e0, float e1, float x) {
 __device__ __forceinline__ float sign_d(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
 
 // block-level sum of the per-thread step counts into one atomic
-__device__ __forceinline__ void add_steps(unsigned long long *total, uint32_t steps) {
+__device__ __forceinline__ void add_steps(unsigned long long *total, uint32_t steps, uint32_t key) {
     __shared__ unsigned long long s_w[16];
     unsigned long long v = steps;
 #pragma unroll
@@ -62,7 +62,7 @@ __device__ __forceinline__ void add_steps(unsigned long long *total, uint32_t st
     if (threadIdx.x == 0) {
         unsigned long long t = 0;
         for (uint32_t w = 0; w < (blockDim.x + 63u) / 64u; ++w) t += s_w[w];
-        if (t) atomicAdd(total, t);
+        if (t) atomicAdd(total + (key % kStepParts) * kStepPartStride, t); // FrameStatsDev::steps_part, one line per slot
     }
 }
 

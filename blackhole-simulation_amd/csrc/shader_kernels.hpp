@@ -230,7 +230,7 @@ __global__ __launch_bounds__(kMarchBlock) void wgsl_symplectic_kernel(FrameGeom 
         if (out_rgba) out_rgba[oi] = make_float4(col[0], col[1], col[2], 1.0f);
         if (out_steps) out_steps[oi] = steps;
     }
-    add_steps(total_steps, steps);
+    add_steps(total_steps, steps, blockIdx.x);
 }
 
 } // namespace

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(kMarchBlock) __attribute__((amdgpu_waves_per_eu(GRV
         unsigned long long tot = 0;
 #pragma unroll
         for (int w = 0; w < kMarchBlock / 64; ++w) tot += s_w[w];
-        if (tot) atomicAdd(total_steps, tot);
+        if (tot) atomicAdd(total_steps + (blockIdx.x % kStepParts) * kStepPartStride, tot); // FrameStatsDev::steps_part
     }
 }
 
