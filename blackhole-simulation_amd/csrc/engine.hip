@@ -1211,7 +1211,7 @@ int grv_render_frame_device(grv_engine *e, const GrvCamera *cam, const GrvRender
     MarchSched sched{nullptr, nullptr};
     int order_parity = -1;
     const uint32_t *head_order = nullptr;
-    if (p->schedule == GRV_SCHEDULE_DEFAULT && P.block_order == 0 && slots >= kSegOneWaveMinRays) {
+    if (p->schedule == GRV_SCHEDULE_DEFAULT && P.block_order == 0 && slots >= kSegOrderMinRays) {
         const uint32_t geom[4] = {p->width, p->height, G.tile_world, G.tile_rank};
         rc = begin_march_order(e, 2, (uint32_t)(slots / 64u), geom, s, &sched, &order_parity);
         if (rc != GRV_OK) return rc;

@@ -17,7 +17,8 @@ constexpr int kBlock = 256;
 // back to the dispatcher only when its whole block has ended; with four-wave blocks the packed march
 // measured 287 G ray-steps/s on the 8K config-4 frame, with one-wave blocks 308 G (A/B on one box,
 // profiles/r03_ab_march_block.jsonl).  The f64 segment kernel chooses per launch (geodesic_kernels.hpp:
-// segment_block_threads): one-wave blocks for one-launch frames of 1.5 M rays and more (+1.1 %), kBlock otherwise.
+// segment_block_threads): one-wave blocks for launches with a dispatch order (whole frames of 65 536 rays and more) and
+// for one-launch launches of 1.5 M rays and more (+1.1 %), kBlock otherwise.
 #ifndef GRV_MARCH_BLOCK
 #define GRV_MARCH_BLOCK 64
 #endif
@@ -126,9 +127,18 @@ struct SegmentParams {
     // costs, march_rank_kernel sorts them); null = block_order decides.  Any permutation gives the same frame.
     const uint32_t *order;
 };
-// one-launch frames of at least this many rays start one-wave blocks (geodesic_kernels.hpp segment_block_threads);
-// only those take a measured dispatch order (its entries are one-wave blocks)
+// one-launch launches WITHOUT a dispatch order (a rank's share of a split frame, which runs centre-out; the compacting
+// schedule's head start) start one-wave blocks from this many rays on (geodesic_kernels.hpp segment_block_threads)
 constexpr uint32_t kSegOneWaveMinRays = 3u << 19; // 1 572 864
+// Whole frames take a measured dispatch order -- and with it one-wave blocks: the order's entries are one-wave blocks --
+// from this many rays on.  Until the resolution sweep of round 6 this was kSegOneWaveMinRays too, and every frame below
+// 1080p ran four-wave blocks in slot order: 720p 44.1 -> 50.5 G ray-steps/s, 540p 40.1 -> 47.6, 360p 31.7 -> 37.9, 720p at
+// r0 = 10 M 34.8 -> 43.6 (profiles/r06_ab_small_frame_order.jsonl).  Below 65 536 rays (1 024 waves, a third of the
+// chip's wave slots) there is nothing to order.
+#ifndef GRV_SEG_ORDER_MIN_RAYS
+#define GRV_SEG_ORDER_MIN_RAYS 65536u
+#endif
+constexpr uint32_t kSegOrderMinRays = GRV_SEG_ORDER_MIN_RAYS;
 // cost entry of a wave whose slowest ray took `tries` integrator tries (march_rank_kernel buckets by cost >> 7)
 constexpr uint32_t kWaveCostShift = 6;
 

@@ -521,8 +521,10 @@ constexpr int kSegBlockOneLaunch = GRV_SEGMENT_BLOCK_ONE_LAUNCH;
 // (a rank's eighth of the 4K frame, 1.04 M rays, with two frames in flight: 3.56 against 3.64 ms) still prefer
 // four-wave blocks; from 2 M rays on one-wave blocks are level or ahead (profiles/r05_rank_share_segment_block.txt)
 // (kSegOneWaveMinRays: engine_types.hpp)
-__host__ inline uint32_t segment_block_threads(const uint32_t *live_out, uint32_t n_live) {
-    return (live_out || n_live < kSegOneWaveMinRays) ? (uint32_t)kSegBlock : (uint32_t)kSegBlockOneLaunch;
+// A launch that is handed a dispatch order starts one-wave blocks whatever its size: the order's entries are one-wave blocks.
+__host__ inline uint32_t segment_block_threads(const uint32_t *live_out, uint32_t n_live, const uint32_t *order) {
+    if (live_out) return (uint32_t)kSegBlock;
+    return (order || n_live >= kSegOneWaveMinRays) ? (uint32_t)kSegBlockOneLaunch : (uint32_t)kSegBlock;
 }
 
 template <int KIND, int ARITH, int METHOD>

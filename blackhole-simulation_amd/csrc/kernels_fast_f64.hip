@@ -13,7 +13,7 @@ namespace {
 template <int KIND, int METHOD>
 hipError_t go(const RayWorkspace &ws, const SegmentParams &P, const uint32_t *live_in,
               uint32_t n_live, uint32_t *live_out, uint32_t *live_out_count, hipStream_t s) {
-    const uint32_t threads = segment_block_threads(live_out, n_live);
+    const uint32_t threads = segment_block_threads(live_out, n_live, P.order);
     const uint32_t grid = (n_live + threads - 1) / threads;
     if (grid == 0) return hipSuccess;
     hipLaunchKernelGGL((integrate_segment_kernel<KIND, GRV_ARITH_FAST, METHOD>), dim3(grid),

@@ -65,6 +65,41 @@ def test_measured_wave_order_never_changes_a_frame(engine_mod, arith):
         assert st.accepted_steps == int(want[cams[-1]][2].sum())
 
 
+def test_small_whole_frames_take_a_measured_order_too(engine_mod):
+    """Whole frames from 65 536 rays on run one-wave blocks longest-first (engine_types.hpp kSegOrderMinRays; before the
+    resolution sweep of round 6 only frames of 1.5 M rays and more did): 640x360 and 1280x720 frames with moving cameras on
+    two streams against slot-order frames, bit for bit; a 192x108 frame (below the bound) the same."""
+    import torch
+    bh = engine_mod
+    cams = [_eye(20.0, 97.0), _eye(12.0, 80.0), _eye(20.0, 97.0), _eye(6.0, 91.0), _eye(20.0, 97.0)]
+    for w, h in ((640, 360), (1280, 720), (192, 108)):
+        n = w * h
+        with bh.PhysicsEngine(1.0, 0.999) as ref, bh.PhysicsEngine(1.0, 0.999) as eng:
+            def frame(e, c, st=None, **kw):
+                out = dict(rgba=torch.full((n, 4), -1.0, dtype=torch.float32, device="cuda"),
+                           final_state=torch.zeros(n, 8, dtype=torch.float64, device="cuda"),
+                           steps=torch.zeros(n, dtype=torch.int32, device="cuda"))
+                p = bh.render_params(w, h, arith=bh.ARITH_FAST, tolerance=1e-7, max_steps=600, **kw)
+                e.render_frame_device(bh.camera_look_at(c, aspect=w / h), p, stream=st, **out)
+                return out
+            want = {}
+            for c in set(cams):
+                o = frame(ref, c, schedule=bh.SCHEDULE_SLOT_ORDER)
+                torch.cuda.synchronize()
+                want[c] = [o[k].cpu().numpy() for k in ("rgba", "final_state", "steps")]
+            side = torch.cuda.Stream()
+            held = []
+            for rep, c in enumerate(cams):
+                st = side if rep % 2 else torch.cuda.current_stream()
+                with torch.cuda.stream(st):
+                    held.append((c, frame(eng, c, st=st.cuda_stream)))
+            torch.cuda.synchronize()
+            for rep, (c, o) in enumerate(held):
+                for k, wv in zip(("rgba", "final_state", "steps"), want[c]):
+                    g = o[k].cpu().numpy()
+                    assert np.array_equal(g.view(np.uint8), wv.view(np.uint8)), (w, h, rep, k)
+
+
 def test_compacting_schedule_equals_the_one_launch_frame(engine_mod):
     bh = engine_mod
     c = _eye(10.0, 97.0)

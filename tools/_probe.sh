@@ -1,7 +1,2 @@
 cd $GRAFT_REPO_ROOT
-export PROFILE_TAG=r06
-mkdir -p gpurun_out/r06zu
-bash tools/profile_gpu.sh prof_r06zu _c2 _c2wgsl _c4 _c4fast > gpurun_out/r06zu/profile.log 2>&1; tail -2 gpurun_out/r06zu/profile.log
-cp gpurun_out/prof_r06zu/summary/traffic.json profiles/traffic.json
-for cfg in "c2" "c2 --one-stream" "c2 --kernel wgsl" "c2 --kernel wgsl --one-stream" "c4"; do tag=$(echo $cfg | tr -d ' -'); timeout 900 python bench.py --config $cfg > gpurun_out/r06zu/bench_$tag.json 2> gpurun_out/r06zu/bench_$tag.err; cut -c1-110 gpurun_out/r06zu/bench_$tag.json; done
-timeout 900 python tools/camera_sweep.py --configs c2 --out gpurun_out/r06zu/camera_sweep_c2.jsonl > gpurun_out/r06zu/sweep.log 2>&1; wc -l gpurun_out/r06zu/camera_sweep_c2.jsonl
+AB_CONFIGS="c3 --width 1920 --height 1080;c3 --width 1280 --height 720;c3 --width 1280 --height 720 --two-streams;c3 --width 960 --height 540;c3 --width 640 --height 360;c3 --width 1280 --height 720 --eye 10,90" AB_REPS=3 AB_STEPS=60 bash tools/ab_configs.sh ab_r06zx > /dev/null 2>&1; wc -l gpurun_out/ab_r06zx/ab.jsonl
