@@ -131,7 +131,7 @@ typedef struct {
 
 /* GRV_SCHEDULE_DEFAULT: the engine's choice -- with segment_tries == 0, one launch whose waves start
  *   longest-first by the PREVIOUS frame's per-wave try counts (a renderer's frames resemble their
- *   predecessors; whole frames of >= 1.5 M rays; the first frame of a geometry runs in slot order):
+ *   predecessors; whole frames of >= 65 536 rays; the first frame of a geometry runs in slot order):
  *   the few waves that graze the photon ring no longer start in the middle of the launch and keep the
  *   chip waiting at its end;
  * GRV_SCHEDULE_SLOT_ORDER: waves start in slot (tile) order, as every launch did before ABI 8. */

@@ -11,7 +11,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-W, H = 1920, 1080   # 2 073 600 rays: above the 1.5 M rays from which one-launch frames take a measured order
+W, H = 1920, 1080   # 2 073 600 rays (whole frames of 65 536 rays and more take a measured order)
 
 
 def _frame(bh, eng, eye, stream=None, **kw):

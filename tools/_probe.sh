@@ -1,2 +1,6 @@
 cd $GRAFT_REPO_ROOT
-AB_CONFIGS="c3 --width 1920 --height 1080;c3 --width 1280 --height 720;c3 --width 1280 --height 720 --two-streams;c3 --width 960 --height 540;c3 --width 640 --height 360;c3 --width 1280 --height 720 --eye 10,90" AB_REPS=3 AB_STEPS=60 bash tools/ab_configs.sh ab_r06zx > /dev/null 2>&1; wc -l gpurun_out/ab_r06zx/ab.jsonl
+export PROFILE_TAG=r06
+mkdir -p gpurun_out/r06zz
+GRV_C2_JSON=gpurun_out/r06zz/full_frame_parity_c2.jsonl timeout 900 python -m pytest tests/test_shader_kernels.py -m gpu -q -k test_config2_bench_form 2>&1 | tail -1
+GRV_C4_STRIDE=1 GRV_C4_JSON=gpurun_out/r06zz/full_frame_parity_c4.jsonl timeout 2400 python -m pytest tests/test_shader_kernels.py -m gpu -q -k test_config4_bench_form 2>&1 | tail -1
+bash tools/gpu_session.sh r06zz fuzzfast:500 2>&1 | tail -4
