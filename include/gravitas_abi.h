@@ -548,6 +548,8 @@ uint32_t grv_renderer_frame_count(const grv_engine *e);
  * _wait / _query / _read / _frame_stats touch the image alone, so one thread may wait for (or read) an
  * image while another queues the next frame into ANOTHER image through the engine. */
 typedef struct grv_image grv_image;
+/* a new image is black (zero-filled on its own stream, waited for: the call returns with the stream's hardware queue
+ * set up, so the first frame into it does not pay for that in the middle of a burst) */
 int grv_image_create(grv_engine *e, uint32_t width, uint32_t height, grv_image **out);
 /* an image whose producers are queued on `stream_of`'s compute stream instead of one of its own:
  * images sharing a stream are written in queue order (frame i+1's kernels start when frame i's have

@@ -239,6 +239,7 @@ def test_image_lifetime_and_refusals(engine_mod):
     img = eng.create_image(W, H)
     with pytest.raises(bh.GravitasError):
         img.stats()                            # nothing rendered yet
+    assert not img.read().any() and img.ready()   # a new image is black, and nothing is pending on it
     eng.render_frame_image(cam, p, img)
     small = eng.create_image(64, 36)
     with pytest.raises(bh.GravitasError, match="into an image"):
