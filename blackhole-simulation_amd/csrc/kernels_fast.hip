@@ -79,12 +79,18 @@ hipError_t launch_wgsl_symplectic_pk(const FrameGeom &G, const WgslParams &P, fl
     return hipGetLastError();
 }
 
-// entries of MarchSched's arrays for a frame (0: this form takes no measured order).  The long packed march
-// (budget > 512: the 8K frame of config 4, a 15 ms launch whose tail is 1 % of it) keeps centre-out: the
-// measured-cost order loses 3.5 % there (259 200 blocks to sort and look up, profiles/r05_ab_pk_long_cost_order.jsonl).
+// entries of MarchSched's arrays for a frame (0: this form takes no measured order).  The long packed march of the
+// 8K frame (config 4: 33 M slots, 1 024 steps, a 15 ms launch whose tail is 1 % of it) keeps centre-out: the measured-cost
+// order loses 2-3.5 % there at the bench camera (259 200 blocks to sort and look up, profiles/r05_ab_pk_long_cost_order.jsonl)
+// and is mixed over the sweep's cameras (-5.7 ... +7.2 %).  Until round 6 the rule read "budget > 512" and so caught every
+// 1 024-step march whatever its size: 1080p 205 -> 268 G ray-steps/s with the order, 4K at r0 = 10 M 195 -> 264 G, 4K at the
+// bench camera 309 -> 304 G (profiles/r06_ab_pk_order_rule.jsonl).  The rule is the frame's size now.
 uint32_t march_blocks_glsl(uint32_t n_slots) { return GRV_MARCH_LPT ? (n_slots + kMarchBlock - 1) / kMarchBlock : 0u; }
 uint32_t march_blocks_pk(uint32_t n_slots, int32_t max_steps) {
-    if (!GRV_MARCH_LPT || max_steps > 512) return 0u;
+#ifndef GRV_PK_ORDER_MAX_SLOTS
+#define GRV_PK_ORDER_MAX_SLOTS (16u << 20)
+#endif
+    if (!GRV_MARCH_LPT || (max_steps > 512 && n_slots > GRV_PK_ORDER_MAX_SLOTS)) return 0u;
     return ((n_slots + 1u) / 2u + kMarchBlock - 1) / kMarchBlock;
 }
 
