@@ -1211,7 +1211,13 @@ int grv_render_frame_device(grv_engine *e, const GrvCamera *cam, const GrvRender
     MarchSched sched{nullptr, nullptr};
     int order_parity = -1;
     const uint32_t *head_order = nullptr;
-    if (p->schedule == GRV_SCHEDULE_DEFAULT && P.block_order == 0 && slots >= kSegOrderMinRays) {
+    // (a rank's share of a split frame too: until the end of round 6 those ran centre-out in four-wave blocks, the choice of
+    // a measurement that predates the order -- the 4K frame's eighth 3.87 -> 3.49 ms with one frame in flight, 3.49 -> 3.43 ms
+    // with two, profiles/r06_ab_rank_share_order.txt; their first frame runs in slot order, every later one longest-first)
+#ifndef GRV_SEG_ORDER_RANK_SHARES
+#define GRV_SEG_ORDER_RANK_SHARES 1
+#endif
+    if (p->schedule == GRV_SCHEDULE_DEFAULT && (P.block_order == 0 || GRV_SEG_ORDER_RANK_SHARES) && slots >= kSegOrderMinRays) {
         const uint32_t geom[4] = {p->width, p->height, G.tile_world, G.tile_rank};
         rc = begin_march_order(e, 2, (uint32_t)(slots / 64u), geom, s, &sched, &order_parity);
         if (rc != GRV_OK) return rc;

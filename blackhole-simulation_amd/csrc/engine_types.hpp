@@ -35,7 +35,10 @@ constexpr int kMarchBlock = GRV_MARCH_BLOCK;
 // take it, and the f64 segment kernel takes it for a rank's share of a split frame only
 // (SegmentParams::block_order, set by grv_render_frame_device when tile_world > 1; measured on the
 // shares of the strong 4K split with two frames in flight: N = 2 14.10 -> 13.84 ms, N = 4 7.07 -> 7.02,
-// N = 8 3.64 -> 3.59) and keeps the natural order for a whole frame.  The GLSL
+// N = 8 3.64 -> 3.59) and keeps the natural order for a whole frame -- until the measured dispatch order (round 6,
+// SegmentParams::order) replaced both for every f64 frame of 65 536 rays and more, rank shares included (N = 8: 3.49 ->
+// 3.43 ms with two frames in flight, 3.87 -> 3.49 ms with one; centre-out is what a share runs under
+// GRV_SCHEDULE_SLOT_ORDER).  The GLSL
 // fragment march was measured too and loses 2-12 % (its long rays are the disk-slab samplers, which
 // contend when they all start together): natural order there.  A prime stride through the block list
 // (consecutive starts a quarter of the image apart) was measured as well and loses everywhere: f64
@@ -121,17 +124,17 @@ struct SegmentParams {
     int32_t shading;
     double disk_inner, disk_outer;
     uint32_t max_crossings;
-    uint32_t block_order; // segment kernel: 0 = blocks in slot order, 1 = centre-out (a rank's share of a split frame)
+    uint32_t block_order; // segment kernel without a dispatch order: 0 = blocks in slot order, 1 = centre-out (a rank share under GRV_SCHEDULE_SLOT_ORDER)
     // segment kernel, one-launch schedule of whole frames: the block a workgroup takes (a permutation of the
     // launch's one-wave blocks, longest first by LAST frame's per-wave tries -- finalize_frame_kernel writes the
     // costs, march_rank_kernel sorts them); null = block_order decides.  Any permutation gives the same frame.
     const uint32_t *order;
 };
-// one-launch launches WITHOUT a dispatch order (a rank's share of a split frame, which runs centre-out; the compacting
-// schedule's head start) start one-wave blocks from this many rays on (geodesic_kernels.hpp segment_block_threads)
+// one-launch launches WITHOUT a dispatch order (the compacting schedule's head start; frames under
+// GRV_SCHEDULE_SLOT_ORDER) start one-wave blocks from this many rays on (geodesic_kernels.hpp segment_block_threads)
 constexpr uint32_t kSegOneWaveMinRays = 3u << 19; // 1 572 864
-// Whole frames take a measured dispatch order -- and with it one-wave blocks: the order's entries are one-wave blocks --
-// from this many rays on.  Until the resolution sweep of round 6 this was kSegOneWaveMinRays too, and every frame below
+// Frames (whole ones and a rank's share of a split one) take a measured dispatch order -- and with it one-wave blocks: the
+// order's entries are one-wave blocks -- from this many rays on.  Until the resolution sweep of round 6 this was kSegOneWaveMinRays too, and every frame below
 // 1080p ran four-wave blocks in slot order: 720p 44.1 -> 50.5 G ray-steps/s, 540p 40.1 -> 47.6, 360p 31.7 -> 37.9, 720p at
 // r0 = 10 M 34.8 -> 43.6 (profiles/r06_ab_small_frame_order.jsonl).  Below 65 536 rays (1 024 waves, a third of the
 // chip's wave slots) there is nothing to order.
