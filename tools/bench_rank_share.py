@@ -18,7 +18,8 @@ import torch  # noqa: E402
 import blackhole_simulation_amd as bh  # noqa: E402
 from blackhole_simulation_amd import distributed as D  # noqa: E402
 
-EYE = (60.0 * np.sin(np.deg2rad(97.0)), 60.0 * np.cos(np.deg2rad(97.0)), 0.0)
+_R0, _TH = [float(x) for x in os.environ.get("RS_EYE", "60,97").split(",")]   # RS_EYE=R0,THETA: another camera of the sweep
+EYE = (_R0 * np.sin(np.deg2rad(_TH)), _R0 * np.cos(np.deg2rad(_TH)), 0.0)
 
 
 WGSL_ARITH = bh.ARITH_FAST
